@@ -1,0 +1,259 @@
+"""Frozen OCR branch of the training step: the ``AsterInferer`` wrapper + an ASTER-shaped network.
+
+Wrapper semantics (exact restatement, reference ``aster_ocr_utils/aster_inferer.py``):
+
+* ``convert_inputs`` (:153-190): crop every fake image to its word's width (index of the first
+  label == blank(1) times char_width), bilinear-resize (TF2 half-pixel centres, no antialias)
+  to 64x256.  Here the per-sample crop+resize is ONE batched matmul with a per-word-length
+  interpolation matrix (the resize is linear in the pixels and the height scale is 1).
+* ``call`` (:28-37) + ``_postprocess_simple`` (:116-151): forward logits, first 8 steps; a
+  sample whose decode stopped before 8 steps is padded with ``1000 * onehot(class 1)``.
+  The reference calls the SavedModel once per sample; the network is frozen/eval so one
+  batched call computes the same function.
+
+The network: the ASTER SavedModel is an external download that is NOT in the reference
+(``aster_weights/.keep`` only) -- architecture, class count and weights cannot be derived
+from it => **parity with the real ASTER is UNPINNED**.  ``AsterLikeOCR`` follows
+the published ASTER design (Shi et al., TPAMI 2018: TPS rectification -> 45-layer ResNet ->
+2x BiLSTM -> Bahdanau-attention LSTM decoder, greedy feedback; the decoder type is also what
+``weigths_tf1_to_tf2.py:3-19`` names) with deterministic synthetic frozen weights, in plain
+PyTorch-ROCm ops as BASELINE.json's north_star prescribes for this branch.
+``load_weights_npz`` is the import hook for someone holding the real weights.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+EOS = 1  # blank / end-of-sequence class (char_tokens.py: <OOV> index 1; utils.py:102-105 pads with 1)
+
+
+# ----------------------------------------------------------------------------------------
+# wrapper pieces
+# ----------------------------------------------------------------------------------------
+def _resize_matrix(in_w: int, out_w: int, full_w: int) -> np.ndarray:
+    """[out_w, full_w] matrix of TF2/torch half-pixel bilinear resize from the first ``in_w``
+    columns (zero weight on columns >= in_w)."""
+    m = np.zeros((out_w, full_w), dtype=np.float64)
+    scale = in_w / out_w
+    for x in range(out_w):
+        src = max((x + 0.5) * scale - 0.5, 0.0)
+        x0 = min(int(math.floor(src)), in_w - 1)
+        x1 = min(x0 + 1, in_w - 1)
+        lam = src - x0
+        m[x, x0] += 1.0 - lam
+        m[x, x1] += lam
+    return m.astype(np.float32)
+
+
+class AsterInferer(nn.Module):
+    """Drop-in for the reference's ``AsterInferer`` (same method names)."""
+
+    def __init__(self, model: Optional[nn.Module] = None, char_width: int = 32, max_char_number: int = 8,
+                 image_dims=(64, 256), combine_forward_and_backward: bool = False):
+        super().__init__()
+        if combine_forward_and_backward:
+            raise NotImplementedError("reference default is forward logits only (aster_inferer.py:19)")
+        self.model = model if model is not None else AsterLikeOCR(max_steps=max_char_number)
+        for p in self.model.parameters():
+            p.requires_grad_(False)
+        self.model.eval()
+        self.char_width = char_width
+        self.max_char_number = max_char_number
+        self.image_dims = tuple(image_dims)
+        full_w = char_width * max_char_number
+        assert image_dims[1] == full_w, "aster_image_dims width must equal the text-box width"
+        mats = np.stack([_resize_matrix(char_width * max(L, 1), image_dims[1], full_w)
+                         for L in range(max_char_number + 1)])
+        mats[0] = mats[max_char_number]  # L=0 never happens for real words; keep it finite
+        self.register_buffer("resize_mats", torch.from_numpy(mats), persistent=False)
+
+    def train(self, mode: bool = True):  # frozen: always eval
+        return super().train(False)
+
+    def convert_inputs(self, fake_images: torch.Tensor, labels: torch.Tensor, blank_label: int = 1) -> torch.Tensor:
+        """[B,3,64,256] NCHW, labels [B,8] -> NHWC [B,64,256,3] resized crop."""
+        B, C, H, W = fake_images.shape
+        assert H == self.image_dims[0], "height resize is the identity in the reference geometry"
+        is_blank = labels == blank_label
+        first_blank = torch.where(is_blank.any(dim=1), is_blank.to(torch.int32).argmax(dim=1),
+                                  torch.full((B,), self.max_char_number, device=labels.device, dtype=torch.int64))
+        m = self.resize_mats[first_blank]  # [B, 256, 256]
+        out = torch.bmm(fake_images.reshape(B, C * H, W), m.transpose(1, 2)).reshape(B, C, H, -1)
+        return out.permute(0, 2, 3, 1)
+
+    def forward(self, inputs_nhwc: torch.Tensor) -> torch.Tensor:
+        logits = self.model(inputs_nhwc.permute(0, 3, 1, 2))  # [B, T, C]
+        return self._postprocess_simple(logits)
+
+    def _postprocess_simple(self, logits: torch.Tensor) -> torch.Tensor:
+        """Keep 8 steps; steps after the first predicted EOS are what a batch-1 dynamic decode
+        never produced, i.e. the reference's ``1000 * onehot(1)`` padding."""
+        logits = logits[:, : self.max_char_number]
+        B, T, C = logits.shape
+        if T < self.max_char_number:
+            pad = logits.new_zeros(B, self.max_char_number - T, C)
+            pad[:, :, EOS] = 1000.0
+            logits = torch.cat([logits, pad], dim=1)
+        is_eos = logits.argmax(dim=2) == EOS
+        after = (torch.cumsum(is_eos.to(torch.int32), dim=1) - is_eos.to(torch.int32)) > 0  # strictly after first EOS
+        pad_row = torch.zeros(C, device=logits.device, dtype=logits.dtype)
+        pad_row[EOS] = 1000.0
+        return torch.where(after[:, :, None], pad_row, logits)
+
+
+# ----------------------------------------------------------------------------------------
+# ASTER-shaped network (published architecture; synthetic weights)
+# ----------------------------------------------------------------------------------------
+def _tps_constants(num_ctrl: int, out_h: int, out_w: int, margin: float = 0.05):
+    """Target control points on the top/bottom edges of the rectified image, the inverse of
+    the TPS system matrix and the lifted target grid (ASTER section 3.1)."""
+    k = num_ctrl // 2
+    xs = np.linspace(margin, 1.0 - margin, k)
+    ctrl = np.concatenate([np.stack([xs, np.full(k, margin)], 1), np.stack([xs, np.full(k, 1.0 - margin)], 1)], 0)
+
+    def phi(d2):
+        return 0.5 * d2 * np.log(np.maximum(d2, 1e-12))  # r^2 log r with r^2 = d2
+
+    d2 = ((ctrl[:, None, :] - ctrl[None, :, :]) ** 2).sum(-1)
+    K = num_ctrl
+    A = np.zeros((K + 3, K + 3))
+    A[:K, :K] = phi(d2)
+    A[:K, K] = 1.0
+    A[:K, K + 1:] = ctrl
+    A[K, :K] = 1.0
+    A[K + 1:, :K] = ctrl.T
+    inv = np.linalg.inv(A)
+    gy, gx = np.meshgrid((np.arange(out_h) + 0.5) / out_h, (np.arange(out_w) + 0.5) / out_w, indexing="ij")
+    pts = np.stack([gx.ravel(), gy.ravel()], 1)
+    d2g = ((pts[:, None, :] - ctrl[None, :, :]) ** 2).sum(-1)
+    lifted = np.concatenate([phi(d2g), np.ones((pts.shape[0], 1)), pts], 1)  # [HW, K+3]
+    return ctrl.astype(np.float32), inv.astype(np.float32), lifted.astype(np.float32)
+
+
+class _ResUnit(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 1, stride, 0, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.short = None
+        if cin != cout or stride != (1, 1):
+            self.short = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, 0, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return F.relu(y + (x if self.short is None else self.short(x)))
+
+
+class AsterLikeOCR(nn.Module):
+    def __init__(self, num_classes: int = 97, max_steps: int = 8, hidden: int = 256, num_ctrl: int = 20,
+                 rect_hw=(32, 100), seed: int = 20180625):
+        super().__init__()
+        self.num_classes, self.max_steps, self.hidden = num_classes, max_steps, hidden
+        self.rect_hw = rect_hw
+        # --- rectification (STN): localisation CNN on a 32x64 thumbnail -> 2K control coordinates
+        chans = [3, 32, 64, 128, 256, 256, 256]
+        loc = []
+        for i in range(6):
+            loc += [nn.Conv2d(chans[i], chans[i + 1], 3, 1, 1), nn.ReLU(inplace=True)]
+            if i < 5:
+                loc.append(nn.MaxPool2d(2, 2))
+        self.loc_cnn = nn.Sequential(*loc)
+        self.loc_fc1 = nn.Linear(256 * 1 * 2, 512)
+        self.loc_fc2 = nn.Linear(512, 2 * num_ctrl)
+        ctrl, inv, lifted = _tps_constants(num_ctrl, rect_hw[0], rect_hw[1])
+        self.register_buffer("tps_inv", torch.from_numpy(inv), persistent=False)
+        self.register_buffer("tps_lifted", torch.from_numpy(lifted), persistent=False)
+        self.register_buffer("ctrl_init", torch.from_numpy(ctrl.reshape(-1)), persistent=False)
+        # --- encoder: ResNet (ASTER table 1) + 2 BiLSTM
+        self.stem = nn.Sequential(nn.Conv2d(3, 32, 3, 1, 1, bias=False), nn.BatchNorm2d(32), nn.ReLU(inplace=True))
+        cfgs = [(32, 3, (2, 2)), (64, 4, (2, 2)), (128, 6, (2, 1)), (256, 6, (2, 1)), (512, 3, (2, 1))]
+        blocks, cin = [], 32
+        for cout, n, stride in cfgs:
+            for u in range(n):
+                blocks.append(_ResUnit(cin, cout, stride if u == 0 else (1, 1)))
+                cin = cout
+        self.resnet = nn.Sequential(*blocks)
+        self.rnn = nn.LSTM(512, hidden, num_layers=2, bidirectional=True, batch_first=True)
+        # --- attention decoder (forward direction only is consumed: aster_inferer.py:35)
+        self.emb = nn.Embedding(num_classes + 1, hidden)  # +1: GO symbol
+        self.att_enc = nn.Linear(2 * hidden, hidden, bias=False)
+        self.att_dec = nn.Linear(hidden, hidden)
+        self.att_v = nn.Linear(hidden, 1, bias=False)
+        self.cell = nn.LSTMCell(2 * hidden + hidden, hidden)
+        self.out = nn.Linear(hidden, num_classes)
+        self._synthetic_init(seed)
+        self.eval()
+
+    @torch.no_grad()
+    def _synthetic_init(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        for name, p in self.named_parameters():
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * math.sqrt(2.0 / fan_in))
+            else:
+                p.zero_()
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.fill_(1.0)
+                m.running_var.fill_(1.0)
+        self.loc_fc2.weight.mul_(0.05)
+        self.loc_fc2.bias.copy_(self.ctrl_init)
+        for n, p in self.rnn.named_parameters():  # unit forget-gate bias
+            if "bias_ih" in n:
+                p[self.hidden: 2 * self.hidden].fill_(1.0)
+
+    def load_weights_npz(self, path: str, name_map: Optional[dict] = None):
+        """Import hook: ``.npz`` of arrays keyed by this module's state_dict names (or mapped
+        through ``name_map``); conv kernels expected HWIO (TF) and transposed here."""
+        data = np.load(path)
+        sd = self.state_dict()
+        for k in sd:
+            src = (name_map or {}).get(k, k)
+            if src in data:
+                a = torch.from_numpy(data[src])
+                if a.dim() == 4 and a.shape != sd[k].shape:
+                    a = a.permute(3, 2, 0, 1)
+                sd[k].copy_(a.reshape(sd[k].shape))
+
+    def rectify(self, img: torch.Tensor) -> torch.Tensor:
+        B = img.shape[0]
+        thumb = F.interpolate(img, size=(32, 64), mode="bilinear", align_corners=False)
+        f = self.loc_cnn(thumb).reshape(B, -1)
+        ctrl = self.loc_fc2(F.relu(self.loc_fc1(f))).reshape(B, -1, 2)  # source control points in [0,1]^2
+        rhs = torch.cat([ctrl, ctrl.new_zeros(B, 3, 2)], dim=1)  # [B, K+3, 2]
+        T = torch.matmul(self.tps_inv, rhs)
+        src = torch.matmul(self.tps_lifted, T)  # [B, HW, 2] in [0,1]
+        grid = (src * 2.0 - 1.0).reshape(B, self.rect_hw[0], self.rect_hw[1], 2)
+        return F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=False)
+
+    def forward(self, img_nchw: torch.Tensor) -> torch.Tensor:
+        """[B,3,64,256] in [-1,1] -> forward logits [B, max_steps, num_classes]."""
+        x = self.rectify(img_nchw)
+        x = self.resnet(self.stem(x))  # [B,512,1,25]
+        seq = x.squeeze(2).permute(0, 2, 1)
+        enc, _ = self.rnn(seq)  # [B,25,512]
+        B = enc.shape[0]
+        enc_proj = self.att_enc(enc)
+        h = enc.new_zeros(B, self.hidden)
+        c = enc.new_zeros(B, self.hidden)
+        prev = torch.full((B,), self.num_classes, dtype=torch.long, device=enc.device)  # GO
+        outs = []
+        for _ in range(self.max_steps):
+            e = self.att_v(torch.tanh(enc_proj + self.att_dec(h)[:, None, :])).squeeze(2)
+            a = torch.softmax(e, dim=1)
+            ctx = torch.bmm(a[:, None, :], enc).squeeze(1)
+            h, c = self.cell(torch.cat([ctx, self.emb(prev)], dim=1), (h, c))
+            logit = self.out(h)
+            outs.append(logit)
+            prev = logit.argmax(dim=1)  # greedy feedback (non-differentiable, as in the TF decoder)
+        return torch.stack(outs, dim=1)
