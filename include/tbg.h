@@ -1,0 +1,175 @@
+/*
+ * tbg.h -- C ABI of libtbg_hip.so: the MI355X (gfx950) kernels behind the TextBoxGAN
+ * training step.
+ *
+ * Boundary contract (mirrors what the reference's only native plugin does; reference
+ * models/custom_stylegan2/layers/upfirdn/upfirdn_2d.cu:232-324 and the loader
+ * custom_ops.py:109-213):
+ *   - every entry point returns 0 (TBG_OK) or a negative error code; nothing throws, aborts,
+ *     synchronises the device, allocates or frees device memory.  The caller's framework
+ *     allocator provides outputs/workspaces (the role of ctx->allocate_output, .cu:258-265).
+ *   - all pointers are DEVICE pointers to contiguous fp32 unless noted; kernels are enqueued
+ *     asynchronously on `stream` (a hipStream_t passed as void*; NULL = default stream), the
+ *     analogue of launching on TF's stream (.cu:234-235,305-306).
+ *   - re-entrant; no mutable global state.
+ *   - shape/argument errors -> TBG_EINVAL (OP_REQUIRES InvalidArgument, .cu:228-256),
+ *     more than INT32_MAX elements -> TBG_ERANGE (.cu:243-244,266), launch failure -> TBG_EHIP
+ *     (.cu:20,306).
+ *
+ * Layouts: activations NCHW; convolution filters in "GEMM layout" [KH*KW][C][ldw]
+ * (tap-major, reduction channel, output channel contiguous) -- the reference's own HWIO
+ * parameter layout [k,k,I,O] IS this layout with ldw = O, so forward passes read the
+ * checkpoint-layout weights directly.
+ */
+#ifndef TBG_H_
+#define TBG_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBG_OK 0
+#define TBG_EINVAL (-1)
+#define TBG_ERANGE (-2)
+#define TBG_EHIP (-3)
+#define TBG_EUNSUPPORTED (-4)
+
+#define TBG_ACT_LINEAR 0
+#define TBG_ACT_LRELU 1
+
+/* library version (major*10000 + minor*100 + patch) and error strings */
+int tbg_version(void);
+const char *tbg_strerror(int code);
+
+/* Fused epilogue shared by the conv / FIR / bias_act kernels.  For an accumulator value
+ * `acc` at (sample b, channel m, pixel p):
+ *   v   = acc * alpha * (out_scale ? out_scale[b*M + m] : 1)
+ *       + (noise ? noise[b*HW + p] * strength[0] : 0) + (bias ? bias[m] * bias_mul : 0)
+ *   v   = (act == LRELU ? (v > 0 ? v : v * slope) : v) * gain
+ *   out = residual ? (v + residual[...]) * res_scale : v
+ * tbg_conv2d_f32 additionally supports a fused per-(b,m) dot product of the UNSCALED accumulator
+ * with a second tensor (dot_aux/dot_out): the style gradient ds[b,i] = sum_p x[b,i,p]*dxhat[b,i,p]
+ * comes out of the same launch that writes dx = s*dxhat.
+ * Replaces reference layers/noise.py:12-22 + layers/bias_act.py:25-34 (+ the demodulation
+ * scale of modulated_conv2d.py:119-121 and the resnet add of discriminator.py:82). */
+typedef struct tbg_epilogue {
+  const float *out_scale; /* [B*M] or NULL */
+  const float *bias;      /* [M] or NULL */
+  const float *noise;     /* [B, H*W] or NULL */
+  const float *strength;  /* device scalar, required with noise */
+  const float *residual;  /* output-shaped or NULL */
+  const float *dot_aux;   /* conv only: output-shaped tensor or NULL */
+  float *dot_out;         /* conv only: [B*M], PRE-ZEROED; += sum_p (acc*alpha) * dot_aux[b,m,p] */
+  float alpha;
+  float bias_mul;
+  float slope;
+  float gain;
+  float res_scale;
+  int act;
+} tbg_epilogue;
+
+/* ------------------------------------------------------------------------------------------
+ * upfirdn2d -- replaces the TF op "UpFirDn2D" (upfirdn_2d.cu:310-324; kernels :64-207).
+ * x: [major, inH, inW, minor], k: [kH, kW] (applied FLIPPED, as the op does), y: [major, outH,
+ * outW, minor] with out = (in*up + pad0 + pad1 - k + down) / down.  The gradient is the same
+ * op with transformed parameters (upfirdn_2d_v2.py:204-244), so no separate backward entry.
+ * _ex adds an optional per-`major` input scale and the fused epilogue (minor must be 1;
+ * channel m = major % M, sample b = major / M).
+ * ---------------------------------------------------------------------------------------- */
+int tbg_upfirdn2d_f32(const float *x, const float *k, float *y, int major, int inH, int inW,
+                      int minor, int kH, int kW, int upx, int upy, int downx, int downy,
+                      int padx0, int padx1, int pady0, int pady1, void *stream);
+
+int tbg_upfirdn2d_ex_f32(const float *x, const float *k, float *y, int major, int inH, int inW,
+                         int kH, int kW, int upx, int upy, int downx, int downy, int padx0,
+                         int padx1, int pady0, int pady1, const float *in_scale, int M,
+                         const tbg_epilogue *epi, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution as fp32-MFMA implicit GEMM (v_mfma_f32_32x32x2_f32).  One descriptor serves:
+ *   transposed = 0 : y[b,m,oy,ox] = sum_{t=(kh,kw),c} x[b,c,oy*sy-py+kh,ox*sx-px+kw] * W[t'][c][m]
+ *   transposed = 1 : y[b,m,sy*a+kh,sx*b'+kw] += x[b,c,a,b'] * W[t'][c][m]      (VALID, py=px=0)
+ * with t' = flip ? KH*KW-1-t : t.  Replaces tf.nn.conv2d / conv2d_transpose as used by
+ * layers/conv.py:51-73, layers/modulated_conv2d.py:85-121, upfirdn_2d_v2.py:65-113 and
+ * their gradients.  in_scale [B*C] (style modulation, modulated_conv2d.py:94-96) is applied
+ * while staging x; the epilogue applies demodulation / noise / bias / activation.
+ * ksplit > 1 splits the reduction over blocks that atomically add alpha*acc into a
+ * PRE-ZEROED y (epilogue must then be alpha-only).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tbg_conv_desc {
+  int B, C, M;
+  int Hin, Win, Hout, Wout;
+  int KH, KW;
+  int sy, sx;
+  int py, px;
+  int transposed;
+  int flip;
+  int ldw;
+  int ksplit;
+} tbg_conv_desc;
+
+int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float *y,
+                   const float *in_scale, const tbg_epilogue *epi, void *stream);
+
+/* Weight gradient:  dW[t*st_t + cl*st_l + cs*st_s] += alpha * sum_{b,u,v}
+ *     S[b,cs,u,v]*s_scale[b,cs] * L[b,cl,u*sy-py+kh,v*sx-px+kw]*l_scale[b,cl]
+ * S is the tensor on the (small) output grid, L the tensor on the input grid; dW must be
+ * PRE-ZEROED (blocks accumulate with atomics).  Gradient of both forms of tbg_conv2d_f32. */
+typedef struct tbg_wgrad_desc {
+  int B, CS, CL;
+  int Hs, Ws, Hl, Wl;
+  int KH, KW;
+  int sy, sx;
+  int py, px;
+  int st_t, st_l, st_s;
+  float alpha;
+} tbg_wgrad_desc;
+
+int tbg_conv2d_wgrad_f32(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
+                         const float *s_scale, const float *l_scale, void *stream);
+
+/* dst[t'][o][ldo: i] = src[t][i][o]  with t' = flip ? T-1-t : t ; rows padded to ldo (zero). Turns
+ * the HWIO parameter into the GEMM layout the data-gradient convolutions need. */
+int tbg_weight_transpose_f32(const float *src, float *dst, int T, int I, int O, int ldo,
+                             int flip, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bias_act: stand-alone epilogue (x: [B,M,HW]) and its backward.
+ * backward, from dout and the SAVED OUTPUT `out` (sign(out) == sign(pre-activation)):
+ *   dpre = (residual_fused ? dout*res_scale : dout) * gain * (out_act > 0 ? 1 : slope)
+ *   dx   = dpre * alpha * out_scale[b,m]                                    (written if dx)
+ *   part_db[b,m,chunk]  = sum_p dpre                (partial sums; caller reduces)
+ *   part_dn[b,m,chunk]  = sum_p dpre*noise[b,p]
+ *   part_dyy[b,m,chunk] = sum_p dpre*y_rec, y_rec = pre - noise*strength - bias (the scaled conv
+ *                         output; gives d(out_scale) = dyy / out_scale)
+ * `out_act` is the activation output before any fused residual, so callers that fused a
+ * residual pass that pre-residual value.  nchunks = tbg_bias_act_bwd_chunks(HW).
+ * ---------------------------------------------------------------------------------------- */
+int tbg_bias_act_fwd_f32(const float *x, float *y, int B, int M, int HW, const tbg_epilogue *epi,
+                         void *stream);
+int tbg_bias_act_bwd_chunks(int HW);
+int tbg_bias_act_bwd_f32(const float *dout, const float *out_act, float *dx, float *dpre_out,
+                         float *part_db, float *part_dn, float *part_dyy, int B, int M, int HW,
+                         const tbg_epilogue *epi, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser / EMA (multi-tensor over one flat buffer).
+ * Keras Adam (reference train.py:58-75 -> ResourceApplyAdam): m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2;
+ * theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps).  `step` is a DEVICE int64 holding t-1
+ * (iterations before this call); the kernel does not modify it.
+ * tbg_ema_lerp: dst = src + (dst - src)*beta   (generator.py:48-59).
+ * ---------------------------------------------------------------------------------------- */
+int tbg_adam_tf_f32(float *theta, float *m, float *v, const float *g, long long n, float lr,
+                    float beta1, float beta2, float eps, const long long *step, void *stream);
+int tbg_ema_lerp_f32(float *dst, const float *src, long long n, float beta, void *stream);
+
+/* demodulation coefficients (modulated_conv2d.py:78-82 in the activation-scaling form):
+ * d[b,o] = rsqrt( sum_i s[b,i]^2 * wsq[i,o] + 1e-8 ),  wsq[i,o] = coef^2 * sum_t w[t,i,o]^2.
+ * wsq is a caller-provided [I*O] workspace (also an output, reused by the backward). */
+int tbg_demod_coefs_f32(const float *s, const float *w, float *wsq, float *d, int B, int T, int I,
+                        int O, float coef, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBG_H_ */

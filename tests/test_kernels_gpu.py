@@ -1,0 +1,327 @@
+"""-m gpu: every libtbg_hip kernel (through the C ABI) against the float64 CPU oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return float((a - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+# ---------------------------------------------------------------------------------------- upfirdn
+UF_CASES = [
+    # (B*C, H, W, up(x,y), down(x,y), pad(x0,x1,y0,y1), gain, note)
+    (6, 16, 64, (1, 1), (1, 1), (1, 1, 1, 1), 4.0, "blur after up-conv"),
+    (6, 17, 65, (1, 1), (1, 1), (1, 1, 1, 1), 4.0, "blur on 2H+1 x 2W+1"),
+    (5, 32, 128, (1, 1), (1, 1), (2, 3, 2, 3), 1.0, "blur before 3x3 down"),
+    (5, 32, 128, (1, 1), (1, 1), (1, 2, 1, 2), 1.0, "blur before 1x1 skip"),
+    (3, 8, 32, (2, 2), (1, 1), (2, 1, 2, 1), 4.0, "rgb upsample"),
+    (4, 16, 64, (1, 1), (2, 2), (1, 2, 1, 2), 1.0, "decimated skip FIR"),
+    (4, 8, 16, (1, 1), (2, 1), (1, 2, 1, 2), 1.0, "decimated skip FIR, keep height"),
+    (4, 8, 16, (2, 1), (1, 1), (2, 1, 2, 1), 1.0, "grad of keep-height decimation"),
+    (2, 64, 256, (1, 1), (1, 1), (2, 3, 2, 3), 1.0, "full-size plane"),
+    (3, 5, 7, (1, 1), (1, 1), (-1, 2, 3, -1), 1.0, "negative pads (crop)"),
+]
+
+
+@pytest.mark.parametrize("case", UF_CASES, ids=[c[-1] for c in UF_CASES])
+def test_upfirdn2d_matches_oracle(dev, case):
+    from textboxgan_amd import ops
+    major, H, W, up, down, pad, gain, _ = case
+    x = rnd(1, major, H, W, seed=1)
+    k = torch.from_numpy(R.setup_kernel([1, 3, 3, 1]).astype(np.float64) * gain)
+    k[0, 1] += 0.05  # asymmetric: catches flip/transposition mistakes
+    ref = R.t_upfirdn2d(x[0][..., None], k.numpy(), upx=up[0], upy=up[1], downx=down[0], downy=down[1],
+                        padx0=pad[0], padx1=pad[1], pady0=pad[2], pady1=pad[3])[..., 0][None]
+    y = ops.upfirdn2d_raw(x.float().to(dev), k.float().to(dev), up, down, pad)
+    assert rel_err(y, ref) < 1e-5
+
+
+def test_upfirdn2d_generic_minor_and_big_filter(dev):
+    from textboxgan_amd import native as N
+    x = rnd(3, 9, 11, 2, seed=2)
+    k = rnd(5, 6, seed=3)
+    ref = R.t_upfirdn2d(x, k.numpy(), upx=2, upy=1, downx=1, downy=2, padx0=2, padx1=3, pady0=1, pady1=2)
+    xd = x.float().to(dev).contiguous()
+    kd = k.float().to(dev).contiguous()
+    y = torch.empty(ref.shape, device=dev)
+    rc = N.lib().tbg_upfirdn2d_f32(N.ptr(xd), N.ptr(kd), N.ptr(y), 3, 9, 11, 2, 5, 6, 2, 1, 1, 2, 2, 3, 1, 2, N.stream())
+    assert rc == 0
+    assert rel_err(y, ref) < 1e-5
+
+
+def test_upfirdn2d_error_codes(dev):
+    from textboxgan_amd import native as N
+    x = torch.zeros(1, 4, 4, 1, device=dev)
+    k = torch.ones(4, 4, device=dev)
+    y = torch.zeros(1, 8, 8, 1, device=dev)
+    L = N.lib()
+    assert L.tbg_upfirdn2d_f32(N.ptr(x), N.ptr(k), N.ptr(y), 1, 4, 4, 1, 4, 4, 0, 1, 1, 1, 0, 0, 0, 0, N.stream()) == -1
+    assert L.tbg_upfirdn2d_f32(N.ptr(x), N.ptr(k), N.ptr(y), 1, 2, 2, 1, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, N.stream()) == -1  # empty out
+    assert L.tbg_upfirdn2d_f32(None, N.ptr(k), N.ptr(y), 1, 4, 4, 1, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, N.stream()) == -1
+    assert b"invalid" in L.tbg_strerror(-1)
+
+
+def test_upfirdn2d_grad_and_gradgrad(dev):
+    """first and second order gradients through the recursive Function == autograd through the oracle."""
+    from textboxgan_amd import ops
+    k64 = torch.from_numpy(R.setup_kernel([1, 3, 3, 1]).astype(np.float64) * 4)
+    for up, down, pad in (((2, 2), (1, 1), (2, 1, 2, 1)), ((1, 1), (2, 2), (1, 2, 1, 2)), ((1, 1), (1, 1), (2, 3, 2, 3))):
+        x = rnd(2, 3, 8, 12, seed=4).requires_grad_(True)
+        y = R.t_simple_upfirdn2d(x, k64.numpy(), up=up[0], down=down[0], pad0=pad[0], pad1=pad[1])
+        gy = rnd(*y.shape, seed=5).requires_grad_(True)
+        (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+        gg = rnd(*gx.shape, seed=6)
+        (ggy,) = torch.autograd.grad(gx, gy, gg)
+
+        xd = x.detach().float().to(dev).requires_grad_(True)
+        gyd = gy.detach().float().to(dev).requires_grad_(True)
+        yd = ops.upfirdn2d(xd, k64.float().to(dev), up, down, pad)
+        (gxd,) = torch.autograd.grad(yd, xd, gyd, create_graph=True)
+        (ggyd,) = torch.autograd.grad(gxd, gyd, gg.float().to(dev))
+        assert rel_err(yd, y) < 1e-5
+        assert rel_err(gxd, gx) < 1e-5
+        assert rel_err(ggyd, ggy) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------- conv
+def ref_conv(x, w_hwio, stride, pad, transposed=False):
+    wt = w_hwio.permute(3, 2, 0, 1)
+    if transposed:
+        return F.conv_transpose2d(x, w_hwio.permute(2, 3, 0, 1), stride=stride)
+    return F.conv2d(x, wt, stride=stride, padding=pad)
+
+
+CONV_CASES = [
+    # B, C, M, H, W, k, stride, pad, note
+    (2, 16, 32, 16, 64, 3, (1, 1), (1, 1), "3x3 small"),
+    (2, 128, 128, 16, 64, 3, (1, 1), (1, 1), "3x3 128ch"),
+    (3, 24, 64, 12, 40, 3, (1, 1), (1, 1), "3x3 odd sizes M64"),
+    (4, 513, 512, 4, 4, 3, (1, 1), (1, 1), "head conv 513 (split-K, 4x4)"),
+    (2, 64, 128, 34, 66, 3, (2, 2), (0, 0), "3x3 stride 2 VALID"),
+    (2, 32, 48, 10, 34, 3, (1, 2), (0, 0), "3x3 stride (1,2) VALID"),
+    (2, 3, 64, 16, 64, 1, (1, 1), (0, 0), "fromRGB 1x1"),
+    (2, 64, 128, 16, 32, 1, (1, 1), (0, 0), "skip 1x1"),
+    (16, 512, 512, 4, 16, 3, (1, 1), (1, 1), "4x16 512ch batch16 (split-K)"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[-1] for c in CONV_CASES])
+def test_conv2d_forward(dev, case):
+    from textboxgan_amd import ops
+    B, C, M, H, W, k, stride, pad, _ = case
+    x = rnd(B, C, H, W, seed=10)
+    w = rnd(k, k, C, M, seed=11)
+    ref = ref_conv(x, w, stride, pad)
+    y = ops.conv2d_raw(x.float().to(dev), w.float().to(dev), M, k, k, (ref.shape[2], ref.shape[3]), stride, pad)
+    assert rel_err(y, ref) < 2e-5
+
+
+def test_conv2d_flip(dev):
+    from textboxgan_amd import ops
+    x = rnd(2, 16, 8, 16, seed=12)
+    w = rnd(3, 3, 16, 32, seed=13)
+    ref = ref_conv(x, torch.flip(w, (0, 1)), (1, 1), (1, 1))
+    y = ops.conv2d_raw(x.float().to(dev), w.float().to(dev), 32, 3, 3, (8, 16), (1, 1), (1, 1), flip=True)
+    assert rel_err(y, ref) < 2e-5
+
+
+TCONV_CASES = [
+    (2, 16, 32, 4, 16, (2, 2), "up 4x16"),
+    (2, 128, 128, 16, 64, (2, 2), "up 16x64 128ch"),
+    (2, 32, 16, 8, 9, (1, 2), "transposed stride (1,2)"),
+    (3, 512, 256, 4, 16, (2, 2), "up 512->256 (split-K)"),
+]
+
+
+@pytest.mark.parametrize("case", TCONV_CASES, ids=[c[-1] for c in TCONV_CASES])
+def test_conv2d_transposed(dev, case):
+    from textboxgan_amd import ops
+    B, C, M, H, W, stride, _ = case
+    x = rnd(B, C, H, W, seed=14)
+    w = rnd(3, 3, C, M, seed=15)
+    ref = F.conv_transpose2d(x, w.permute(2, 3, 0, 1), stride=stride)
+    y = ops.conv2d_raw(x.float().to(dev), w.float().to(dev), M, 3, 3, (ref.shape[2], ref.shape[3]), stride, (0, 0),
+                       transposed=True)
+    assert rel_err(y, ref) < 2e-5
+    # padded output (rows/cols past the natural extent must be written as zeros)
+    y2 = ops.conv2d_raw(x.float().to(dev), w.float().to(dev), M, 3, 3, (ref.shape[2] + 1, ref.shape[3] + 1), stride,
+                        (0, 0), transposed=True)
+    ref2 = F.pad(ref, (0, 1, 0, 1))
+    assert rel_err(y2, ref2) < 2e-5
+
+
+def test_conv2d_fused_epilogue(dev):
+    from textboxgan_amd import ops, native as N
+    B, C, M, H, W = 3, 32, 48, 8, 32
+    x, w = rnd(B, C, H, W, seed=16), rnd(3, 3, C, M, seed=17)
+    s, d = rnd(B, C, seed=18) + 1.0, rnd(B, M, seed=19).abs() + 0.5
+    noise, bias, res = rnd(B, 1, H, W, seed=20), rnd(M, seed=21), rnd(B, M, H, W, seed=22)
+    strength = torch.tensor(0.37, dtype=torch.float64)
+    alpha = 0.123
+    pre = F.conv2d(x * s[:, :, None, None], w.permute(3, 2, 0, 1), padding=1) * alpha * d[:, :, None, None]
+    pre = pre + noise * strength + bias[None, :, None, None] * 0.5
+    ref = (F.leaky_relu(pre, 0.2) * math.sqrt(2) + res) * 0.7
+    f = lambda t: t.float().to(dev).contiguous()
+    dd, bd, nd, sd, rd = f(d), f(bias), f(noise), f(strength), f(res)  # keep alive: the epilogue holds raw pointers
+    epi = N.epilogue(out_scale=dd, bias=bd, noise=nd, strength=sd, residual=rd, alpha=alpha,
+                     bias_mul=0.5, act=N.ACT_LRELU, res_scale=0.7)
+    y = ops.conv2d_raw(f(x), f(w), M, 3, 3, (H, W), (1, 1), (1, 1), in_scale=f(s), epi=epi)
+    assert rel_err(y, ref) < 2e-5
+    # fused dot product of the unscaled accumulator
+    aux = rnd(B, M, H, W, seed=23)
+    dot = torch.zeros(B, M, device=dev)
+    epi2 = N.epilogue(out_scale=dd, alpha=alpha)
+    y2 = ops.conv2d_raw(f(x), f(w), M, 3, 3, (H, W), (1, 1), (1, 1), epi=epi2, dot=(f(aux), dot))
+    raw = F.conv2d(x, w.permute(3, 2, 0, 1), padding=1) * alpha
+    assert rel_err(y2, raw * d[:, :, None, None]) < 2e-5
+    assert rel_err(dot, (raw * aux).sum(dim=(2, 3))) < 2e-5
+
+
+WG_CASES = [
+    (2, 16, 32, 16, 64, 3, (1, 1), (1, 1), "3x3 s1"),
+    (2, 128, 128, 16, 64, 3, (1, 1), (1, 1), "3x3 s1 128ch"),
+    (3, 24, 40, 9, 21, 3, (1, 1), (1, 1), "3x3 odd"),
+    (2, 64, 96, 34, 66, 3, (2, 2), (0, 0), "3x3 s2 VALID"),
+    (2, 32, 48, 10, 34, 3, (1, 2), (0, 0), "3x3 s(1,2) VALID"),
+    (2, 3, 64, 16, 64, 1, (1, 1), (0, 0), "1x1 fromRGB"),
+    (4, 513, 512, 4, 4, 3, (1, 1), (1, 1), "513->512 4x4"),
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[c[-1] for c in WG_CASES])
+def test_conv2d_wgrad(dev, case):
+    from textboxgan_amd import ops
+    B, C, M, H, W, k, stride, pad, _ = case
+    x = rnd(B, C, H, W, seed=30).requires_grad_(True)
+    w = rnd(k, k, C, M, seed=31).requires_grad_(True)
+    y = ref_conv(x, w, stride, pad)
+    dy = rnd(*y.shape, seed=32)
+    (dw_ref,) = torch.autograd.grad(y, w, dy)
+    g = ops._Geom(stride, pad, k, k, (H, W), (y.shape[2], y.shape[3]))
+    dw = ops._bwd_weight_launch(x.detach().float().to(dev), dy.float().to(dev), g, C, M, alpha=1.0)
+    assert rel_err(dw, dw_ref) < 3e-5
+
+
+def test_conv_primitives_double_backward(dev):
+    """conv2d / bwd_data / bwd_weight close under differentiation (R1 and path-length need it)."""
+    from textboxgan_amd import ops
+    for stride, pad, H, W in (((1, 1), (1, 1), 8, 12), ((2, 2), (0, 0), 9, 13), ((1, 2), (0, 0), 6, 13)):
+        x = rnd(2, 8, H, W, seed=40).requires_grad_(True)
+        w = rnd(3, 3, 8, 16, seed=41).requires_grad_(True)
+        y = ref_conv(x, w, stride, pad)
+        gy = rnd(*y.shape, seed=42).requires_grad_(True)
+        gx, gw = torch.autograd.grad(y, (x, w), gy, create_graph=True)
+        loss = gx.square().sum() + (gw * rnd(*gw.shape, seed=43)).sum()
+        r = torch.autograd.grad(loss, (x, w, gy))
+
+        f = lambda t: t.detach().float().to(dev).requires_grad_(True)
+        xd, wd, gyd = f(x), f(w), f(gy)
+        yd = ops.conv2d(xd, wd, stride, pad)
+        gxd, gwd = torch.autograd.grad(yd, (xd, wd), gyd, create_graph=True)
+        lossd = gxd.square().sum() + (gwd * rnd(*gw.shape, seed=43).float().to(dev)).sum()
+        rd = torch.autograd.grad(lossd, (xd, wd, gyd))
+        assert rel_err(yd, y) < 2e-5 and rel_err(gxd, gx) < 2e-5 and rel_err(gwd, gw) < 2e-5
+        for a, b in zip(rd, r):
+            assert rel_err(a, b) < 5e-5
+
+
+def test_conv_transpose_primitive(dev):
+    from textboxgan_amd import ops
+    x = rnd(2, 8, 5, 7, seed=44).requires_grad_(True)
+    wt = rnd(3, 3, 8, 12, seed=45).requires_grad_(True)
+    y = F.conv_transpose2d(x, wt.permute(2, 3, 0, 1), stride=2)
+    gy = rnd(*y.shape, seed=46)
+    gx, gw = torch.autograd.grad(y, (x, wt), gy)
+    f = lambda t: t.detach().float().to(dev).requires_grad_(True)
+    xd, wd = f(x), f(wt)
+    yd = ops.conv_transpose2d_s2(xd, wd)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), gy.float().to(dev))
+    assert rel_err(yd, y) < 2e-5 and rel_err(gxd, gx) < 2e-5 and rel_err(gwd, gw) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------- elementwise
+def test_bias_act_fwd_bwd(dev):
+    from textboxgan_amd import ops, native as N
+    for HW in (64, 4096 + 12, 16384):
+        B, M = 2, 5
+        x = rnd(B, M, HW, seed=50).requires_grad_(True)
+        d = (rnd(B, M, seed=51).abs() + 0.5).requires_grad_(True)
+        bias = rnd(M, seed=52).requires_grad_(True)
+        noise = rnd(B, 1, HW, seed=53)
+        strength = torch.tensor(0.3, dtype=torch.float64, requires_grad=True)
+        pre = x * d[:, :, None] + noise * strength + bias[None, :, None]
+        out = F.leaky_relu(pre, 0.2) * math.sqrt(2)
+        dout = rnd(B, M, HW, seed=54)
+        gx, gd, gb, gs = torch.autograd.grad(out, (x, d, bias, strength), dout)
+        f = lambda t: t.detach().float().to(dev).contiguous()
+        dd, bd, nd, sd = f(d), f(bias), f(noise), f(strength)  # keep alive: the epilogue holds raw pointers
+        epi = N.epilogue(out_scale=dd, bias=bd, noise=nd, strength=sd, act=N.ACT_LRELU)
+        y = ops.bias_act_fwd_raw(f(x), epi)
+        assert rel_err(y, out) < 1e-5
+        dx, dpre, pdb, pdn, pdy = ops.bias_act_bwd_raw(f(dout), y, epi, want_dx=True, want_dn=True, want_dyy=True)
+        assert rel_err(dx, gx) < 1e-5
+        assert rel_err(pdb.sum(dim=(0, 2)), gb) < 1e-4
+        assert rel_err(pdn.sum(), gs) < 1e-4
+        assert rel_err(pdy.sum(dim=2) / dd, gd) < 1e-4
+
+
+def test_weight_transpose(dev):
+    from textboxgan_amd import ops
+    w = rnd(3, 3, 13, 20, seed=60).float().double()
+    for flip in (False, True):
+        out, ldo = ops.weight_transpose_raw(w.float().to(dev), flip)
+        ref = (torch.flip(w, (0, 1)) if flip else w).reshape(9, 13, 20).permute(0, 2, 1)
+        assert ldo == 16
+        assert rel_err(out[:, :, :13], ref) == 0.0
+        assert float(out[:, :, 13:].abs().max()) == 0.0
+
+
+def test_adam_and_ema(dev):
+    from textboxgan_amd import ops
+    n = 10007
+    th, g = rnd(n, seed=70), rnd(n, seed=71)
+    m, v = rnd(n, seed=72) * 0.1, rnd(n, seed=73).abs() * 0.1
+    lr, b1, b2, eps, t = 1.7778e-3, 0.0, 0.99111, 1e-8, 7
+    m2 = b1 * m + (1 - b1) * g
+    v2 = b2 * v + (1 - b2) * g * g
+    th2 = th - lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m2 / (v2.sqrt() + eps)
+    f = lambda x: x.float().to(dev).contiguous()
+    thd, md, vd, gd = f(th), f(m), f(v), f(g)
+    step = torch.tensor([t - 1], dtype=torch.int64, device=dev)
+    ops.adam_tf_(thd, md, vd, gd, step, lr, b1, b2, eps)
+    assert rel_err(thd, th2) < 1e-6 and rel_err(md, m2) < 1e-6 and rel_err(vd, v2) < 1e-6
+    dst, src = f(th), f(g)
+    ops.ema_lerp_(dst, src, 0.99)
+    assert rel_err(dst, g + (th - g) * 0.99) < 1e-6
+
+
+def test_demod_coefs(dev):
+    from textboxgan_amd import ops
+    s = (rnd(5, 24, seed=80) + 1).requires_grad_(True)
+    w = rnd(3, 3, 24, 40, seed=81).requires_grad_(True)
+    coef = 1 / math.sqrt(9 * 24)
+    ww = (w * coef)[None] * s[:, None, None, :, None]
+    d = torch.rsqrt(ww.square().sum(dim=(1, 2, 3)) + 1e-8)
+    gd = rnd(5, 40, seed=82)
+    gs, gw = torch.autograd.grad(d, (s, w), gd)
+    f = lambda t: t.detach().float().to(dev).requires_grad_(True)
+    sd, wd = f(s), f(w)
+    dd = ops.demod_coefs(sd, wd)
+    gsd, gwd = torch.autograd.grad(dd, (sd, wd), gd.float().to(dev))
+    assert rel_err(dd, d) < 1e-5 and rel_err(gsd, gs) < 1e-4 and rel_err(gwd, gw) < 1e-4

@@ -1,0 +1,159 @@
+"""-m gpu: fused HIP layers and whole networks against the oracle (float64 on CPU)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model as M, ref_ops as R
+from textboxgan_amd.config import small_config
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return float((a - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64)
+
+
+def to64(P):
+    return {k: v.double() for k, v in P.items()}
+
+
+@pytest.mark.parametrize("up", [False, True], ids=["conv_1", "conv_0_up"])
+@pytest.mark.parametrize("shape", [(3, 16, 24, 8, 32), (2, 128, 128, 16, 64), (16, 512, 512, 4, 16)],
+                         ids=["small", "128ch", "512ch-splitk"])
+def test_modconv_fused_fwd_bwd(dev, up, shape):
+    """fused modulated conv (+up) + noise + bias + lrelu: forward and all seven gradients."""
+    from textboxgan_amd import ops
+    B, I, O, H, W = shape
+    if up and I == 512:
+        O = 256
+    sd = 20
+    x, style = rnd(B, I, H, W, seed=1), rnd(B, sd, seed=2)
+    w, mw, mb = rnd(3, 3, I, O, seed=3), rnd(sd, I, seed=4), rnd(I, seed=5) * 0.1
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    noise, strength, bias = rnd(B, 1, Ho, Wo, seed=6), torch.tensor(0.3, dtype=torch.float64), rnd(O, seed=7) * 0.2
+    leaves = [t.requires_grad_(True) for t in (x, w, mw, mb, strength, bias)]
+    y = R.t_modulated_conv2d(x, style, w, mw, mb, up=up, demodulate=True, fused=False)
+    out = R.t_bias_act(R.t_noise(y, noise, strength), bias, "lrelu")
+    dout = rnd(*out.shape, seed=8)
+    s_ref = R.t_bias_act(R.t_dense(style, mw), mb, "linear") + 1.0
+    grads = torch.autograd.grad(out, leaves, dout, retain_graph=True)
+    (gs_total,) = torch.autograd.grad(out, s_ref, dout, allow_unused=True) if False else (None,)
+
+    f = lambda t: t.detach().float().to(dev).contiguous()
+    xd, wd, nd, std, bd = f(x).requires_grad_(True), f(w).requires_grad_(True), f(noise), f(strength).requires_grad_(True), f(bias).requires_grad_(True)
+    mwd, mbd = f(mw).requires_grad_(True), f(mb).requires_grad_(True)
+    s = torch.addmm(mbd + 1.0, f(style), mwd / math.sqrt(sd))
+    d = ops.demod_coefs(s, wd)
+    fn = ops.modconv_up_fused if up else ops.modconv_fused
+    outd = fn(xd, wd, s, d, nd, std, bd)
+    assert rel_err(outd, out) < 3e-5
+    gd = torch.autograd.grad(outd, (xd, wd, mwd, mbd, std, bd), f(dout))
+    for name, a, b in zip(("dx", "dw", "dmod_w", "dmod_b", "dstrength", "dbias"), gd, grads):
+        assert rel_err(a, b) < 2e-4, name
+
+
+def test_torgb_fused(dev):
+    from textboxgan_amd import ops
+    B, I, H, W, sd = 3, 24, 8, 32, 16
+    x, style, skip = rnd(B, I, H, W, seed=11), rnd(B, sd, seed=12), rnd(B, 3, H, W, seed=13)
+    w, mw, mb, b = rnd(1, 1, I, 3, seed=14), rnd(sd, I, seed=15), rnd(I, seed=16) * 0.1, rnd(3, seed=17)
+    leaves = [t.requires_grad_(True) for t in (x, w, mw, mb, b, skip)]
+    y = R.t_modulated_conv2d(x, style, w, mw, mb, up=False, demodulate=False, fused=False)
+    out = R.t_bias_act(y, b, "linear") + skip
+    dout = rnd(*out.shape, seed=18)
+    grads = torch.autograd.grad(out, leaves, dout)
+    f = lambda t: t.detach().float().to(dev).contiguous().requires_grad_(True)
+    xd, wd, mwd, mbd, bd, skd = [f(t) for t in (x, w, mw, mb, b, skip)]
+    s = torch.addmm(mbd + 1.0, style.float().to(dev), mwd / math.sqrt(sd))
+    outd = ops.torgb_fused(xd, wd, s, bd, skd)
+    assert rel_err(outd, out) < 3e-5
+    gd = torch.autograd.grad(outd, (xd, wd, mwd, mbd, bd, skd), dout.float().to(dev))
+    for name, a, b_ in zip(("dx", "dw", "dmod_w", "dmod_b", "db", "dskip"), gd, grads):
+        assert rel_err(a, b_) < 2e-4, name
+
+
+def _load(module, P, dev):
+    sd = {k: v.detach().float() for k, v in P.items()}
+    missing = module.load_state_dict(sd, strict=True)
+    return module.to(dev)
+
+
+@pytest.mark.parametrize("mode", ["fused", "composable"])
+def test_discriminator_matches_oracle(dev, mode):
+    from textboxgan_amd.models import Discriminator
+    cfg = small_config(4)
+    P = to64(M.init_discriminator(cfg, seed=3, bench_init=True))
+    for v in P.values():
+        v.requires_grad_(True)
+    img = rnd(4, 3, 64, 256, seed=21).requires_grad_(True)
+    scores = M.discriminator(P, cfg, img)
+    gs = rnd(4, 1, seed=22)
+    names = list(P.keys())
+    grads = torch.autograd.grad(scores, [img] + [P[n] for n in names], gs)
+    D = _load(Discriminator(cfg), P, dev)
+    imgd = img.detach().float().to(dev).requires_grad_(True)
+    sc = D(imgd, mode=mode)
+    assert rel_err(sc, scores) < 1e-4
+    pd = dict(D.named_parameters())
+    gd = torch.autograd.grad(sc, [imgd] + [pd[n] for n in names], gs.float().to(dev))
+    assert rel_err(gd[0], grads[0]) < 5e-4, "d/dimage"
+    for n, a, b in zip(names, gd[1:], grads[1:]):
+        assert rel_err(a, b) < 5e-4, n
+
+
+@pytest.mark.parametrize("mode", ["fused", "composable"])
+@pytest.mark.parametrize("training", [True, False])
+def test_generator_matches_oracle(dev, mode, training):
+    from textboxgan_amd.models import Generator
+    cfg = small_config(4)
+    P = to64(M.init_generator(cfg, seed=5, bench_init=True))
+    names = [k for k in P if k not in M.NON_TRAINABLE]
+    for n in names:
+        P[n].requires_grad_(True)
+    batch = M.make_batch(cfg)
+    rand = M.make_rand(cfg, seed=7)
+    rand64 = {k: ([t.double() for t in v] if isinstance(v, list) else (v.double() if torch.is_tensor(v) else v))
+              for k, v in rand.items()}
+    G = _load(Generator(cfg), P, dev)  # before the oracle call: training=True updates w_avg in place
+    img = M.generator(P, cfg, batch["input_words"], rand64["z"], rand64, training=training)
+    gi = rnd(*img.shape, seed=23)
+    grads = torch.autograd.grad(img, [P[n] for n in names], gi, allow_unused=True)
+    randd = {k: ([t.to(dev) for t in v] if isinstance(v, list) else (v.to(dev) if torch.is_tensor(v) else v))
+             for k, v in rand.items()}
+    imgd = G((batch["input_words"].to(dev), randd["z"]), training=training, rand=randd, mode=mode)
+    assert rel_err(imgd, img) < 1e-4
+    pd = dict(G.named_parameters())
+    gd = torch.autograd.grad(imgd, [pd[n] for n in names], gi.float().to(dev), allow_unused=True)
+    for n, a, b in zip(names, gd, grads):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0, n
+            continue
+        assert rel_err(a, b) < 1e-2, n  # fp32 through ~30 layers (cancelling sums) vs the float64 oracle
+    if training:
+        assert rel_err(G.latent_encoder.w_avg, P["latent_encoder.w_avg"]) < 1e-5
+
+
+def test_generator_hello_known_answer_geometry(dev):
+    """config 1 of BASELINE.json (plumbing): 'Hello' -> [1,3,64,256] -> uint8 crop [64,160,3]."""
+    from textboxgan_amd.models import Generator, generator_output_to_uint8, mask_text_box
+    from textboxgan_amd.char_tokens import string_to_main_int_sequence
+    from textboxgan_amd.config import cfg
+    words = torch.from_numpy(string_to_main_int_sequence(["Hello"])).to(dev)
+    torch.manual_seed(0)
+    G = Generator(cfg).to(dev)
+    z = torch.randn(1, cfg.z_dim, device=dev)
+    with torch.no_grad():
+        img = G((words, z), training=False, truncation_psi=1.0)
+    assert img.shape == (1, 3, 64, 256) and torch.isfinite(img).all()
+    u8 = generator_output_to_uint8(mask_text_box(img, words, cfg.char_width))[0, :, : 32 * 5]
+    assert u8.shape == (64, 160, 3) and u8.dtype == torch.uint8

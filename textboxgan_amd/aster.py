@@ -62,7 +62,7 @@ class AsterInferer(nn.Module):
         self.model = model if model is not None else AsterLikeOCR(max_steps=max_char_number)
         for p in self.model.parameters():
             p.requires_grad_(False)
-        self.model.eval()
+        self.model.train(False)
         self.char_width = char_width
         self.max_char_number = max_char_number
         self.image_dims = tuple(image_dims)
@@ -73,8 +73,10 @@ class AsterInferer(nn.Module):
         mats[0] = mats[max_char_number]  # L=0 never happens for real words; keep it finite
         self.register_buffer("resize_mats", torch.from_numpy(mats), persistent=False)
 
-    def train(self, mode: bool = True):  # frozen: always eval
-        return super().train(False)
+    def train(self, mode: bool = True):  # frozen: always inference behaviour
+        super().train(False)
+        self.model.train(False)
+        return self
 
     def convert_inputs(self, fake_images: torch.Tensor, labels: torch.Tensor, blank_label: int = 1) -> torch.Tensor:
         """[B,3,64,256] NCHW, labels [B,8] -> NHWC [B,64,256,3] resized crop."""
@@ -133,7 +135,10 @@ def _tps_constants(num_ctrl: int, out_h: int, out_w: int, margin: float = 0.05):
     pts = np.stack([gx.ravel(), gy.ravel()], 1)
     d2g = ((pts[:, None, :] - ctrl[None, :, :]) ** 2).sum(-1)
     lifted = np.concatenate([phi(d2g), np.ones((pts.shape[0], 1)), pts], 1)  # [HW, K+3]
-    return ctrl.astype(np.float32), inv.astype(np.float32), lifted.astype(np.float32)
+    # source = lifted @ inv @ [ctrl_src; 0]: fold the two constant factors in float64 -- the TPS system
+    # matrix is ill conditioned and its fp32 inverse alone costs 1e-3 of accuracy on the sampling grid
+    interp = (lifted @ inv)[:, :K]  # [HW, K] interpolation weights of the K source control points
+    return ctrl.astype(np.float32), interp.astype(np.float32)
 
 
 class _ResUnit(nn.Module):
@@ -169,9 +174,8 @@ class AsterLikeOCR(nn.Module):
         self.loc_cnn = nn.Sequential(*loc)
         self.loc_fc1 = nn.Linear(256 * 1 * 2, 512)
         self.loc_fc2 = nn.Linear(512, 2 * num_ctrl)
-        ctrl, inv, lifted = _tps_constants(num_ctrl, rect_hw[0], rect_hw[1])
-        self.register_buffer("tps_inv", torch.from_numpy(inv), persistent=False)
-        self.register_buffer("tps_lifted", torch.from_numpy(lifted), persistent=False)
+        ctrl, interp = _tps_constants(num_ctrl, rect_hw[0], rect_hw[1])
+        self.register_buffer("tps_interp", torch.from_numpy(interp), persistent=False)
         self.register_buffer("ctrl_init", torch.from_numpy(ctrl.reshape(-1)), persistent=False)
         # --- encoder: ResNet (ASTER table 1) + 2 BiLSTM
         self.stem = nn.Sequential(nn.Conv2d(3, 32, 3, 1, 1, bias=False), nn.BatchNorm2d(32), nn.ReLU(inplace=True))
@@ -191,15 +195,17 @@ class AsterLikeOCR(nn.Module):
         self.cell = nn.LSTMCell(2 * hidden + hidden, hidden)
         self.out = nn.Linear(hidden, num_classes)
         self._synthetic_init(seed)
-        self.eval()
+        self.train(False)
 
     @torch.no_grad()
     def _synthetic_init(self, seed):
         g = torch.Generator().manual_seed(seed)
         for name, p in self.named_parameters():
-            if p.dim() >= 2:
-                fan_in = p[0].numel()
-                p.copy_(torch.randn(p.shape, generator=g) * math.sqrt(2.0 / fan_in))
+            if p.dim() == 4:  # convolutions: He normal
+                p.copy_(torch.randn(p.shape, generator=g) * math.sqrt(2.0 / p[0].numel()))
+            elif p.dim() >= 2:  # dense / recurrent: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) keeps the gates unsaturated
+                lim = 1.0 / math.sqrt(p.shape[1])
+                p.copy_((torch.rand(p.shape, generator=g) * 2.0 - 1.0) * lim)
             else:
                 p.zero_()
         for m in self.modules():
@@ -211,6 +217,14 @@ class AsterLikeOCR(nn.Module):
         for n, p in self.rnn.named_parameters():  # unit forget-gate bias
             if "bias_ih" in n:
                 p[self.hidden: 2 * self.hidden].fill_(1.0)
+
+    def train(self, mode: bool = True):
+        """Frozen network: BatchNorm always uses its running statistics.  The (dropout-free) LSTM
+        is kept in 'training' mode because MIOpen only provides the RNN data gradient there --
+        numerically identical, and the OCR loss must back-propagate into the generator."""
+        super().train(False)
+        self.rnn.train(True)
+        return self
 
     def load_weights_npz(self, path: str, name_map: Optional[dict] = None):
         """Import hook: ``.npz`` of arrays keyed by this module's state_dict names (or mapped
@@ -230,9 +244,7 @@ class AsterLikeOCR(nn.Module):
         thumb = F.interpolate(img, size=(32, 64), mode="bilinear", align_corners=False)
         f = self.loc_cnn(thumb).reshape(B, -1)
         ctrl = self.loc_fc2(F.relu(self.loc_fc1(f))).reshape(B, -1, 2)  # source control points in [0,1]^2
-        rhs = torch.cat([ctrl, ctrl.new_zeros(B, 3, 2)], dim=1)  # [B, K+3, 2]
-        T = torch.matmul(self.tps_inv, rhs)
-        src = torch.matmul(self.tps_lifted, T)  # [B, HW, 2] in [0,1]
+        src = torch.matmul(self.tps_interp, ctrl)  # [B, HW, 2] in [0,1]
         grid = (src * 2.0 - 1.0).reshape(B, self.rect_hw[0], self.rect_hw[1], 2)
         return F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=False)
 

@@ -1,0 +1,579 @@
+// fp32 implicit-GEMM convolutions on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact
+// f32, 64 cycles / instruction / SIMD, 157 TFLOP/s chip peak).
+//
+// Design (MI355X-first, not a port of cuDNN calls):
+//   * GEMM view  M = output channels, N = output pixels (batch folded in), K = taps x channels.
+//   * One 256-thread block (4 wave64) owns a BM x BN tile; every wave owns WTM x WTN MFMA tiles
+//     of 32x32 whose accumulators stay in registers for the whole K loop.
+//   * K is walked in chunks of CK input channels.  Per chunk the block stages into LDS
+//       As[tap][c][BM]  the filter slice (16-byte loads; the HWIO parameter layout is already
+//                       "output channel contiguous", i.e. the MFMA A-operand order) and
+//       Xs[c][halo tile] ONE halo tile of the input -- the 9 taps re-read it at shifted LDS
+//                       offsets (implicit im2col, no 9x expansion); the style modulation
+//                       s[b,c] is multiplied in while staging.
+//     MFMA operands are single ds_read_b32 per lane: A lanes walk 32 consecutive channels,
+//     B lanes walk 32 consecutive pixels -> bank-conflict free; the two half-waves read the
+//     two k-slices.  Stride-2 inputs are de-interleaved (even | odd columns) on the way in so
+//     the strided taps stay unit-stride in LDS.
+//   * Stride-2 TRANSPOSED convolution is decomposed into its sy*sx output-parity classes; each
+//     class is a dense small-tap correlation on the class grid, so the same kernel runs it with
+//     a per-class tap table and a strided output mapping (no zero-insertion, no atomics).
+//   * Epilogue fused: runtime coef, demodulation d[b,m], noise, bias, LeakyReLU*sqrt2, residual.
+//   * Small-spatial / wide-channel layers get split-K over channel chunks (atomic add).
+// Weight gradient: M = 32 S-channels, N = 32 L-channels per wave, 9 taps = 9 accumulators that
+// share ONE staged halo tile of L; K = pixels; blocks split K and atomically add.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MAXCLS 4
+#define MAXTAPS 9
+#define MAXNJ 6
+
+struct ClassInfo {
+  int ntaps, KWc;
+  int py, px;
+  int ooy, oox;
+  int Ug, Vg;
+  int tilesU, tilesV;
+  int wtap[MAXTAPS];
+};
+
+struct ConvP {
+  const float *x, *w, *in_scale;
+  float *y;
+  int B, C, M, Hin, Win, Hout, Wout;
+  int sy, sx, osy, osx;
+  int ldw;
+  int logTW, logTHs, NSEG, IHs, IWs, IWp, HALFW, planeStride, ppc, NJ, nBG;
+  int nclass, ksplit, nchunks, cps;
+  int a_floats;
+  ClassInfo cls[MAXCLS];
+  EpiK e;
+};
+
+template <int WGM, int WGN, int WTM, int WTN, int CK>
+__global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
+  constexpr int BM = WGM * WTM * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *As = smem;
+  float *Xs = smem + p.a_floats;
+  int *tabs = reinterpret_cast<int *>(Xs + CK * p.planeStride);  // [0..8] weight tap, [9..17] LDS tap offset
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const int cls = blockIdx.z / p.ksplit;
+  const int ks = blockIdx.z - cls * p.ksplit;
+  const ClassInfo &ci = p.cls[cls];
+
+  const int tn = blockIdx.x;
+  const int tv = tn % ci.tilesV;
+  const int t2 = tn / ci.tilesV;
+  const int tu = t2 % ci.tilesU;
+  const int bg = t2 / ci.tilesU;
+  if (bg >= p.nBG) return;
+  const int m0 = blockIdx.y * BM;
+  const int u0 = tu << p.logTHs, v0 = tv << p.logTW;
+  const int ntaps = ci.ntaps;
+  const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTHs) - 1;
+
+  if (tid == 0) {
+    for (int t = 0; t < ntaps; ++t) {
+      const int khp = t / ci.KWc, kwp = t - khp * ci.KWc;
+      tabs[t] = ci.wtap[t];
+      tabs[MAXTAPS + t] = khp * p.IWp + (p.sx == 2 ? (kwp & 1) * p.HALFW + (kwp >> 1) : kwp);
+    }
+  }
+
+  // ---- per-thread staging descriptors for the input halo tile (same for every chunk)
+  int goff[MAXNJ], loff[MAXNJ], sbc[MAXNJ];
+#pragma unroll
+  for (int j = 0; j < MAXNJ; ++j) {
+    goff[j] = -1; loff[j] = -1; sbc[j] = 0;
+    const int e = tid + 256 * j;
+    if (j < p.NJ && e < p.ppc) {
+      const int per = p.IHs * p.IWs;
+      const int seg = e / per;
+      const int rem = e - seg * per;
+      const int iyl = rem / p.IWs;
+      const int ixl = rem - iyl * p.IWs;
+      const int b = bg * p.NSEG + seg;
+      const int iy = u0 * p.sy - ci.py + iyl;
+      const int ix = v0 * p.sx - ci.px + ixl;
+      const bool ok = b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+      goff[j] = ok ? ((b * p.C) * p.Hin + iy) * p.Win + ix : -1;
+      sbc[j] = b * p.C;
+      const int col = (p.sx == 2) ? (ixl & 1) * p.HALFW + (ixl >> 1) : ixl;
+      loff[j] = (seg * p.IHs + iyl) * p.IWp + col;
+    }
+  }
+
+  // ---- per-lane pixel decode for the B operand / epilogue
+  int bofs[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    const int n = (wn * WTN + j) * 32 + (lane & 31);
+    const int q = n & TWm, rr = n >> p.logTW;
+    const int seg = rr >> p.logTHs, r = rr & THm;
+    bofs[j] = (seg * p.IHs + r * p.sy) * p.IWp + q;
+  }
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int HWin = p.Hin * p.Win;
+  const int kbeg = ks * p.cps;
+  const int kend = min(kbeg + p.cps, p.nchunks);
+
+  for (int kc = kbeg; kc < kend; ++kc) {
+    const int c0 = kc * CK;
+    __syncthreads();
+    // stage the filter slice: rows (tap, c) of BM floats, 16 B per lane
+    for (int idx = tid; idx < ntaps * CK * (BM / 4); idx += 256) {
+      const int row = idx / (BM / 4);
+      const int m4 = idx - row * (BM / 4);
+      const int t = row / CK, c = row - t * CK;
+      const int cc = min(c0 + c, p.C - 1);
+      const int mm = min(m0 + 4 * m4, p.ldw - 4);
+      const float4 v = *reinterpret_cast<const float4 *>(p.w + ((size_t)tabs[t] * p.C + cc) * p.ldw + mm);
+      *reinterpret_cast<float4 *>(As + row * BM + 4 * m4) = v;
+    }
+    // stage the input halo tile (zero fill, style modulation folded in)
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const bool cok = (c0 + c) < p.C;
+#pragma unroll
+      for (int j = 0; j < MAXNJ; ++j) {
+        if (j < p.NJ && loff[j] >= 0) {
+          float v = 0.f;
+          if (cok && goff[j] >= 0) {
+            v = p.x[goff[j] + (c0 + c) * HWin];
+            if (p.in_scale) v *= p.in_scale[sbc[j] + c0 + c];
+          }
+          Xs[c * p.planeStride + loff[j]] = v;
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = 0; t < ntaps; ++t) {
+      const float *Ap = As + t * CK * BM + wm * (WTM * 32) + (lane & 31) + (lane >> 5) * BM;
+      const float *Bp = Xs + (lane >> 5) * p.planeStride + tabs[MAXTAPS + t];
+#pragma unroll
+      for (int cp = 0; cp < CK / 2; ++cp) {
+        float a[WTM], b[WTN];
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) a[i] = Ap[cp * 2 * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) b[j] = Bp[cp * 2 * p.planeStride + bofs[j]];
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue
+  const int HWout = p.Hout * p.Wout;
+  const float str = p.e.noise ? p.e.strength[0] : 0.f;
+  const bool do_dot = p.e.dot_aux != nullptr && p.ksplit == 1;
+  float dsum[WTM][16];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dsum[i][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    const int n = (wn * WTN + j) * 32 + (lane & 31);
+    const int q = n & TWm, rr = n >> p.logTW;
+    const int seg = rr >> p.logTHs, r = rr & THm;
+    const int b = bg * p.NSEG + seg, u = u0 + r, v = v0 + q;
+    const bool okpix = b < p.B && u < ci.Ug && v < ci.Vg;
+    const int Y = u * p.osy + ci.ooy, X = v * p.osx + ci.oox;
+    const int pix = Y * p.Wout + X;
+    const float nz = (okpix && p.e.noise) ? p.e.noise[(size_t)b * HWout + pix] * str : 0.f;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+        if (okpix && m < p.M) {
+          const size_t idx = ((size_t)b * p.M + m) * HWout + pix;
+          float val = acc[i][j][r16] * p.e.alpha;
+          if (p.ksplit > 1) {
+            atomicAdd(p.y + idx, val);
+          } else {
+            if (do_dot) {
+              const float pv = val * p.e.dot_aux[idx];
+              if (p.NSEG == 1) dsum[i][r16] += pv;
+              else atomicAdd(p.e.dot_out + b * p.M + m, pv);
+            }
+            if (p.e.out_scale) val *= p.e.out_scale[b * p.M + m];
+            val += nz;
+            if (p.e.bias) val += p.e.bias[m] * p.e.bias_mul;
+            val = epi_act(p.e, val);
+            if (p.e.residual) val = (val + p.e.residual[idx]) * p.e.res_scale;
+            p.y[idx] = val;
+          }
+        }
+      }
+    }
+  }
+  if (do_dot && p.NSEG == 1) {  // one image per tile: reduce the 32 pixel lanes of each half-wave
+    const int b = bg;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        float s = dsum[i][r16];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+        if ((lane & 31) == 0 && m < p.M && b < p.B) atomicAdd(p.e.dot_out + b * p.M + m, s);
+      }
+  }
+}
+
+static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+template <int WGM, int WGN, int WTM, int WTN, int CK>
+static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
+  constexpr int BM = WGM * WTM * 32;
+  p.a_floats = maxtaps * CK * BM;
+  const size_t lds = ((size_t)p.a_floats + (size_t)CK * p.planeStride + 2 * MAXTAPS + 2) * sizeof(float);
+  if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
+  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return TBG_EHIP;
+  }
+  dim3 grid(maxTilesN, ceil_div(p.M, BM), p.nclass * p.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float *y,
+                              const float *in_scale, const tbg_epilogue *epi, void *stream) {
+  if (!d || !x || !w || !y || !epi_valid(epi)) return TBG_EINVAL;
+  if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1 || d->Hout < 1 || d->Wout < 1) return TBG_EINVAL;
+  if (d->KH < 1 || d->KW < 1 || d->KH * d->KW > MAXTAPS) return TBG_EUNSUPPORTED;
+  if (d->sy < 1 || d->sy > 2 || d->sx < 1 || d->sx > 2) return TBG_EUNSUPPORTED;
+  if (d->ldw < d->M || (d->ldw & 3) != 0) return TBG_EINVAL;
+  if ((((uintptr_t)w) & 15) != 0) return TBG_EINVAL;
+  if (d->ksplit < 1) return TBG_EINVAL;
+  if (d->ksplit > 1 && epi && (epi->out_scale || epi->bias || epi->noise || epi->residual || epi->dot_aux || epi->act != TBG_ACT_LINEAR))
+    return TBG_EINVAL;
+  if ((double)d->B * d->C * d->Hin * d->Win > 2147483647.0 || (double)d->B * d->M * d->Hout * d->Wout > 2147483647.0)
+    return TBG_ERANGE;
+  if (d->transposed) {
+    if (d->py != 0 || d->px != 0) return TBG_EINVAL;
+    if (d->Hout < (d->Hin - 1) * d->sy + d->KH || d->Wout < (d->Win - 1) * d->sx + d->KW) return TBG_EINVAL;
+  } else {
+    // every output pixel must exist: (Hout-1)*sy - py + KH-1 may run past Hin (zero fill) -- allowed
+    if (d->py < 0 || d->px < 0) return TBG_EINVAL;
+  }
+
+  ConvP p;
+  p.x = x; p.w = w; p.in_scale = in_scale; p.y = y;
+  p.B = d->B; p.C = d->C; p.M = d->M; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
+  p.ldw = d->ldw;
+  p.e = make_epi(epi);
+  const int T = d->KH * d->KW;
+  int maxUg = 0, maxVg = 0, maxKH = 0, maxKW = 0, maxtaps = 0;
+  if (!d->transposed) {
+    p.sy = d->sy; p.sx = d->sx; p.osy = 1; p.osx = 1; p.nclass = 1;
+    ClassInfo &c = p.cls[0];
+    c.ntaps = T; c.KWc = d->KW; c.py = d->py; c.px = d->px; c.ooy = 0; c.oox = 0; c.Ug = d->Hout; c.Vg = d->Wout;
+    for (int t = 0; t < T; ++t) c.wtap[t] = d->flip ? T - 1 - t : t;
+    maxUg = c.Ug; maxVg = c.Vg; maxKH = d->KH; maxKW = d->KW; maxtaps = T;
+  } else {
+    p.sy = 1; p.sx = 1; p.osy = d->sy; p.osx = d->sx; p.nclass = d->sy * d->sx;
+    int k = 0;
+    for (int cy = 0; cy < d->sy; ++cy)
+      for (int cx = 0; cx < d->sx; ++cx, ++k) {
+        ClassInfo &c = p.cls[k];
+        const int KHc = cy < d->KH ? ceil_div(d->KH - cy, d->sy) : 0;
+        const int KWc = cx < d->KW ? ceil_div(d->KW - cx, d->sx) : 0;
+        c.ntaps = KHc * KWc; c.KWc = KWc > 0 ? KWc : 1;
+        c.py = KHc > 0 ? KHc - 1 : 0; c.px = KWc > 0 ? KWc - 1 : 0;
+        c.ooy = cy; c.oox = cx;
+        c.Ug = d->Hout > cy ? ceil_div(d->Hout - cy, d->sy) : 0;
+        c.Vg = d->Wout > cx ? ceil_div(d->Wout - cx, d->sx) : 0;
+        for (int khp = 0; khp < KHc; ++khp)
+          for (int kwp = 0; kwp < KWc; ++kwp) {
+            const int kh = cy + d->sy * (KHc - 1 - khp), kw = cx + d->sx * (KWc - 1 - kwp);
+            const int t = kh * d->KW + kw;
+            c.wtap[khp * KWc + kwp] = d->flip ? T - 1 - t : t;
+          }
+        if (c.Ug > maxUg) maxUg = c.Ug;
+        if (c.Vg > maxVg) maxVg = c.Vg;
+        if (KHc > maxKH) maxKH = KHc;
+        if (KWc > maxKW) maxKW = KWc;
+        if (c.ntaps > maxtaps) maxtaps = c.ntaps;
+      }
+  }
+  if (maxtaps < 1) maxtaps = 1;
+  if (maxKH < 1) maxKH = 1;
+  if (maxKW < 1) maxKW = 1;
+
+  // tile configuration
+  int BM, BN;
+  if (d->M <= 32) { BM = 32; BN = 256; }
+  else if (d->M <= 64) { BM = 64; BN = 256; }
+  else { BM = 128; BN = 128; }
+  const int CK = 8;
+  const int TW = pow2ceil(maxVg) < 32 ? pow2ceil(maxVg) : 32;
+  const int TR = BN / TW;
+  const int THs = pow2ceil(maxUg) < TR ? pow2ceil(maxUg) : TR;
+  p.logTW = ilog2(TW); p.logTHs = ilog2(THs); p.NSEG = TR / THs;
+  p.IHs = (THs - 1) * p.sy + maxKH;
+  p.IWs = (TW - 1) * p.sx + maxKW;
+  p.HALFW = (p.IWs + 1) / 2;
+  int iwp = (p.sx == 2) ? 2 * p.HALFW : p.IWs;
+  if (TW < 32 && TW >= 2) {
+    for (int it = 0; it < 64 && ((p.sy * iwp) & 31) != (TW & 31); ++it) ++iwp;
+  }
+  p.IWp = iwp;
+  p.planeStride = p.NSEG * p.IHs * p.IWp;
+  p.ppc = p.NSEG * p.IHs * p.IWs;
+  p.NJ = ceil_div(p.ppc, 256);
+  if (p.NJ > MAXNJ) return TBG_EUNSUPPORTED;
+  p.nBG = ceil_div(p.B, p.NSEG);
+  int maxTilesN = 0;
+  for (int k = 0; k < p.nclass; ++k) {
+    ClassInfo &c = p.cls[k];
+    c.tilesU = c.Ug > 0 ? ceil_div(c.Ug, THs) : 1;
+    c.tilesV = c.Vg > 0 ? ceil_div(c.Vg, TW) : 1;
+    const int tiles = c.tilesU * c.tilesV * p.nBG;
+    if (tiles > maxTilesN) maxTilesN = tiles;
+  }
+  p.nchunks = ceil_div(p.C, CK);
+  p.ksplit = d->ksplit < p.nchunks ? d->ksplit : p.nchunks;
+  if (d->ksplit > 1 && p.ksplit < 1) p.ksplit = 1;
+  p.cps = ceil_div(p.nchunks, p.ksplit);
+  if (d->ksplit > 1 && p.ksplit == 1) {
+    // caller promised a zeroed buffer + alpha-only epilogue; plain stores give the same result
+  }
+  hipStream_t st = tbg_stream(stream);
+  if (BM == 32) return launch_fprop<1, 4, 1, 2, 8>(p, st, maxtaps, maxTilesN);
+  if (BM == 64) return launch_fprop<1, 4, 2, 2, 8>(p, st, maxtaps, maxTilesN);
+  return launch_fprop<2, 2, 2, 2, 8>(p, st, maxtaps, maxTilesN);
+}
+
+// ============================================================================================
+// weight gradient
+// ============================================================================================
+#define WG_MAXNJ 6
+
+struct WgradP {
+  const float *S, *L, *s_scale, *l_scale;
+  float *dW;
+  int B, CS, CL, Hs, Ws, Hl, Wl, KW, sy, sx, py, px;
+  int st_t, st_l, st_s;
+  float alpha;
+  int logTW, logTHs, NSEG, IHs, IWs, IWp, HALFW, lplane, ppc, NJ, nBG, tilesU, tilesV, nchunks, ksplit;
+};
+
+template <int WGS, int WGL, int NT, int PIX>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
+  constexpr int BS = WGS * 32, BL = WGL * 32, SP = PIX + 1;
+  constexpr int KWt = (NT == 9) ? 3 : 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Ss = smem;            // [BS][SP]
+  float *Ls = smem + BS * SP;  // [BL][lplane]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ws = wave / WGL, wl = wave - ws * WGL;
+  const int cs0 = blockIdx.x * BS, cl0 = blockIdx.y * BL;
+  const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTHs) - 1;
+
+  // position descriptors inside one L channel plane: a wave stages one channel at a time
+  int d_seg[WG_MAXNJ], d_iyl[WG_MAXNJ], d_ixl[WG_MAXNJ], d_loff[WG_MAXNJ];
+#pragma unroll
+  for (int j = 0; j < WG_MAXNJ; ++j) {
+    d_seg[j] = -1; d_iyl[j] = 0; d_ixl[j] = 0; d_loff[j] = 0;
+    const int e = lane + 64 * j;
+    if (j < p.NJ && e < p.ppc) {
+      const int per = p.IHs * p.IWs;
+      const int seg = e / per;
+      const int rem = e - seg * per;
+      const int iyl = rem / p.IWs;
+      const int ixl = rem - iyl * p.IWs;
+      d_seg[j] = seg; d_iyl[j] = iyl; d_ixl[j] = ixl;
+      const int col = (p.sx == 2) ? (ixl & 1) * p.HALFW + (ixl >> 1) : ixl;
+      d_loff[j] = (seg * p.IHs + iyl) * p.IWp + col;
+    }
+  }
+  // S staging: pixel fixed per thread (256 % PIX == 0)
+  const int spix = tid & (PIX - 1);
+  const int sch0 = tid / PIX;
+  const int sq = spix & TWm, srr = spix >> p.logTW;
+  const int sseg = srr >> p.logTHs, sr = srr & THm;
+
+  int toff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int kh = t / KWt, kw = t - kh * KWt;
+    toff[t] = kh * p.IWp + (p.sx == 2 ? (kw & 1) * p.HALFW + (kw >> 1) : kw);
+  }
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int HWs = p.Hs * p.Ws, HWl = p.Hl * p.Wl;
+
+  for (int chunk = blockIdx.z; chunk < p.nchunks; chunk += p.ksplit) {
+    const int tv = chunk % p.tilesV;
+    const int t2 = chunk / p.tilesV;
+    const int tu = t2 % p.tilesU;
+    const int bg = t2 / p.tilesU;
+    const int u0 = tu << p.logTHs, v0 = tv << p.logTW;
+    __syncthreads();
+    {  // S tile
+      const int b = bg * p.NSEG + sseg, u = u0 + sr, v = v0 + sq;
+      const bool ok = b < p.B && u < p.Hs && v < p.Ws;
+      const int base = ok ? (b * p.CS) * HWs + u * p.Ws + v : -1;
+#pragma unroll 4
+      for (int ch = sch0; ch < BS; ch += 256 / PIX) {
+        float val = 0.f;
+        if (ok && cs0 + ch < p.CS) {
+          val = p.S[base + (cs0 + ch) * HWs];
+          if (p.s_scale) val *= p.s_scale[b * p.CS + cs0 + ch];
+        }
+        Ss[ch * SP + spix] = val;
+      }
+    }
+    {  // L halo tile: wave w stages channels w, w+4, ...
+      int g[WG_MAXNJ], bb[WG_MAXNJ];
+#pragma unroll
+      for (int j = 0; j < WG_MAXNJ; ++j) {
+        g[j] = -1; bb[j] = 0;
+        if (j < p.NJ && d_seg[j] >= 0) {
+          const int b = bg * p.NSEG + d_seg[j];
+          const int iy = u0 * p.sy - p.py + d_iyl[j];
+          const int ix = v0 * p.sx - p.px + d_ixl[j];
+          const bool ok = b < p.B && iy >= 0 && iy < p.Hl && ix >= 0 && ix < p.Wl;
+          g[j] = ok ? (b * p.CL) * HWl + iy * p.Wl + ix : -1;
+          bb[j] = b * p.CL;
+        }
+      }
+      for (int ch = wave; ch < BL; ch += 4) {
+        const bool cok = cl0 + ch < p.CL;
+#pragma unroll
+        for (int j = 0; j < WG_MAXNJ; ++j) {
+          if (j < p.NJ && d_seg[j] >= 0) {
+            float val = 0.f;
+            if (cok && g[j] >= 0) {
+              val = p.L[g[j] + (cl0 + ch) * HWl];
+              if (p.l_scale) val *= p.l_scale[bb[j] + cl0 + ch];
+            }
+            Ls[ch * p.lplane + d_loff[j]] = val;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const float *Sp = Ss + (ws * 32 + (lane & 31)) * SP + (lane >> 5);
+    const float *Lp = Ls + (wl * 32 + (lane & 31)) * p.lplane;
+#pragma unroll 2
+    for (int kp = 0; kp < PIX / 2; ++kp) {
+      const int pp = 2 * kp + (lane >> 5);
+      const int q = pp & TWm, rr = pp >> p.logTW;
+      const int seg = rr >> p.logTHs, r = rr & THm;
+      const int poff = (seg * p.IHs + r * p.sy) * p.IWp + q;
+      const float a = Sp[2 * kp];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float bv = Lp[poff + toff[t]];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  const int cl = cl0 + wl * 32 + (lane & 31);
+  if (cl < p.CL) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int cs = cs0 + ws * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+        if (cs < p.CS) atomicAdd(p.dW + ((long long)t * p.st_t + (long long)cl * p.st_l + (long long)cs * p.st_s), acc[t][r16] * p.alpha);
+      }
+  }
+}
+
+template <int WGS, int WGL, int NT, int PIX>
+static int launch_wgrad(WgradP &p, hipStream_t st) {
+  constexpr int BS = WGS * 32, BL = WGL * 32;
+  const size_t lds = ((size_t)BS * (PIX + 1) + (size_t)BL * p.lplane) * sizeof(float);
+  if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
+  auto kern = conv_wgrad_kernel<WGS, WGL, NT, PIX>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return TBG_EHIP;
+  }
+  const int tiles = ceil_div(p.CS, BS) * ceil_div(p.CL, BL);
+  int ksplit = ceil_div(1024, tiles);
+  if (ksplit > p.nchunks) ksplit = p.nchunks;
+  if (ksplit < 1) ksplit = 1;
+  p.ksplit = ksplit;
+  dim3 grid(ceil_div(p.CS, BS), ceil_div(p.CL, BL), ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_conv2d_wgrad_f32(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
+                                    const float *s_scale, const float *l_scale, void *stream) {
+  if (!d || !S || !L || !dW) return TBG_EINVAL;
+  if (d->B < 1 || d->CS < 1 || d->CL < 1 || d->Hs < 1 || d->Ws < 1 || d->Hl < 1 || d->Wl < 1) return TBG_EINVAL;
+  const int NT = d->KH * d->KW;
+  if (!((d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 1))) return TBG_EUNSUPPORTED;
+  if (d->sy < 1 || d->sy > 2 || d->sx < 1 || d->sx > 2) return TBG_EUNSUPPORTED;
+  if ((double)d->B * d->CS * d->Hs * d->Ws > 2147483647.0 || (double)d->B * d->CL * d->Hl * d->Wl > 2147483647.0)
+    return TBG_ERANGE;
+  WgradP p;
+  p.S = S; p.L = L; p.s_scale = s_scale; p.l_scale = l_scale; p.dW = dW;
+  p.B = d->B; p.CS = d->CS; p.CL = d->CL; p.Hs = d->Hs; p.Ws = d->Ws; p.Hl = d->Hl; p.Wl = d->Wl;
+  p.KW = d->KW; p.sy = d->sy; p.sx = d->sx; p.py = d->py; p.px = d->px;
+  p.st_t = d->st_t; p.st_l = d->st_l; p.st_s = d->st_s; p.alpha = d->alpha;
+  const bool strided = d->sy == 2 || d->sx == 2;
+  const int PIX = strided ? 32 : 64;
+  const int TW = pow2ceil(d->Ws) < 32 ? pow2ceil(d->Ws) : 32;
+  const int TR = PIX / TW;
+  const int THs = pow2ceil(d->Hs) < TR ? pow2ceil(d->Hs) : TR;
+  p.logTW = ilog2(TW); p.logTHs = ilog2(THs); p.NSEG = TR / THs;
+  p.IHs = (THs - 1) * d->sy + d->KH;
+  p.IWs = (TW - 1) * d->sx + d->KW;
+  p.HALFW = (p.IWs + 1) / 2;
+  p.IWp = (d->sx == 2) ? 2 * p.HALFW : p.IWs;
+  p.lplane = (p.NSEG * p.IHs * p.IWp) | 1;  // odd plane pitch: lanes walk channels conflict-free
+  p.ppc = p.NSEG * p.IHs * p.IWs;
+  p.NJ = ceil_div(p.ppc, 64);
+  if (p.NJ > WG_MAXNJ) return TBG_EUNSUPPORTED;
+  p.nBG = ceil_div(d->B, p.NSEG);
+  p.tilesU = ceil_div(d->Hs, THs);
+  p.tilesV = ceil_div(d->Ws, TW);
+  p.nchunks = p.tilesU * p.tilesV * p.nBG;
+  hipStream_t st = tbg_stream(stream);
+  const bool wideS = d->CS >= 128 && d->CL <= 32;
+  (void)wideS;
+  if (NT == 9) {
+    if (strided) return launch_wgrad<2, 2, 9, 32>(p, st);
+    return launch_wgrad<2, 2, 9, 64>(p, st);
+  }
+  if (strided) return launch_wgrad<2, 2, 1, 32>(p, st);
+  return launch_wgrad<2, 2, 1, 64>(p, st);
+}

@@ -1,0 +1,499 @@
+// HBM-bound kernels of libtbg_hip.so (gfx950): upfirdn2d, bias_act fwd/bwd, weight transpose,
+// Keras-semantics Adam, EMA lerp, demodulation coefficients.
+//
+// upfirdn2d follows the MATHS of the reference op (upfirdn_2d.cu:64-207: pad -> zero-insert ->
+// FIR with flipped k -> decimate) but is laid out for CDNA4: 256-thread blocks = 4 wave64,
+// one LDS-staged input tile per block, 4 consecutive outputs per lane so the store is one
+// 16-byte global_store per lane (1 KiB per wave), taps held in registers for the up=1 forms.
+#include "common.h"
+
+// ============================================================================================
+// upfirdn2d
+// ============================================================================================
+struct UpfirdnP {
+  const float *x, *k, *in_scale;
+  float *y;
+  int major, inH, inW, minor, kH, kW;
+  int upx, upy, downx, downy, padx0, pady0;
+  int outH, outW;
+  int M, has_epi;
+  EpiK e;
+};
+
+__device__ __forceinline__ int floor_div(int a, int b) {
+  int c = a / b;
+  if (c * b > a) c--;
+  return c;
+}
+
+__device__ __forceinline__ float upfirdn_epilogue(const UpfirdnP &p, float v, int major, int oy, int ox) {
+  if (!p.has_epi) return v;
+  const int b = major / p.M, m = major - b * p.M;
+  float pre = v * p.e.alpha;
+  if (p.e.out_scale) pre *= p.e.out_scale[major];
+  if (p.e.noise) pre += p.e.noise[(size_t)b * p.outH * p.outW + (size_t)oy * p.outW + ox] * p.e.strength[0];
+  if (p.e.bias) pre += p.e.bias[m] * p.e.bias_mul;
+  return epi_act(p.e, pre);
+}
+
+template <int UPX, int UPY, int DNX, int DNY, int KW, int KH, int TOW, int TOH>
+__global__ __launch_bounds__(256) void upfirdn2d_small_kernel(const UpfirdnP p) {
+  constexpr int TIW = ((TOW - 1) * DNX + KW - 1) / UPX + 1;
+  constexpr int TIH = ((TOH - 1) * DNY + KH - 1) / UPY + 1;
+  constexpr int TIWP = TIW | 1;  // odd row pitch
+  static_assert(TOW % 4 == 0 && (TOW / 4) * TOH == 256, "one float4 of outputs per lane");
+  __shared__ float sk[KH][KW];
+  __shared__ float sx[TIH][TIWP];
+
+  const int tid = threadIdx.x;
+  const int tileOutX = blockIdx.x * TOW;
+  const int tileOutY = blockIdx.y * TOH;
+
+  for (int tap = tid; tap < KH * KW; tap += 256) {
+    const int ky = tap / KW, kx = tap - ky * KW;
+    float v = 0.f;
+    if (kx < p.kW && ky < p.kH) v = p.k[(p.kH - 1 - ky) * p.kW + (p.kW - 1 - kx)];  // flipped
+    sk[ky][kx] = v;
+  }
+
+  const int tileMidX = tileOutX * DNX + UPX - 1 - p.padx0;
+  const int tileMidY = tileOutY * DNY + UPY - 1 - p.pady0;
+  const int tileInX = floor_div(tileMidX, UPX);
+  const int tileInY = floor_div(tileMidY, UPY);
+  const int remX = tileMidX - tileInX * UPX;  // >= 0
+  const int remY = tileMidY - tileInY * UPY;
+
+  const int relOutY = tid / (TOW / 4);
+  const int relOutX0 = (tid - relOutY * (TOW / 4)) * 4;
+
+  for (int major = blockIdx.z; major < p.major; major += gridDim.z) {
+    const float isc = p.in_scale ? p.in_scale[major] : 1.f;
+    const float *xin = p.x + (size_t)major * p.inH * p.inW;
+    __syncthreads();
+    for (int idx = tid; idx < TIH * TIW; idx += 256) {
+      const int ry = idx / TIW, rx = idx - ry * TIW;
+      const int ix = rx + tileInX, iy = ry + tileInY;
+      float v = 0.f;
+      if (ix >= 0 && iy >= 0 && ix < p.inW && iy < p.inH) v = xin[(size_t)iy * p.inW + ix] * isc;
+      sx[ry][rx] = v;
+    }
+    __syncthreads();
+
+    const int outY = tileOutY + relOutY;
+    const int relY = remY + relOutY * DNY;
+    const int relInY = relY / UPY;
+    const int kernelY = (relInY + 1) * UPY - relY - 1;
+    float res[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int relX = remX + (relOutX0 + o) * DNX;
+      const int relInX = relX / UPX;
+      const int kernelX = (relInX + 1) * UPX - relX - 1;
+      float v = 0.f;
+#pragma unroll
+      for (int yy = 0; yy < KH / UPY; ++yy)
+#pragma unroll
+        for (int xx = 0; xx < KW / UPX; ++xx)
+          v += sx[relInY + yy][relInX + xx] * sk[kernelY + yy * UPY][kernelX + xx * UPX];
+      res[o] = v;
+    }
+    if (outY < p.outH) {
+      const int outX0 = tileOutX + relOutX0;
+      float *yo = p.y + ((size_t)major * p.outH + outY) * p.outW + outX0;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (outX0 + o < p.outW) res[o] = upfirdn_epilogue(p, res[o], major, outY, outX0 + o);
+      if ((p.outW & 3) == 0 && outX0 + 3 < p.outW) {
+        *reinterpret_cast<float4 *>(yo) = make_float4(res[0], res[1], res[2], res[3]);
+      } else {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+          if (outX0 + o < p.outW) yo[o] = res[o];
+      }
+    }
+  }
+}
+
+// Generic form (any filter size / factors / minor): one lane per output element, explicit
+// receptive-field clamp.  Same arithmetic as upfirdn_2d.cu:64-117.
+__global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const UpfirdnP p) {
+  const size_t total = (size_t)p.major * p.outH * p.outW * p.minor;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    size_t r = idx;
+    const int mi = (int)(r % p.minor); r /= p.minor;
+    const int ox = (int)(r % p.outW); r /= p.outW;
+    const int oy = (int)(r % p.outH);
+    const int major = (int)(r / p.outH);
+    const int midY = oy * p.downy + p.upy - 1 - p.pady0;
+    const int inY = min(max(floor_div(midY, p.upy), 0), p.inH);
+    const int h = min(max(floor_div(midY + p.kH, p.upy), 0), p.inH) - inY;
+    const int kernelY = midY + p.kH - (inY + 1) * p.upy;
+    const int midX = ox * p.downx + p.upx - 1 - p.padx0;
+    const int inX = min(max(floor_div(midX, p.upx), 0), p.inW);
+    const int w = min(max(floor_div(midX + p.kW, p.upx), 0), p.inW) - inX;
+    const int kernelX = midX + p.kW - (inX + 1) * p.upx;
+    float v = 0.f;
+    for (int yy = 0; yy < h; ++yy)
+      for (int xx = 0; xx < w; ++xx)
+        v += p.x[(((size_t)major * p.inH + inY + yy) * p.inW + inX + xx) * p.minor + mi] *
+             p.k[(kernelY - yy * p.upy) * p.kW + (kernelX - xx * p.upx)];
+    if (p.in_scale) v *= p.in_scale[major];
+    p.y[idx] = upfirdn_epilogue(p, v, major, oy, ox);
+  }
+}
+
+template <int UPX, int UPY, int DNX, int DNY, int KW, int KH>
+static int launch_upfirdn_small(const UpfirdnP &p, hipStream_t st) {
+  constexpr int TOW = 64, TOH = 16;
+  dim3 grid((p.outW + TOW - 1) / TOW, (p.outH + TOH - 1) / TOH, p.major > 65535 ? 65535 : p.major);
+  hipLaunchKernelGGL((upfirdn2d_small_kernel<UPX, UPY, DNX, DNY, KW, KH, TOW, TOH>), grid, dim3(256), 0, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+static int upfirdn_dispatch(UpfirdnP &p, hipStream_t st) {
+  if (p.minor == 1 && p.kW <= 4 && p.kH <= 4) {
+#define TBG_UF(ux, uy, dx, dy) \
+  if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy) return launch_upfirdn_small<ux, uy, dx, dy, 4, 4>(p, st);
+    TBG_UF(1, 1, 1, 1) TBG_UF(2, 2, 1, 1) TBG_UF(1, 1, 2, 2) TBG_UF(1, 1, 2, 1) TBG_UF(2, 1, 1, 1)
+#undef TBG_UF
+  }
+  const size_t total = (size_t)p.major * p.outH * p.outW * p.minor;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(upfirdn2d_generic_kernel, dim3(blocks), dim3(256), 0, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+static int upfirdn_fill(UpfirdnP &p, const float *x, const float *k, float *y, int major, int inH, int inW,
+                        int minor, int kH, int kW, int upx, int upy, int downx, int downy, int padx0,
+                        int padx1, int pady0, int pady1) {
+  if (!x || !k || !y) return TBG_EINVAL;
+  if (major < 1 || inH < 1 || inW < 1 || minor < 1) return TBG_EINVAL;
+  if (upx < 1 || upy < 1 || downx < 1 || downy < 1) return TBG_EINVAL;  // .cu:228-229
+  if (kW < 1 || kH < 1) return TBG_EINVAL;                            // .cu:252
+  const int outW = (inW * upx + padx0 + padx1 - kW + downx) / downx;  // .cu:254-255
+  const int outH = (inH * upy + pady0 + pady1 - kH + downy) / downy;
+  if (outW < 1 || outH < 1) return TBG_EINVAL;  // .cu:256
+  if ((double)major * inH * inW * minor > 2147483647.0 || (double)major * outH * outW * minor > 2147483647.0)
+    return TBG_ERANGE;  // .cu:243,266
+  p.x = x; p.k = k; p.y = y; p.in_scale = nullptr;
+  p.major = major; p.inH = inH; p.inW = inW; p.minor = minor; p.kH = kH; p.kW = kW;
+  p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
+  p.outH = outH; p.outW = outW; p.M = 1; p.has_epi = 0; p.e = make_epi(nullptr);
+  return TBG_OK;
+}
+
+extern "C" int tbg_upfirdn2d_f32(const float *x, const float *k, float *y, int major, int inH, int inW,
+                                 int minor, int kH, int kW, int upx, int upy, int downx, int downy,
+                                 int padx0, int padx1, int pady0, int pady1, void *stream) {
+  UpfirdnP p;
+  int rc = upfirdn_fill(p, x, k, y, major, inH, inW, minor, kH, kW, upx, upy, downx, downy, padx0, padx1, pady0, pady1);
+  if (rc != TBG_OK) return rc;
+  return upfirdn_dispatch(p, tbg_stream(stream));
+}
+
+extern "C" int tbg_upfirdn2d_ex_f32(const float *x, const float *k, float *y, int major, int inH, int inW,
+                                    int kH, int kW, int upx, int upy, int downx, int downy, int padx0,
+                                    int padx1, int pady0, int pady1, const float *in_scale, int M,
+                                    const tbg_epilogue *epi, void *stream) {
+  UpfirdnP p;
+  int rc = upfirdn_fill(p, x, k, y, major, inH, inW, 1, kH, kW, upx, upy, downx, downy, padx0, padx1, pady0, pady1);
+  if (rc != TBG_OK) return rc;
+  if (!epi_valid(epi) || (epi && epi->residual)) return TBG_EINVAL;
+  if (epi && (M < 1 || major % M != 0)) return TBG_EINVAL;
+  p.in_scale = in_scale;
+  if (epi) { p.has_epi = 1; p.M = M; p.e = make_epi(epi); }
+  return upfirdn_dispatch(p, tbg_stream(stream));
+}
+
+// ============================================================================================
+// bias_act forward / backward
+// ============================================================================================
+#define BA_CHUNK 4096  // elements of one (b,m) plane handled by one block
+
+extern "C" int tbg_bias_act_bwd_chunks(int HW) { return HW < 1 ? 0 : (HW + BA_CHUNK - 1) / BA_CHUNK; }
+
+struct BiasActP {
+  const float *x;
+  float *y;
+  int B, M, HW;
+  EpiK e;
+};
+
+__global__ __launch_bounds__(256) void bias_act_fwd_kernel(const BiasActP p) {
+  const int plane = blockIdx.x;  // b*M + m
+  const int b = plane / p.M, m = plane - b * p.M;
+  const int p0 = blockIdx.y * BA_CHUNK;
+  const int p1 = min(p0 + BA_CHUNK, p.HW);
+  const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[plane] : 1.f);
+  const float bias = p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f;
+  const float str = p.e.noise ? p.e.strength[0] : 0.f;
+  const float *xin = p.x + (size_t)plane * p.HW;
+  const float *nz = p.e.noise ? p.e.noise + (size_t)b * p.HW : nullptr;
+  const float *rs = p.e.residual ? p.e.residual + (size_t)plane * p.HW : nullptr;
+  float *yo = p.y + (size_t)plane * p.HW;
+  if ((p.HW & 3) == 0) {
+    for (int i = p0 + threadIdx.x * 4; i < p1; i += 1024) {
+      float4 v = *reinterpret_cast<const float4 *>(xin + i);
+      float4 n = nz ? *reinterpret_cast<const float4 *>(nz + i) : make_float4(0, 0, 0, 0);
+      float4 o;
+      o.x = epi_act(p.e, v.x * sc + n.x * str + bias);
+      o.y = epi_act(p.e, v.y * sc + n.y * str + bias);
+      o.z = epi_act(p.e, v.z * sc + n.z * str + bias);
+      o.w = epi_act(p.e, v.w * sc + n.w * str + bias);
+      if (rs) {
+        float4 r = *reinterpret_cast<const float4 *>(rs + i);
+        o.x = (o.x + r.x) * p.e.res_scale; o.y = (o.y + r.y) * p.e.res_scale;
+        o.z = (o.z + r.z) * p.e.res_scale; o.w = (o.w + r.w) * p.e.res_scale;
+      }
+      *reinterpret_cast<float4 *>(yo + i) = o;
+    }
+  } else {
+    for (int i = p0 + threadIdx.x; i < p1; i += 256) {
+      float o = epi_act(p.e, xin[i] * sc + (nz ? nz[i] * str : 0.f) + bias);
+      if (rs) o = (o + rs[i]) * p.e.res_scale;
+      yo[i] = o;
+    }
+  }
+}
+
+extern "C" int tbg_bias_act_fwd_f32(const float *x, float *y, int B, int M, int HW, const tbg_epilogue *epi,
+                                    void *stream) {
+  if (!x || !y || B < 1 || M < 1 || HW < 1 || !epi_valid(epi)) return TBG_EINVAL;
+  if ((double)B * M * HW > 2147483647.0) return TBG_ERANGE;
+  BiasActP p{x, y, B, M, HW, make_epi(epi)};
+  dim3 grid(B * M, tbg_bias_act_bwd_chunks(HW));
+  hipLaunchKernelGGL(bias_act_fwd_kernel, grid, dim3(256), 0, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+struct BiasActBwdP {
+  const float *dout, *out_act;
+  float *dx, *dpre_out, *part_db, *part_dn, *part_dyy;
+  int B, M, HW, nchunks;
+  EpiK e;
+};
+
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const BiasActBwdP p) {
+  __shared__ float red[3][4];
+  const int plane = blockIdx.x;
+  const int b = plane / p.M, m = plane - b * p.M;
+  const int p0 = blockIdx.y * BA_CHUNK;
+  const int p1 = min(p0 + BA_CHUNK, p.HW);
+  const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[plane] : 1.f);
+  const float bias = p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f;
+  const float str = p.e.noise ? p.e.strength[0] : 0.f;
+  const float gin = p.e.residual ? p.e.res_scale : 1.f;  // residual != NULL only flags "fused residual"
+  const float g_pos = p.e.gain, g_neg = p.e.gain * (p.e.act == TBG_ACT_LRELU ? p.e.slope : 1.f);
+  const float ig_pos = 1.f / g_pos, ig_neg = 1.f / g_neg;
+  const float *dout = p.dout + (size_t)plane * p.HW;
+  const float *oa = p.out_act + (size_t)plane * p.HW;
+  const float *nz = p.e.noise ? p.e.noise + (size_t)b * p.HW : nullptr;
+  float s_db = 0.f, s_dn = 0.f, s_dyy = 0.f;
+  for (int i = p0 + threadIdx.x; i < p1; i += 256) {
+    const float o = oa[i];
+    const bool pos = o > 0.f;
+    const float dpre = dout[i] * gin * (pos ? g_pos : g_neg);
+    const float n = nz ? nz[i] : 0.f;
+    const float pre = o * (pos ? ig_pos : ig_neg);
+    s_db += dpre;
+    s_dn += dpre * n;
+    s_dyy += dpre * (pre - n * str - bias);
+    if (p.dx) p.dx[(size_t)plane * p.HW + i] = dpre * sc;
+    if (p.dpre_out) p.dpre_out[(size_t)plane * p.HW + i] = dpre;
+  }
+  s_db = wave_sum(s_db); s_dn = wave_sum(s_dn); s_dyy = wave_sum(s_dyy);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[0][wave] = s_db; red[1][wave] = s_dn; red[2][wave] = s_dyy; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const size_t o = (size_t)plane * p.nchunks + blockIdx.y;
+    if (p.part_db) p.part_db[o] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    if (p.part_dn) p.part_dn[o] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (p.part_dyy) p.part_dyy[o] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+  }
+}
+
+extern "C" int tbg_bias_act_bwd_f32(const float *dout, const float *out_act, float *dx, float *dpre_out,
+                                    float *part_db, float *part_dn, float *part_dyy, int B, int M, int HW,
+                                    const tbg_epilogue *epi, void *stream) {
+  if (!dout || !out_act || B < 1 || M < 1 || HW < 1 || !epi || !epi_valid(epi)) return TBG_EINVAL;
+  if ((double)B * M * HW > 2147483647.0) return TBG_ERANGE;
+  if (part_dn && !epi->noise) return TBG_EINVAL;
+  BiasActBwdP p{dout, out_act, dx, dpre_out, part_db, part_dn, part_dyy, B, M, HW, tbg_bias_act_bwd_chunks(HW), make_epi(epi)};
+  dim3 grid(B * M, p.nchunks);
+  hipLaunchKernelGGL(bias_act_bwd_kernel, grid, dim3(256), 0, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// ============================================================================================
+// weight transpose  dst[t'][o][i (ldo)] = src[t][i][o]
+// ============================================================================================
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                               int T, int I, int O, int ldo, int flip) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int td = flip ? T - 1 - t : t;
+  const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, o = o0 + tx;
+    tile[r][tx] = (i < I && o < O) ? src[((size_t)t * I + i) * O + o] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int o = o0 + r, i = i0 + tx;
+    if (o < O && i < ldo) dst[((size_t)td * O + o) * ldo + i] = tile[tx][r];
+  }
+}
+
+extern "C" int tbg_weight_transpose_f32(const float *src, float *dst, int T, int I, int O, int ldo, int flip,
+                                        void *stream) {
+  if (!src || !dst || T < 1 || I < 1 || O < 1 || ldo < I) return TBG_EINVAL;
+  dim3 grid((ldo + 31) / 32, (O + 31) / 32, T);
+  hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, tbg_stream(stream), src, dst, T, I, O, ldo, flip);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// ============================================================================================
+// Adam (Keras / ResourceApplyAdam semantics) and EMA lerp over flat buffers
+// ============================================================================================
+__global__ __launch_bounds__(256) void adam_tf_kernel(float *__restrict__ theta, float *__restrict__ m,
+                                                      float *__restrict__ v, const float *__restrict__ g, long long n,
+                                                      float lr, float b1, float b2, float eps,
+                                                      const long long *__restrict__ step) {
+  const double t = (double)(step[0] + 1);
+  const double c1 = 1.0 - pow((double)b1, t);
+  const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / c1);
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 gg = reinterpret_cast<const float4 *>(g)[i];
+    float4 mm = reinterpret_cast<float4 *>(m)[i];
+    float4 vv = reinterpret_cast<float4 *>(v)[i];
+    float4 th = reinterpret_cast<float4 *>(theta)[i];
+#define TBG_ADAM1(c)                                   \
+  mm.c = b1 * mm.c + (1.f - b1) * gg.c;                \
+  vv.c = b2 * vv.c + (1.f - b2) * gg.c * gg.c;         \
+  th.c -= lr_t * mm.c / (sqrtf(vv.c) + eps);
+    TBG_ADAM1(x) TBG_ADAM1(y) TBG_ADAM1(z) TBG_ADAM1(w)
+#undef TBG_ADAM1
+    reinterpret_cast<float4 *>(m)[i] = mm;
+    reinterpret_cast<float4 *>(v)[i] = vv;
+    reinterpret_cast<float4 *>(theta)[i] = th;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float gg = g[i];
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm; v[i] = vv;
+    theta[i] -= lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+extern "C" int tbg_adam_tf_f32(float *theta, float *m, float *v, const float *g, long long n, float lr, float beta1,
+                               float beta2, float eps, const long long *step, void *stream) {
+  if (!theta || !m || !v || !g || !step || n < 1) return TBG_EINVAL;
+  if ((((uintptr_t)theta | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) != 0) return TBG_EINVAL;
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_tf_kernel, dim3((int)blocks), dim3(256), 0, tbg_stream(stream), theta, m, v, g, n, lr, beta1,
+                     beta2, eps, step);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+__global__ __launch_bounds__(256) void ema_lerp_kernel(float *__restrict__ dst, const float *__restrict__ src,
+                                                       long long n, float beta) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 s = reinterpret_cast<const float4 *>(src)[i];
+    float4 d = reinterpret_cast<float4 *>(dst)[i];
+    d.x = s.x + (d.x - s.x) * beta; d.y = s.y + (d.y - s.y) * beta;
+    d.z = s.z + (d.z - s.z) * beta; d.w = s.w + (d.w - s.w) * beta;
+    reinterpret_cast<float4 *>(dst)[i] = d;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    dst[i] = src[i] + (dst[i] - src[i]) * beta;
+}
+
+extern "C" int tbg_ema_lerp_f32(float *dst, const float *src, long long n, float beta, void *stream) {
+  if (!dst || !src || n < 1) return TBG_EINVAL;
+  if ((((uintptr_t)dst | (uintptr_t)src) & 15) != 0) return TBG_EINVAL;
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ema_lerp_kernel, dim3((int)blocks), dim3(256), 0, tbg_stream(stream), dst, src, n, beta);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// ============================================================================================
+// demodulation coefficients
+// ============================================================================================
+__global__ __launch_bounds__(256) void wsq_kernel(const float *__restrict__ w, float *__restrict__ wsq, int T, int IO,
+                                                  float coef2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= IO) return;
+  float a = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float v = w[(size_t)t * IO + i];
+    a += v * v;
+  }
+  wsq[i] = a * coef2;
+}
+
+// block = 4 waves; lane = (isub = lane>>4, o = lane&15): every wave reduces its 4 i-subgroups
+// with two wavefront shuffles, the 4 waves meet in LDS.
+__global__ __launch_bounds__(256) void demod_kernel(const float *__restrict__ s, const float *__restrict__ wsq,
+                                                    float *__restrict__ d, int I, int O) {
+  __shared__ float red[4][16];
+  const int b = blockIdx.y;
+  const int o = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int isub = threadIdx.x >> 4;  // 0..15
+  float a = 0.f;
+  if (o < O)
+    for (int i = isub; i < I; i += 16) {
+      const float sv = s[(size_t)b * I + i];
+      a += sv * sv * wsq[(size_t)i * O + o];
+    }
+  a += __shfl_xor(a, 16, 64);
+  a += __shfl_xor(a, 32, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < 16) red[wave][lane] = a;
+  __syncthreads();
+  if (threadIdx.x < 16 && o < O)
+    d[(size_t)b * O + o] = rsqrtf(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x] + 1e-8f);
+}
+
+extern "C" int tbg_demod_coefs_f32(const float *s, const float *w, float *wsq, float *d, int B, int T, int I, int O,
+                                   float coef, void *stream) {
+  if (!s || !w || !wsq || !d || B < 1 || T < 1 || I < 1 || O < 1) return TBG_EINVAL;
+  hipStream_t st = tbg_stream(stream);
+  hipLaunchKernelGGL(wsq_kernel, dim3((I * O + 255) / 256), dim3(256), 0, st, w, wsq, T, I * O, coef * coef);
+  TBG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(demod_kernel, dim3((O + 15) / 16, B), dim3(256), 0, st, s, wsq, d, I, O);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// ============================================================================================
+extern "C" int tbg_version(void) { return 100; }
+
+extern "C" const char *tbg_strerror(int code) {
+  switch (code) {
+    case TBG_OK: return "ok";
+    case TBG_EINVAL: return "invalid argument (shape / pointer / factor)";
+    case TBG_ERANGE: return "tensor has more than INT32_MAX elements";
+    case TBG_EHIP: return "HIP kernel launch failed";
+    case TBG_EUNSUPPORTED: return "configuration not supported by this build";
+    default: return "unknown tbg error";
+  }
+}

@@ -1,0 +1,404 @@
+"""Generator / discriminator of TextBoxGAN on the HIP kernels.
+
+The module tree reproduces the reference's attribute paths (= its ``tf.train.Checkpoint`` keys,
+SURVEY section 5; reference models/custom_stylegan2/{generator,discriminator,latent_encoder}.py,
+layers/*.py, models/word_encoder.py), and parameters keep the reference's layouts, so
+``state_dict()`` keys/shapes are the checkpoint layout.  Two execution modes:
+
+* ``mode="fused"``      first-order training/inference path: fused HIP layers (ops.*_fused).
+* ``mode="composable"`` every conv / FIR is a HIP primitive whose backward is again a primitive,
+                        elementwise glue is torch -- gradients of any order (R1, path length).
+
+Mapping MLP, word encoder and the discriminator's dense head stay PyTorch-ROCm GEMMs
+(BASELINE.json north_star); minibatch-std stays torch (true second-order term for R1).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .config import Config
+from .native import ACT_LINEAR, ACT_LRELU, SQRT2
+
+FIR = (1, 3, 3, 1)
+
+
+def _coef(weight_shape, gain=1.0, lrmul=1.0) -> float:
+    """layers/commons.py:4-12."""
+    fan_in = 1
+    for v in weight_shape[:-1]:
+        fan_in *= int(v)
+    return gain / math.sqrt(fan_in) * lrmul
+
+
+class Dense(nn.Module):
+    """layers/dense.py:6-29 (equalised-LR dense; torch GEMM)."""
+
+    def __init__(self, fan_in, fmaps, gain=1.0, lrmul=1.0):
+        super().__init__()
+        self.gain, self.lrmul = gain, lrmul
+        self.w = nn.Parameter(torch.randn(fan_in, fmaps) / lrmul)
+
+    def forward(self, x):
+        return x.reshape(x.shape[0], -1) @ (self.w * _coef(self.w.shape, self.gain, self.lrmul))
+
+
+class BiasAct(nn.Module):
+    """layers/bias_act.py:7-34 (parameter holder; the add/activation is fused into the producer)."""
+
+    def __init__(self, n, lrmul=1.0, act="linear"):
+        super().__init__()
+        self.lrmul, self.act = lrmul, act
+        self.b = nn.Parameter(torch.zeros(n))
+
+    def forward(self, x):
+        b = self.b * self.lrmul
+        x = x + (b if x.dim() == 2 else b.reshape(1, -1, 1, 1))
+        return F.leaky_relu(x, 0.2) * SQRT2 if self.act == "lrelu" else x
+
+
+class Noise(nn.Module):
+    """layers/noise.py:4-22."""
+
+    def __init__(self):
+        super().__init__()
+        self.noise_strength = nn.Parameter(torch.zeros(()))
+
+
+class Mapping(nn.Module):
+    """layers/mapping_block.py:7-45."""
+
+    def __init__(self, z_dim, style_dim, n_mapping):
+        super().__init__()
+        self.dense_layers = nn.ModuleList(
+            [Dense(z_dim if i == 0 else style_dim, style_dim, 1.0, 0.01) for i in range(n_mapping)])
+        self.bias_act_layers = nn.ModuleList([BiasAct(style_dim, 0.01, "lrelu") for _ in range(n_mapping)])
+
+    def forward(self, z):
+        x = z * torch.rsqrt(z.square().mean(dim=1, keepdim=True) + 1e-8)
+        for dense, ba in zip(self.dense_layers, self.bias_act_layers):
+            x = ba(dense(x))
+        return x
+
+
+class LatentEncoder(nn.Module):
+    """models/custom_stylegan2/latent_encoder.py:9-99."""
+
+    def __init__(self, cfg: Config, n_broadcast: int):
+        super().__init__()
+        self.n_broadcast = n_broadcast
+        self.w_ema_decay, self.style_mixing_prob = 0.995, 0.9
+        self.g_mapping = Mapping(cfg.z_dim, cfg.style_dim, cfg.n_mapping)
+        self.register_buffer("w_avg", torch.zeros(cfg.style_dim))
+
+    def forward(self, z, training: bool, truncation_psi=1.0, rand: Optional[dict] = None):
+        ns = self.n_broadcast
+        w = self.g_mapping(z)
+        wb = w[:, None, :].expand(-1, ns, -1)
+        if training:
+            with torch.no_grad():  # :39-45
+                batch_avg = w.mean(dim=0)
+                self.w_avg.copy_(batch_avg + (self.w_avg - batch_avg) * self.w_ema_decay)
+            if rand is not None and "z2" in rand:
+                z2, cutoff = rand["z2"], int(rand["mix_cutoff"])
+            else:  # :47-60
+                z2 = torch.randn_like(z)
+                cutoff = int(torch.randint(1, ns, ()).item()) if float(torch.rand(())) < self.style_mixing_prob else ns
+            w2 = self.g_mapping(z2)
+            idx = torch.arange(ns, device=z.device)[None, :, None]
+            wb = torch.where(idx < cutoff, wb, w2[:, None, :].expand(-1, ns, -1))
+        else:  # :73-78
+            wb = self.w_avg + (wb - self.w_avg) * truncation_psi
+        return wb
+
+
+class WordEncoder(nn.Module):
+    """models/word_encoder.py:8-63."""
+
+    class _FC(nn.Module):
+        def __init__(self, fin, fout):
+            super().__init__()
+            lim = math.sqrt(6.0 / (fin + fout))  # Keras glorot_uniform
+            self.kernel = nn.Parameter(torch.empty(fin, fout).uniform_(-lim, lim))
+            self.bias = nn.Parameter(torch.zeros(fout))
+
+    def __init__(self, cfg: Config, dropout_rate=0.3):
+        super().__init__()
+        self.cfg, self.dropout_rate = cfg, dropout_rate
+        self.w_embedding = nn.Parameter(torch.randn(cfg.main_vocab, cfg.embedding_out_dim))
+        self.register_buffer("w0_embedding", torch.zeros(1, cfg.embedding_out_dim))
+        self.fc = WordEncoder._FC(cfg.embedding_out_dim, cfg.word_encoder_dense_dim)
+
+    def forward(self, words, batch_size=None, training=False, dropout_mask=None):
+        cfg = self.cfg
+        B = words.shape[0] if batch_size is None else batch_size
+        table = torch.cat([self.w0_embedding, self.w_embedding], dim=0)
+        emb = table[words.long()]
+        if training:
+            if dropout_mask is None:
+                keep = 1.0 - self.dropout_rate
+                dropout_mask = torch.bernoulli(torch.full_like(emb, keep)) / keep
+            emb = emb * dropout_mask
+        x = emb.reshape(B * cfg.max_char_number, cfg.embedding_out_dim)
+        x = F.relu(x @ self.fc.kernel + self.fc.bias)
+        h0, w0 = cfg.generator_resolutions[0]
+        return x.reshape(B, w0, cfg.generator_feat_maps[0], h0).permute(0, 2, 3, 1).contiguous()
+
+
+class ModulatedConv2D(nn.Module):
+    """layers/modulated_conv2d.py:16-122 (parameters + style/demod coefficients)."""
+
+    def __init__(self, cfg: Config, in_fmaps, out_fmaps, k, up, demodulate):
+        super().__init__()
+        self.up, self.demodulate, self.k = up, demodulate, k
+        self.w = nn.Parameter(torch.randn(k, k, in_fmaps, out_fmaps))
+        self.mod_dense = Dense(cfg.style_dim, in_fmaps, 1.0, 1.0)
+        self.mod_bias = BiasAct(in_fmaps, 1.0, "linear")
+
+    def style(self, y):
+        """s = mod_dense(y) + b + 1   (:74-76)."""
+        return torch.addmm(self.mod_bias.b + 1.0, y, self.mod_dense.w * _coef(self.mod_dense.w.shape))
+
+    def demod(self, s, mode):
+        if not self.demodulate:
+            return None
+        if mode == "fused":
+            return ops.demod_coefs(s, self.w)
+        wsq = (self.w * _coef(self.w.shape)).square().sum(dim=(0, 1))
+        return torch.rsqrt(s.square() @ wsq + 1e-8)
+
+    def conv_composable(self, x, s, d):
+        """any-order path: x*s -> conv / up-conv+FIR -> *d   (the reference's CPU branch :94-96,:119-121)."""
+        wc = self.w * _coef(self.w.shape)
+        xs = x * s[:, :, None, None]
+        if self.up:
+            y = ops.conv_transpose2d_s2(xs, torch.flip(wc, (0, 1)))
+            y = ops.upfirdn2d(y, ops.fir_kernel(x.device, 4.0), pad=(1, 1, 1, 1))
+        else:
+            y = ops.conv2d(xs, wc, (1, 1), (self.k // 2, self.k // 2))
+        if d is not None:
+            y = y * d[:, :, None, None]
+        return y
+
+
+class ToRGB(nn.Module):
+    """layers/to_rgb.py:7-33."""
+
+    def __init__(self, cfg, in_ch):
+        super().__init__()
+        self.conv = ModulatedConv2D(cfg, in_ch, 3, 1, up=False, demodulate=False)
+        self.apply_bias = BiasAct(3, 1.0, "linear")
+
+    def forward(self, x, style, skip=None, mode="fused"):
+        s = self.conv.style(style)
+        if mode == "fused":
+            return ops.torgb_fused(x, self.conv.w, s, self.apply_bias.b, skip)
+        y = self.apply_bias(self.conv.conv_composable(x, s, None))
+        return y if skip is None else skip + y
+
+
+class SynthesisBlock(nn.Module):
+    """layers/synthesis_block.py:14-74."""
+
+    def __init__(self, cfg, in_ch, fmaps):
+        super().__init__()
+        self.conv_0 = ModulatedConv2D(cfg, in_ch, fmaps, 3, up=True, demodulate=True)
+        self.apply_noise_0 = Noise()
+        self.apply_bias_act_0 = BiasAct(fmaps, 1.0, "lrelu")
+        self.conv_1 = ModulatedConv2D(cfg, fmaps, fmaps, 3, up=False, demodulate=True)
+        self.apply_noise_1 = Noise()
+        self.apply_bias_act_1 = BiasAct(fmaps, 1.0, "lrelu")
+
+    def forward(self, x, w0, w1, noise0, noise1, mode="fused"):
+        for conv, nz, ba, style, noise in ((self.conv_0, self.apply_noise_0, self.apply_bias_act_0, w0, noise0),
+                                           (self.conv_1, self.apply_noise_1, self.apply_bias_act_1, w1, noise1)):
+            s = conv.style(style)
+            d = conv.demod(s, mode)
+            if mode == "fused":
+                fn = ops.modconv_up_fused if conv.up else ops.modconv_fused
+                x = fn(x, conv.w, s, d, noise, nz.noise_strength, ba.b)
+            else:
+                x = ba(conv.conv_composable(x, s, d) + noise * nz.noise_strength)
+        return x
+
+
+class Synthesis(nn.Module):
+    """layers/synthesis_block.py:90-156."""
+
+    def __init__(self, cfg: Config):
+        super().__init__()
+        fm = cfg.generator_feat_maps
+        self.resolutions = cfg.generator_resolutions
+        self.initial_torgb = ToRGB(cfg, fm[0])
+        self.synth_blocks = nn.ModuleList()
+        self.torgbs = nn.ModuleList()
+        prev = fm[0]
+        for f in fm[1:]:
+            self.synth_blocks.append(SynthesisBlock(cfg, prev, f))
+            self.torgbs.append(ToRGB(cfg, f))
+            prev = f
+
+    def noise_shapes(self, B):
+        return [(B, 1, h, w) for (h, w) in self.resolutions[1:] for _ in range(2)]
+
+    def forward(self, x, style, noises: Optional[List[torch.Tensor]] = None, mode="fused"):
+        B = x.shape[0]
+        if noises is None:  # fresh noise on every call, also at inference (noise.py:16-19)
+            noises = [torch.randn(s, device=x.device) for s in self.noise_shapes(B)]
+        k_up = ops.fir_kernel(x.device, 4.0)
+        y = self.initial_torgb(x, style[:, 0], None, mode)
+        for i, (block, torgb) in enumerate(zip(self.synth_blocks, self.torgbs)):
+            x = block(x, style[:, 3 * i], style[:, 3 * i + 1], noises[2 * i], noises[2 * i + 1], mode)
+            y = ops.upfirdn2d(y, k_up, up=(2, 2), pad=(2, 1, 2, 1))  # upsample_2d, :152
+            y = torgb(x, style[:, 3 * i + 2], y, mode)
+        return y
+
+
+class Generator(nn.Module):
+    """models/custom_stylegan2/generator.py:10-59."""
+
+    def __init__(self, cfg: Config):
+        super().__init__()
+        self.cfg = cfg
+        self.word_encoder = WordEncoder(cfg)
+        self.synthesis = Synthesis(cfg)
+        self.n_style = 2 * len(self.synthesis.synth_blocks) + len(self.synthesis.torgbs)
+        self.latent_encoder = LatentEncoder(cfg, self.n_style)
+
+    def forward(self, inputs, batch_size=None, ret_style=False, truncation_psi=1.0, training=False,
+                rand: Optional[dict] = None, noises_key="noises", mode="fused"):
+        words, z = inputs
+        rand = rand or {}
+        we = self.word_encoder(words, batch_size, training=training, dropout_mask=rand.get("dropout_mask"))
+        style = self.latent_encoder(z, training=training, truncation_psi=truncation_psi, rand=rand)
+        if ret_style:
+            style = style.clone()
+        img = self.synthesis(we, style, rand.get(noises_key), mode)
+        return (img, style) if ret_style else img
+
+    @torch.no_grad()
+    def set_as_moving_average_of(self, src: "Generator", beta=0.99):
+        """generator.py:48-59: every weight lerps with beta, w_avg is copied."""
+        from .optim import ema_update
+        ema_update(self, src, beta)
+
+
+# ----------------------------------------------------------------------------------------
+class Conv2D(nn.Module):
+    """layers/conv.py:11-73 (parameter holder)."""
+
+    def __init__(self, in_fmaps, out_fmaps, k):
+        super().__init__()
+        self.w = nn.Parameter(torch.randn(k, k, in_fmaps, out_fmaps))
+
+
+class FromRGB(nn.Module):
+    """layers/from_rgb.py:7-29."""
+
+    def __init__(self, fmaps):
+        super().__init__()
+        self.conv = Conv2D(3, fmaps, 1)
+        self.apply_bias_act = BiasAct(fmaps, 1.0, "lrelu")
+
+    def forward(self, x, mode="fused"):
+        if mode == "fused":
+            return ops.conv_bias_act_fused(x, self.conv.w, self.apply_bias_act.b)
+        return self.apply_bias_act(ops.conv2d(x, self.conv.w * _coef(self.conv.w.shape)))
+
+
+class DiscriminatorBlock(nn.Module):
+    """models/custom_stylegan2/discriminator.py:11-84."""
+
+    def __init__(self, n_f0, n_f1, reduce_height):
+        super().__init__()
+        self.reduce_height = reduce_height
+        self.conv_0 = Conv2D(n_f0, n_f0, 3)
+        self.apply_bias_act_0 = BiasAct(n_f0, 1.0, "lrelu")
+        self.conv_1 = Conv2D(n_f0, n_f1, 3)
+        self.apply_bias_act_1 = BiasAct(n_f1, 1.0, "lrelu")
+        self.conv_skip = Conv2D(n_f0, n_f1, 1)
+
+    def forward(self, x, mode="fused"):
+        sh = 2 if self.reduce_height else 1
+        k = ops.fir_kernel(x.device, 1.0)
+        rs = 1.0 / math.sqrt(2.0)
+        # skip: blur + strided 1x1 conv == (blur evaluated only at the strided sites) + 1x1 conv
+        xd = ops.upfirdn2d(x, k, down=(2, sh), pad=(1, 2, 1, 2))
+        if mode == "fused":
+            t = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1))
+            tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3))  # conv_downsample_2d, upfirdn_2d_v2.py:106-113
+            u = ops.conv_bias_act_fused(tb, self.conv_1.w, self.apply_bias_act_1.b, stride=(sh, 2))
+            return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=rs)
+        t = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w * _coef(self.conv_0.w.shape), (1, 1), (1, 1)))
+        tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3))
+        u = self.apply_bias_act_1(ops.conv2d(tb, self.conv_1.w * _coef(self.conv_1.w.shape), (sh, 2)))
+        skip = ops.conv2d(xd, self.conv_skip.w * _coef(self.conv_skip.w.shape))
+        return (u + skip) * rs
+
+
+def minibatch_std(x, group_size=4):
+    """layers/mini_batch_std.py:10-35 (statistics groups live inside the per-GPU batch)."""
+    B, C, H, W = x.shape
+    G = min(group_size, B)
+    y = x.reshape(G, -1, 1, C, H, W)
+    y = y - y.mean(dim=0, keepdim=True)
+    y = (y.square().mean(dim=0) + 1e-8).sqrt()
+    y = y.mean(dim=(2, 3, 4), keepdim=True).mean(dim=2)
+    return torch.cat([x, y.repeat(G, 1, H, W)], dim=1)
+
+
+class DiscriminatorLastBlock(nn.Module):
+    """discriminator.py:101-142."""
+
+    def __init__(self, n_f0, n_f1, hw):
+        super().__init__()
+        self.conv_0 = Conv2D(n_f0 + 1, n_f0, 3)
+        self.apply_bias_act_0 = BiasAct(n_f0, 1.0, "lrelu")
+        self.dense_1 = Dense(n_f0 * hw[0] * hw[1], n_f1)
+        self.apply_bias_act_1 = BiasAct(n_f1, 1.0, "lrelu")
+
+    def forward(self, x, mode="fused"):
+        x = minibatch_std(x, 4).contiguous()
+        if mode == "fused":
+            x = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1))
+        else:
+            x = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w * _coef(self.conv_0.w.shape), (1, 1), (1, 1)))
+        return self.apply_bias_act_1(self.dense_1(x))
+
+
+class Discriminator(nn.Module):
+    """models/custom_stylegan2/discriminator.py:157-214."""
+
+    def __init__(self, cfg: Config):
+        super().__init__()
+        res, fm = cfg.discrim_resolutions, cfg.discrim_feat_maps
+        self.initial_fromrgb = FromRGB(fm[0])
+        self.blocks = nn.ModuleList([
+            DiscriminatorBlock(f0, f1, r[0] != rn[0]) for r, rn, f0, f1 in zip(res[:-1], res[1:], fm[:-1], fm[1:])])
+        self.last_block = DiscriminatorLastBlock(fm[-2], fm[-1], res[-1])
+        self.last_dense = Dense(fm[-1], 1)
+        self.last_bias = BiasAct(1, 1.0, "linear")
+
+    def forward(self, images, mode="fused"):
+        x = self.initial_fromrgb(images.contiguous(), mode)
+        for block in self.blocks:
+            x = block(x, mode)
+        x = self.last_block(x, mode)
+        return self.last_bias(self.last_dense(x))
+
+
+def mask_text_box(fake_images, input_words, char_width: int):
+    """utils/utils.py:11-45."""
+    mask = (input_words != 0).to(fake_images.dtype).repeat_interleave(char_width, dim=1)
+    return fake_images * mask[:, None, None, :]
+
+
+def generator_output_to_uint8(fake_images):
+    """utils/utils.py:48-63."""
+    x = (fake_images.clamp(-1.0, 1.0) + 1.0) * 127.5
+    return x.permute(0, 2, 3, 1).to(torch.uint8)

@@ -1,0 +1,105 @@
+"""ctypes binding of libtbg_hip.so (include/tbg.h).
+
+Plumbing only: PyTorch provides device memory (caching allocator = the role of TF's
+``allocate_output``) and the current HIP stream; every compute call goes through the C ABI.
+There is NO fallback: if the library is missing or a tensor is not a contiguous fp32 device
+tensor, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtbg_hip.so")
+
+ACT_LINEAR, ACT_LRELU = 0, 1
+SQRT2 = 1.4142135623730951
+
+EXPORTS = [
+    "tbg_version", "tbg_strerror", "tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_conv2d_f32",
+    "tbg_conv2d_wgrad_f32", "tbg_weight_transpose_f32", "tbg_bias_act_fwd_f32", "tbg_bias_act_bwd_chunks",
+    "tbg_bias_act_bwd_f32", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
+]
+
+
+class TbgError(RuntimeError):
+    pass
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("out_scale", C.c_void_p), ("bias", C.c_void_p), ("noise", C.c_void_p), ("strength", C.c_void_p),
+                ("residual", C.c_void_p), ("dot_aux", C.c_void_p), ("dot_out", C.c_void_p), ("alpha", C.c_float), ("bias_mul", C.c_float), ("slope", C.c_float),
+                ("gain", C.c_float), ("res_scale", C.c_float), ("act", C.c_int)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "C", "M", "Hin", "Win", "Hout", "Wout", "KH", "KW", "sy", "sx", "py", "px",
+                                       "transposed", "flip", "ldw", "ksplit")]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "CS", "CL", "Hs", "Ws", "Hl", "Wl", "KH", "KW", "sy", "sx", "py", "px",
+                                       "st_t", "st_l", "st_s")] + [("alpha", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (fails loudly -- there is no CPU/eager fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TbgError(f"{LIB_PATH} not found: run `python -m textboxgan_amd.build` (hipcc, gfx950)")
+        l = C.CDLL(LIB_PATH)
+        l.tbg_strerror.restype = C.c_char_p
+        l.tbg_strerror.argtypes = [C.c_int]
+        l.tbg_version.restype = C.c_int
+        l.tbg_bias_act_bwd_chunks.restype = C.c_int
+        l.tbg_bias_act_bwd_chunks.argtypes = [C.c_int]
+        vp, ci, cf, ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+        l.tbg_upfirdn2d_f32.argtypes = [vp, vp, vp] + [ci] * 14 + [vp]
+        l.tbg_upfirdn2d_ex_f32.argtypes = [vp, vp, vp] + [ci] * 13 + [vp, ci, C.POINTER(Epilogue), vp]
+        l.tbg_conv2d_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(Epilogue), vp]
+        l.tbg_conv2d_wgrad_f32.argtypes = [C.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp]
+        l.tbg_weight_transpose_f32.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+        l.tbg_bias_act_fwd_f32.argtypes = [vp, vp, ci, ci, ci, C.POINTER(Epilogue), vp]
+        l.tbg_bias_act_bwd_f32.argtypes = [vp] * 7 + [ci, ci, ci, C.POINTER(Epilogue), vp]
+        l.tbg_adam_tf_f32.argtypes = [vp, vp, vp, vp, ll, cf, cf, cf, cf, vp, vp]
+        l.tbg_ema_lerp_f32.argtypes = [vp, vp, ll, cf, vp]
+        l.tbg_demod_coefs_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, cf, vp]
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise TbgError(f"{what}: {lib().tbg_strerror(rc).decode()} (code {rc})")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise TbgError("libtbg_hip kernels need device tensors (no CPU path in the product)")
+    if t.dtype != torch.float32 and t.dtype != torch.int64:
+        raise TbgError(f"unsupported dtype {t.dtype}")
+    if not t.is_contiguous():
+        raise TbgError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def epilogue(out_scale=None, bias=None, noise=None, strength=None, residual=None, alpha=1.0, bias_mul=1.0,
+             act=ACT_LINEAR, slope=0.2, gain=None, res_scale=1.0, dot_aux=None, dot_out=None) -> Epilogue:
+    if gain is None:
+        gain = SQRT2 if act == ACT_LRELU else 1.0
+    return Epilogue(ptr(out_scale), ptr(bias), ptr(noise), ptr(strength), ptr(residual), ptr(dot_aux), ptr(dot_out), alpha, bias_mul, slope, gain,
+                    res_scale, act)

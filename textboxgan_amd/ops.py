@@ -1,0 +1,532 @@
+"""Operators of the TextBoxGAN step on top of libtbg_hip.so.
+
+Two layers:
+
+* ``*_raw`` helpers: allocate outputs with torch's caching allocator and enqueue ONE C-ABI call
+  on the current stream.  No autograd.
+* ``torch.autograd.Function`` wrappers, in two families
+    - composable primitives (``upfirdn2d``, ``conv2d``, ``conv2d_bwd_data``, ``conv2d_bwd_weight``)
+      whose backward is written with the same primitives, so gradients of ANY order exist -- the
+      property the reference gets from its recursive ``tf.custom_gradient``
+      (upfirdn_2d_v2.py:204-246) and needs for R1 / path-length (training_step.py:300-373);
+    - fused first-order layers (modulated conv + noise + bias + lrelu, up-conv + FIR + epilogue,
+      conv + bias + lrelu, toRGB, ...) used on every non-regularised pass.
+
+Weights stay in the reference's parameter layout ([k,k,I,O], modulated_conv2d.py:57-64).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import native as N
+from .native import ACT_LINEAR, ACT_LRELU, SQRT2
+
+
+class _Flags:
+    """Set by the training step around each of its three backward passes so layers skip
+    gradients nobody consumes (torch gives custom Functions no per-call pruning info)."""
+    skip_d_wgrad = False     # G-loss pass only needs dL/d(image) through the discriminator
+    skip_image_grad = False  # D-loss pass does not need dL/d(image)
+
+
+FLAGS = _Flags()
+
+# ----------------------------------------------------------------------------------------
+# FIR filters (upfirdn_2d_v2.py:18-25) cached per device
+# ----------------------------------------------------------------------------------------
+_FIR_CACHE = {}
+
+
+def fir_kernel(device, gain: float = 1.0, taps=(1, 3, 3, 1)) -> torch.Tensor:
+    key = (str(device), float(gain), tuple(taps))
+    if key not in _FIR_CACHE:
+        k = np.asarray(taps, dtype=np.float32)
+        k = np.outer(k, k)
+        k = k / k.sum() * gain
+        _FIR_CACHE[key] = torch.from_numpy(k).to(device)
+    return _FIR_CACHE[key]
+
+
+# ----------------------------------------------------------------------------------------
+# raw launches
+# ----------------------------------------------------------------------------------------
+def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0),
+                  in_scale: Optional[torch.Tensor] = None, epi: Optional[N.Epilogue] = None) -> torch.Tensor:
+    """x NCHW (treated as [B*C, H, W, 1], upfirdn_2d_v2.py:166-183); up/down = (x, y);
+    pad = (x0, x1, y0, y1)."""
+    B, Cc, H, W = x.shape
+    kH, kW = k.shape
+    outW = (W * up[0] + pad[0] + pad[1] - kW + down[0]) // down[0]
+    outH = (H * up[1] + pad[2] + pad[3] - kH + down[1]) // down[1]
+    y = torch.empty((B, Cc, outH, outW), device=x.device, dtype=torch.float32)
+    if in_scale is None and epi is None:
+        rc = N.lib().tbg_upfirdn2d_f32(N.ptr(x), N.ptr(k), N.ptr(y), B * Cc, H, W, 1, kH, kW, up[0], up[1], down[0],
+                                       down[1], pad[0], pad[1], pad[2], pad[3], N.stream())
+    else:
+        rc = N.lib().tbg_upfirdn2d_ex_f32(N.ptr(x), N.ptr(k), N.ptr(y), B * Cc, H, W, kH, kW, up[0], up[1], down[0],
+                                          down[1], pad[0], pad[1], pad[2], pad[3], N.ptr(in_scale), Cc,
+                                          C.byref(epi) if epi is not None else None, N.stream())
+    N.check(rc, "tbg_upfirdn2d")
+    return y
+
+
+def _conv_tiles(M, npix):
+    if M <= 32:
+        bm, bn = 32, 256
+    elif M <= 64:
+        bm, bn = 64, 256
+    else:
+        bm, bn = 128, 128
+    return math.ceil(M / bm) * math.ceil(npix / bn)
+
+
+def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_hw: Tuple[int, int], stride=(1, 1),
+               pad=(0, 0), transposed=False, flip=False, in_scale=None, epi: Optional[N.Epilogue] = None,
+               ldw: Optional[int] = None, allow_split=True, dot=None) -> torch.Tensor:
+    """w: GEMM layout [KH*KW, C, ldw] (any view with that memory layout, e.g. the HWIO parameter).
+    dot = (aux, out): out[b,m] = sum_p (alpha*acc)[b,m,p] * aux[b,m,p]  (fused when K is not split)."""
+    B, Cc, Hin, Win = x.shape
+    ldw = M if ldw is None else ldw
+    Hout, Wout = out_hw
+    nchunks = math.ceil(Cc / 8)
+    ksplit = 1
+    if allow_split:
+        tiles = _conv_tiles(M, B * Hout * Wout)
+        if tiles < 192 and nchunks >= 8:
+            ksplit = max(1, min(nchunks // 4, math.ceil(384 / tiles)))
+    d = N.ConvDesc(B, Cc, M, Hin, Win, Hout, Wout, KH, KW, stride[0], stride[1], pad[0], pad[1], int(transposed),
+                   int(flip), ldw, ksplit)
+    if epi is None:
+        epi = N.epilogue()
+    trivial = not (epi.out_scale or epi.bias or epi.noise or epi.residual or epi.act != ACT_LINEAR or dot is not None)
+    if ksplit > 1 and not trivial:
+        tmp = torch.zeros((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
+        e0 = N.epilogue(alpha=epi.alpha)
+        N.check(N.lib().tbg_conv2d_f32(C.byref(d), N.ptr(x), N.ptr(w), N.ptr(tmp), N.ptr(in_scale), C.byref(e0),
+                                       N.stream()), "tbg_conv2d(split)")
+        if dot is not None:
+            dot[1].copy_((tmp * dot[0]).sum(dim=(2, 3)))
+        e1 = N.Epilogue.from_buffer_copy(epi)
+        e1.alpha = 1.0
+        y = torch.empty_like(tmp)
+        N.check(N.lib().tbg_bias_act_fwd_f32(N.ptr(tmp), N.ptr(y), B, M, Hout * Wout, C.byref(e1), N.stream()),
+                "tbg_bias_act_fwd")
+        return y
+    if dot is not None:
+        epi = N.Epilogue.from_buffer_copy(epi)
+        epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(dot[1])
+    alloc = torch.zeros if ksplit > 1 else torch.empty
+    y = alloc((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
+    N.check(N.lib().tbg_conv2d_f32(C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi),
+                                   N.stream()), "tbg_conv2d")
+    return y
+
+
+def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, out: torch.Tensor, st_t: int, st_l: int,
+              st_s: int, alpha: float, s_scale=None, l_scale=None, out_offset: int = 0):
+    """Accumulates into ``out`` (pre-zeroed by the caller)."""
+    B, CS, Hs, Ws = S.shape
+    _, CL, Hl, Wl = L.shape
+    d = N.WgradDesc(B, CS, CL, Hs, Ws, Hl, Wl, KH, KW, stride[0], stride[1], pad[0], pad[1], st_t, st_l, st_s, alpha)
+    N.check(N.lib().tbg_conv2d_wgrad_f32(C.byref(d), N.ptr(S), N.ptr(L), N.ptr(out) + 4 * out_offset, N.ptr(s_scale),
+                                         N.ptr(l_scale), N.stream()), "tbg_conv2d_wgrad")
+    return out
+
+
+def weight_transpose_raw(w: torch.Tensor, flip: bool) -> Tuple[torch.Tensor, int]:
+    """HWIO [k,k,I,O] -> GEMM layout for the data gradient [T][O][ldo>=I]."""
+    KH, KW, I, O = w.shape
+    ldo = (I + 3) // 4 * 4
+    out = torch.empty((KH * KW, O, ldo), device=w.device, dtype=torch.float32)
+    N.check(N.lib().tbg_weight_transpose_f32(N.ptr(w), N.ptr(out), KH * KW, I, O, ldo, int(flip), N.stream()),
+            "tbg_weight_transpose")
+    return out, ldo
+
+
+def bias_act_bwd_raw(dout, out_act, epi: N.Epilogue, want_dx=False, want_dpre=True, want_db=True, want_dn=False,
+                     want_dyy=False):
+    B, M = dout.shape[0], dout.shape[1]
+    HW = dout.numel() // (B * M)
+    nch = N.lib().tbg_bias_act_bwd_chunks(HW)
+    mk = lambda: torch.empty((B, M, nch), device=dout.device, dtype=torch.float32)
+    dx = torch.empty_like(dout) if want_dx else None
+    dpre = torch.empty_like(dout) if want_dpre else None
+    pdb = mk() if want_db else None
+    pdn = mk() if want_dn else None
+    pdy = mk() if want_dyy else None
+    N.check(N.lib().tbg_bias_act_bwd_f32(N.ptr(dout), N.ptr(out_act), N.ptr(dx), N.ptr(dpre), N.ptr(pdb), N.ptr(pdn),
+                                         N.ptr(pdy), B, M, HW, C.byref(epi), N.stream()), "tbg_bias_act_bwd")
+    return dx, dpre, pdb, pdn, pdy
+
+
+def bias_act_fwd_raw(x, epi: N.Epilogue):
+    B, M = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * M)
+    y = torch.empty_like(x)
+    N.check(N.lib().tbg_bias_act_fwd_f32(N.ptr(x), N.ptr(y), B, M, HW, C.byref(epi), N.stream()), "tbg_bias_act_fwd")
+    return y
+
+
+def demod_coefs_raw(s: torch.Tensor, w: torch.Tensor, coef: float):
+    KH, KW, I, O = w.shape
+    B = s.shape[0]
+    wsq = torch.empty((I, O), device=w.device, dtype=torch.float32)
+    d = torch.empty((B, O), device=w.device, dtype=torch.float32)
+    N.check(N.lib().tbg_demod_coefs_f32(N.ptr(s), N.ptr(w), N.ptr(wsq), N.ptr(d), B, KH * KW, I, O, coef, N.stream()),
+            "tbg_demod_coefs")
+    return d, wsq
+
+
+# ----------------------------------------------------------------------------------------
+# composable primitives (gradients of any order)
+# ----------------------------------------------------------------------------------------
+class _UpFirDn2D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, up, down, pad):
+        ctx.save_for_backward(k)
+        ctx.geom = (x.shape[2], x.shape[3], up, down, pad)
+        return upfirdn2d_raw(x.contiguous(), k, up, down, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (k,) = ctx.saved_tensors
+        inH, inW, up, down, pad = ctx.geom
+        kH, kW = k.shape
+        outW = (inW * up[0] + pad[0] + pad[1] - kW) // down[0] + 1
+        outH = (inH * up[1] + pad[2] + pad[3] - kH) // down[1] + 1
+        # upfirdn_2d_v2.py:204-209
+        gpad = (kW - pad[0] - 1, inW * up[0] - outW * down[0] + pad[0] - up[0] + 1,
+                kH - pad[2] - 1, inH * up[1] - outH * down[1] + pad[2] - up[1] + 1)
+        kf = torch.flip(k, (0, 1)).contiguous()
+        return _UpFirDn2D.apply(dy, kf, down, up, gpad), None, None, None, None
+
+
+def upfirdn2d(x, k, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0)):
+    """The reference op on NCHW input; differentiable to any order."""
+    return _UpFirDn2D.apply(x, k, tuple(up), tuple(down), tuple(pad))
+
+
+class _Geom:
+    """Geometry of y = conv(x, w): stride, top/left pad, filter, spatial sizes of x and y."""
+    __slots__ = ("stride", "pad", "KH", "KW", "xhw", "yhw")
+
+    def __init__(self, stride, pad, KH, KW, xhw, yhw):
+        self.stride, self.pad, self.KH, self.KW, self.xhw, self.yhw = stride, pad, KH, KW, xhw, yhw
+
+
+def _fwd_launch(x, w, g: _Geom, alpha=1.0):
+    O = w.shape[3]
+    ldw = O
+    if O % 4:  # 16-byte filter rows (toRGB: O = 3)
+        ldw = (O + 3) // 4 * 4
+        w = torch.nn.functional.pad(w, (0, ldw - O)).contiguous()
+    return conv2d_raw(x, w, O, g.KH, g.KW, g.yhw, g.stride, g.pad, epi=N.epilogue(alpha=alpha), ldw=ldw)
+
+
+def _bwd_data_launch(dy, w, g: _Geom, alpha=1.0, in_scale=None, epi=None, dot=None):
+    """dx[i,Y,X] = sum dy[o,oy,ox] w[kh,kw,i,o] over oy*s - p + kh = Y."""
+    I = w.shape[2]
+    epi = epi if epi is not None else N.epilogue(alpha=alpha)
+    if g.stride == (1, 1):
+        wt, ldo = weight_transpose_raw(w, flip=True)
+        return conv2d_raw(dy, wt, I, g.KH, g.KW, g.xhw, (1, 1), (g.KH - 1 - g.pad[0], g.KW - 1 - g.pad[1]),
+                          in_scale=in_scale, epi=epi, ldw=ldo, dot=dot)
+    assert g.pad == (0, 0), "strided convolutions on this path are VALID"
+    wt, ldo = weight_transpose_raw(w, flip=False)
+    return conv2d_raw(dy, wt, I, g.KH, g.KW, g.xhw, g.stride, (0, 0), transposed=True, in_scale=in_scale, epi=epi,
+                      ldw=ldo, dot=dot)
+
+
+def _bwd_weight_launch(x, dy, g: _Geom, I, O, alpha=1.0, x_scale=None, dy_scale=None):
+    dw = torch.zeros((g.KH, g.KW, I, O), device=x.device, dtype=torch.float32)
+    wgrad_raw(dy, x, g.KH, g.KW, g.stride, g.pad, dw, I * O, O, 1, alpha, s_scale=dy_scale, l_scale=x_scale)
+    return dw
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, g):
+        ctx.save_for_backward(x, w)
+        ctx.g = g
+        return _fwd_launch(x.contiguous(), w.contiguous(), g)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = _Conv2dBwdData.apply(dy, w, ctx.g) if ctx.needs_input_grad[0] else None
+        dw = _Conv2dBwdWeight.apply(x, dy, ctx.g) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class _Conv2dBwdData(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, w, g):
+        ctx.save_for_backward(dy, w)
+        ctx.g = g
+        return _bwd_data_launch(dy.contiguous(), w.contiguous(), g)
+
+    @staticmethod
+    def backward(ctx, gdx):
+        dy, w = ctx.saved_tensors
+        g_dy = _Conv2d.apply(gdx, w, ctx.g) if ctx.needs_input_grad[0] else None
+        g_w = _Conv2dBwdWeight.apply(gdx, dy, ctx.g) if ctx.needs_input_grad[1] else None
+        return g_dy, g_w, None
+
+
+class _Conv2dBwdWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dy, g):
+        ctx.save_for_backward(x, dy)
+        ctx.g = g
+        return _bwd_weight_launch(x.contiguous(), dy.contiguous(), g, x.shape[1], dy.shape[1])
+
+    @staticmethod
+    def backward(ctx, gw):
+        x, dy = ctx.saved_tensors
+        gw = gw.contiguous()
+        g_x = _Conv2dBwdData.apply(dy, gw, ctx.g) if ctx.needs_input_grad[0] else None
+        g_dy = _Conv2d.apply(x, gw, ctx.g) if ctx.needs_input_grad[1] else None
+        return g_x, g_dy, None
+
+
+def conv2d(x, w, stride=(1, 1), pad=(0, 0)):
+    """y[b,o] = sum x[b,i, oy*s-p+kh, ox*s-p+kw] w[kh,kw,i,o]  (HWIO filter)."""
+    KH, KW = w.shape[0], w.shape[1]
+    H, W = x.shape[2], x.shape[3]
+    yhw = ((H + 2 * pad[0] - KH) // stride[0] + 1, (W + 2 * pad[1] - KW) // stride[1] + 1)
+    if stride != (1, 1):
+        assert pad == (0, 0)
+    return _Conv2d.apply(x, w, _Geom(tuple(stride), tuple(pad), KH, KW, (H, W), yhw))
+
+
+def conv_transpose2d_s2(x, wt):
+    """y[b,o,2a+kh,2b'+kw] += x[b,i,a,b'] wt[kh,kw,i,o]: the data gradient of a stride-2 VALID conv whose
+    'input channels' are o -- expressed with the same primitive so it stays differentiable."""
+    KH, KW = wt.shape[0], wt.shape[1]
+    H, W = x.shape[2], x.shape[3]
+    yhw = ((H - 1) * 2 + KH, (W - 1) * 2 + KW)
+    g = _Geom((2, 2), (0, 0), KH, KW, yhw, (H, W))
+    return _Conv2dBwdData.apply(x, wt.transpose(2, 3).contiguous(), g)
+
+
+# ----------------------------------------------------------------------------------------
+# fused first-order layers
+# ----------------------------------------------------------------------------------------
+def _lrelu_epi(**kw):
+    return N.epilogue(act=ACT_LRELU, slope=0.2, gain=SQRT2, **kw)
+
+
+class _ModConvFused(torch.autograd.Function):
+    """out = lrelu(d * coef*conv(s*x, w) + noise*strength + b) * sqrt2   (3x3, SAME).
+    modulated_conv2d.py:66-122 (activation-scaling form :94-96,:119-121) + noise.py + bias_act.py."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, d, noise, strength, b):
+        KH, KW, I, O = w.shape
+        coef = 1.0 / math.sqrt(KH * KW * I)
+        x = x.contiguous()
+        epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=coef)
+        out = conv2d_raw(x, w, O, KH, KW, (x.shape[2], x.shape[3]), (1, 1), (KH // 2, KW // 2), in_scale=s, epi=epi)
+        ctx.save_for_backward(x, w, s, d, noise, strength, b, out)
+        ctx.coef = coef
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x, w, s, d, noise, strength, b, out = ctx.saved_tensors
+        KH, KW, I, O = w.shape
+        coef = ctx.coef
+        epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
+        _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
+        db = pdb.sum(dim=(0, 2))
+        dstrength = pdn.sum()
+        dd = pdy.sum(dim=2) / d
+        g = _Geom((1, 1), (KH // 2, KW // 2), KH, KW, (x.shape[2], x.shape[3]), (out.shape[2], out.shape[3]))
+        ds = torch.zeros_like(s)
+        dx = _bwd_data_launch(dpre, w, g, in_scale=d, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds))
+        dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef, x_scale=s, dy_scale=d)
+        return dx, dw, ds, dd, None, dstrength, db
+
+
+class _ModConvUpFused(torch.autograd.Function):
+    """out = lrelu(d * FIR(coef*convT_s2(s*x, flip w)) + noise*strength + b) * sqrt2.
+    upfirdn_2d_v2.py:65-103 (upsample_conv_2d) + the same epilogue, the FIR pass carries the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, d, noise, strength, b):
+        KH, KW, I, O = w.shape
+        coef = 1.0 / math.sqrt(KH * KW * I)
+        x = x.contiguous()
+        H, W = x.shape[2], x.shape[3]
+        y_up = conv2d_raw(x, w, O, KH, KW, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, flip=True,
+                          in_scale=s, epi=N.epilogue(alpha=coef))
+        k = fir_kernel(x.device, gain=4.0)
+        epi = _lrelu_epi(out_scale=d.reshape(-1), bias=b, noise=noise, strength=strength, alpha=1.0)
+        out = upfirdn2d_raw(y_up, k, pad=(1, 1, 1, 1), epi=epi)
+        ctx.save_for_backward(x, w, s, d, noise, strength, b, out)
+        ctx.coef = coef
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x, w, s, d, noise, strength, b, out = ctx.saved_tensors
+        KH, KW, I, O = w.shape
+        coef = ctx.coef
+        H, W = x.shape[2], x.shape[3]
+        epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
+        _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
+        db = pdb.sum(dim=(0, 2))
+        dstrength = pdn.sum()
+        dd = pdy.sum(dim=2) / d
+        k = fir_kernel(x.device, gain=4.0)  # symmetric: flipped == itself
+        dy_up = upfirdn2d_raw(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))  # [B,O,2H+1,2W+1]
+        wt, ldo = weight_transpose_raw(w, flip=True)
+        ds = torch.zeros_like(s)
+        dx = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0), ldw=ldo,
+                        epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds))
+        dw = torch.zeros_like(w)
+        T = KH * KW
+        # dW_t[t][i][o] = sum x*s . dy_up shifted;  w = flip(w_t)  -> write tap t at T-1-t
+        wgrad_raw(x, dy_up, KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O)
+        return dx, dw, ds, dd, None, dstrength, db
+
+
+class _ToRGBFused(torch.autograd.Function):
+    """y = coef*conv1x1(s*x, w) + b (+ skip).  to_rgb.py:28-33 (modconv without demod) and the
+    ``y = upsample(y) + torgb`` add of synthesis_block.py:152-153."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, b, skip):
+        _, _, I, O = w.shape
+        coef = 1.0 / math.sqrt(I)
+        x = x.contiguous()
+        wp = torch.zeros((1, I, 4), device=w.device, dtype=torch.float32)
+        wp[0, :, :O] = w.reshape(I, O)
+        epi = N.epilogue(alpha=coef, bias=b, residual=skip, res_scale=1.0)
+        y = conv2d_raw(x, wp, O, 1, 1, (x.shape[2], x.shape[3]), in_scale=s, epi=epi, ldw=4, allow_split=False)
+        ctx.save_for_backward(x, w, s)
+        ctx.has_skip = skip is not None
+        ctx.coef = coef
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w, s = ctx.saved_tensors
+        _, _, I, O = w.shape
+        dy = dy.contiguous()
+        db = dy.sum(dim=(0, 2, 3))
+        wt, ldo = weight_transpose_raw(w, flip=False)  # [1][O][I]
+        ds = torch.zeros_like(s)
+        dx = conv2d_raw(dy, wt, I, 1, 1, (x.shape[2], x.shape[3]), ldw=ldo, allow_split=False,
+                        epi=N.epilogue(alpha=ctx.coef, out_scale=s), dot=(x, ds))
+        dw = torch.zeros_like(w)
+        wgrad_raw(dy, x, 1, 1, (1, 1), (0, 0), dw, I * O, O, 1, ctx.coef, l_scale=s)
+        return dx, dw, ds, db, (dy if ctx.has_skip else None)
+
+
+class _ConvBiasActFused(torch.autograd.Function):
+    """out = act(coef*conv(x, w) + b) * gain  (optionally (.. + residual)*res_scale with act linear).
+    conv.py:51-73 + bias_act.py:25-34; discriminator.py:68-84 for the residual form."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, stride, pad, act, res_scale):
+        KH, KW, I, O = w.shape
+        coef = 1.0 / math.sqrt(KH * KW * I)
+        x = x.contiguous()
+        H, W = x.shape[2], x.shape[3]
+        yhw = ((H + 2 * pad[0] - KH) // stride[0] + 1, (W + 2 * pad[1] - KW) // stride[1] + 1)
+        epi = N.epilogue(alpha=coef, bias=b, act=act, residual=residual, res_scale=res_scale)
+        out = conv2d_raw(x, w, O, KH, KW, yhw, stride, pad, epi=epi)
+        ctx.save_for_backward(x, w, b, out if act == ACT_LRELU else None)
+        ctx.cfgv = (stride, pad, act, res_scale, coef, residual is not None, yhw)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x, w, b, out = ctx.saved_tensors
+        stride, pad, act, res_scale, coef, has_res, yhw = ctx.cfgv
+        KH, KW, I, O = w.shape
+        dout = dout.contiguous()
+        dres = None
+        if act == ACT_LRELU:
+            assert not has_res
+            _, dpre, pdb, _, _ = bias_act_bwd_raw(dout, out, _lrelu_epi(bias=b), want_db=b is not None)
+            db = pdb.sum(dim=(0, 2)) if b is not None else None
+        else:
+            dpre = dout * res_scale if has_res else dout
+            dres = dpre if has_res else None
+            db = dpre.sum(dim=(0, 2, 3)) if b is not None else None
+        g = _Geom(stride, pad, KH, KW, (x.shape[2], x.shape[3]), yhw)
+        dx = None
+        if ctx.needs_input_grad[0] and not (FLAGS.skip_image_grad and I == 3):
+            dx = _bwd_data_launch(dpre, w, g, alpha=coef)
+        dw = None
+        if not FLAGS.skip_d_wgrad:
+            dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef)
+        else:
+            db = None
+        return dx, dw, db, dres, None, None, None, None
+
+
+def modconv_fused(x, w, s, d, noise, strength, b):
+    return _ModConvFused.apply(x, w, s, d, noise, strength, b)
+
+
+def modconv_up_fused(x, w, s, d, noise, strength, b):
+    return _ModConvUpFused.apply(x, w, s, d, noise, strength, b)
+
+
+def torgb_fused(x, w, s, b, skip=None):
+    return _ToRGBFused.apply(x, w, s, b, skip)
+
+
+def conv_bias_act_fused(x, w, b, stride=(1, 1), pad=(0, 0), act=ACT_LRELU, residual=None, res_scale=1.0):
+    return _ConvBiasActFused.apply(x, w, b, residual, tuple(stride), tuple(pad), act, res_scale)
+
+
+class _DemodCoefs(torch.autograd.Function):
+    """d[b,o] = rsqrt(sum_i s^2 wsq + 1e-8), wsq = coef^2 sum_t w^2  (modulated_conv2d.py:78-82)."""
+
+    @staticmethod
+    def forward(ctx, s, w):
+        KH, KW, I, O = w.shape
+        coef = 1.0 / math.sqrt(KH * KW * I)
+        d, wsq = demod_coefs_raw(s.contiguous(), w.contiguous(), coef)
+        ctx.save_for_backward(s, w, wsq, d)
+        ctx.coef = coef
+        return d
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dd):
+        s, w, wsq, d = ctx.saved_tensors
+        t = dd * d * d * d  # [B,O];  dq = -1/2 t
+        ds = -s * (t @ wsq.t())
+        dwsq = -0.5 * (s.square().t() @ t)  # [I,O]
+        dw = (2.0 * ctx.coef * ctx.coef) * w * dwsq[None, None]
+        return ds, dw
+
+
+def demod_coefs(s, w):
+    return _DemodCoefs.apply(s, w)
+
+
+# ----------------------------------------------------------------------------------------
+# optimiser / EMA over flat buffers
+# ----------------------------------------------------------------------------------------
+def adam_tf_(theta, m, v, g, step, lr, beta1, beta2, eps):
+    N.check(N.lib().tbg_adam_tf_f32(N.ptr(theta), N.ptr(m), N.ptr(v), N.ptr(g), theta.numel(), lr, beta1, beta2, eps,
+                                    N.ptr(step), N.stream()), "tbg_adam_tf")
+
+
+def ema_lerp_(dst, src, beta):
+    N.check(N.lib().tbg_ema_lerp_f32(N.ptr(dst), N.ptr(src), dst.numel(), beta, N.stream()), "tbg_ema_lerp")

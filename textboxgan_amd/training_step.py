@@ -1,0 +1,220 @@
+"""One optimisation step of TextBoxGAN on MI355X -- drop-in for the reference's ``TrainingStep``
+(training_step.py:14-402) with the same constructor / ``dist_train_step`` signature and return
+structure, plus ``build_trainer_state`` (the wiring of train.py:25-108).
+
+Per step (training_step.py:138-222): G forward, mask, D(fake), D(real), OCR; three losses;
+three gradient sets taken at the PRE-update weights; three Adam updates in the reference's
+order (g, ocr, d).  Lazy regularisers: path length every ``g_reg_interval`` steps on B//2
+samples, R1 every ``d_reg_interval`` (both need second-order gradients -> composable mode).
+
+Data parallel = one process per GPU (torch.distributed / RCCL): losses are pre-divided by the
+GLOBAL batch, so the exchange is a plain SUM all-reduce of the three flat gradient buffers,
+issued asynchronously as soon as each backward pass has produced its buffer so it overlaps
+the following backward pass (the reference hides this inside MirroredStrategy's
+apply_gradients, training_step.py:233-235).  pl_mean / w_avg stay rank-local
+(ONLY_FIRST_REPLICA, train.py:40-46).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import ops
+from .config import Config, cfg as default_cfg
+from .models import Discriminator, Generator, mask_text_box
+from .optim import AdamTF, flatten_generator, flatten_module, write_grads
+
+
+def generator_loss(fake_scores, batch_size):
+    """models/losses/gan_losses.py:8-10."""
+    return F.softplus(-fake_scores).sum() / batch_size
+
+
+def discriminator_loss(fake_scores, real_scores, batch_size):
+    """models/losses/gan_losses.py:13-16."""
+    return (F.softplus(fake_scores) + F.softplus(-real_scores)).sum() / batch_size
+
+
+def softmax_cross_entropy_loss(logits, labels, batch_size):
+    """models/losses/ocr_losses.py:8-11."""
+    ce = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1).long(), reduction="none")
+    return ce.sum() / batch_size
+
+
+def mean_squared_loss(y_a, y_b, batch_size):
+    """models/losses/ocr_losses.py:14-20."""
+    return (y_a - y_b).square().mean(dim=-1).sum() / batch_size
+
+
+class TrainingStep:
+    def __init__(self, generator: Generator, discriminator: Discriminator, aster_ocr, g_optimizer: AdamTF,
+                 ocr_optimizer: AdamTF, d_optimizer: AdamTF, g_reg_interval: int, d_reg_interval: int,
+                 pl_mean: torch.Tensor, cfg: Config = default_cfg, process_group=None):
+        self.generator, self.discriminator, self.aster_ocr = generator, discriminator, aster_ocr
+        self.g_optimizer, self.ocr_optimizer, self.d_optimizer = g_optimizer, ocr_optimizer, d_optimizer
+        self.g_reg_interval, self.d_reg_interval = g_reg_interval, d_reg_interval
+        self.cfg = cfg
+        self.batch_size = cfg.batch_size
+        self.batch_size_per_gpu = cfg.batch_size_per_gpu
+        self.pl_mean = pl_mean
+        self.pl_minibatch_shrink = 2 if self.batch_size_per_gpu // 2 >= 1 else self.batch_size_per_gpu
+        self.pl_decay = 0.01
+        self.r1_gamma = 10.0
+        self.pl_noise_scaler = 1.0 / math.sqrt(float(cfg.image_width) * float(cfg.char_height))
+        self.pg = process_group
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+
+        gf, df = generator._flat, discriminator._flat
+        self.g_range = gf.range_of(("latent_encoder.", "synthesis."))
+        self.o_range = gf.range_of(("synthesis.", "word_encoder."))
+        self.g_params = gf.select(("latent_encoder.", "synthesis."))
+        self.o_params = gf.select(("synthesis.", "word_encoder."))
+        self.d_params = list(df.params)
+        self.g_grad, self.g_views = gf.make_grad_buffer(*self.g_range)
+        self.o_grad, self.o_views = gf.make_grad_buffer(*self.o_range)
+        self.d_grad, self.d_views = df.make_grad_buffer(0, df.total)
+
+    # ------------------------------------------------------------------------------------
+    def dist_train_step(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg: bool, do_pl_reg: bool,
+                        ocr_loss_weight: float, rand: Optional[dict] = None):
+        """training_step.py:57-136.  Inputs are this rank's shard of the global batch."""
+        gen_losses, disc_losses, ocr_loss = self._train_step(real_images, ocr_images, input_words, ocr_labels,
+                                                             do_r1_reg, do_pl_reg, ocr_loss_weight, rand)
+        if self.distributed:  # strategy.reduce(SUM) of the 7 scalars, one collective
+            packed = torch.stack([*gen_losses, *disc_losses, ocr_loss])
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.pg)
+            gen_losses, disc_losses, ocr_loss = tuple(packed[0:3]), tuple(packed[3:6]), packed[6]
+        return gen_losses, disc_losses, ocr_loss
+
+    def _all_reduce_async(self, buf):
+        if not self.distributed:
+            return None
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _train_step(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg, do_pl_reg, ocr_loss_weight,
+                    rand):
+        cfg, G, D = self.cfg, self.generator, self.discriminator
+        dev = real_images.device
+        zero = torch.zeros((), device=dev)
+        rand = rand or {}
+        z = rand["z"] if "z" in rand else torch.randn(self.batch_size_per_gpu, cfg.z_dim, device=dev)
+
+        fake_images = G((input_words, z), training=True, rand=rand)
+        fake_images = mask_text_box(fake_images, input_words, cfg.char_width)
+
+        fake_scores = D(fake_images)
+        g_loss = generator_loss(fake_scores, self.batch_size)
+        pl_penalty = self._path_length_reg(input_words, rand) if do_pl_reg else zero
+        reg_g_loss = g_loss + pl_penalty
+
+        if do_r1_reg:
+            real_scores, r1_penalty = self._r1_reg(real_images)
+        else:
+            real_scores = D(real_images)
+            r1_penalty = zero
+        d_loss = discriminator_loss(fake_scores, real_scores, self.batch_size)
+        reg_d_loss = d_loss + r1_penalty
+
+        ocr_loss = self._get_ocr_loss(fake_images, ocr_labels, ocr_images)
+        ocr_loss_w = ocr_loss_weight * ocr_loss
+
+        # --- three backward passes at the pre-update weights (training_step.py:194-213)
+        ops.FLAGS.skip_d_wgrad = True
+        try:
+            grads = torch.autograd.grad(reg_g_loss, self.g_params, retain_graph=True, allow_unused=True)
+        finally:
+            ops.FLAGS.skip_d_wgrad = False
+        write_grads(self.g_views, grads)
+        h_g = self._all_reduce_async(self.g_grad)
+
+        grads = torch.autograd.grad(ocr_loss_w, self.o_params, retain_graph=True, allow_unused=True)
+        write_grads(self.o_views, grads)
+        h_o = self._all_reduce_async(self.o_grad)
+
+        ops.FLAGS.skip_image_grad = True
+        try:
+            grads = torch.autograd.grad(reg_d_loss, self.d_params, allow_unused=True)
+        finally:
+            ops.FLAGS.skip_image_grad = False
+        write_grads(self.d_views, grads)
+        h_d = self._all_reduce_async(self.d_grad)
+
+        # --- three Adam updates in the reference's order
+        if h_g is not None:
+            h_g.wait()
+        self.g_optimizer.apply_gradients(self.g_grad)
+        if h_o is not None:
+            h_o.wait()
+        self.ocr_optimizer.apply_gradients(self.o_grad)
+        if h_d is not None:
+            h_d.wait()
+        self.d_optimizer.apply_gradients(self.d_grad)
+
+        return ((reg_g_loss.detach(), g_loss.detach(), pl_penalty.detach()),
+                (reg_d_loss.detach(), d_loss.detach(), r1_penalty.detach()),
+                (ocr_loss_w / ocr_loss_weight).detach())
+
+    # ------------------------------------------------------------------------------------
+    def _path_length_reg(self, input_words, rand):
+        """training_step.py:300-347."""
+        cfg = self.cfg
+        pl_mb = max(1, self.batch_size_per_gpu // self.pl_minibatch_shrink)
+        dev = input_words.device
+        pl_z = rand["pl_z"] if "pl_z" in rand else torch.randn(pl_mb, cfg.z_dim, device=dev)
+        img, style = self.generator((input_words[:pl_mb], pl_z), batch_size=pl_mb, ret_style=True, training=False,
+                                    rand=rand, noises_key="pl_noises", mode="composable")
+        noise = rand["pl_noise"] if "pl_noise" in rand else torch.randn_like(img)
+        (g,) = torch.autograd.grad((img * (noise * self.pl_noise_scaler)).sum(), style, create_graph=True)
+        lengths = g.square().sum(dim=2).mean(dim=1).sqrt()
+        with torch.no_grad():  # assigned BEFORE use, read back as a constant (:336-342)
+            self.pl_mean.copy_(self.pl_mean + self.pl_decay * (lengths.mean() - self.pl_mean))
+        pen = (lengths - self.pl_mean.detach()).square() * self.pl_minibatch_shrink * self.g_reg_interval
+        return pen.sum() / self.batch_size
+
+    def _r1_reg(self, real_images):
+        """training_step.py:349-373."""
+        real = real_images.detach().clone().requires_grad_(True)
+        real_scores = self.discriminator(real, mode="composable")
+        (g,) = torch.autograd.grad(real_scores.sum(), real, create_graph=True)
+        pen = g.square().sum(dim=(1, 2, 3)) * (0.5 * self.r1_gamma) * self.d_reg_interval
+        return real_scores, pen.sum() / self.batch_size
+
+    def _get_ocr_loss(self, fake_images, ocr_labels, ocr_images):
+        """training_step.py:375-402."""
+        inp = self.aster_ocr.convert_inputs(fake_images, ocr_labels, blank_label=1)
+        logits = self.aster_ocr(inp)
+        if self.cfg.ocr_loss_type == "mse":
+            return mean_squared_loss(self.aster_ocr(ocr_images), logits, self.batch_size)
+        return softmax_cross_entropy_loss(logits, ocr_labels, self.batch_size)
+
+
+def build_trainer_state(cfg: Config, device, aster_ocr=None, seed: int = 0, process_group=None):
+    """The wiring of reference train.py:25-108 / model_loader.py:13-20: models (g_clone starts as a
+    copy of G), lazy-reg-rescaled optimiser settings, three Adam states, pl_mean, TrainingStep."""
+    from .aster import AsterInferer
+    torch.manual_seed(seed)
+    G, D, g_clone = Generator(cfg), Discriminator(cfg), Generator(cfg)
+    g_clone.load_state_dict(G.state_dict())
+    gf = flatten_generator(G, device)
+    flatten_generator(g_clone, device)
+    df = flatten_module(D, device)
+    g_opt, d_opt = cfg.g_opt.lazy_reg_rescaled(), cfg.d_opt.lazy_reg_rescaled()
+    gb, ge = gf.range_of(("latent_encoder.", "synthesis."))
+    ob, oe = gf.range_of(("synthesis.", "word_encoder."))
+    g_optimizer = AdamTF(gf.flat[gb:ge], g_opt)
+    ocr_optimizer = AdamTF(gf.flat[ob:oe], g_opt)
+    d_optimizer = AdamTF(df.flat, d_opt)
+    pl_mean = torch.zeros((), device=device)
+    if aster_ocr is None:
+        aster_ocr = AsterInferer(char_width=cfg.char_width, max_char_number=cfg.max_char_number,
+                                 image_dims=cfg.aster_image_dims)
+    aster_ocr = aster_ocr.to(device)
+    step = TrainingStep(G, D, aster_ocr, g_optimizer, ocr_optimizer, d_optimizer, cfg.g_opt.reg_interval,
+                        cfg.d_opt.reg_interval, pl_mean, cfg, process_group)
+    return dict(generator=G, discriminator=D, g_clone=g_clone, g_optimizer=g_optimizer,
+                ocr_optimizer=ocr_optimizer, d_optimizer=d_optimizer, pl_mean=pl_mean, aster_ocr=aster_ocr,
+                training_step=step)
