@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- text-boxes/s through the full TextBoxGAN training step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one ``TrainingStep.dist_train_step`` (G fwd, mask, D(fake), D(real), frozen OCR,
+three backward passes, three Adam updates; path-length every 8th and R1 every 16th step per
+the reference's config.py:81-94 and the caller protocol of train.py:178-208) + the g_clone EMA,
+on synthetic words / N(0,1) latents / U(-1,1) "real" images already resident in HBM.
+Workload = BASELINE.json configs[1]: per-GPU batch 16, 64x256 boxes, fp32, weak scaling
+(global batch = 16 * N, the reference's rule config.py:141).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     : the dominant kernel (the fp32-MFMA implicit-GEMM convolution), algorithmic
+                 FLOPs of its launches / their HIP-event durations, measured in a separate
+                 instrumented pass over the same step (events on the launch stream).
+  cpu_baseline : the CPU restatement of the same step (oracle/, PyTorch-oneDNN, "port") timed on
+                 this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+CONV_GFLOP_PER_IMAGE = 85.2   # dense-conv work of one non-regularised step
+
+
+def synthetic_batch(cfg, device, seed):
+    """words U{1..69} of length U{1..8}, ASTER labels, U(-1,1) images zero-padded right."""
+    from textboxgan_amd.char_tokens import main_to_aster_labels
+    g = np.random.default_rng(seed)
+    B = cfg.batch_size_per_gpu
+    L = g.integers(1, cfg.max_char_number + 1, size=B)
+    words = np.zeros((B, cfg.max_char_number), dtype=np.int32)
+    for b in range(B):
+        words[b, : L[b]] = g.integers(1, cfg.main_vocab + 1, size=L[b])
+    real = g.uniform(-1, 1, size=(B, 3, cfg.char_height, cfg.image_width)).astype(np.float32)
+    for b in range(B):
+        real[b, :, :, cfg.char_width * L[b]:] = 0.0
+    return dict(real_images=torch.from_numpy(real).to(device), ocr_images=torch.zeros((), device=device),
+                input_words=torch.from_numpy(words).to(device),
+                ocr_labels=torch.from_numpy(main_to_aster_labels(words)).to(device))
+
+
+def bench_init_(state):
+    """non-trivial epilogues: noise_strength 0.1, biases ~ N(0, 0.1)."""
+    g = torch.Generator().manual_seed(4321)
+    with torch.no_grad():
+        for mod in (state["generator"], state["discriminator"]):
+            for n, p in mod.named_parameters():
+                if n.endswith("noise_strength"):
+                    p.fill_(0.1)
+                elif n.endswith(".b") or n.endswith(".bias"):
+                    p.copy_((torch.randn(p.shape, generator=g) * 0.1).to(p.device))
+        state["g_clone"].load_state_dict(state["generator"].state_dict())
+
+
+def run_steps(state, batch, n, ocr_w_late=True):
+    ts = state["training_step"]
+    for _ in range(n):
+        step = ts.g_optimizer.iterations
+        do_r1 = (step + 1) % ts.d_reg_interval == 0
+        do_pl = (step + 1) % ts.g_reg_interval == 0
+        ts.dist_train_step(batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"],
+                           do_r1, do_pl, 1e-4 if ocr_w_late else 1e-8)
+        state["g_clone"].set_as_moving_average_of(state["generator"])
+
+
+def cpu_baseline(batch_size=4, steps=2):
+    """CPU restatement of the reference path (PyTorch/oneDNN), NOT the TF2 reference (TF absent)."""
+    from oracle import ref_model as M
+    from textboxgan_amd.aster import AsterInferer
+    from textboxgan_amd.config import Config
+    cfg = Config(batch_size_per_gpu=batch_size)
+    st = M.make_state(cfg, 0, bench_init=True)
+    batch, rand = M.make_batch(cfg), M.make_rand(cfg, with_pl=False)
+    ocr = AsterInferer()
+    fn = lambda x: ocr(x)
+    args = (batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"], False, False, 1e-4)
+    M.training_step(st, cfg, *args, rand, fn)  # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        M.training_step(st, cfg, *args, rand, fn)
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch_size * steps / dt, 3), unit="text-boxes/s", cores=torch.get_num_threads(),
+                kind="port",
+                sample=f"{steps} non-regularised full-size steps (64x256, full channel widths) at batch {batch_size} "
+                       f"after 1 warm-up step; oracle/ref_model.py training_step (torch-CPU fp32, oneDNN); "
+                       f"{dt / steps:.2f} s/step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from textboxgan_amd import ops
+    from textboxgan_amd.config import Config
+    from textboxgan_amd.training_step import build_trainer_state
+
+    cfg = Config(batch_size_per_gpu=args.batch, num_replicas=world)
+    state = build_trainer_state(cfg, device, seed=0)  # identical replicas on every rank
+    bench_init_(state)
+    batch = synthetic_batch(cfg, device, 1234 + rank)
+
+    run_steps(state, batch, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(state, batch, args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        value = args.batch * world * args.steps / dt
+        out = {
+            "metric": "text-boxes/sec (G+D+OCR training_step)", "value": round(value, 2), "unit": "text-boxes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "training_step G+D+OCR, bs=16/GPU, 64x256 boxes, max_char_number=8, fp32 "
+                                   "(BASELINE configs[1]); PL every 8th / R1 every 16th step (config.py:81-94); "
+                                   "g_clone EMA included; OCR = ASTER-shaped frozen net (synthetic weights)",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "conv_gflop_per_image_nonreg_step": CONV_GFLOP_PER_IMAGE},
+            "conv_tflops_vs_step_time": round(value * CONV_GFLOP_PER_IMAGE / 1e3 / world, 2),
+        }
+
+    # ---- roofline pass: same step, every conv launch bracketed by HIP events on its stream
+    if rank == 0 and not args.no_roofline:
+        ops.PROFILE.enable()
+        ts = state["training_step"]
+        for _ in range(2):
+            ts.dist_train_step(batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"],
+                               False, False, 1e-4) if world == 1 else None
+        torch.cuda.synchronize()
+        recs = ops.PROFILE.collect()
+        ops.PROFILE.disable()
+        if recs:
+            dom = max(recs.items(), key=lambda kv: kv[1]["ms"])
+            name, r = dom
+            achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
+                               "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "launches": r["n"], "avg_launch_us": round(1e3 * r["ms"] / r["n"], 2),
+                               "gflop_per_launch": round(r["flops"] / r["n"] / 1e9, 3),
+                               "all_kernels": {k: {"n": v["n"], "ms": round(v["ms"], 3),
+                                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                               for k, v in recs.items()}}
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

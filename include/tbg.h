@@ -111,10 +111,12 @@ typedef struct tbg_conv_desc {
 int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                    const float *in_scale, const tbg_epilogue *epi, void *stream);
 
-/* Weight gradient:  dW[t*st_t + cl*st_l + cs*st_s] += alpha * sum_{b,u,v}
+/* Weight gradient:  dW[t*st_t + cl*st_l + cs*st_s] = alpha * sum_{b,u,v}
  *     S[b,cs,u,v]*s_scale[b,cs] * L[b,cl,u*sy-py+kh,v*sx-px+kw]*l_scale[b,cl]
- * S is the tensor on the (small) output grid, L the tensor on the input grid; dW must be
- * PRE-ZEROED (blocks accumulate with atomics).  Gradient of both forms of tbg_conv2d_f32. */
+ * S is the tensor on the (small) output grid, L the tensor on the input grid.  Every element of dW
+ * in range is OVERWRITTEN.  The pixel reduction is split over blocks that write partial tiles to
+ * `workspace` (caller-provided, tbg_conv2d_wgrad_workspace_bytes(d) bytes), which a second kernel
+ * sums -- no atomics, deterministic.  Gradient of both forms of tbg_conv2d_f32. */
 typedef struct tbg_wgrad_desc {
   int B, CS, CL;
   int Hs, Ws, Hl, Wl;
@@ -125,8 +127,10 @@ typedef struct tbg_wgrad_desc {
   float alpha;
 } tbg_wgrad_desc;
 
+long long tbg_conv2d_wgrad_workspace_bytes(const tbg_wgrad_desc *d);
 int tbg_conv2d_wgrad_f32(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
-                         const float *s_scale, const float *l_scale, void *stream);
+                         const float *s_scale, const float *l_scale, float *workspace,
+                         long long workspace_bytes, void *stream);
 
 /* dst[t'][o][ldo: i] = src[t][i][o]  with t' = flip ? T-1-t : t ; rows padded to ldo (zero). Turns
  * the HWIO parameter into the GEMM layout the data-gradient convolutions need. */

@@ -376,7 +376,7 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
 
 struct WgradP {
   const float *S, *L, *s_scale, *l_scale;
-  float *dW;
+  float *dW, *ws;
   int B, CS, CL, Hs, Ws, Hl, Wl, KW, sy, sx, py, px;
   int st_t, st_l, st_s;
   float alpha;
@@ -502,20 +502,43 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     }
   }
 
+  // partial tile -> workspace, fully coalesced: [block][t][r16][wave][lane]
+  const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float *wsp = p.ws + blk * (size_t)(NT * 16 * 256);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r16 = 0; r16 < 16; ++r16) wsp[(t * 16 + r16) * 256 + tid] = acc[t][r16];
+}
+
+// sum the ksplit partial tiles of every output tile and scatter into dW (alpha applied once)
+template <int WGS, int WGL, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradP p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ws_ = wave / WGL, wl = wave - ws_ * WGL;
+  const int cs0 = blockIdx.x * (WGS * 32), cl0 = blockIdx.y * (WGL * 32);
+  const int tr = blockIdx.z;  // (t, r16)
+  const int t = tr >> 4, r16 = tr & 15;
+  const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const size_t per_split = (size_t)gridDim.x * gridDim.y;
+  float a = 0.f;
+  for (int kz = 0; kz < p.ksplit; ++kz)
+    a += p.ws[((size_t)kz * per_split + tile) * (size_t)(NT * 16 * 256) + (size_t)tr * 256 + tid];
   const int cl = cl0 + wl * 32 + (lane & 31);
-  if (cl < p.CL) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r16 = 0; r16 < 16; ++r16) {
-        const int cs = cs0 + ws * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
-        if (cs < p.CS) atomicAdd(p.dW + ((long long)t * p.st_t + (long long)cl * p.st_l + (long long)cs * p.st_s), acc[t][r16] * p.alpha);
-      }
-  }
+  const int cs = cs0 + ws_ * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+  if (cl < p.CL && cs < p.CS)
+    p.dW[(long long)t * p.st_t + (long long)cl * p.st_l + (long long)cs * p.st_s] = a * p.alpha;
+}
+
+static int wgrad_ksplit(int tiles, int nchunks) {
+  int ksplit = ceil_div(512, tiles);  // ~2 resident blocks per CU
+  if (ksplit > nchunks) ksplit = nchunks;
+  if (ksplit < 1) ksplit = 1;
+  return ksplit;
 }
 
 template <int WGS, int WGL, int NT, int PIX>
-static int launch_wgrad(WgradP &p, hipStream_t st) {
+static int launch_wgrad(WgradP &p, hipStream_t st, size_t ws_bytes) {
   constexpr int BS = WGS * 32, BL = WGL * 32;
   const size_t lds = ((size_t)BS * (PIX + 1) + (size_t)BL * p.lplane) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
@@ -524,33 +547,29 @@ static int launch_wgrad(WgradP &p, hipStream_t st) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TBG_EHIP;
   }
-  const int tiles = ceil_div(p.CS, BS) * ceil_div(p.CL, BL);
-  int ksplit = ceil_div(1024, tiles);
-  if (ksplit > p.nchunks) ksplit = p.nchunks;
-  if (ksplit < 1) ksplit = 1;
-  p.ksplit = ksplit;
-  dim3 grid(ceil_div(p.CS, BS), ceil_div(p.CL, BL), ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  const int tx = ceil_div(p.CS, BS), ty = ceil_div(p.CL, BL);
+  p.ksplit = wgrad_ksplit(tx * ty, p.nchunks);
+  if ((size_t)p.ksplit * tx * ty * NT * 16 * 256 * sizeof(float) > ws_bytes) return TBG_EINVAL;
+  hipLaunchKernelGGL(kern, dim3(tx, ty, p.ksplit), dim3(256), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  hipLaunchKernelGGL((conv_wgrad_reduce_kernel<WGS, WGL, NT>), dim3(tx, ty, NT * 16), dim3(256), 0, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
 
-extern "C" int tbg_conv2d_wgrad_f32(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
-                                    const float *s_scale, const float *l_scale, void *stream) {
-  if (!d || !S || !L || !dW) return TBG_EINVAL;
+// geometry shared by the launcher and the workspace query
+static int wgrad_geometry(const tbg_wgrad_desc *d, WgradP &p, int &PIX) {
+  if (!d) return TBG_EINVAL;
   if (d->B < 1 || d->CS < 1 || d->CL < 1 || d->Hs < 1 || d->Ws < 1 || d->Hl < 1 || d->Wl < 1) return TBG_EINVAL;
-  const int NT = d->KH * d->KW;
   if (!((d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 1))) return TBG_EUNSUPPORTED;
   if (d->sy < 1 || d->sy > 2 || d->sx < 1 || d->sx > 2) return TBG_EUNSUPPORTED;
   if ((double)d->B * d->CS * d->Hs * d->Ws > 2147483647.0 || (double)d->B * d->CL * d->Hl * d->Wl > 2147483647.0)
     return TBG_ERANGE;
-  WgradP p;
-  p.S = S; p.L = L; p.s_scale = s_scale; p.l_scale = l_scale; p.dW = dW;
   p.B = d->B; p.CS = d->CS; p.CL = d->CL; p.Hs = d->Hs; p.Ws = d->Ws; p.Hl = d->Hl; p.Wl = d->Wl;
   p.KW = d->KW; p.sy = d->sy; p.sx = d->sx; p.py = d->py; p.px = d->px;
   p.st_t = d->st_t; p.st_l = d->st_l; p.st_s = d->st_s; p.alpha = d->alpha;
   const bool strided = d->sy == 2 || d->sx == 2;
-  const int PIX = strided ? 32 : 64;
+  PIX = strided ? 32 : 64;
   const int TW = pow2ceil(d->Ws) < 32 ? pow2ceil(d->Ws) : 32;
   const int TR = PIX / TW;
   const int THs = pow2ceil(d->Hs) < TR ? pow2ceil(d->Hs) : TR;
@@ -567,13 +586,34 @@ extern "C" int tbg_conv2d_wgrad_f32(const tbg_wgrad_desc *d, const float *S, con
   p.tilesU = ceil_div(d->Hs, THs);
   p.tilesV = ceil_div(d->Ws, TW);
   p.nchunks = p.tilesU * p.tilesV * p.nBG;
+  return TBG_OK;
+}
+
+extern "C" long long tbg_conv2d_wgrad_workspace_bytes(const tbg_wgrad_desc *d) {
+  WgradP p;
+  int PIX;
+  if (wgrad_geometry(d, p, PIX) != TBG_OK) return -1;
+  const int tiles = ceil_div(p.CS, 64) * ceil_div(p.CL, 64);
+  const int NT = d->KH * d->KW;
+  return (long long)wgrad_ksplit(tiles, p.nchunks) * tiles * NT * 16 * 256 * (long long)sizeof(float);
+}
+
+extern "C" int tbg_conv2d_wgrad_f32(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
+                                    const float *s_scale, const float *l_scale, float *workspace,
+                                    long long workspace_bytes, void *stream) {
+  if (!d || !S || !L || !dW || !workspace) return TBG_EINVAL;
+  WgradP p;
+  int PIX;
+  const int rc = wgrad_geometry(d, p, PIX);
+  if (rc != TBG_OK) return rc;
+  p.S = S; p.L = L; p.s_scale = s_scale; p.l_scale = l_scale; p.dW = dW; p.ws = workspace;
+  const int NT = d->KH * d->KW;
   hipStream_t st = tbg_stream(stream);
-  const bool wideS = d->CS >= 128 && d->CL <= 32;
-  (void)wideS;
+  const size_t wsb = workspace_bytes < 0 ? 0 : (size_t)workspace_bytes;
   if (NT == 9) {
-    if (strided) return launch_wgrad<2, 2, 9, 32>(p, st);
-    return launch_wgrad<2, 2, 9, 64>(p, st);
+    if (PIX == 32) return launch_wgrad<2, 2, 9, 32>(p, st, wsb);
+    return launch_wgrad<2, 2, 9, 64>(p, st, wsb);
   }
-  if (strided) return launch_wgrad<2, 2, 1, 32>(p, st);
-  return launch_wgrad<2, 2, 1, 64>(p, st);
+  if (PIX == 32) return launch_wgrad<2, 2, 1, 32>(p, st, wsb);
+  return launch_wgrad<2, 2, 1, 64>(p, st, wsb);
 }

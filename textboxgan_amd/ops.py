@@ -36,6 +36,51 @@ class _Flags:
 
 FLAGS = _Flags()
 
+
+class _Profile:
+    """bench.py's roofline pass: bracket every convolution launch with HIP events on the stream the
+    kernel is enqueued on and attribute its ALGORITHMIC FLOPs (2 x MACs of the dense contraction) to
+    the kernel instantiation that ran it.  Off by default (zero overhead)."""
+
+    def __init__(self):
+        self.on = False
+        self.recs = []
+
+    def enable(self):
+        self.on, self.recs = True, []
+
+    def disable(self):
+        self.on = False
+
+    def launch(self, name, flops, fn):
+        if not self.on:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        self.recs.append((name, flops, e0, e1))
+        return rc
+
+    def collect(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in self.recs:
+            r = out.setdefault(name, dict(n=0, ms=0.0, flops=0.0))
+            r["n"] += 1
+            r["ms"] += e0.elapsed_time(e1)
+            r["flops"] += flops
+        self.recs = []
+        return out
+
+
+PROFILE = _Profile()
+
+
+def _fprop_kernel_name(M):
+    cfgs = "1,4,1,2,8" if M <= 32 else ("1,4,2,2,8" if M <= 64 else "2,2,2,2,8")
+    return f"conv_fprop_kernel<{cfgs}>"
+
 # ----------------------------------------------------------------------------------------
 # FIR filters (upfirdn_2d_v2.py:18-25) cached per device
 # ----------------------------------------------------------------------------------------
@@ -103,12 +148,14 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
                    int(flip), ldw, ksplit)
     if epi is None:
         epi = N.epilogue()
+    _flops = 2.0 * B * M * Cc * KH * KW * (Hin * Win if transposed else Hout * Wout)
+    _kname = _fprop_kernel_name(M)
     trivial = not (epi.out_scale or epi.bias or epi.noise or epi.residual or epi.act != ACT_LINEAR or dot is not None)
     if ksplit > 1 and not trivial:
         tmp = torch.zeros((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
         e0 = N.epilogue(alpha=epi.alpha)
-        N.check(N.lib().tbg_conv2d_f32(C.byref(d), N.ptr(x), N.ptr(w), N.ptr(tmp), N.ptr(in_scale), C.byref(e0),
-                                       N.stream()), "tbg_conv2d(split)")
+        N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
+            C.byref(d), N.ptr(x), N.ptr(w), N.ptr(tmp), N.ptr(in_scale), C.byref(e0), N.stream())), "tbg_conv2d(split)")
         if dot is not None:
             dot[1].copy_((tmp * dot[0]).sum(dim=(2, 3)))
         e1 = N.Epilogue.from_buffer_copy(epi)
@@ -122,19 +169,39 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(dot[1])
     alloc = torch.zeros if ksplit > 1 else torch.empty
     y = alloc((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
-    N.check(N.lib().tbg_conv2d_f32(C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi),
-                                   N.stream()), "tbg_conv2d")
+    N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
+        C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream())), "tbg_conv2d")
     return y
+
+
+_WS = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, stream): consumed by the very next launch on that stream."""
+    key = (str(device), N.stream())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((max(nbytes, 1 << 20) + 3) // 4, device=device, dtype=torch.float32)
+        _WS[key] = buf
+    return buf
 
 
 def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, out: torch.Tensor, st_t: int, st_l: int,
               st_s: int, alpha: float, s_scale=None, l_scale=None, out_offset: int = 0):
-    """Accumulates into ``out`` (pre-zeroed by the caller)."""
+    """Overwrites ``out`` (every in-range element written exactly once)."""
     B, CS, Hs, Ws = S.shape
     _, CL, Hl, Wl = L.shape
     d = N.WgradDesc(B, CS, CL, Hs, Ws, Hl, Wl, KH, KW, stride[0], stride[1], pad[0], pad[1], st_t, st_l, st_s, alpha)
-    N.check(N.lib().tbg_conv2d_wgrad_f32(C.byref(d), N.ptr(S), N.ptr(L), N.ptr(out) + 4 * out_offset, N.ptr(s_scale),
-                                         N.ptr(l_scale), N.stream()), "tbg_conv2d_wgrad")
+    nbytes = N.lib().tbg_conv2d_wgrad_workspace_bytes(C.byref(d))
+    if nbytes < 0:
+        raise N.TbgError("tbg_conv2d_wgrad: unsupported geometry")
+    ws = _workspace(S.device, nbytes)
+    _flops = 2.0 * B * CS * CL * Hs * Ws * KH * KW
+    _kname = f"conv_wgrad_kernel<2,2,{KH * KW},{32 if (stride[0] == 2 or stride[1] == 2) else 64}>"
+    N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_wgrad_f32(
+        C.byref(d), N.ptr(S), N.ptr(L), N.ptr(out) + 4 * out_offset, N.ptr(s_scale), N.ptr(l_scale), N.ptr(ws),
+        ws.numel() * 4, N.stream())), "tbg_conv2d_wgrad")
     return out
 
 
@@ -243,7 +310,7 @@ def _bwd_data_launch(dy, w, g: _Geom, alpha=1.0, in_scale=None, epi=None, dot=No
 
 
 def _bwd_weight_launch(x, dy, g: _Geom, I, O, alpha=1.0, x_scale=None, dy_scale=None):
-    dw = torch.zeros((g.KH, g.KW, I, O), device=x.device, dtype=torch.float32)
+    dw = torch.empty((g.KH, g.KW, I, O), device=x.device, dtype=torch.float32)
     wgrad_raw(dy, x, g.KH, g.KW, g.stride, g.pad, dw, I * O, O, 1, alpha, s_scale=dy_scale, l_scale=x_scale)
     return dw
 
@@ -391,7 +458,7 @@ class _ModConvUpFused(torch.autograd.Function):
         ds = torch.zeros_like(s)
         dx = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0), ldw=ldo,
                         epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds))
-        dw = torch.zeros_like(w)
+        dw = torch.empty_like(w)
         T = KH * KW
         # dW_t[t][i][o] = sum x*s . dy_up shifted;  w = flip(w_t)  -> write tap t at T-1-t
         wgrad_raw(x, dy_up, KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O)
@@ -427,7 +494,7 @@ class _ToRGBFused(torch.autograd.Function):
         ds = torch.zeros_like(s)
         dx = conv2d_raw(dy, wt, I, 1, 1, (x.shape[2], x.shape[3]), ldw=ldo, allow_split=False,
                         epi=N.epilogue(alpha=ctx.coef, out_scale=s), dot=(x, ds))
-        dw = torch.zeros_like(w)
+        dw = torch.empty_like(w)
         wgrad_raw(dy, x, 1, 1, (1, 1), (0, 0), dw, I * O, O, 1, ctx.coef, l_scale=s)
         return dx, dw, ds, db, (dy if ctx.has_skip else None)
 
