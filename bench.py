@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="eager launches instead of HIP-graph replay")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,10 +128,13 @@ def main():
     from textboxgan_amd.training_step import build_trainer_state
 
     cfg = Config(batch_size_per_gpu=args.batch, num_replicas=world)
-    state = build_trainer_state(cfg, device, seed=0)  # identical replicas on every rank
+    state = build_trainer_state(cfg, device, seed=0, use_graphs=not args.no_graphs)  # identical replicas on every rank
     bench_init_(state)
     batch = synthetic_batch(cfg, device, 1234 + rank)
 
+    if not args.no_graphs:  # untimed: warm up + capture the three step variants (6 real steps)
+        state["training_step"].prepare_graphs(batch["real_images"], batch["ocr_images"], batch["input_words"],
+                                              batch["ocr_labels"])
     run_steps(state, batch, args.warmup)
     torch.cuda.synchronize()
     if world > 1:
@@ -167,6 +171,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         ops.PROFILE.enable()
         ts = state["training_step"]
+        ts.use_graphs = False  # the instrumented pass brackets individual launches
         for _ in range(2):
             ts.dist_train_step(batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"],
                                False, False, 1e-4) if world == 1 else None

@@ -47,6 +47,7 @@ const char *tbg_strerror(int code);
  *       + (noise ? noise[b*HW + p] * strength[0] : 0) + (bias ? bias[m] * bias_mul : 0)
  *   v   = (act == LRELU ? (v > 0 ? v : v * slope) : v) * gain
  *   out = residual ? (v + residual[...]) * res_scale : v
+ * (res_first != 0: the residual is added BEFORE the activation instead -- ResNet units of the OCR.)
  * tbg_conv2d_f32 additionally supports a fused per-(b,m) dot product of the UNSCALED accumulator
  * with a second tensor (dot_aux/dot_out): the style gradient ds[b,i] = sum_p x[b,i,p]*dxhat[b,i,p]
  * comes out of the same launch that writes dx = s*dxhat.
@@ -66,6 +67,7 @@ typedef struct tbg_epilogue {
   float gain;
   float res_scale;
   int act;
+  int res_first;
 } tbg_epilogue;
 
 /* ------------------------------------------------------------------------------------------

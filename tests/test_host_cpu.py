@@ -1,0 +1,160 @@
+"""CPU (-m "not gpu"): host logic, the C-ABI surface, and the 2-process gradient exchange (gloo)."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tokenizers_known_answers():
+    from textboxgan_amd.char_tokens import (main_to_aster_labels, string_to_aster_int_sequence,
+                                            string_to_main_int_sequence)
+    assert string_to_main_int_sequence(["Hello"]).tolist() == [[44, 15, 22, 22, 25, 0, 0, 0]]
+    assert string_to_aster_int_sequence(["Hello"]).tolist() == [[45, 16, 23, 23, 26, 1, 1, 1]]
+    assert string_to_main_int_sequence(["0", "\""]).tolist()[0][0] == 1 and string_to_main_int_sequence(["\""]).tolist()[0][0] == 69
+    assert string_to_main_int_sequence(["aéb"]).tolist()[0][:3] == [11, 0, 12]  # OOV -> 0
+    assert string_to_main_int_sequence(["ABCDEFGHIJ"]).tolist() == [[39, 40, 41, 42, 43, 44, 45, 46]]  # truncating="pre"
+    w = string_to_main_int_sequence(["Hello", "a-'b"])
+    assert main_to_aster_labels(w).tolist() == string_to_aster_int_sequence(["Hello", "a-'b"]).tolist()
+
+
+def test_config_matches_reference_values():
+    from textboxgan_amd.config import Config, cfg
+    assert cfg.image_width == 256 and cfg.generator_feat_maps == [128, 512, 256, 256, 128, 128]
+    assert cfg.discrim_feat_maps == [64, 128, 128, 256, 256, 512, 512] and cfg.batch_size == 4
+    g, d = cfg.g_opt.lazy_reg_rescaled(), cfg.d_opt.lazy_reg_rescaled()
+    assert abs(g.learning_rate - 1.7778e-3) < 1e-7 and abs(g.beta2 - 0.99111) < 1e-5
+    assert abs(d.learning_rate - 1.8824e-3) < 1e-7 and abs(d.beta2 - 0.99059) < 1e-5 and g.beta1 == 0.0
+    assert Config(batch_size_per_gpu=32, num_replicas=8).batch_size == 256
+    with pytest.raises(AssertionError):
+        Config(char_height=32)
+
+
+def test_header_symbols_are_exported_by_the_library():
+    """every function include/tbg.h declares must be an exported symbol of libtbg_hip.so (no compute call)."""
+    from textboxgan_amd import native
+    from textboxgan_amd.build import build_native
+    lib = ctypes.CDLL(build_native(verbose=False))
+    header = open(os.path.join(ROOT, "include", "tbg.h")).read()
+    declared = sorted(set(re.findall(r"\b(tbg_[a-z0-9_]+)\s*\(", header)) - {"tbg_epilogue"})
+    assert len(declared) >= 13
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in tbg.h but not exported"
+    assert set(native.EXPORTS) == set(declared)
+    lib.tbg_strerror.restype = ctypes.c_char_p
+    assert lib.tbg_version() >= 100 and b"ok" in lib.tbg_strerror(0) and b"HIP" in lib.tbg_strerror(-3)
+    assert lib.tbg_bias_act_bwd_chunks(16384) == 4 and lib.tbg_bias_act_bwd_chunks(64) == 1
+
+
+def test_ctypes_struct_layout_matches_header():
+    from textboxgan_amd import native
+    assert ctypes.sizeof(native.Epilogue) == 7 * 8 + 5 * 4 + 2 * 4 + 4  # 7 pointers, 5 floats, 2 ints, tail padding
+    assert ctypes.sizeof(native.ConvDesc) == 17 * 4 and ctypes.sizeof(native.WgradDesc) == 17 * 4
+
+
+def test_product_refuses_cpu_tensors():
+    """no CPU fallback in the product path: kernels need device tensors, the library must exist."""
+    from textboxgan_amd import native, ops
+    with pytest.raises(native.TbgError):
+        ops.upfirdn2d_raw(torch.zeros(1, 1, 4, 4), torch.ones(4, 4))
+
+
+def test_state_dict_is_the_reference_checkpoint_layout():
+    from oracle import ref_model as M
+    from textboxgan_amd.config import cfg
+    from textboxgan_amd.models import Discriminator, Generator
+    G, D = Generator(cfg), Discriminator(cfg)
+    Pg, Pd = M.init_generator(cfg), M.init_discriminator(cfg)
+    assert {k: tuple(v.shape) for k, v in G.state_dict().items()} == {k: tuple(v.shape) for k, v in Pg.items()}
+    assert {k: tuple(v.shape) for k, v in D.state_dict().items()} == {k: tuple(v.shape) for k, v in Pd.items()}
+    assert "synthesis.synth_blocks.3.conv_1.w" in Pg and "blocks.5.conv_skip.w" in Pd and "latent_encoder.w_avg" in Pg
+    assert G.n_style == 15
+
+
+def test_flat_params_ranges_and_grad_views():
+    from textboxgan_amd.config import small_config
+    from textboxgan_amd.models import Generator
+    from textboxgan_amd.optim import flatten_generator, write_grads
+    G = Generator(small_config(2))
+    before = {k: v.clone() for k, v in G.state_dict().items()}
+    fp = flatten_generator(G, torch.device("cpu"))
+    for k, v in G.state_dict().items():
+        assert torch.equal(v, before[k])
+    gb, ge = fp.range_of(("latent_encoder.", "synthesis."))
+    ob, oe = fp.range_of(("synthesis.", "word_encoder."))
+    assert gb == 0 and oe == fp.total and ob < ge  # synthesis is shared by both optimisers
+    assert all(o % 4 == 0 for o in fp.offsets)  # 16-byte aligned conv weights
+    buf, views = fp.make_grad_buffer(ob, oe)
+    params = fp.select(("synthesis.", "word_encoder."))
+    assert [v.shape for v in views] == [p.shape for p in params]
+    write_grads(views, [torch.full_like(p, 2.0) if i % 2 else None for i, p in enumerate(params)])
+    assert float(buf.sum()) == 2.0 * sum(p.numel() for i, p in enumerate(params) if i % 2)
+    p0 = fp.params[0]
+    fp.flat[fp.offsets[0]] = 123.0  # parameters are views of the flat buffer
+    assert float(p0.detach().reshape(-1)[0]) == 123.0
+
+
+def test_aster_wrapper_matches_oracle_wrapper_on_cpu():
+    from oracle import ref_model as M
+    from textboxgan_amd.aster import AsterInferer
+    from textboxgan_amd.config import cfg
+    o = AsterInferer()
+    fake = torch.randn(3, 3, 64, 256)
+    labels = torch.tensor([[5, 6, 7, 1, 1, 1, 1, 1], [2, 3, 4, 5, 6, 7, 8, 9], [4, 1, 1, 1, 1, 1, 1, 1]])
+    np.testing.assert_allclose(o.convert_inputs(fake, labels).numpy(), M.ocr_convert_inputs(fake, labels, cfg).numpy(), atol=1e-5)
+    logits = torch.randn(2, 8, 97, generator=torch.Generator().manual_seed(0)) * 0.01
+    logits[:, :, 1] = -5.0  # nobody predicts EOS ...
+    logits[0, 2, 1] = 5.0   # ... except sample 0 at step 2 -> its steps 3.. are the reference's padding
+    out = o._postprocess_simple(logits)
+    assert torch.equal(out[0, :3], logits[0, :3]) and float(out[0, 3, 1]) == 1000.0 and float(out[0, 7].sum()) == 1000.0
+    assert torch.equal(out[1], logits[1])
+    assert not any(p.requires_grad for p in o.parameters())
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _exchange_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from textboxgan_amd.dist_utils import GradExchange
+    ex = GradExchange()
+    bufs = [torch.full((n,), float(rank + 1) * (i + 1)) for i, n in enumerate((1000, 37, 5003))]
+    handles = [ex.start(b) for b in bufs]  # issued back to back, waited for in order (as the step does)
+    for h in handles:
+        GradExchange.finish(h)
+    scal = ex.reduce_scalars([torch.tensor(float(rank + 1)), torch.tensor(10.0 * (rank + 1))])
+    more = [torch.ones(4) * (rank + 1)]
+    ex.reduce_now(more)
+    q.put((rank, [float(b[0]) for b in bufs], [float(b.sum()) for b in bufs], [float(s) for s in scal], float(more[0][0]), ex.world_size()))
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_two_processes_gloo():
+    """the N>1 path: SUM all-reduce of the three flat gradient buffers + the loss scalars, world_size 2."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(timeout=60) for p in procs]
+    for rank, firsts, sums, scal, more, ws in res:
+        assert firsts == [3.0, 6.0, 9.0] and sums == [3000.0, 6.0 * 37, 9.0 * 5003]
+        assert scal == [3.0, 30.0] and more == 3.0 and ws == 2
+
+
+def test_grad_exchange_is_a_noop_single_process():
+    from textboxgan_amd.dist_utils import GradExchange
+    ex = GradExchange()
+    b = torch.ones(5)
+    assert ex.start(b) is None and ex.world_size() == 1
+    ex.reduce_now([b])
+    assert float(b.sum()) == 5.0 and [float(v) for v in ex.reduce_scalars([torch.tensor(2.0)])] == [2.0]

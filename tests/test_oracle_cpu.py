@@ -1,0 +1,239 @@
+"""CPU (-m "not gpu"): pin the oracle.  The reference has no tests / vectors and cannot be imported
+(TensorFlow absent) => parity with TF2 is UNPINNED; what CAN be pinned is pinned here:
+  (i)   float64 numpy definitions vs the torch twins,
+  (ii)  scipy.signal.upfirdn as an independent separable cross-check,
+  (iii) the reference's two internal twins, restated: .cu index maths (upfirdn_2d.cu:64-117) vs the
+        TF-ops path (upfirdn_2d_v2.py:249-305); fused vs non-fused modconv (modulated_conv2d.py:85-121),
+  (iv)  hand-computable known answers,
+  (v)   the committed golden fixtures (tests/golden/*.npz)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_model as M, ref_ops as R
+from textboxgan_amd.config import cfg as full_cfg, small_config
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_compute_paddings_known_answers():
+    # (1,1) up-conv, (2,1) rgb upsample, (2,3) 3x3 down, (1,2) 1x1 down
+    assert R.compute_paddings([1, 3, 3, 1], True, False, is_conv=True, convW=3)[1:] == (1, 1)
+    assert R.compute_paddings([1, 3, 3, 1], True, False, is_conv=False)[1:] == (2, 1)
+    assert R.compute_paddings([1, 3, 3, 1], False, True, is_conv=True, convW=3)[1:] == (2, 3)
+    assert R.compute_paddings([1, 3, 3, 1], False, True, is_conv=True, convW=1)[1:] == (1, 2)
+    k_up = R.compute_paddings([1, 3, 3, 1], True, False, is_conv=True)[0]
+    assert abs(float(k_up.sum()) - 4.0) < 1e-6  # FIR gain factor**2
+    assert R.upfirdn_out_size(65, 1, 1, 1, 1, 4) == 64 and R.upfirdn_out_size(32, 2, 1, 2, 1, 4) == 64
+    assert R.upfirdn_out_size(64, 1, 1, 2, 3, 4) == 66 and R.upfirdn_out_size(64, 1, 2, 1, 2, 4) == 32
+
+
+UF = [(1, 1, 1, 1, (1, 1, 1, 1)), (2, 2, 1, 1, (2, 1, 2, 1)), (1, 1, 2, 2, (1, 2, 1, 2)), (1, 1, 1, 1, (2, 3, 2, 3)),
+      (2, 1, 1, 2, (0, 3, -1, 2)), (3, 2, 2, 3, (4, 1, 2, 5))]
+
+
+@pytest.mark.parametrize("ux,uy,dx,dy,pad", UF)
+def test_upfirdn_cu_index_maths_equals_tf_ops_twin(ux, uy, dx, dy, pad):
+    g = np.random.default_rng(0)
+    x = g.standard_normal((2, 7, 9, 3))
+    k = g.standard_normal((4, 5))  # asymmetric, non-square
+    a = R.np_upfirdn2d_cu(x, k, ux, uy, dx, dy, *pad)
+    b = R.t_upfirdn2d(torch.from_numpy(x), k, ux, uy, dx, dy, *pad).numpy()
+    assert a.shape == b.shape
+    np.testing.assert_allclose(a, b, atol=1e-12)
+
+
+def test_upfirdn_vs_scipy_separable():
+    from scipy.signal import upfirdn
+    g = np.random.default_rng(1)
+    x = g.standard_normal((8, 11))
+    h = np.array([1.0, 3.0, 3.0, 1.0]) / 8
+    for up, down in ((1, 1), (2, 1), (1, 2)):
+        y = upfirdn(h, upfirdn(h, x, up=up, down=down, axis=0), up=up, down=down, axis=1)  # full convolution
+        ours = R.np_upfirdn2d_cu(x[None, :, :, None], np.outer(h, h), up, up, down, down, 3, 3 + up - 1, 3, 3 + up - 1)[0, :, :, 0]
+        np.testing.assert_allclose(ours[: y.shape[0], : y.shape[1]], y[: ours.shape[0], : ours.shape[1]], atol=1e-12)
+
+
+def test_upfirdn_gradient_parameter_transform():
+    """upfirdn_2d_v2.py:204-209: dx = upfirdn(dy, flip(k), up<->down, gpads) == autograd of the twin."""
+    k = torch.from_numpy(R.setup_kernel([1, 3, 3, 1]).astype(np.float64)); k[0, 1] += 0.1
+    for ux, uy, dx, dy, pad in UF[:4]:
+        x = torch.randn(2, 6, 8, 1, dtype=torch.float64, requires_grad=True)
+        y = R.t_upfirdn2d(x, k.numpy(), ux, uy, dx, dy, *pad)
+        gy = torch.randn_like(y)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        gp = R.upfirdn2d_grad_params(6, 8, 4, 4, ux, uy, dx, dy, *pad)
+        gx2 = R.t_upfirdn2d(gy, torch.flip(k, (0, 1)).numpy(), **gp)
+        np.testing.assert_allclose(gx.numpy(), gx2.numpy(), atol=1e-12)
+
+
+def test_fused_vs_nonfused_modconv_twins_and_definition():
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    x, style, w, mw, mb = r(3, 5, 6, 8), r(3, 4), r(3, 3, 5, 7), r(4, 5), r(5) * 0.1
+    for up in (False, True):
+        a = R.t_modulated_conv2d(x, style, w, mw, mb, up=up, demodulate=True, fused=True)
+        b = R.t_modulated_conv2d(x, style, w, mw, mb, up=up, demodulate=True, fused=False)
+        np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-10)
+    s = (R.t_bias_act(R.t_dense(style, mw), mb, "linear") + 1.0).numpy()
+    d = R.np_modulated_conv2d_def(x.numpy(), s, w.numpy(), demodulate=True)
+    a = R.t_modulated_conv2d(x, style, w, mw, mb, up=False, demodulate=True, fused=True)
+    np.testing.assert_allclose(a.numpy(), d, atol=1e-10)
+
+
+def test_demodulated_weights_have_unit_norm():
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(3, 3, 6, 5, generator=g, dtype=torch.float64)
+    s = torch.randn(2, 6, generator=g, dtype=torch.float64) + 1
+    ww = (w / math.sqrt(54))[None] * s[:, None, None, :, None]
+    ww = ww * torch.rsqrt(ww.square().sum(dim=(1, 2, 3)) + 1e-8)[:, None, None, None, :]
+    np.testing.assert_allclose(ww.square().sum(dim=(1, 2, 3)).numpy(), 1.0, atol=1e-6)
+
+
+def test_upsample_conv_is_zero_insert_then_correlation_then_fir():
+    """upfirdn_2d_v2.py:65-103 == scatter-definition transposed conv with the flipped filter + 4x4 FIR*4."""
+    g = np.random.default_rng(5)
+    x, w = g.standard_normal((2, 3, 4, 5)), g.standard_normal((3, 3, 3, 4))
+    k, p0, p1 = R.compute_paddings([1, 3, 3, 1], True, False, is_conv=True)
+    a = R.t_upsample_conv2d(torch.from_numpy(x), torch.from_numpy(w), k, p0, p1).numpy()
+    up = R.np_conv_transpose2d_s2(x, w[::-1, ::-1])
+    b = R.np_upfirdn2d_cu(up.reshape(-1, 9, 11, 1), k, padx0=p0, padx1=p1, pady0=p0, pady1=p1).reshape(2, 4, 8, 10)
+    np.testing.assert_allclose(a, b, atol=1e-10)
+    z = np.zeros((2, 3, 7, 9)); z[:, :, ::2, ::2] = x  # zero-insert, then ordinary correlation with w (pad 2)
+    c = R.np_conv2d(z, w, pad=(2, 2, 2, 2))
+    np.testing.assert_allclose(c, up, atol=1e-12)
+
+
+def test_conv_down_and_minibatch_std_definitions():
+    g = np.random.default_rng(6)
+    x, w = g.standard_normal((2, 3, 8, 12)), g.standard_normal((3, 3, 3, 5))
+    k, p0, p1 = R.compute_paddings([1, 3, 3, 1], False, True, is_conv=True, convW=3)
+    for rh in (True, False):
+        a = R.t_conv_downsample2d(torch.from_numpy(x), torch.from_numpy(w), k, p0, p1, rh).numpy()
+        xb = R.np_upfirdn2d_cu(x.reshape(-1, 8, 12, 1), k, padx0=p0, padx1=p1, pady0=p0, pady1=p1).reshape(2, 3, 10, 14)
+        b = R.np_conv2d(xb, w, stride=(2 if rh else 1, 2))
+        assert a.shape == (2, 5, 4 if rh else 8, 6)
+        np.testing.assert_allclose(a, b, atol=1e-10)
+    y = g.standard_normal((8, 4, 2, 2))
+    np.testing.assert_allclose(R.t_minibatch_std(torch.from_numpy(y)).numpy(), R.np_minibatch_std(y), atol=1e-12)
+    m = R.np_minibatch_std(y)[:, -1, 0, 0]  # statistics group of sample n is n mod (B/G)
+    assert np.allclose(m[0], m[2]) and np.allclose(m[1], m[3]) and not np.allclose(m[0], m[1])
+
+
+def test_decimated_skip_fir_equals_blur_then_strided_1x1():
+    """the HIP path evaluates the skip branch's FIR only at the strided sites; same function."""
+    g = np.random.default_rng(7)
+    x, w = torch.from_numpy(g.standard_normal((2, 3, 8, 12))), torch.from_numpy(g.standard_normal((1, 1, 3, 4)))
+    k, p0, p1 = R.compute_paddings([1, 3, 3, 1], False, True, is_conv=True, convW=1)
+    for rh in (True, False):
+        a = R.t_conv_downsample2d(x, w, k, p0, p1, rh)
+        xd = R.t_simple_upfirdn2d(x, k, down=2, downy=2 if rh else 1, pad0=p0, pad1=p1)
+        np.testing.assert_allclose(a.numpy(), R.t_conv2d_valid(xd, w, (1, 1)).numpy(), atol=1e-12)
+
+
+def test_adam_tf_semantics_vs_manual_and_torch_difference():
+    from textboxgan_amd.config import OptParams
+    opt = OptParams(0.002, 0.0, 0.99, 1e-8, 8).lazy_reg_rescaled()
+    assert abs(opt.learning_rate - 0.002 * 8 / 9) < 1e-12 and opt.beta1 == 0.0 and abs(opt.beta2 - 0.99 ** (8 / 9)) < 1e-12
+    P = {"w": torch.tensor([1.0, -2.0, 3.0])}
+    adam = M.AdamTF(opt)
+    g1 = torch.tensor([0.5, -1e-9, 2.0])
+    adam.apply(P, ["w"], [g1])
+    v = (1 - opt.beta2) * g1 ** 2
+    exp = torch.tensor([1.0, -2.0, 3.0]) - opt.learning_rate * math.sqrt(1 - opt.beta2) * g1 / (v.sqrt() + 1e-8)
+    np.testing.assert_allclose(P["w"].numpy(), exp.numpy(), rtol=1e-6)
+    assert adam.iterations == 1
+    # epsilon is NOT bias corrected (differs from torch.optim.Adam for tiny gradients)
+    upd = (1.0 * 0 + exp - torch.tensor([1.0, -2.0, 3.0]))[1]
+    torch_like = -opt.learning_rate * g1[1] / (g1[1].abs() + 1e-8)
+    assert abs(float(upd) - float(torch_like)) > 1e-5
+
+
+def test_mask_and_losses_known_answers():
+    img = torch.ones(2, 3, 4, 256)
+    words = torch.tensor([[5, 6, 0, 0, 0, 0, 0, 0], [1, 2, 3, 4, 5, 6, 7, 8]])
+    m = R.t_mask_text_box(img, words, 32)
+    assert float(m[0, :, :, :64].sum()) == 3 * 4 * 64 and float(m[0, :, :, 64:].sum()) == 0 and float(m[1].sum()) == 3 * 4 * 256
+    s = torch.tensor([[0.0], [0.0]])
+    assert abs(float(M.generator_loss(s, 4)) - 2 * math.log(2) / 4) < 1e-7  # sum / GLOBAL batch
+    assert abs(float(M.discriminator_loss(s, s, 4)) - 4 * math.log(2) / 4) < 1e-7
+    logits = torch.zeros(2, 8, 10)
+    assert abs(float(M.softmax_cross_entropy_loss(logits, torch.ones(2, 8), 2)) - 8 * math.log(10)) < 1e-5
+
+
+def test_ocr_wrapper_semantics():
+    """aster_inferer.py:116-190: crop-to-word + half-pixel bilinear resize; pad short decodes with 1000*onehot(1)."""
+    cfg = full_cfg
+    fake = torch.randn(3, 3, 64, 256)
+    labels = torch.tensor([[5, 6, 7, 1, 1, 1, 1, 1], [2, 3, 4, 5, 6, 7, 8, 9], [4, 1, 1, 1, 1, 1, 1, 1]])
+    out = M.ocr_convert_inputs(fake, labels, cfg)
+    assert out.shape == (3, 64, 256, 3)
+    np.testing.assert_allclose(out[1].numpy(), fake[1].permute(1, 2, 0).numpy(), atol=1e-6)  # full width: identity
+    ref0 = F.interpolate(fake[0:1, :, :, :96], size=(64, 256), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+    np.testing.assert_allclose(out[0].numpy(), ref0.numpy(), atol=1e-6)
+    short = torch.randn(2, 5, 7)
+    padded = M.ocr_postprocess_simple(short, 8)
+    assert padded.shape == (2, 8, 7) and float(padded[0, 5, 1]) == 1000.0 and float(padded[0, 5, 0]) == 0.0
+    long = torch.randn(2, 30, 7)
+    assert M.ocr_postprocess_simple(long, 8).shape == (2, 8, 7)
+
+
+def test_generator_geometry_and_style_indexing():
+    cfg = small_config(2)
+    P = M.init_generator(cfg, seed=0, bench_init=True)
+    assert M.n_style(cfg) == 15
+    batch, rand = M.make_batch(cfg), M.make_rand(cfg, seed=1, with_pl=False)
+    img = M.generator(P, cfg, batch["input_words"], rand["z"], rand, training=False)
+    assert img.shape == (2, 3, 64, 256)
+    D = M.init_discriminator(cfg, seed=1)
+    assert M.discriminator(D, cfg, img).shape == (2, 1)
+    # parameter counts of the full-size model
+    Pf, Df = M.init_generator(full_cfg), M.init_discriminator(full_cfg)
+    syn = sum(v.numel() for k, v in Pf.items() if k.startswith("synthesis."))
+    lat = sum(v.numel() for k, v in Pf.items() if k.startswith("latent_encoder.") and "w_avg" not in k)
+    wen = sum(v.numel() for k, v in Pf.items() if k.startswith("word_encoder.") and "w0_" not in k)
+    assert (syn, lat, wen, sum(v.numel() for v in Df.values())) == (8677916, 1313280, 10656, 15594817)
+
+
+def test_golden_upfirdn_and_modconv_and_networks():
+    z = np.load(os.path.join(GOLD, "upfirdn2d.npz"))
+    for name in ("blur_up", "blur_down3", "blur_skip", "rgb_up", "skip_dec", "skip_dec_w"):
+        ux, uy, dx, dy, p0, p1, p2, p3 = [int(v) for v in z[name + "_p"]]
+        y = R.t_upfirdn2d(torch.from_numpy(z[name + "_x"]).double(), z[name + "_k"].astype(np.float64), ux, uy, dx, dy, p0, p1, p2, p3)
+        np.testing.assert_allclose(y.numpy(), z[name + "_y"], atol=2e-6)
+    m = np.load(os.path.join(GOLD, "modconv.npz"))
+    t = lambda a: torch.from_numpy(a).double()
+    for up, key in ((False, "y"), (True, "y_up")):
+        y = R.t_modulated_conv2d(t(m["x"]), t(m["style"]), t(m["w"]), t(m["mod_w"]), t(m["mod_b"]), up=up, demodulate=True, fused=False)
+        np.testing.assert_allclose(y.numpy(), m[key], atol=5e-6)
+    n = np.load(os.path.join(GOLD, "networks_small.npz"))
+    cfg = small_config(2)
+    G = {k: v.double() for k, v in M.init_generator(cfg, seed=11, bench_init=True).items()}
+    D = {k: v.double() for k, v in M.init_discriminator(cfg, seed=12, bench_init=True).items()}
+    rand = dict(z=t(n["z"]), noises=[t(n[f"noise{i}"]) for i in range(10)])
+    words = torch.from_numpy(n["words"])
+    assert words[0].tolist() == [44, 15, 22, 22, 25, 0, 0, 0]  # "Hello" 
+    img = M.generator(G, cfg, words, rand["z"], rand, training=False)
+    np.testing.assert_allclose(img[:, :, 31, :].numpy(), n["image_row"], atol=1e-4)
+    np.testing.assert_allclose([float(img.sum()), float(img.abs().sum()), float(img.square().sum())], n["image_checksum"], rtol=1e-5)
+    sc = M.discriminator(D, cfg, R.t_mask_text_box(img, words, cfg.char_width))
+    np.testing.assert_allclose(sc.numpy(), n["scores"], rtol=1e-4, atol=1e-5)
+
+
+def test_training_step_oracle_runs_and_is_deterministic():
+    from textboxgan_amd.aster import AsterInferer
+    cfg = small_config(2)
+    ocr = AsterInferer()
+    outs = []
+    for _ in range(2):
+        st = M.make_state(cfg, 0, bench_init=True)
+        batch, rand = M.make_batch(cfg), M.make_rand(cfg, seed=99)
+        losses = M.training_step(st, cfg, batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"],
+                                 True, True, 1e-4, rand, lambda x: ocr(x), update_clone=True)
+        outs.append([float(v) for v in losses[0]] + [float(v) for v in losses[1]] + [float(losses[2])])
+        assert st["g_opt"].iterations == 1 and float(st["pl_mean"]) > 0
+    assert outs[0] == outs[1] and all(math.isfinite(v) for v in outs[0])

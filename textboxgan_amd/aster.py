@@ -99,13 +99,11 @@ class AsterInferer(nn.Module):
         logits = logits[:, : self.max_char_number]
         B, T, C = logits.shape
         if T < self.max_char_number:
-            pad = logits.new_zeros(B, self.max_char_number - T, C)
-            pad[:, :, EOS] = 1000.0
-            logits = torch.cat([logits, pad], dim=1)
+            row = (torch.arange(C, device=logits.device) == EOS).to(logits.dtype) * 1000.0
+            logits = torch.cat([logits, row.expand(B, self.max_char_number - T, C)], dim=1)
         is_eos = logits.argmax(dim=2) == EOS
         after = (torch.cumsum(is_eos.to(torch.int32), dim=1) - is_eos.to(torch.int32)) > 0  # strictly after first EOS
-        pad_row = torch.zeros(C, device=logits.device, dtype=logits.dtype)
-        pad_row[EOS] = 1000.0
+        pad_row = (torch.arange(C, device=logits.device) == EOS).to(logits.dtype) * 1000.0  # capture-safe
         return torch.where(after[:, :, None], pad_row, logits)
 
 
@@ -141,21 +139,41 @@ def _tps_constants(num_ctrl: int, out_h: int, out_w: int, margin: float = 0.05):
     return ctrl.astype(np.float32), interp.astype(np.float32)
 
 
+class _ConvBN(nn.Module):
+    """conv (+ optional eval-mode BatchNorm) (+ residual) (+ ReLU): the only convolution form in the net.
+    ``AsterLikeOCR._run`` executes it with torch ops; ``AsterLikeOCRHip`` overrides the executor."""
+
+    def __init__(self, cin, cout, k, stride=(1, 1), bn=True, relu=True, bias=False):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=bias)
+        self.bn = nn.BatchNorm2d(cout) if bn else None
+        self.relu = relu
+
+    def torch_forward(self, x, residual=None):
+        y = self.conv(x)
+        if self.bn is not None:
+            y = self.bn(y)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if self.relu else y
+
+    def folded(self):
+        """(w [k,k,I,O] HWIO, b [O]) with the frozen BatchNorm folded in."""
+        w = self.conv.weight
+        b = self.conv.bias if self.conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+        if self.bn is not None:
+            g = self.bn.weight / torch.sqrt(self.bn.running_var + self.bn.eps)
+            w = w * g[:, None, None, None]
+            b = (b - self.bn.running_mean) * g + self.bn.bias
+        return w.permute(2, 3, 1, 0).contiguous(), b.contiguous()
+
+
 class _ResUnit(nn.Module):
     def __init__(self, cin, cout, stride):
         super().__init__()
-        self.conv1 = nn.Conv2d(cin, cout, 1, stride, 0, bias=False)
-        self.bn1 = nn.BatchNorm2d(cout)
-        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(cout)
-        self.short = None
-        if cin != cout or stride != (1, 1):
-            self.short = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, 0, bias=False), nn.BatchNorm2d(cout))
-
-    def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        return F.relu(y + (x if self.short is None else self.short(x)))
+        self.c1 = _ConvBN(cin, cout, 1, stride)
+        self.c2 = _ConvBN(cout, cout, 3, (1, 1))  # relu applied after the residual add
+        self.short = _ConvBN(cin, cout, 1, stride, relu=False) if (cin != cout or stride != (1, 1)) else None
 
 
 class AsterLikeOCR(nn.Module):
@@ -166,26 +184,21 @@ class AsterLikeOCR(nn.Module):
         self.rect_hw = rect_hw
         # --- rectification (STN): localisation CNN on a 32x64 thumbnail -> 2K control coordinates
         chans = [3, 32, 64, 128, 256, 256, 256]
-        loc = []
-        for i in range(6):
-            loc += [nn.Conv2d(chans[i], chans[i + 1], 3, 1, 1), nn.ReLU(inplace=True)]
-            if i < 5:
-                loc.append(nn.MaxPool2d(2, 2))
-        self.loc_cnn = nn.Sequential(*loc)
+        self.loc_convs = nn.ModuleList([_ConvBN(chans[i], chans[i + 1], 3, bn=False, bias=True) for i in range(6)])
         self.loc_fc1 = nn.Linear(256 * 1 * 2, 512)
         self.loc_fc2 = nn.Linear(512, 2 * num_ctrl)
         ctrl, interp = _tps_constants(num_ctrl, rect_hw[0], rect_hw[1])
         self.register_buffer("tps_interp", torch.from_numpy(interp), persistent=False)
         self.register_buffer("ctrl_init", torch.from_numpy(ctrl.reshape(-1)), persistent=False)
         # --- encoder: ResNet (ASTER table 1) + 2 BiLSTM
-        self.stem = nn.Sequential(nn.Conv2d(3, 32, 3, 1, 1, bias=False), nn.BatchNorm2d(32), nn.ReLU(inplace=True))
+        self.stem = _ConvBN(3, 32, 3)
         cfgs = [(32, 3, (2, 2)), (64, 4, (2, 2)), (128, 6, (2, 1)), (256, 6, (2, 1)), (512, 3, (2, 1))]
         blocks, cin = [], 32
         for cout, n, stride in cfgs:
             for u in range(n):
                 blocks.append(_ResUnit(cin, cout, stride if u == 0 else (1, 1)))
                 cin = cout
-        self.resnet = nn.Sequential(*blocks)
+        self.resnet = nn.ModuleList(blocks)
         self.rnn = nn.LSTM(512, hidden, num_layers=2, bidirectional=True, batch_first=True)
         # --- attention decoder (forward direction only is consumed: aster_inferer.py:35)
         self.emb = nn.Embedding(num_classes + 1, hidden)  # +1: GO symbol
@@ -238,20 +251,37 @@ class AsterLikeOCR(nn.Module):
                 if a.dim() == 4 and a.shape != sd[k].shape:
                     a = a.permute(3, 2, 0, 1)
                 sd[k].copy_(a.reshape(sd[k].shape))
+        self._invalidate()
+
+    def _invalidate(self):
+        pass
+
+    # the single convolution executor (overridden by the HIP subclass)
+    def _run(self, blk: _ConvBN, x, residual=None):
+        return blk.torch_forward(x, residual)
 
     def rectify(self, img: torch.Tensor) -> torch.Tensor:
         B = img.shape[0]
-        thumb = F.interpolate(img, size=(32, 64), mode="bilinear", align_corners=False)
-        f = self.loc_cnn(thumb).reshape(B, -1)
-        ctrl = self.loc_fc2(F.relu(self.loc_fc1(f))).reshape(B, -1, 2)  # source control points in [0,1]^2
+        f = F.interpolate(img, size=(32, 64), mode="bilinear", align_corners=False)
+        for i, blk in enumerate(self.loc_convs):
+            f = self._run(blk, f)
+            if i < 5:
+                f = F.max_pool2d(f, 2, 2)
+        ctrl = self.loc_fc2(F.relu(self.loc_fc1(f.reshape(B, -1)))).reshape(B, -1, 2)  # source control points
         src = torch.matmul(self.tps_interp, ctrl)  # [B, HW, 2] in [0,1]
         grid = (src * 2.0 - 1.0).reshape(B, self.rect_hw[0], self.rect_hw[1], 2)
         return F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=False)
 
+    def encode(self, x):
+        x = self._run(self.stem, x)
+        for u in self.resnet:
+            sc = x if u.short is None else self._run(u.short, x)
+            x = self._run(u.c2, self._run(u.c1, x), residual=sc)
+        return x
+
     def forward(self, img_nchw: torch.Tensor) -> torch.Tensor:
         """[B,3,64,256] in [-1,1] -> forward logits [B, max_steps, num_classes]."""
-        x = self.rectify(img_nchw)
-        x = self.resnet(self.stem(x))  # [B,512,1,25]
+        x = self.encode(self.rectify(img_nchw))  # [B,512,1,25]
         seq = x.squeeze(2).permute(0, 2, 1)
         enc, _ = self.rnn(seq)  # [B,25,512]
         B = enc.shape[0]
@@ -269,3 +299,31 @@ class AsterLikeOCR(nn.Module):
             outs.append(logit)
             prev = logit.argmax(dim=1)  # greedy feedback (non-differentiable, as in the TF decoder)
         return torch.stack(outs, dim=1)
+
+
+class AsterLikeOCRHip(AsterLikeOCR):
+    """Same network; every convolution (+folded BN, +residual, +ReLU) runs as ONE launch of the
+    fp32-MFMA implicit-GEMM kernel (forward) and one for the data gradient (the net is frozen, so no
+    weight gradients).  MIOpen served several of these shapes with its naive fallback kernels."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._cache = {}
+
+    def _invalidate(self):
+        self._cache = {}
+
+    def _apply(self, fn, *a, **kw):
+        self._cache = {}
+        return super()._apply(fn, *a, **kw)
+
+    def _run(self, blk: _ConvBN, x, residual=None):
+        from . import ops
+        if not x.is_cuda:
+            raise RuntimeError("AsterLikeOCRHip runs on the GPU only (use AsterLikeOCR for the CPU definition)")
+        key = id(blk)
+        if key not in self._cache:
+            with torch.no_grad():
+                self._cache[key] = blk.folded()
+        w, b = self._cache[key]
+        return ops.frozen_conv(x, w, b, tuple(blk.conv.stride), tuple(blk.conv.padding), blk.relu, residual)

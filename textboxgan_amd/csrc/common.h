@@ -17,7 +17,7 @@ struct EpiK {
   const float *out_scale, *bias, *noise, *strength, *residual, *dot_aux;
   float *dot_out;
   float alpha, bias_mul, slope, gain, res_scale;
-  int act;
+  int act, res_first;
 };
 
 static inline EpiK make_epi(const tbg_epilogue *e) {
@@ -25,10 +25,10 @@ static inline EpiK make_epi(const tbg_epilogue *e) {
   if (e) {
     k.out_scale = e->out_scale; k.bias = e->bias; k.noise = e->noise; k.strength = e->strength;
     k.residual = e->residual; k.dot_aux = e->dot_aux; k.dot_out = e->dot_out; k.alpha = e->alpha; k.bias_mul = e->bias_mul; k.slope = e->slope;
-    k.gain = e->gain; k.res_scale = e->res_scale; k.act = e->act;
+    k.gain = e->gain; k.res_scale = e->res_scale; k.act = e->act; k.res_first = e->res_first;
   } else {
     k.out_scale = k.bias = k.noise = k.strength = k.residual = k.dot_aux = nullptr; k.dot_out = nullptr;
-    k.alpha = 1.f; k.bias_mul = 1.f; k.slope = 1.f; k.gain = 1.f; k.res_scale = 1.f; k.act = TBG_ACT_LINEAR;
+    k.alpha = 1.f; k.bias_mul = 1.f; k.slope = 1.f; k.gain = 1.f; k.res_scale = 1.f; k.act = TBG_ACT_LINEAR; k.res_first = 0;
   }
   return k;
 }

@@ -22,6 +22,9 @@
 //   * Small-spatial / wide-channel layers get split-K over channel chunks (atomic add).
 // Weight gradient: M = 32 S-channels, N = 32 L-channels per wave, 9 taps = 9 accumulators that
 // share ONE staged halo tile of L; K = pixels; blocks split K and atomically add.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -179,15 +182,12 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
     }
   }
 
-  // ---- epilogue
+  // ---- epilogue (m outer, pixel sub-tile inner: the fused dot needs only one running scalar)
   const int HWout = p.Hout * p.Wout;
   const float str = p.e.noise ? p.e.strength[0] : 0.f;
   const bool do_dot = p.e.dot_aux != nullptr && p.ksplit == 1;
-  float dsum[WTM][16];
-#pragma unroll
-  for (int i = 0; i < WTM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dsum[i][r] = 0.f;
+  int e_pix[WTN], e_b[WTN];
+  float e_nz[WTN];
 #pragma unroll
   for (int j = 0; j < WTN; ++j) {
     const int n = (wn * WTN + j) * 32 + (lane & 31);
@@ -196,47 +196,46 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
     const int b = bg * p.NSEG + seg, u = u0 + r, v = v0 + q;
     const bool okpix = b < p.B && u < ci.Ug && v < ci.Vg;
     const int Y = u * p.osy + ci.ooy, X = v * p.osx + ci.oox;
-    const int pix = Y * p.Wout + X;
-    const float nz = (okpix && p.e.noise) ? p.e.noise[(size_t)b * HWout + pix] * str : 0.f;
+    e_pix[j] = okpix ? Y * p.Wout + X : -1;
+    e_b[j] = b;
+    e_nz[j] = (okpix && p.e.noise) ? p.e.noise[(size_t)b * HWout + e_pix[j]] * str : 0.f;
+  }
 #pragma unroll
-    for (int i = 0; i < WTM; ++i) {
+  for (int i = 0; i < WTM; ++i) {
 #pragma unroll
-      for (int r16 = 0; r16 < 16; ++r16) {
-        const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
-        if (okpix && m < p.M) {
-          const size_t idx = ((size_t)b * p.M + m) * HWout + pix;
+    for (int r16 = 0; r16 < 16; ++r16) {
+      const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+      const bool okm = m < p.M;
+      const float bias = (okm && p.e.bias) ? p.e.bias[m] * p.e.bias_mul : 0.f;
+      float dsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) {
+        if (okm && e_pix[j] >= 0) {
+          const size_t idx = ((size_t)e_b[j] * p.M + m) * HWout + e_pix[j];
           float val = acc[i][j][r16] * p.e.alpha;
           if (p.ksplit > 1) {
             atomicAdd(p.y + idx, val);
           } else {
             if (do_dot) {
               const float pv = val * p.e.dot_aux[idx];
-              if (p.NSEG == 1) dsum[i][r16] += pv;
-              else atomicAdd(p.e.dot_out + b * p.M + m, pv);
+              if (p.NSEG == 1) dsum += pv;
+              else atomicAdd(p.e.dot_out + e_b[j] * p.M + m, pv);
             }
-            if (p.e.out_scale) val *= p.e.out_scale[b * p.M + m];
-            val += nz;
-            if (p.e.bias) val += p.e.bias[m] * p.e.bias_mul;
+            if (p.e.out_scale) val *= p.e.out_scale[e_b[j] * p.M + m];
+            val += e_nz[j] + bias;
+            if (p.e.residual && p.e.res_first) val += p.e.residual[idx];
             val = epi_act(p.e, val);
-            if (p.e.residual) val = (val + p.e.residual[idx]) * p.e.res_scale;
+            if (p.e.residual && !p.e.res_first) val = (val + p.e.residual[idx]) * p.e.res_scale;
             p.y[idx] = val;
           }
         }
       }
-    }
-  }
-  if (do_dot && p.NSEG == 1) {  // one image per tile: reduce the 32 pixel lanes of each half-wave
-    const int b = bg;
+      if (do_dot && p.NSEG == 1) {  // one image per tile: reduce the 32 pixel lanes of each half-wave
 #pragma unroll
-    for (int i = 0; i < WTM; ++i)
-#pragma unroll
-      for (int r16 = 0; r16 < 16; ++r16) {
-        float s = dsum[i][r16];
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
-        if ((lane & 31) == 0 && m < p.M && b < p.B) atomicAdd(p.e.dot_out + b * p.M + m, s);
+        for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+        if ((lane & 31) == 0 && okm && bg < p.B) atomicAdd(p.e.dot_out + bg * p.M + m, dsum);
       }
+    }
   }
 }
 
@@ -248,9 +247,29 @@ template <int WGM, int WGN, int WTM, int WTN, int CK>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
   constexpr int BM = WGM * WTM * 32;
   p.a_floats = maxtaps * CK * BM;
+  p.nchunks = ceil_div(p.C, CK);
+  if (p.ksplit > p.nchunks) p.ksplit = p.nchunks;
+  p.cps = ceil_div(p.nchunks, p.ksplit);
   const size_t lds = ((size_t)p.a_floats + (size_t)CK * p.planeStride + 2 * MAXTAPS + 2) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK>;
+  if (getenv("TBG_DEBUG_OCC")) {
+    int nb = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, lds);
+    fprintf(stderr, "[tbg] fprop<%d,%d,%d,%d,%d> lds=%zu occupancy(blocks/CU)=%d grid=%d x %d x %d\n", WGM, WGN, WTM, WTN, CK,
+            lds, nb, maxTilesN, ceil_div(p.M, BM), p.nclass * p.ksplit);
+    hipFuncAttributes fa;
+    hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
+    fprintf(stderr, "[tbg]   numRegs=%d sharedSizeBytes=%zu localSizeBytes=%zu maxThreadsPerBlock=%d maxDynShared=%d\n", fa.numRegs,
+            fa.sharedSizeBytes, fa.localSizeBytes, fa.maxThreadsPerBlock, fa.maxDynamicSharedSizeBytes);
+    for (size_t l : {(size_t)0, (size_t)8192, (size_t)16384, (size_t)24576, (size_t)32768, (size_t)49152, (size_t)65536}) {
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, l);
+      fprintf(stderr, "[tbg]   dyn lds %zu -> %d blocks/CU\n", l, nb);
+    }
+    hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
+    fprintf(stderr, "[tbg]   device: sharedMemPerMultiprocessor=%zu sharedMemPerBlock=%zu regsPerMultiprocessor=%d regsPerBlock=%d maxThreadsPerMP=%d\n",
+            pr.sharedMemPerMultiprocessor, pr.sharedMemPerBlock, pr.regsPerMultiprocessor, pr.regsPerBlock, pr.maxThreadsPerMultiProcessor);
+  }
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TBG_EHIP;
@@ -339,8 +358,10 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
   p.IWs = (TW - 1) * p.sx + maxKW;
   p.HALFW = (p.IWs + 1) / 2;
   int iwp = (p.sx == 2) ? 2 * p.HALFW : p.IWs;
-  if (TW < 32 && TW >= 2) {
-    for (int it = 0; it < 64 && ((p.sy * iwp) & 31) != (TW & 31); ++it) ++iwp;
+  if (TW < 32 && TW >= 8) {  // rows of a 32-lane B read land on disjoint banks (cheap for TW >= 8 only)
+    int cand = iwp;
+    for (int it = 0; it < 32 && ((p.sy * cand) & 31) != (TW & 31); ++it) ++cand;
+    if (((p.sy * cand) & 31) == (TW & 31) && cand <= iwp + iwp / 2 + 8) iwp = cand;
   }
   p.IWp = iwp;
   p.planeStride = p.NSEG * p.IHs * p.IWp;
@@ -364,8 +385,10 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
     // caller promised a zeroed buffer + alpha-only epilogue; plain stores give the same result
   }
   hipStream_t st = tbg_stream(stream);
+  static const int dbg_ck = getenv("TBG_CONV_CK") ? atoi(getenv("TBG_CONV_CK")) : 8;  // experiment knob
   if (BM == 32) return launch_fprop<1, 4, 1, 2, 8>(p, st, maxtaps, maxTilesN);
   if (BM == 64) return launch_fprop<1, 4, 2, 2, 8>(p, st, maxtaps, maxTilesN);
+  if (dbg_ck == 4) return launch_fprop<2, 2, 2, 2, 4>(p, st, maxtaps, maxTilesN);
   return launch_fprop<2, 2, 2, 2, 8>(p, st, maxtaps, maxTilesN);
 }
 

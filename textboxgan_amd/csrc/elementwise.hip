@@ -234,17 +234,19 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const BiasActP p) {
   const float *nz = p.e.noise ? p.e.noise + (size_t)b * p.HW : nullptr;
   const float *rs = p.e.residual ? p.e.residual + (size_t)plane * p.HW : nullptr;
   float *yo = p.y + (size_t)plane * p.HW;
+  const bool rf = rs && p.e.res_first;
   if ((p.HW & 3) == 0) {
     for (int i = p0 + threadIdx.x * 4; i < p1; i += 1024) {
       float4 v = *reinterpret_cast<const float4 *>(xin + i);
       float4 n = nz ? *reinterpret_cast<const float4 *>(nz + i) : make_float4(0, 0, 0, 0);
+      float4 r = rs ? *reinterpret_cast<const float4 *>(rs + i) : make_float4(0, 0, 0, 0);
+      const float4 ra = rf ? r : make_float4(0, 0, 0, 0);
       float4 o;
-      o.x = epi_act(p.e, v.x * sc + n.x * str + bias);
-      o.y = epi_act(p.e, v.y * sc + n.y * str + bias);
-      o.z = epi_act(p.e, v.z * sc + n.z * str + bias);
-      o.w = epi_act(p.e, v.w * sc + n.w * str + bias);
-      if (rs) {
-        float4 r = *reinterpret_cast<const float4 *>(rs + i);
+      o.x = epi_act(p.e, v.x * sc + n.x * str + bias + ra.x);
+      o.y = epi_act(p.e, v.y * sc + n.y * str + bias + ra.y);
+      o.z = epi_act(p.e, v.z * sc + n.z * str + bias + ra.z);
+      o.w = epi_act(p.e, v.w * sc + n.w * str + bias + ra.w);
+      if (rs && !rf) {
         o.x = (o.x + r.x) * p.e.res_scale; o.y = (o.y + r.y) * p.e.res_scale;
         o.z = (o.z + r.z) * p.e.res_scale; o.w = (o.w + r.w) * p.e.res_scale;
       }
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const BiasActP p) {
     }
   } else {
     for (int i = p0 + threadIdx.x; i < p1; i += 256) {
-      float o = epi_act(p.e, xin[i] * sc + (nz ? nz[i] * str : 0.f) + bias);
-      if (rs) o = (o + rs[i]) * p.e.res_scale;
+      float o = epi_act(p.e, xin[i] * sc + (nz ? nz[i] * str : 0.f) + bias + (rf ? rs[i] : 0.f));
+      if (rs && !rf) o = (o + rs[i]) * p.e.res_scale;
       yo[i] = o;
     }
   }
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const BiasActBwdP p) 
   const float str = p.e.noise ? p.e.strength[0] : 0.f;
   const float gin = p.e.residual ? p.e.res_scale : 1.f;  // residual != NULL only flags "fused residual"
   const float g_pos = p.e.gain, g_neg = p.e.gain * (p.e.act == TBG_ACT_LRELU ? p.e.slope : 1.f);
-  const float ig_pos = 1.f / g_pos, ig_neg = 1.f / g_neg;
+  const float ig_pos = 1.f / g_pos, ig_neg = g_neg != 0.f ? 1.f / g_neg : 0.f;  // slope 0 = ReLU
   const float *dout = p.dout + (size_t)plane * p.HW;
   const float *oa = p.out_act + (size_t)plane * p.HW;
   const float *nz = p.e.noise ? p.e.noise + (size_t)b * p.HW : nullptr;

@@ -106,9 +106,10 @@ class LatentEncoder(nn.Module):
                 self.w_avg.copy_(batch_avg + (self.w_avg - batch_avg) * self.w_ema_decay)
             if rand is not None and "z2" in rand:
                 z2, cutoff = rand["z2"], int(rand["mix_cutoff"])
-            else:  # :47-60
+            else:  # :47-60 -- drawn on the device, no host sync (the step is HIP-graph capturable)
                 z2 = torch.randn_like(z)
-                cutoff = int(torch.randint(1, ns, ()).item()) if float(torch.rand(())) < self.style_mixing_prob else ns
+                cutoff = torch.where(torch.rand((), device=z.device) < self.style_mixing_prob,
+                                     torch.randint(1, ns, (), device=z.device), torch.full((), ns, device=z.device))
             w2 = self.g_mapping(z2)
             idx = torch.arange(ns, device=z.device)[None, :, None]
             wb = torch.where(idx < cutoff, wb, w2[:, None, :].expand(-1, ns, -1))

@@ -148,6 +148,8 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
                    int(flip), ldw, ksplit)
     if epi is None:
         epi = N.epilogue()
+    _what = (f"tbg_conv2d[B={B} C={Cc} M={M} in={Hin}x{Win} out={Hout}x{Wout} k={KH}x{KW} s={tuple(stride)} "
+             f"p={tuple(pad)} T={int(transposed)} ldw={ldw} ksplit={ksplit}]")
     _flops = 2.0 * B * M * Cc * KH * KW * (Hin * Win if transposed else Hout * Wout)
     _kname = _fprop_kernel_name(M)
     trivial = not (epi.out_scale or epi.bias or epi.noise or epi.residual or epi.act != ACT_LINEAR or dot is not None)
@@ -155,7 +157,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         tmp = torch.zeros((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
         e0 = N.epilogue(alpha=epi.alpha)
         N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
-            C.byref(d), N.ptr(x), N.ptr(w), N.ptr(tmp), N.ptr(in_scale), C.byref(e0), N.stream())), "tbg_conv2d(split)")
+            C.byref(d), N.ptr(x), N.ptr(w), N.ptr(tmp), N.ptr(in_scale), C.byref(e0), N.stream())), _what)
         if dot is not None:
             dot[1].copy_((tmp * dot[0]).sum(dim=(2, 3)))
         e1 = N.Epilogue.from_buffer_copy(epi)
@@ -170,7 +172,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     alloc = torch.zeros if ksplit > 1 else torch.empty
     y = alloc((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
     N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
-        C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream())), "tbg_conv2d")
+        C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream())), _what)
     return y
 
 
@@ -597,3 +599,49 @@ def adam_tf_(theta, m, v, g, step, lr, beta1, beta2, eps):
 
 def ema_lerp_(dst, src, beta):
     N.check(N.lib().tbg_ema_lerp_f32(N.ptr(dst), N.ptr(src), dst.numel(), beta, N.stream()), "tbg_ema_lerp")
+
+
+# ----------------------------------------------------------------------------------------
+# frozen convolution of the OCR branch (no weight gradient)
+# ----------------------------------------------------------------------------------------
+class _FrozenConv(torch.autograd.Function):
+    """y = [relu]( conv(x, w) + b [+ residual] ) with constant (w, b); only d/dx and d/dresidual exist."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, relu, residual):
+        KH, KW, I, O = w.shape
+        x = x.contiguous()
+        H, W = x.shape[2], x.shape[3]
+        yhw = ((H + 2 * pad[0] - KH) // stride[0] + 1, (W + 2 * pad[1] - KW) // stride[1] + 1)
+        if residual is not None:
+            residual = residual.contiguous()
+        epi = N.epilogue(bias=b, residual=residual, res_first=1, act=ACT_LRELU if relu else ACT_LINEAR, slope=0.0,
+                         gain=1.0)
+        y = conv2d_raw(x, w, O, KH, KW, yhw, stride, pad, epi=epi)
+        ctx.save_for_backward(w, y if relu else None)
+        ctx.cfgv = (stride, pad, relu, residual is not None, (H, W), yhw)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        w, y = ctx.saved_tensors
+        stride, pad, relu, has_res, xhw, yhw = ctx.cfgv
+        KH, KW, I, O = w.shape
+        dy = dy.contiguous()
+        if relu:
+            _, dy, _, _, _ = bias_act_bwd_raw(dy, y, N.epilogue(act=ACT_LRELU, slope=0.0, gain=1.0), want_db=False)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if stride == (1, 1):
+                wt, ldo = weight_transpose_raw(w, flip=True)
+                dx = conv2d_raw(dy, wt, I, KH, KW, xhw, (1, 1), (KH - 1 - pad[0], KW - 1 - pad[1]), ldw=ldo)
+            else:
+                assert KH == 1 and KW == 1 and pad == (0, 0), "strided OCR convolutions are 1x1"
+                wt, ldo = weight_transpose_raw(w, flip=False)
+                dx = conv2d_raw(dy, wt, I, 1, 1, xhw, stride, (0, 0), transposed=True, ldw=ldo)
+        return dx, None, None, None, None, None, (dy if has_res else None)
+
+
+def frozen_conv(x, w, b, stride=(1, 1), pad=(0, 0), relu=True, residual=None):
+    return _FrozenConv.apply(x, w, b, tuple(stride), tuple(pad), relu, residual)

@@ -81,8 +81,7 @@ class AdamTF:
 
     def apply_gradients(self, g_flat: torch.Tensor) -> None:
         ops.adam_tf_(self.theta, self.m, self.v, g_flat, self.step, self.lr, self.beta1, self.beta2, self.eps)
-        self.step += 1
-        self._iterations += 1
+        self.step += 1  # device counter (part of the captured graph); the host mirror is bumped by the caller
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return dict(m=self.m, v=self.v, step=self.step)

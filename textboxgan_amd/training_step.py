@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .config import Config, cfg as default_cfg
+from .dist_utils import GradExchange
 from .models import Discriminator, Generator, mask_text_box
 from .optim import AdamTF, flatten_generator, flatten_module, write_grads
 
@@ -53,7 +54,7 @@ def mean_squared_loss(y_a, y_b, batch_size):
 class TrainingStep:
     def __init__(self, generator: Generator, discriminator: Discriminator, aster_ocr, g_optimizer: AdamTF,
                  ocr_optimizer: AdamTF, d_optimizer: AdamTF, g_reg_interval: int, d_reg_interval: int,
-                 pl_mean: torch.Tensor, cfg: Config = default_cfg, process_group=None):
+                 pl_mean: torch.Tensor, cfg: Config = default_cfg, process_group=None, use_graphs: bool = False):
         self.generator, self.discriminator, self.aster_ocr = generator, discriminator, aster_ocr
         self.g_optimizer, self.ocr_optimizer, self.d_optimizer = g_optimizer, ocr_optimizer, d_optimizer
         self.g_reg_interval, self.d_reg_interval = g_reg_interval, d_reg_interval
@@ -66,7 +67,12 @@ class TrainingStep:
         self.r1_gamma = 10.0
         self.pl_noise_scaler = 1.0 / math.sqrt(float(cfg.image_width) * float(cfg.char_height))
         self.pg = process_group
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.use_graphs = use_graphs
+        self._graphs = {}
+        self._warmed = set()
+        self._static = None
+        self.exchange = GradExchange(process_group)
+        self.distributed = self.exchange.active
 
         gf, df = generator._flat, discriminator._flat
         self.g_range = gf.range_of(("latent_encoder.", "synthesis."))
@@ -82,25 +88,96 @@ class TrainingStep:
     def dist_train_step(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg: bool, do_pl_reg: bool,
                         ocr_loss_weight: float, rand: Optional[dict] = None):
         """training_step.py:57-136.  Inputs are this rank's shard of the global batch."""
-        gen_losses, disc_losses, ocr_loss = self._train_step(real_images, ocr_images, input_words, ocr_labels,
-                                                             do_r1_reg, do_pl_reg, ocr_loss_weight, rand)
+        if self.use_graphs and rand is None:
+            gen_losses, disc_losses, ocr_loss = self._graphed_step(real_images, ocr_images, input_words, ocr_labels,
+                                                                   bool(do_r1_reg), bool(do_pl_reg), ocr_loss_weight)
+        else:
+            gen_losses, disc_losses, ocr_loss = self._train_step(real_images, ocr_images, input_words, ocr_labels,
+                                                                 do_r1_reg, do_pl_reg, ocr_loss_weight, rand)
+        self._count_step()
         if self.distributed:  # strategy.reduce(SUM) of the 7 scalars, one collective
-            packed = torch.stack([*gen_losses, *disc_losses, ocr_loss])
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.pg)
-            gen_losses, disc_losses, ocr_loss = tuple(packed[0:3]), tuple(packed[3:6]), packed[6]
+            r = self.exchange.reduce_scalars([*gen_losses, *disc_losses, ocr_loss])
+            gen_losses, disc_losses, ocr_loss = tuple(r[0:3]), tuple(r[3:6]), r[6]
         return gen_losses, disc_losses, ocr_loss
 
+    def _count_step(self):
+        for o in (self.g_optimizer, self.ocr_optimizer, self.d_optimizer):
+            o._iterations += 1
+
+    # ------------------------------------------------------------------------------------
+    # HIP-graph replay of the whole step (one graph per lazy-regularisation variant)
+    def _graphed_step(self, real_images, ocr_images, input_words, ocr_labels, do_r1, do_pl, ocr_w):
+        if self._static is None:
+            self._static = dict(real=real_images.clone(), ocr_img=ocr_images.clone(), words=input_words.clone(),
+                                labels=ocr_labels.clone(), w=torch.zeros((), device=real_images.device))
+        st = self._static
+        st["real"].copy_(real_images); st["ocr_img"].copy_(ocr_images); st["words"].copy_(input_words)
+        st["labels"].copy_(ocr_labels); st["w"].fill_(ocr_w)
+        key = (do_r1, do_pl)
+        if key not in self._warmed:
+            # first use of a variant: a real eager step on a side stream (doubles as the capture warm-up)
+            self._warmed.add(key)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = self._run_phases(st, do_r1, do_pl)
+            torch.cuda.current_stream().wait_stream(side)
+            return out
+        if key not in self._graphs:
+            torch.cuda.synchronize()
+            if self.distributed:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl,
+                                               st["w"], {})
+                with torch.cuda.graph(gb, pool=ga.pool()):
+                    self._apply_updates()
+                self._graphs[key] = (ga, gb, outs)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl,
+                                               st["w"], {})
+                    self._apply_updates()
+                self._graphs[key] = (g, None, outs)
+        ga, gb, outs = self._graphs[key]
+        ga.replay()
+        if gb is not None:
+            self.exchange.reduce_now((self.g_grad, self.o_grad, self.d_grad))
+            gb.replay()
+        return outs
+
+    def prepare_graphs(self, real_images, ocr_images, input_words, ocr_labels, ocr_loss_weight: float = 1e-4):
+        """Warm up and capture the three step variants (plain, +PL, +PL+R1) ahead of time.  Every call
+        below is a REAL optimisation step (2 per variant: eager warm-up, then capture + first replay)."""
+        assert self.use_graphs
+        for do_r1, do_pl in ((False, False), (False, True), (True, True)):
+            for _ in range(2):
+                self.dist_train_step(real_images, ocr_images, input_words, ocr_labels, do_r1, do_pl, ocr_loss_weight)
+
+    def _run_phases(self, st, do_r1, do_pl):
+        outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl, st["w"], {})
+        self.exchange.reduce_now((self.g_grad, self.o_grad, self.d_grad))
+        self._apply_updates()
+        return outs
+
     def _all_reduce_async(self, buf):
-        if not self.distributed:
-            return None
-        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        return self.exchange.start(buf)
 
     def _train_step(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg, do_pl_reg, ocr_loss_weight,
                     rand):
+        """eager path: the three all-reduces are issued asynchronously right after their backward pass."""
+        handles = []
+        outs = self._compute_grads(real_images, ocr_images, input_words, ocr_labels, do_r1_reg, do_pl_reg,
+                                   ocr_loss_weight, rand or {}, handles)
+        self._apply_updates(handles)
+        return outs
+
+    def _compute_grads(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg, do_pl_reg, ocr_loss_weight,
+                       rand, handles=None):
         cfg, G, D = self.cfg, self.generator, self.discriminator
         dev = real_images.device
         zero = torch.zeros((), device=dev)
-        rand = rand or {}
         z = rand["z"] if "z" in rand else torch.randn(self.batch_size_per_gpu, cfg.z_dim, device=dev)
 
         fake_images = G((input_words, z), training=True, rand=rand)
@@ -129,11 +206,13 @@ class TrainingStep:
         finally:
             ops.FLAGS.skip_d_wgrad = False
         write_grads(self.g_views, grads)
-        h_g = self._all_reduce_async(self.g_grad)
+        if handles is not None:
+            handles.append(self._all_reduce_async(self.g_grad))
 
         grads = torch.autograd.grad(ocr_loss_w, self.o_params, retain_graph=True, allow_unused=True)
         write_grads(self.o_views, grads)
-        h_o = self._all_reduce_async(self.o_grad)
+        if handles is not None:
+            handles.append(self._all_reduce_async(self.o_grad))
 
         ops.FLAGS.skip_image_grad = True
         try:
@@ -141,22 +220,20 @@ class TrainingStep:
         finally:
             ops.FLAGS.skip_image_grad = False
         write_grads(self.d_views, grads)
-        h_d = self._all_reduce_async(self.d_grad)
-
-        # --- three Adam updates in the reference's order
-        if h_g is not None:
-            h_g.wait()
-        self.g_optimizer.apply_gradients(self.g_grad)
-        if h_o is not None:
-            h_o.wait()
-        self.ocr_optimizer.apply_gradients(self.o_grad)
-        if h_d is not None:
-            h_d.wait()
-        self.d_optimizer.apply_gradients(self.d_grad)
+        if handles is not None:
+            handles.append(self._all_reduce_async(self.d_grad))
 
         return ((reg_g_loss.detach(), g_loss.detach(), pl_penalty.detach()),
                 (reg_d_loss.detach(), d_loss.detach(), r1_penalty.detach()),
                 (ocr_loss_w / ocr_loss_weight).detach())
+
+    def _apply_updates(self, handles=None):
+        """three Adam updates in the reference's order (g, ocr, d)."""
+        hs = list(handles) if handles else [None, None, None]
+        for h, opt, buf in zip(hs, (self.g_optimizer, self.ocr_optimizer, self.d_optimizer),
+                               (self.g_grad, self.o_grad, self.d_grad)):
+            GradExchange.finish(h)
+            opt.apply_gradients(buf)
 
     # ------------------------------------------------------------------------------------
     def _path_length_reg(self, input_words, rand):
@@ -192,7 +269,8 @@ class TrainingStep:
         return softmax_cross_entropy_loss(logits, ocr_labels, self.batch_size)
 
 
-def build_trainer_state(cfg: Config, device, aster_ocr=None, seed: int = 0, process_group=None):
+def build_trainer_state(cfg: Config, device, aster_ocr=None, seed: int = 0, process_group=None,
+                        use_graphs: bool = False):
     """The wiring of reference train.py:25-108 / model_loader.py:13-20: models (g_clone starts as a
     copy of G), lazy-reg-rescaled optimiser settings, three Adam states, pl_mean, TrainingStep."""
     from .aster import AsterInferer
@@ -209,12 +287,13 @@ def build_trainer_state(cfg: Config, device, aster_ocr=None, seed: int = 0, proc
     ocr_optimizer = AdamTF(gf.flat[ob:oe], g_opt)
     d_optimizer = AdamTF(df.flat, d_opt)
     pl_mean = torch.zeros((), device=device)
-    if aster_ocr is None:
-        aster_ocr = AsterInferer(char_width=cfg.char_width, max_char_number=cfg.max_char_number,
-                                 image_dims=cfg.aster_image_dims)
+    if aster_ocr is None:  # frozen OCR with its convolutions on the HIP kernels
+        from .aster import AsterLikeOCRHip
+        aster_ocr = AsterInferer(model=AsterLikeOCRHip(max_steps=cfg.max_char_number), char_width=cfg.char_width,
+                                 max_char_number=cfg.max_char_number, image_dims=cfg.aster_image_dims)
     aster_ocr = aster_ocr.to(device)
     step = TrainingStep(G, D, aster_ocr, g_optimizer, ocr_optimizer, d_optimizer, cfg.g_opt.reg_interval,
-                        cfg.d_opt.reg_interval, pl_mean, cfg, process_group)
+                        cfg.d_opt.reg_interval, pl_mean, cfg, process_group, use_graphs)
     return dict(generator=G, discriminator=D, g_clone=g_clone, g_optimizer=g_optimizer,
                 ocr_optimizer=ocr_optimizer, d_optimizer=d_optimizer, pl_mean=pl_mean, aster_ocr=aster_ocr,
                 training_step=step)
