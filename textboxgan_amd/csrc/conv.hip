@@ -136,15 +136,30 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
   for (int kc = kbeg; kc < kend; ++kc) {
     const int c0 = kc * CK;
     __syncthreads();
-    // stage the filter slice: rows (tap, c) of BM floats, 16 B per lane
-    for (int idx = tid; idx < ntaps * CK * (BM / 4); idx += 256) {
-      const int row = idx / (BM / 4);
-      const int m4 = idx - row * (BM / 4);
-      const int t = row / CK, c = row - t * CK;
-      const int cc = min(c0 + c, p.C - 1);
-      const int mm = min(m0 + 4 * m4, p.ldw - 4);
-      const float4 v = *reinterpret_cast<const float4 *>(p.w + ((size_t)tabs[t] * p.C + cc) * p.ldw + mm);
-      *reinterpret_cast<float4 *>(As + row * BM + 4 * m4) = v;
+    // stage the filter slice As[tap][c][BM] with the direct global->LDS DMA (global_load_lds, 16 B per lane,
+    // 1 KiB per wave instruction): no staging registers and every row group is in flight at once, so the block
+    // pays ONE memory round trip per chunk.  LDS destination = wave-uniform base + lane*16 (linear image);
+    // the per-lane SOURCE address carries the tap table / channel / M-tail clamps.
+    {
+      constexpr int TPI = 1024 / (BM * CK);  // taps covered by one 256-lane pass (1, 2 or 4)
+      static_assert(TPI >= 1 && TPI <= 4 && TPI * BM * CK == 1024, "tile/chunk combination");
+      constexpr int A_IT = (MAXTAPS + TPI - 1) / TPI;
+      const int r_local = tid / (BM / 4);
+      const int t_local = __builtin_amdgcn_readfirstlane(r_local / CK);  // wave-uniform (64 lanes <= one tap)
+      const int c = r_local - (r_local / CK) * CK;
+      const int m4 = tid - r_local * (BM / 4);
+      const int laneoff = min(c0 + c, p.C - 1) * p.ldw + min(m0 + 4 * m4, p.ldw - 4);  // ONE per-lane offset
+      const size_t tapstride = (size_t)p.C * p.ldw;
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) {
+        const int t = it * TPI + t_local;
+        if (t < ntaps) {
+          const float *src = p.w + (size_t)ci.wtap[t] * tapstride + laneoff;  // scalar base + lane offset
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                           (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
+                                           16, 0, 0);
+        }
+      }
     }
     // stage the input halo tile (zero fill, style modulation folded in)
 #pragma unroll
@@ -468,14 +483,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
       const int b = bg * p.NSEG + sseg, u = u0 + sr, v = v0 + sq;
       const bool ok = b < p.B && u < p.Hs && v < p.Ws;
       const int base = ok ? (b * p.CS) * HWs + u * p.Ws + v : -1;
-#pragma unroll 4
-      for (int ch = sch0; ch < BS; ch += 256 / PIX) {
-        float val = 0.f;
-        if (ok && cs0 + ch < p.CS) {
-          val = p.S[base + (cs0 + ch) * HWs];
-          if (p.s_scale) val *= p.s_scale[b * p.CS + cs0 + ch];
+      constexpr int S_IT = BS / (256 / PIX), S_B = 8;
+#pragma unroll
+      for (int it0 = 0; it0 < S_IT; it0 += S_B) {
+        float sv[S_B];
+#pragma unroll
+        for (int u = 0; u < S_B; ++u) {
+          const int ch = sch0 + (it0 + u) * (256 / PIX);
+          sv[u] = 0.f;
+          if (ok && cs0 + ch < p.CS) {
+            sv[u] = p.S[base + (cs0 + ch) * HWs];
+            if (p.s_scale) sv[u] *= p.s_scale[b * p.CS + cs0 + ch];
+          }
         }
-        Ss[ch * SP + spix] = val;
+#pragma unroll
+        for (int u = 0; u < S_B; ++u) Ss[(sch0 + (it0 + u) * (256 / PIX)) * SP + spix] = sv[u];
       }
     }
     {  // L halo tile: wave w stages channels w, w+4, ...
@@ -492,18 +514,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
           bb[j] = b * p.CL;
         }
       }
-      for (int ch = wave; ch < BL; ch += 4) {
-        const bool cok = cl0 + ch < p.CL;
+      constexpr int LB = 2;  // channels per batch: LB * NJ loads in flight per lane
+      for (int ch0 = wave; ch0 < BL; ch0 += 4 * LB) {
+        float lv[LB][WG_MAXNJ];
 #pragma unroll
-        for (int j = 0; j < WG_MAXNJ; ++j) {
-          if (j < p.NJ && d_seg[j] >= 0) {
-            float val = 0.f;
-            if (cok && g[j] >= 0) {
-              val = p.L[g[j] + (cl0 + ch) * HWl];
-              if (p.l_scale) val *= p.l_scale[bb[j] + cl0 + ch];
+        for (int u = 0; u < LB; ++u) {
+          const int ch = ch0 + 4 * u;
+          const bool cok = ch < BL && cl0 + ch < p.CL;
+#pragma unroll
+          for (int j = 0; j < WG_MAXNJ; ++j) {
+            lv[u][j] = 0.f;
+            if (j < p.NJ && d_seg[j] >= 0 && cok && g[j] >= 0) {
+              lv[u][j] = p.L[g[j] + (cl0 + ch) * HWl];
+              if (p.l_scale) lv[u][j] *= p.l_scale[bb[j] + cl0 + ch];
             }
-            Ls[ch * p.lplane + d_loff[j]] = val;
           }
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+          const int ch = ch0 + 4 * u;
+#pragma unroll
+          for (int j = 0; j < WG_MAXNJ; ++j)
+            if (j < p.NJ && d_seg[j] >= 0 && ch < BL) Ls[ch * p.lplane + d_loff[j]] = lv[u][j];
         }
       }
     }

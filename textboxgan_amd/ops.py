@@ -44,6 +44,7 @@ class _Profile:
 
     def __init__(self):
         self.on = False
+        self.by_shape = False
         self.recs = []
 
     def enable(self):
@@ -52,9 +53,11 @@ class _Profile:
     def disable(self):
         self.on = False
 
-    def launch(self, name, flops, fn):
+    def launch(self, name, flops, fn, shape=None):
         if not self.on:
             return fn()
+        if self.by_shape and shape is not None:
+            name = name + " " + shape
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn()
@@ -157,7 +160,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         tmp = torch.zeros((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
         e0 = N.epilogue(alpha=epi.alpha)
         N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
-            C.byref(d), N.ptr(x), N.ptr(w), N.ptr(tmp), N.ptr(in_scale), C.byref(e0), N.stream())), _what)
+            C.byref(d), N.ptr(x), N.ptr(w), N.ptr(tmp), N.ptr(in_scale), C.byref(e0), N.stream()), _what), _what)
         if dot is not None:
             dot[1].copy_((tmp * dot[0]).sum(dim=(2, 3)))
         e1 = N.Epilogue.from_buffer_copy(epi)
@@ -172,7 +175,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     alloc = torch.zeros if ksplit > 1 else torch.empty
     y = alloc((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
     N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
-        C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream())), _what)
+        C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream()), _what), _what)
     return y
 
 
@@ -203,7 +206,8 @@ def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, o
     _kname = f"conv_wgrad_kernel<2,2,{KH * KW},{32 if (stride[0] == 2 or stride[1] == 2) else 64}>"
     N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_wgrad_f32(
         C.byref(d), N.ptr(S), N.ptr(L), N.ptr(out) + 4 * out_offset, N.ptr(s_scale), N.ptr(l_scale), N.ptr(ws),
-        ws.numel() * 4, N.stream())), "tbg_conv2d_wgrad")
+        ws.numel() * 4, N.stream()), f"wgrad[B={B} CS={CS} CL={CL} S={Hs}x{Ws} L={Hl}x{Wl} k={KH} s={tuple(stride)}]"),
+        "tbg_conv2d_wgrad")
     return out
 
 
