@@ -361,9 +361,16 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
 
   // tile configuration
   int BM, BN;
-  if (d->M <= 32) { BM = 32; BN = 256; }
-  else if (d->M <= 64) { BM = 64; BN = 256; }
-  else { BM = 128; BN = 128; }
+  {
+    const long long npix = (long long)d->B * maxUg * maxVg;  // N of the (largest class) GEMM
+    if (d->M <= 32) { BM = 32; BN = 256; }
+    else if (d->M <= 64) { BM = 64; BN = (npix + 255) / 256 < 96 ? 64 : 256; }
+    else {
+      const long long tiles128 = (long long)ceil_div(d->M, 128) * ((npix + 127) / 128);
+      if (tiles128 <= 16) { BM = 64; BN = 64; }  // tiny-spatial / wide-channel: more, smaller blocks
+      else { BM = 128; BN = 128; }
+    }
+  }
   const int CK = 8;
   const int TW = pow2ceil(maxVg) < 32 ? pow2ceil(maxVg) : 32;
   const int TR = BN / TW;
@@ -402,6 +409,7 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
   hipStream_t st = tbg_stream(stream);
   static const int dbg_ck = getenv("TBG_CONV_CK") ? atoi(getenv("TBG_CONV_CK")) : 8;  // experiment knob
   if (BM == 32) return launch_fprop<1, 4, 1, 2, 8>(p, st, maxtaps, maxTilesN);
+  if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8>(p, st, maxtaps, maxTilesN);
   if (BM == 64) return launch_fprop<1, 4, 2, 2, 8>(p, st, maxtaps, maxTilesN);
   if (dbg_ck == 4) return launch_fprop<2, 2, 2, 2, 4>(p, st, maxtaps, maxTilesN);
   return launch_fprop<2, 2, 2, 2, 8>(p, st, maxtaps, maxTilesN);

@@ -80,9 +80,16 @@ class _Profile:
 PROFILE = _Profile()
 
 
-def _fprop_kernel_name(M):
-    cfgs = "1,4,1,2,8" if M <= 32 else ("1,4,2,2,8" if M <= 64 else "2,2,2,2,8")
-    return f"conv_fprop_kernel<{cfgs}>"
+def _fprop_tile(M, npix):
+    """mirror of the tile choice in tbg_conv2d_f32 (csrc/conv.hip)."""
+    if M <= 32:
+        return 32, 256, "1,4,1,2,8"
+    if M <= 64:
+        return (64, 64, "2,2,1,1,8") if math.ceil(npix / 256) < 96 else (64, 256, "1,4,2,2,8")
+    if math.ceil(M / 128) * math.ceil(npix / 128) <= 16:
+        return 64, 64, "2,2,1,1,8"
+    return 128, 128, "2,2,2,2,8"
+
 
 # ----------------------------------------------------------------------------------------
 # FIR filters (upfirdn_2d_v2.py:18-25) cached per device
@@ -124,12 +131,7 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
 
 
 def _conv_tiles(M, npix):
-    if M <= 32:
-        bm, bn = 32, 256
-    elif M <= 64:
-        bm, bn = 64, 256
-    else:
-        bm, bn = 128, 128
+    bm, bn, _ = _fprop_tile(M, npix)
     return math.ceil(M / bm) * math.ceil(npix / bn)
 
 
@@ -143,8 +145,9 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     Hout, Wout = out_hw
     nchunks = math.ceil(Cc / 8)
     ksplit = 1
+    _npix = B * (math.ceil(Hout / stride[0]) * math.ceil(Wout / stride[1]) if transposed else Hout * Wout)
     if allow_split:
-        tiles = _conv_tiles(M, B * Hout * Wout)
+        tiles = _conv_tiles(M, _npix)
         if tiles < 192 and nchunks >= 8:
             ksplit = max(1, min(nchunks // 4, math.ceil(384 / tiles)))
     d = N.ConvDesc(B, Cc, M, Hin, Win, Hout, Wout, KH, KW, stride[0], stride[1], pad[0], pad[1], int(transposed),
@@ -154,7 +157,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     _what = (f"tbg_conv2d[B={B} C={Cc} M={M} in={Hin}x{Win} out={Hout}x{Wout} k={KH}x{KW} s={tuple(stride)} "
              f"p={tuple(pad)} T={int(transposed)} ldw={ldw} ksplit={ksplit}]")
     _flops = 2.0 * B * M * Cc * KH * KW * (Hin * Win if transposed else Hout * Wout)
-    _kname = _fprop_kernel_name(M)
+    _kname = f"conv_fprop_kernel<{_fprop_tile(M, _npix)[2]}>"
     trivial = not (epi.out_scale or epi.bias or epi.noise or epi.residual or epi.act != ACT_LINEAR or dot is not None)
     if ksplit > 1 and not trivial:
         tmp = torch.zeros((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
@@ -483,7 +486,7 @@ class _ToRGBFused(torch.autograd.Function):
         wp = torch.zeros((1, I, 4), device=w.device, dtype=torch.float32)
         wp[0, :, :O] = w.reshape(I, O)
         epi = N.epilogue(alpha=coef, bias=b, residual=skip, res_scale=1.0)
-        y = conv2d_raw(x, wp, O, 1, 1, (x.shape[2], x.shape[3]), in_scale=s, epi=epi, ldw=4, allow_split=False)
+        y = conv2d_raw(x, wp, O, 1, 1, (x.shape[2], x.shape[3]), in_scale=s, epi=epi, ldw=4)
         ctx.save_for_backward(x, w, s)
         ctx.has_skip = skip is not None
         ctx.coef = coef
@@ -498,7 +501,7 @@ class _ToRGBFused(torch.autograd.Function):
         db = dy.sum(dim=(0, 2, 3))
         wt, ldo = weight_transpose_raw(w, flip=False)  # [1][O][I]
         ds = torch.zeros_like(s)
-        dx = conv2d_raw(dy, wt, I, 1, 1, (x.shape[2], x.shape[3]), ldw=ldo, allow_split=False,
+        dx = conv2d_raw(dy, wt, I, 1, 1, (x.shape[2], x.shape[3]), ldw=ldo,
                         epi=N.epilogue(alpha=ctx.coef, out_scale=s), dot=(x, ds))
         dw = torch.empty_like(w)
         wgrad_raw(dy, x, 1, 1, (1, 1), (0, 0), dw, I * O, O, 1, ctx.coef, l_scale=s)
