@@ -140,6 +140,24 @@ int tbg_weight_transpose_f32(const float *src, float *dst, int T, int I, int O, 
                              int flip, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Thin 1x1 convolutions at the RGB ends (one side has O <= 4 channels): HBM-bound streaming kernels.
+ * project:      y[b,o,p] = alpha * sum_c x[b,c,p] * w[c*ldw+o] * (scale ? scale[b*C+c] : 1)
+ *                          + (bias ? bias[o]*bias_mul : 0) + (skip ? skip[b,o,p] : 0)
+ *               = ToRGB.call (layers/to_rgb.py:28-33) incl. the `y = upsample(y) + torgb` add
+ *               (synthesis_block.py:152-153); also the image gradient of FromRGB.
+ * backproject:  dx[b,c,p] = alpha * (scale ? scale[b*C+c] : 1) * sum_o w[c*ldw+o] * dy[b,o,p]   (if dx)
+ *               G[b,c,o] += sum_p x[b,c,p] * dy[b,o,p]                                    (if G; PRE-ZEROED)
+ *               = data gradient of ToRGB plus the channel Gram from which d(weight) and d(style) follow;
+ *               with dx = NULL the filter gradient of FromRGB (layers/from_rgb.py:26-29).
+ * ---------------------------------------------------------------------------------------- */
+int tbg_rgb_project_f32(const float *x, const float *w, const float *scale, const float *bias,
+                        const float *skip, float *y, int B, int C, int O, int ldw, int HW, float alpha,
+                        float bias_mul, void *stream);
+int tbg_rgb_backproject_f32(const float *x, const float *dy, const float *w, const float *scale,
+                            float *dx, float *G, int B, int C, int O, int ldw, int HW, float alpha,
+                            void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * bias_act: stand-alone epilogue (x: [B,M,HW]) and its backward.
  * backward, from dout and the SAVED OUTPUT `out` (sign(out) == sign(pre-activation)):
  *   dpre = (residual_fused ? dout*res_scale : dout) * gain * (out_act > 0 ? 1 : slope)

@@ -50,12 +50,12 @@ struct ConvP {
   int ldw;
   int logTW, logTHs, NSEG, IHs, IWs, IWp, HALFW, planeStride, ppc, NJ, nBG;
   int nclass, ksplit, nchunks, cps;
-  int a_floats;
+  int a_floats, ck_rt;
   ClassInfo cls[MAXCLS];
   EpiK e;
 };
 
-template <int WGM, int WGN, int WTM, int WTN, int CK>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT>
 __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
   constexpr int BM = WGM * WTM * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -141,39 +141,61 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
     // pays ONE memory round trip per chunk.  LDS destination = wave-uniform base + lane*16 (linear image);
     // the per-lane SOURCE address carries the tap table / channel / M-tail clamps.
     {
-      constexpr int TPI = 1024 / (BM * CK);  // taps covered by one 256-lane pass (1, 2 or 4)
-      static_assert(TPI >= 1 && TPI <= 4 && TPI * BM * CK == 1024, "tile/chunk combination");
-      constexpr int A_IT = (MAXTAPS + TPI - 1) / TPI;
+      constexpr int RPI = 1024 / BM;  // filter rows (tap, c) covered by one 256-lane pass
+      constexpr int A_IT = (MT * CK + RPI - 1) / RPI;
       const int r_local = tid / (BM / 4);
-      const int t_local = __builtin_amdgcn_readfirstlane(r_local / CK);  // wave-uniform (64 lanes <= one tap)
-      const int c = r_local - (r_local / CK) * CK;
       const int m4 = tid - r_local * (BM / 4);
-      const int laneoff = min(c0 + c, p.C - 1) * p.ldw + min(m0 + 4 * m4, p.ldw - 4);  // ONE per-lane offset
+      const int mmoff = min(m0 + 4 * m4, p.ldw - 4);
       const size_t tapstride = (size_t)p.C * p.ldw;
+      if constexpr (CK >= RPI) {
+        static_assert(CK % RPI == 0, "chunk must hold whole passes");
 #pragma unroll
-      for (int it = 0; it < A_IT; ++it) {
-        const int t = it * TPI + t_local;
-        if (t < ntaps) {
-          const float *src = p.w + (size_t)ci.wtap[t] * tapstride + laneoff;  // scalar base + lane offset
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                           (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
-                                           16, 0, 0);
+        for (int it = 0; it < A_IT; ++it) {
+          constexpr int dummy = 0; (void)dummy;
+          const int t = (it * RPI) / CK;            // compile-time per pass
+          const int c = (it * RPI) % CK + r_local;
+          if (t < ntaps) {
+            const float *src = p.w + (size_t)ci.wtap[t] * tapstride + (min(c0 + c, p.C - 1) * p.ldw + mmoff);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
+                                             16, 0, 0);
+          }
+        }
+      } else {
+        constexpr int TPI = RPI / CK;  // taps per pass (2 or 4); 64 lanes never straddle a tap
+        static_assert(RPI % CK == 0 && TPI <= 4, "tile/chunk combination");
+        const int t_local = __builtin_amdgcn_readfirstlane(r_local / CK);
+        const int c = r_local - (r_local / CK) * CK;
+        const int laneoff = min(c0 + c, p.C - 1) * p.ldw + mmoff;  // ONE per-lane offset
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+          const int t = it * TPI + t_local;
+          if (t < ntaps) {
+            const float *src = p.w + (size_t)ci.wtap[t] * tapstride + laneoff;  // scalar base + lane offset
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
+                                             16, 0, 0);
+          }
         }
       }
     }
     // stage the input halo tile (zero fill, style modulation folded in)
+#pragma unroll 1
+    for (int cb = 0; cb < CK; cb += 8) {  // groups of 8 channels: 8*NJ loads in flight per lane
 #pragma unroll
-    for (int c = 0; c < CK; ++c) {
-      const bool cok = (c0 + c) < p.C;
+      for (int cc = 0; cc < 8; ++cc) {
+        const int c = cb + cc;
+        const bool cok = (c0 + c) < p.C;
 #pragma unroll
-      for (int j = 0; j < MAXNJ; ++j) {
-        if (j < p.NJ && loff[j] >= 0) {
-          float v = 0.f;
-          if (cok && goff[j] >= 0) {
-            v = p.x[goff[j] + (c0 + c) * HWin];
-            if (p.in_scale) v *= p.in_scale[sbc[j] + c0 + c];
+        for (int j = 0; j < MAXNJ; ++j) {
+          if (j < p.NJ && loff[j] >= 0) {
+            float v = 0.f;
+            if (cok && goff[j] >= 0) {
+              v = p.x[goff[j] + (c0 + c) * HWin];
+              if (p.in_scale) v *= p.in_scale[sbc[j] + c0 + c];
+            }
+            Xs[c * p.planeStride + loff[j]] = v;
           }
-          Xs[c * p.planeStride + loff[j]] = v;
         }
       }
     }
@@ -181,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
     for (int t = 0; t < ntaps; ++t) {
       const float *Ap = As + t * CK * BM + wm * (WTM * 32) + (lane & 31) + (lane >> 5) * BM;
       const float *Bp = Xs + (lane >> 5) * p.planeStride + tabs[MAXTAPS + t];
-#pragma unroll
+#pragma unroll 4
       for (int cp = 0; cp < CK / 2; ++cp) {
         float a[WTM], b[WTN];
 #pragma unroll
@@ -258,16 +280,18 @@ static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-template <int WGM, int WGN, int WTM, int WTN, int CK>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
   constexpr int BM = WGM * WTM * 32;
   p.a_floats = maxtaps * CK * BM;
+  p.ck_rt = CK;
   p.nchunks = ceil_div(p.C, CK);
   if (p.ksplit > p.nchunks) p.ksplit = p.nchunks;
   p.cps = ceil_div(p.nchunks, p.ksplit);
   const size_t lds = ((size_t)p.a_floats + (size_t)CK * p.planeStride + 2 * MAXTAPS + 2) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
-  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK>;
+  if (maxtaps > MT) return TBG_EUNSUPPORTED;
+  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT>;
   if (getenv("TBG_DEBUG_OCC")) {
     int nb = -1;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, lds);
@@ -371,7 +395,6 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
       else { BM = 128; BN = 128; }
     }
   }
-  const int CK = 8;
   const int TW = pow2ceil(maxVg) < 32 ? pow2ceil(maxVg) : 32;
   const int TR = BN / TW;
   const int THs = pow2ceil(maxUg) < TR ? pow2ceil(maxUg) : TR;
@@ -399,20 +422,22 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
     const int tiles = c.tilesU * c.tilesV * p.nBG;
     if (tiles > maxTilesN) maxTilesN = tiles;
   }
-  p.nchunks = ceil_div(p.C, CK);
-  p.ksplit = d->ksplit < p.nchunks ? d->ksplit : p.nchunks;
-  if (d->ksplit > 1 && p.ksplit < 1) p.ksplit = 1;
-  p.cps = ceil_div(p.nchunks, p.ksplit);
+  p.ksplit = d->ksplit;  // clamped to the chunk count in launch_fprop
   if (d->ksplit > 1 && p.ksplit == 1) {
     // caller promised a zeroed buffer + alpha-only epilogue; plain stores give the same result
   }
   hipStream_t st = tbg_stream(stream);
-  static const int dbg_ck = getenv("TBG_CONV_CK") ? atoi(getenv("TBG_CONV_CK")) : 8;  // experiment knob
-  if (BM == 32) return launch_fprop<1, 4, 1, 2, 8>(p, st, maxtaps, maxTilesN);
-  if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8>(p, st, maxtaps, maxTilesN);
-  if (BM == 64) return launch_fprop<1, 4, 2, 2, 8>(p, st, maxtaps, maxTilesN);
-  if (dbg_ck == 4) return launch_fprop<2, 2, 2, 2, 4>(p, st, maxtaps, maxTilesN);
-  return launch_fprop<2, 2, 2, 2, 8>(p, st, maxtaps, maxTilesN);
+  static const bool ck32 = getenv("TBG_CONV_1X1_CK32") != nullptr;  // experiment knob: measured no gain (1x1 is HBM/latency bound)
+  if (maxtaps == 1 && ck32) {
+    if (BM == 32) return launch_fprop<1, 4, 1, 2, 32, 1>(p, st, maxtaps, maxTilesN);
+    if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 32, 1>(p, st, maxtaps, maxTilesN);
+    if (BM == 64) return launch_fprop<1, 4, 2, 2, 32, 1>(p, st, maxtaps, maxTilesN);
+    return launch_fprop<2, 2, 2, 2, 32, 1>(p, st, maxtaps, maxTilesN);
+  }
+  if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
+  if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
+  if (BM == 64) return launch_fprop<1, 4, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
+  return launch_fprop<2, 2, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
 }
 
 // ============================================================================================

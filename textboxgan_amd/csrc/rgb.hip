@@ -1,0 +1,170 @@
+// HBM-bound "thin" 1x1 convolutions of the RGB ends of both networks (gfx950).
+//   toRGB   (layers/to_rgb.py:28-33): C feature maps -> 3 channels, style-modulated, + bias + skip image
+//   fromRGB (layers/from_rgb.py:26-29) gradients: 3 <-> 64 channels
+// One operand has <= 4 channels, so the contraction is a streaming pass over the wide tensor: these
+// kernels read it exactly once with 16-byte loads (1 KiB per wave instruction) instead of pushing a
+// 3-wide GEMM through 32x32 MFMA tiles.
+#include "common.h"
+
+#define RGB_MAXO 4
+
+struct RgbP {
+  const float *x, *w, *scale, *bias, *skip, *dy;
+  float *y, *dx, *G;
+  int B, C, O, ldw, HW;
+  float alpha, bias_mul;
+};
+
+// y[b,o,p] = alpha * sum_c x[b,c,p] * w[c,o] * scale[b,c] + bias[o]*bias_mul + skip[b,o,p]
+// block = 256 lanes x 4 pixels; the per-sample effective weights live in LDS.
+__global__ __launch_bounds__(256) void rgb_project_kernel(const RgbP p) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [C][RGB_MAXO]
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < p.C * RGB_MAXO; i += 256) {
+    const int c = i / RGB_MAXO, o = i - c * RGB_MAXO;
+    float v = 0.f;
+    if (o < p.O) v = p.w[c * p.ldw + o] * p.alpha * (p.scale ? p.scale[b * p.C + c] : 1.f);
+    wsm[i] = v;
+  }
+  __syncthreads();
+  const int q = blockIdx.x * 256 + threadIdx.x;  // pixel quad
+  const int p0 = q * 4;
+  if (p0 >= p.HW) return;
+  const bool vec = (p.HW & 3) == 0;
+  float acc[RGB_MAXO][4];
+#pragma unroll
+  for (int o = 0; o < RGB_MAXO; ++o)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[o][e] = 0.f;
+  const float *xb = p.x + (size_t)b * p.C * p.HW + p0;
+  if (vec) {
+#pragma unroll 8
+    for (int c = 0; c < p.C; ++c) {
+      const float4 xv = *reinterpret_cast<const float4 *>(xb + (size_t)c * p.HW);
+      const float4 wv = *reinterpret_cast<const float4 *>(wsm + c * RGB_MAXO);
+      const float wo[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+      for (int o = 0; o < RGB_MAXO; ++o) {
+        acc[o][0] += xv.x * wo[o]; acc[o][1] += xv.y * wo[o]; acc[o][2] += xv.z * wo[o]; acc[o][3] += xv.w * wo[o];
+      }
+    }
+  } else {
+    for (int c = 0; c < p.C; ++c)
+      for (int e = 0; e < 4; ++e)
+        if (p0 + e < p.HW) {
+          const float xv = xb[(size_t)c * p.HW + e];
+          for (int o = 0; o < RGB_MAXO; ++o) acc[o][e] += xv * wsm[c * RGB_MAXO + o];
+        }
+  }
+  for (int o = 0; o < p.O; ++o) {
+    const float bo = p.bias ? p.bias[o] * p.bias_mul : 0.f;
+    const size_t off = ((size_t)b * p.O + o) * p.HW + p0;
+    if (vec) {
+      float4 r = make_float4(acc[o][0] + bo, acc[o][1] + bo, acc[o][2] + bo, acc[o][3] + bo);
+      if (p.skip) {
+        const float4 s = *reinterpret_cast<const float4 *>(p.skip + off);
+        r.x += s.x; r.y += s.y; r.z += s.z; r.w += s.w;
+      }
+      *reinterpret_cast<float4 *>(p.y + off) = r;
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (p0 + e < p.HW) p.y[off + e] = acc[o][e] + bo + (p.skip ? p.skip[off + e] : 0.f);
+    }
+  }
+}
+
+// dx[b,c,p] = alpha * scale[b,c] * sum_o w[c,o] * dy[b,o,p]     (optional)
+// G[b,c,o] += sum_p x[b,c,p] * dy[b,o,p]                          (optional; pre-zeroed)
+// block (pixel chunk, channel group, b): the dy chunk is staged once in LDS; every WAVE walks one
+// wide channel at a time, so the three partial sums per channel need one shuffle tree per chunk.
+#define RGB_CHUNK 2048
+#define RGB_CPB 32  // channels per block (8 per wave)
+__global__ __launch_bounds__(256) void rgb_backproject_kernel(const RgbP p) {
+  __shared__ __attribute__((aligned(16))) float dys[RGB_MAXO][RGB_CHUNK];
+  const int b = blockIdx.z;
+  const int pc0 = blockIdx.x * RGB_CHUNK;
+  const int npx = min(RGB_CHUNK, p.HW - pc0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < RGB_MAXO * RGB_CHUNK; i += 256) {
+    const int o = i / RGB_CHUNK, px = i - o * RGB_CHUNK;
+    dys[o][px] = (o < p.O && px < npx) ? p.dy[((size_t)b * p.O + o) * p.HW + pc0 + px] : 0.f;
+  }
+  __syncthreads();
+  const bool vec = (p.HW & 3) == 0;
+  for (int cc = wave; cc < RGB_CPB; cc += 4) {
+    const int c = blockIdx.y * RGB_CPB + cc;
+    if (c >= p.C) break;
+    float wv[RGB_MAXO];
+    const float sc = p.alpha * (p.scale ? p.scale[b * p.C + c] : 1.f);
+#pragma unroll
+    for (int o = 0; o < RGB_MAXO; ++o) wv[o] = (p.dx && o < p.O) ? p.w[c * p.ldw + o] * sc : 0.f;
+    const size_t base = ((size_t)b * p.C + c) * p.HW + pc0;
+    float g[RGB_MAXO] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      for (int px = lane * 4; px < npx; px += 256) {
+        float4 d[RGB_MAXO];
+#pragma unroll
+        for (int o = 0; o < RGB_MAXO; ++o) d[o] = *reinterpret_cast<const float4 *>(&dys[o][px]);
+        if (p.dx) {
+          float4 r = make_float4(0, 0, 0, 0);
+#pragma unroll
+          for (int o = 0; o < RGB_MAXO; ++o) { r.x += wv[o] * d[o].x; r.y += wv[o] * d[o].y; r.z += wv[o] * d[o].z; r.w += wv[o] * d[o].w; }
+          *reinterpret_cast<float4 *>(p.dx + base + px) = r;
+        }
+        if (p.G) {
+          const float4 xv = *reinterpret_cast<const float4 *>(p.x + base + px);
+#pragma unroll
+          for (int o = 0; o < RGB_MAXO; ++o) g[o] += xv.x * d[o].x + xv.y * d[o].y + xv.z * d[o].z + xv.w * d[o].w;
+        }
+      }
+    } else {
+      for (int px = lane; px < npx; px += 64) {
+        if (p.dx) {
+          float r = 0.f;
+          for (int o = 0; o < RGB_MAXO; ++o) r += wv[o] * dys[o][px];
+          p.dx[base + px] = r;
+        }
+        if (p.G) {
+          const float xv = p.x[base + px];
+          for (int o = 0; o < RGB_MAXO; ++o) g[o] += xv * dys[o][px];
+        }
+      }
+    }
+    if (p.G) {
+#pragma unroll
+      for (int o = 0; o < RGB_MAXO; ++o) {
+        const float s = wave_sum(g[o]);
+        if (lane == 0 && o < p.O) atomicAdd(p.G + ((size_t)b * p.C + c) * p.O + o, s);
+      }
+    }
+  }
+}
+
+extern "C" int tbg_rgb_project_f32(const float *x, const float *w, const float *scale, const float *bias,
+                                   const float *skip, float *y, int B, int C, int O, int ldw, int HW, float alpha,
+                                   float bias_mul, void *stream) {
+  if (!x || !w || !y || B < 1 || C < 1 || O < 1 || O > RGB_MAXO || ldw < O || HW < 1) return TBG_EINVAL;
+  if ((double)B * C * HW > 2147483647.0) return TBG_ERANGE;
+  if ((size_t)C * RGB_MAXO * sizeof(float) > 64 * 1024) return TBG_EUNSUPPORTED;
+  RgbP p{};
+  p.x = x; p.w = w; p.scale = scale; p.bias = bias; p.skip = skip; p.y = y;
+  p.B = B; p.C = C; p.O = O; p.ldw = ldw; p.HW = HW; p.alpha = alpha; p.bias_mul = bias_mul;
+  dim3 grid((((HW + 3) / 4) + 255) / 256, B);
+  hipLaunchKernelGGL(rgb_project_kernel, grid, dim3(256), (size_t)C * RGB_MAXO * sizeof(float), tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_rgb_backproject_f32(const float *x, const float *dy, const float *w, const float *scale, float *dx,
+                                       float *G, int B, int C, int O, int ldw, int HW, float alpha, void *stream) {
+  if (!dy || B < 1 || C < 1 || O < 1 || O > RGB_MAXO || HW < 1 || (!dx && !G)) return TBG_EINVAL;
+  if ((dx && (!w || ldw < O)) || (G && !x)) return TBG_EINVAL;
+  if ((double)B * C * HW > 2147483647.0) return TBG_ERANGE;
+  RgbP p{};
+  p.x = x; p.dy = dy; p.w = w; p.scale = scale; p.dx = dx; p.G = G;
+  p.B = B; p.C = C; p.O = O; p.ldw = ldw; p.HW = HW; p.alpha = alpha;
+  dim3 grid((HW + RGB_CHUNK - 1) / RGB_CHUNK, (C + RGB_CPB - 1) / RGB_CPB, B);
+  hipLaunchKernelGGL(rgb_backproject_kernel, grid, dim3(256), 0, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}

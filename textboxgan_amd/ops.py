@@ -248,6 +248,26 @@ def bias_act_fwd_raw(x, epi: N.Epilogue):
     return y
 
 
+def rgb_project_raw(x, w2d, O, scale, bias, skip, alpha, bias_mul=1.0):
+    """y[b,o,p] = alpha * sum_c x[b,c,p] w2d[c,o] scale[b,c] + bias[o] + skip[b,o,p]   (O <= 4; w2d rows of ldw = O)."""
+    B, Cc, H, W = x.shape
+    y = torch.empty((B, O, H, W), device=x.device, dtype=torch.float32)
+    N.check(N.lib().tbg_rgb_project_f32(N.ptr(x), N.ptr(w2d), N.ptr(scale), N.ptr(bias), N.ptr(skip), N.ptr(y), B, Cc, O,
+                                        O, H * W, alpha, bias_mul, N.stream()), "tbg_rgb_project")
+    return y
+
+
+def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True):
+    """dx[b,c,p] = alpha*scale[b,c]*sum_o w2d[c,o] dy[b,o,p];  G[b,c,o] = sum_p x[b,c,p] dy[b,o,p]."""
+    B, Cc, H, W = x.shape
+    O = dy.shape[1]
+    dx = torch.empty_like(x) if want_dx else None
+    G = torch.zeros((B, Cc, O), device=x.device, dtype=torch.float32) if want_G else None
+    N.check(N.lib().tbg_rgb_backproject_f32(N.ptr(x), N.ptr(dy), N.ptr(w2d), N.ptr(scale), N.ptr(dx), N.ptr(G), B, Cc, O,
+                                            O, H * W, alpha, N.stream()), "tbg_rgb_backproject")
+    return dx, G
+
+
 def demod_coefs_raw(s: torch.Tensor, w: torch.Tensor, coef: float):
     KH, KW, I, O = w.shape
     B = s.shape[0]
@@ -483,10 +503,7 @@ class _ToRGBFused(torch.autograd.Function):
         _, _, I, O = w.shape
         coef = 1.0 / math.sqrt(I)
         x = x.contiguous()
-        wp = torch.zeros((1, I, 4), device=w.device, dtype=torch.float32)
-        wp[0, :, :O] = w.reshape(I, O)
-        epi = N.epilogue(alpha=coef, bias=b, residual=skip, res_scale=1.0)
-        y = conv2d_raw(x, wp, O, 1, 1, (x.shape[2], x.shape[3]), in_scale=s, epi=epi, ldw=4)
+        y = rgb_project_raw(x, w, O, s, b, None if skip is None else skip.contiguous(), coef)
         ctx.save_for_backward(x, w, s)
         ctx.has_skip = skip is not None
         ctx.coef = coef
@@ -499,12 +516,10 @@ class _ToRGBFused(torch.autograd.Function):
         _, _, I, O = w.shape
         dy = dy.contiguous()
         db = dy.sum(dim=(0, 2, 3))
-        wt, ldo = weight_transpose_raw(w, flip=False)  # [1][O][I]
-        ds = torch.zeros_like(s)
-        dx = conv2d_raw(dy, wt, I, 1, 1, (x.shape[2], x.shape[3]), ldw=ldo,
-                        epi=N.epilogue(alpha=ctx.coef, out_scale=s), dot=(x, ds))
-        dw = torch.empty_like(w)
-        wgrad_raw(dy, x, 1, 1, (1, 1), (0, 0), dw, I * O, O, 1, ctx.coef, l_scale=s)
+        dx, G = rgb_backproject_raw(x, dy, w, s, ctx.coef, want_dx=True, want_G=True)  # G[b,c,o] = sum_p x*dy
+        w2 = w.reshape(I, O)
+        ds = ctx.coef * (G * w2[None]).sum(dim=2)
+        dw = (ctx.coef * (G * s[:, :, None]).sum(dim=0)).reshape(w.shape)
         return dx, dw, ds, db, (dy if ctx.has_skip else None)
 
 
@@ -543,11 +558,19 @@ class _ConvBiasActFused(torch.autograd.Function):
             db = dpre.sum(dim=(0, 2, 3)) if b is not None else None
         g = _Geom(stride, pad, KH, KW, (x.shape[2], x.shape[3]), yhw)
         dx = None
+        thin = KH == 1 and KW == 1 and I <= 4 and stride == (1, 1)  # fromRGB: streaming kernels, not MFMA tiles
         if ctx.needs_input_grad[0] and not (FLAGS.skip_image_grad and I == 3):
-            dx = _bwd_data_launch(dpre, w, g, alpha=coef)
+            if thin:  # d(image)[b,c,p] = coef * sum_o w[c,o] dpre[b,o,p]
+                dx = rgb_project_raw(dpre, w.reshape(I, O).t().contiguous(), I, None, None, None, coef)
+            else:
+                dx = _bwd_data_launch(dpre, w, g, alpha=coef)
         dw = None
         if not FLAGS.skip_d_wgrad:
-            dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef)
+            if thin:  # G[b,o,c] = sum_p dpre[b,o,p] x[b,c,p]
+                _, G = rgb_backproject_raw(dpre, x, None, None, 1.0, want_dx=False, want_G=True)
+                dw = (coef * G.sum(dim=0).t()).reshape(w.shape).contiguous()
+            else:
+                dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef)
         else:
             db = None
         return dx, dw, db, dres, None, None, None, None
