@@ -55,6 +55,10 @@ struct ConvP {
   EpiK e;
 };
 
+static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
 template <int WGM, int WGN, int WTM, int WTN, int CK, int MT>
 __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
   constexpr int BM = WGM * WTM * 32;
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
         }
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of the filter slice has landed (explicit, not left to the fence)
     __syncthreads();
     for (int t = 0; t < ntaps; ++t) {
       const float *Ap = As + t * CK * BM + wm * (WTM * 32) + (lane & 31) + (lane >> 5) * BM;
@@ -276,9 +281,6 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
   }
 }
 
-static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
-static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 template <int WGM, int WGN, int WTM, int WTN, int CK, int MT>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
@@ -319,6 +321,240 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
   return TBG_OK;
 }
 
+
+// ============================================================================================
+// 3x3 TRANSPOSED convolution with all sy*sx output-parity classes merged into one block:
+// the block stages ONE input halo tile + the 9-tap filter slice per chunk (exactly what the
+// forward 3x3 conv stages) and keeps one accumulator set per class -- tap (kh,kw) feeds class
+// (kh % sy, kw % sx) with input shift (kh / sy, kw / sx), all compile-time.  Versus one launch
+// per class this reads x once instead of 4x and turns the 1- and 2-tap classes (16/32 MFMAs per
+// barrier pair) into a 72-MFMA chunk.  Epilogue: alpha only (what every caller of the transposed
+// form needs); split-K via atomics.
+// ============================================================================================
+template <int SY, int SX, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_tmerge_kernel(const ConvP p) {
+  constexpr int CK = 8, WTN = 2, NC = SY * SX, BM = WGM * 32;
+  constexpr int PY = 2 / SY, PX = 2 / SX;  // largest input shift per axis
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *As = smem;
+  float *Xs = smem + p.a_floats;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const ClassInfo &ci = p.cls[0];
+  const int ks = blockIdx.z;
+  const int tn = blockIdx.x;
+  const int tv = tn % ci.tilesV;
+  const int t2 = tn / ci.tilesV;
+  const int tu = t2 % ci.tilesU;
+  const int bg = t2 / ci.tilesU;
+  if (bg >= p.nBG) return;
+  const int m0 = blockIdx.y * BM;
+  const int u0 = tu << p.logTHs, v0 = tv << p.logTW;
+  const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTHs) - 1;
+
+  int goff[MAXNJ], loff[MAXNJ], sbc[MAXNJ];
+#pragma unroll
+  for (int j = 0; j < MAXNJ; ++j) {
+    goff[j] = -1; loff[j] = -1; sbc[j] = 0;
+    const int e = tid + 256 * j;
+    if (j < p.NJ && e < p.ppc) {
+      const int per = p.IHs * p.IWs;
+      const int seg = e / per;
+      const int rem = e - seg * per;
+      const int iyl = rem / p.IWs;
+      const int ixl = rem - iyl * p.IWs;
+      const int b = bg * p.NSEG + seg;
+      const int iy = u0 - PY + iyl, ix = v0 - PX + ixl;
+      const bool ok = b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+      goff[j] = ok ? ((b * p.C) * p.Hin + iy) * p.Win + ix : -1;
+      sbc[j] = b * p.C;
+      loff[j] = (seg * p.IHs + iyl) * p.IWp + ixl;
+    }
+  }
+  int bofs[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    const int n = (wn * WTN + j) * 32 + (lane & 31);
+    const int q = n & TWm, rr = n >> p.logTW;
+    const int seg = rr >> p.logTHs, r = rr & THm;
+    bofs[j] = (seg * p.IHs + r) * p.IWp + q;
+  }
+  f32x16 acc[NC][WTN];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+
+  const int HWin = p.Hin * p.Win;
+  const int kbeg = ks * p.cps;
+  const int kend = min(kbeg + p.cps, p.nchunks);
+  for (int kc = kbeg; kc < kend; ++kc) {
+    const int c0 = kc * CK;
+    __syncthreads();
+    {  // 9-tap filter slice As[tap][c][BM] by LDS-DMA (same scheme as conv_fprop_kernel)
+      constexpr int RPI = 1024 / BM;
+      const int r_local = tid / (BM / 4);
+      const int m4 = tid - r_local * (BM / 4);
+      const int mmoff = min(m0 + 4 * m4, p.ldw - 4);
+      const size_t tapstride = (size_t)p.C * p.ldw;
+      if constexpr (RPI <= CK) {
+        constexpr int A_IT = 9 * CK / RPI;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+          const int t = (it * RPI) / CK;
+          const int c = (it * RPI) % CK + r_local;
+          const float *src = p.w + (size_t)ci.wtap[t] * tapstride + (min(c0 + c, p.C - 1) * p.ldw + mmoff);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                           (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
+                                           16, 0, 0);
+        }
+      } else {
+        constexpr int TPI = RPI / CK;
+        constexpr int A_IT = (9 + TPI - 1) / TPI;
+        const int t_local = __builtin_amdgcn_readfirstlane(r_local / CK);
+        const int c = r_local - (r_local / CK) * CK;
+        const int laneoff = min(c0 + c, p.C - 1) * p.ldw + mmoff;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+          const int t = it * TPI + t_local;
+          if (t < 9) {
+            const float *src = p.w + (size_t)ci.wtap[t] * tapstride + laneoff;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
+                                             16, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const bool cok = (c0 + c) < p.C;
+#pragma unroll
+      for (int j = 0; j < MAXNJ; ++j) {
+        if (j < p.NJ && loff[j] >= 0) {
+          float v = 0.f;
+          if (cok && goff[j] >= 0) {
+            v = p.x[goff[j] + (c0 + c) * HWin];
+            if (p.in_scale) v *= p.in_scale[sbc[j] + c0 + c];
+          }
+          Xs[c * p.planeStride + loff[j]] = v;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // runtime tap loop + switch on the tap's class: accumulators stay statically indexed while operand
+    // loads are NOT hoisted nine taps deep (that cost 148 non-accumulator registers)
+#define TBG_TM_BODY(CLS)                                                                         \
+  {                                                                                              \
+    _Pragma("unroll") for (int cp = 0; cp < CK / 2; ++cp) {                                      \
+      const float a = Ap[cp * 2 * BM];                                                           \
+      _Pragma("unroll") for (int j = 0; j < WTN; ++j) {                                          \
+        const float b = Bp[cp * 2 * p.planeStride + bofs[j]];                                    \
+        acc[CLS][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[CLS][j], 0, 0, 0);          \
+      }                                                                                          \
+    }                                                                                            \
+  }
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      const int kh = t / 3, kw = t - kh * 3;
+      const int cls = (kh % SY) * SX + (kw % SX);
+      const int toff = (PY - kh / SY) * p.IWp + (PX - kw / SX);
+      const float *Ap = As + t * CK * BM + wm * 32 + (lane & 31) + (lane >> 5) * BM;
+      const float *Bp = Xs + (lane >> 5) * p.planeStride + toff;
+      switch (cls) {
+        case 0: TBG_TM_BODY(0) break;
+        case 1: if constexpr (NC > 1) TBG_TM_BODY(1) break;
+        case 2: if constexpr (NC > 2) TBG_TM_BODY(2) break;
+        default: if constexpr (NC > 3) TBG_TM_BODY(3) break;
+      }
+    }
+#undef TBG_TM_BODY
+  }
+  const int HWout = p.Hout * p.Wout;
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    const int n = (wn * WTN + j) * 32 + (lane & 31);
+    const int q = n & TWm, rr = n >> p.logTW;
+    const int seg = rr >> p.logTHs, r = rr & THm;
+    const int b = bg * p.NSEG + seg, u = u0 + r, v = v0 + q;
+    if (b >= p.B) continue;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int Y = u * SY + c / SX, X = v * SX + c % SX;
+      if (Y >= p.Hout || X >= p.Wout) continue;
+      const int pix = Y * p.Wout + X;
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int m = m0 + wm * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+        if (m < p.M) {
+          const size_t idx = ((size_t)b * p.M + m) * HWout + pix;
+          const float val = acc[c][j][r16] * p.e.alpha;
+          if (p.ksplit > 1) atomicAdd(p.y + idx, val);
+          else p.y[idx] = val;
+        }
+      }
+    }
+  }
+}
+
+template <int SY, int SX, int WGM, int WGN>
+static int launch_tmerge(ConvP &p, hipStream_t st, int tilesN) {
+  constexpr int BM = WGM * 32, CK = 8;
+  p.a_floats = 9 * CK * BM;
+  p.nchunks = ceil_div(p.C, CK);
+  if (p.ksplit > p.nchunks) p.ksplit = p.nchunks;
+  p.cps = ceil_div(p.nchunks, p.ksplit);
+  const size_t lds = ((size_t)p.a_floats + (size_t)CK * p.planeStride) * sizeof(float);
+  if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
+  auto kern = conv_tmerge_kernel<SY, SX, WGM, WGN>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return TBG_EHIP;
+  }
+  hipLaunchKernelGGL(kern, dim3(tilesN, ceil_div(p.M, BM), p.ksplit), dim3(256), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// returns TBG_EUNSUPPORTED when the merged form does not apply (caller falls back to per-class launches)
+static int try_tmerge(const tbg_conv_desc *d, ConvP p, hipStream_t st) {
+  if (d->KH != 3 || d->KW != 3 || (d->sy == 1 && d->sx == 1)) return TBG_EUNSUPPORTED;
+  if (p.e.out_scale || p.e.bias || p.e.noise || p.e.residual || p.e.dot_aux || p.e.act != TBG_ACT_LINEAR) return TBG_EUNSUPPORTED;
+  const int T = 9;
+  ClassInfo &c = p.cls[0];
+  for (int t = 0; t < T; ++t) c.wtap[t] = d->flip ? T - 1 - t : t;
+  c.Ug = ceil_div(d->Hout, d->sy); c.Vg = ceil_div(d->Wout, d->sx);
+  const int BM = d->M <= 32 ? 32 : (d->M <= 64 ? 64 : 128);
+  const int BN = 256 * 32 / BM;  // 4 waves x (32 x 64)
+  const int PY = 2 / d->sy, PX = 2 / d->sx;
+  const int TW = pow2ceil(c.Vg) < 32 ? pow2ceil(c.Vg) : 32;
+  const int TR = BN / TW;
+  const int THs = pow2ceil(c.Ug) < TR ? pow2ceil(c.Ug) : TR;
+  p.logTW = ilog2(TW); p.logTHs = ilog2(THs); p.NSEG = TR / THs;
+  p.IHs = THs + PY; p.IWs = TW + PX; p.IWp = p.IWs; p.HALFW = 0;
+  p.planeStride = p.NSEG * p.IHs * p.IWp;
+  p.ppc = p.NSEG * p.IHs * p.IWs;
+  p.NJ = ceil_div(p.ppc, 256);
+  if (p.NJ > MAXNJ) return TBG_EUNSUPPORTED;
+  p.nBG = ceil_div(p.B, p.NSEG);
+  c.tilesU = ceil_div(c.Ug, THs); c.tilesV = ceil_div(c.Vg, TW);
+  const int tilesN = c.tilesU * c.tilesV * p.nBG;
+  p.ksplit = d->ksplit;
+  p.nclass = 1;
+#define TBG_TM(sy_, sx_)                                                         \
+  if (d->sy == sy_ && d->sx == sx_) {                                            \
+    if (BM == 32) return launch_tmerge<sy_, sx_, 1, 4>(p, st, tilesN);           \
+    if (BM == 64) return launch_tmerge<sy_, sx_, 2, 2>(p, st, tilesN);           \
+    return launch_tmerge<sy_, sx_, 4, 1>(p, st, tilesN);                         \
+  }
+  TBG_TM(2, 2) TBG_TM(1, 2) TBG_TM(2, 1)
+#undef TBG_TM
+  return TBG_EUNSUPPORTED;
+}
+
 extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                               const float *in_scale, const tbg_epilogue *epi, void *stream) {
   if (!d || !x || !w || !y || !epi_valid(epi)) return TBG_EINVAL;
@@ -346,6 +582,12 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
   p.ldw = d->ldw;
   p.e = make_epi(epi);
   const int T = d->KH * d->KW;
+  // merged-class kernel: opt-in experiment (TBG_TMERGE=1).  Measured on MI355X: 4 classes x 2 MFMA tiles = 128
+  // accumulators + operands = 276 registers -> 1 wave/SIMD, 16-48 TFLOP/s, i.e. no better than per-class launches.
+  if (d->transposed && getenv("TBG_TMERGE")) {
+    const int rc = try_tmerge(d, p, tbg_stream(stream));
+    if (rc != TBG_EUNSUPPORTED) return rc;
+  }
   int maxUg = 0, maxVg = 0, maxKH = 0, maxKW = 0, maxtaps = 0;
   if (!d->transposed) {
     p.sy = d->sy; p.sx = d->sx; p.osy = 1; p.osx = 1; p.nclass = 1;
