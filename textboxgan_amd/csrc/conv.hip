@@ -633,7 +633,9 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
     else if (d->M <= 64) { BM = 64; BN = (npix + 255) / 256 < 96 ? 64 : 256; }
     else {
       const long long tiles128 = (long long)ceil_div(d->M, 128) * ((npix + 127) / 128);
+      static const int big = getenv("TBG_CONV_BN256") ? atoi(getenv("TBG_CONV_BN256")) : 0;  // experiment knob
       if (tiles128 <= 16) { BM = 64; BN = 64; }  // tiny-spatial / wide-channel: more, smaller blocks
+      else if (big > 0 && tiles128 >= big && maxtaps == 9) { BM = 128; BN = 256; }
       else { BM = 128; BN = 128; }
     }
   }
@@ -679,6 +681,7 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
   if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
   if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
   if (BM == 64) return launch_fprop<1, 4, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
+  if (BN == 256) return launch_fprop<2, 2, 2, 4, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
   return launch_fprop<2, 2, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
 }
 
