@@ -137,45 +137,58 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
   const int kbeg = ks * p.cps;
   const int kend = min(kbeg + p.cps, p.nchunks);
 
+  // filter-DMA addressing, hoisted out of the K loop: the tap table lives in the kernarg segment and a scalar
+  // load per DMA piece cost ~500 cycles each (measured with s_memtime); wave-uniform -> stays in SGPRs
+  constexpr int RPI_ = 1024 / BM;  // filter rows (tap, c) covered by one 256-lane pass
+  constexpr int TPI_ = (CK >= RPI_) ? 1 : RPI_ / CK;
+  constexpr int A_IT_ = (CK >= RPI_) ? (MT * CK + RPI_ - 1) / RPI_ : (MT + TPI_ - 1) / TPI_;
+  static_assert((CK >= RPI_) ? (CK % RPI_ == 0) : (RPI_ % CK == 0 && TPI_ <= 4), "tile/chunk combination");
+  const int r_local = tid / (BM / 4);
+  const int m4 = tid - r_local * (BM / 4);
+  const int mmoff = min(m0 + 4 * m4, p.ldw - 4);
+  const int t_local = (CK >= RPI_) ? 0 : __builtin_amdgcn_readfirstlane(r_local / CK);
+  const int c_loc = r_local - (r_local / CK) * CK;
+  int tapbase[A_IT_];
+#pragma unroll
+  for (int it = 0; it < A_IT_; ++it) {
+    const int t = (CK >= RPI_) ? (it * RPI_) / CK : it * TPI_ + t_local;
+    tapbase[it] = (t < ntaps) ? ci.wtap[t] * p.C * p.ldw : 0;
+  }
   for (int kc = kbeg; kc < kend; ++kc) {
     const int c0 = kc * CK;
     __syncthreads();
+    // halo positions 0..255 (batch j = 0; the only batch of the large stride-1 shapes): issue the 8 channel loads
+    // FIRST -- their round trip then hides under the ~4k-cycle issue phase of the filter DMA below
+    float xv0[8];
+    const bool ok0 = goff[0] >= 0;
+    {
+      const int gi = ok0 ? goff[0] : 0;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) xv0[cc] = p.x[gi + min(c0 + cc, p.C - 1) * HWin];
+    }
     // stage the filter slice As[tap][c][BM] with the direct global->LDS DMA (global_load_lds, 16 B per lane,
     // 1 KiB per wave instruction): no staging registers and every row group is in flight at once, so the block
     // pays ONE memory round trip per chunk.  LDS destination = wave-uniform base + lane*16 (linear image);
     // the per-lane SOURCE address carries the tap table / channel / M-tail clamps.
     {
-      constexpr int RPI = 1024 / BM;  // filter rows (tap, c) covered by one 256-lane pass
-      constexpr int A_IT = (MT * CK + RPI - 1) / RPI;
-      const int r_local = tid / (BM / 4);
-      const int m4 = tid - r_local * (BM / 4);
-      const int mmoff = min(m0 + 4 * m4, p.ldw - 4);
-      const size_t tapstride = (size_t)p.C * p.ldw;
-      if constexpr (CK >= RPI) {
-        static_assert(CK % RPI == 0, "chunk must hold whole passes");
+      if constexpr (CK >= RPI_) {
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-          constexpr int dummy = 0; (void)dummy;
-          const int t = (it * RPI) / CK;            // compile-time per pass
-          const int c = (it * RPI) % CK + r_local;
+        for (int it = 0; it < A_IT_; ++it) {
+          const int t = (it * RPI_) / CK;            // compile-time per pass
+          const int c = (it * RPI_) % CK + r_local;
           if (t < ntaps) {
-            const float *src = p.w + (size_t)ci.wtap[t] * tapstride + (min(c0 + c, p.C - 1) * p.ldw + mmoff);
+            const float *src = p.w + tapbase[it] + (min(c0 + c, p.C - 1) * p.ldw + mmoff);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
                                              16, 0, 0);
           }
         }
       } else {
-        constexpr int TPI = RPI / CK;  // taps per pass (2 or 4); 64 lanes never straddle a tap
-        static_assert(RPI % CK == 0 && TPI <= 4, "tile/chunk combination");
-        const int t_local = __builtin_amdgcn_readfirstlane(r_local / CK);
-        const int c = r_local - (r_local / CK) * CK;
-        const int laneoff = min(c0 + c, p.C - 1) * p.ldw + mmoff;  // ONE per-lane offset
+        const int laneoff = min(c0 + c_loc, p.C - 1) * p.ldw + mmoff;  // ONE per-lane offset
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-          const int t = it * TPI + t_local;
-          if (t < ntaps) {
-            const float *src = p.w + (size_t)ci.wtap[t] * tapstride + laneoff;  // scalar base + lane offset
+        for (int it = 0; it < A_IT_; ++it) {
+          if (it * TPI_ + t_local < ntaps) {
+            const float *src = p.w + tapbase[it] + laneoff;  // scalar base (hoisted) + lane offset
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
                                              16, 0, 0);
@@ -183,22 +196,36 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
         }
       }
     }
-    // stage the input halo tile (zero fill, style modulation folded in)
+    // Branch-free: every lane always loads (address clamped to element 0 when the position is padding / out of
+    // range) and selects 0 afterwards, so the 8 channel loads of a position are in flight together instead of
+    // one memory round trip per `if (valid)` basic block.
 #pragma unroll 1
-    for (int cb = 0; cb < CK; cb += 8) {  // groups of 8 channels: 8*NJ loads in flight per lane
+    for (int cb = 0; cb < CK; cb += 8) {
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        const int c = cb + cc;
-        const bool cok = (c0 + c) < p.C;
+      for (int j = 0; j < MAXNJ; ++j) {
+        if (j < p.NJ) {  // uniform
+          const bool lane_ok = goff[j] >= 0;
+          const int gi = lane_ok ? goff[j] : 0;
+          float xv[8];
+          if (j == 0 && cb == 0) {
 #pragma unroll
-        for (int j = 0; j < MAXNJ; ++j) {
-          if (j < p.NJ && loff[j] >= 0) {
-            float v = 0.f;
-            if (cok && goff[j] >= 0) {
-              v = p.x[goff[j] + (c0 + c) * HWin];
-              if (p.in_scale) v *= p.in_scale[sbc[j] + c0 + c];
+            for (int cc = 0; cc < 8; ++cc) xv[cc] = xv0[cc];
+          } else {
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+              const int ch = min(c0 + cb + cc, p.C - 1);
+              xv[cc] = p.x[gi + ch * HWin];
             }
-            Xs[c * p.planeStride + loff[j]] = v;
+          }
+          if (p.in_scale) {
+            const int si = lane_ok ? sbc[j] : 0;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) xv[cc] *= p.in_scale[si + min(c0 + cb + cc, p.C - 1)];
+          }
+          if (loff[j] >= 0) {
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc)
+              Xs[(cb + cc) * p.planeStride + loff[j]] = (lane_ok && (c0 + cb + cc) < p.C) ? xv[cc] : 0.f;
           }
         }
       }
