@@ -715,7 +715,7 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
 // ============================================================================================
 // weight gradient
 // ============================================================================================
-#define WG_MAXNJ 6
+#define WG_MAXNJ 4
 
 struct WgradP {
   const float *S, *L, *s_scale, *l_scale;
@@ -784,25 +784,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     const int bg = t2 / p.tilesU;
     const int u0 = tu << p.logTHs, v0 = tv << p.logTW;
     __syncthreads();
+    // Branch-free staging (same lesson as conv_fprop_kernel): clamp the address, always load, select 0 -- the loads
+    // of a batch are then in flight together instead of one round trip per `if (valid)` block.
     {  // S tile
       const int b = bg * p.NSEG + sseg, u = u0 + sr, v = v0 + sq;
       const bool ok = b < p.B && u < p.Hs && v < p.Ws;
-      const int base = ok ? (b * p.CS) * HWs + u * p.Ws + v : -1;
+      const int base = ok ? (b * p.CS) * HWs + u * p.Ws + v : 0;
+      const int sb = ok ? b * p.CS : 0;
       constexpr int S_IT = BS / (256 / PIX), S_B = 8;
 #pragma unroll
       for (int it0 = 0; it0 < S_IT; it0 += S_B) {
         float sv[S_B];
 #pragma unroll
         for (int u = 0; u < S_B; ++u) {
-          const int ch = sch0 + (it0 + u) * (256 / PIX);
-          sv[u] = 0.f;
-          if (ok && cs0 + ch < p.CS) {
-            sv[u] = p.S[base + (cs0 + ch) * HWs];
-            if (p.s_scale) sv[u] *= p.s_scale[b * p.CS + cs0 + ch];
-          }
+          const int chc = min(cs0 + sch0 + (it0 + u) * (256 / PIX), p.CS - 1);
+          sv[u] = p.S[base + chc * HWs];
+        }
+        if (p.s_scale) {
+#pragma unroll
+          for (int u = 0; u < S_B; ++u) sv[u] *= p.s_scale[sb + min(cs0 + sch0 + (it0 + u) * (256 / PIX), p.CS - 1)];
         }
 #pragma unroll
-        for (int u = 0; u < S_B; ++u) Ss[(sch0 + (it0 + u) * (256 / PIX)) * SP + spix] = sv[u];
+        for (int u = 0; u < S_B; ++u) {
+          const int ch = sch0 + (it0 + u) * (256 / PIX);
+          Ss[ch * SP + spix] = (ok && cs0 + ch < p.CS) ? sv[u] : 0.f;
+        }
       }
     }
     {  // L halo tile: wave w stages channels w, w+4, ...
@@ -816,23 +822,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
           const int ix = v0 * p.sx - p.px + d_ixl[j];
           const bool ok = b < p.B && iy >= 0 && iy < p.Hl && ix >= 0 && ix < p.Wl;
           g[j] = ok ? (b * p.CL) * HWl + iy * p.Wl + ix : -1;
-          bb[j] = b * p.CL;
+          bb[j] = ok ? b * p.CL : 0;
         }
       }
-      constexpr int LB = 2;  // channels per batch: LB * NJ loads in flight per lane
+      constexpr int LB = 4;  // channels per batch: LB * NJ loads in flight per lane
       for (int ch0 = wave; ch0 < BL; ch0 += 4 * LB) {
         float lv[LB][WG_MAXNJ];
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
-          const int ch = ch0 + 4 * u;
-          const bool cok = ch < BL && cl0 + ch < p.CL;
+          const int chc = min(cl0 + ch0 + 4 * u, p.CL - 1);
 #pragma unroll
           for (int j = 0; j < WG_MAXNJ; ++j) {
             lv[u][j] = 0.f;
-            if (j < p.NJ && d_seg[j] >= 0 && cok && g[j] >= 0) {
-              lv[u][j] = p.L[g[j] + (cl0 + ch) * HWl];
-              if (p.l_scale) lv[u][j] *= p.l_scale[bb[j] + cl0 + ch];
-            }
+            if (j < p.NJ) lv[u][j] = p.L[(g[j] >= 0 ? g[j] : 0) + chc * HWl];  // uniform guard only
+          }
+        }
+        if (p.l_scale) {
+#pragma unroll
+          for (int u = 0; u < LB; ++u) {
+            const int chc = min(cl0 + ch0 + 4 * u, p.CL - 1);
+#pragma unroll
+            for (int j = 0; j < WG_MAXNJ; ++j)
+              if (j < p.NJ) lv[u][j] *= p.l_scale[bb[j] + chc];
           }
         }
 #pragma unroll
@@ -840,7 +851,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
           const int ch = ch0 + 4 * u;
 #pragma unroll
           for (int j = 0; j < WG_MAXNJ; ++j)
-            if (j < p.NJ && d_seg[j] >= 0 && ch < BL) Ls[ch * p.lplane + d_loff[j]] = lv[u][j];
+            if (j < p.NJ && d_seg[j] >= 0 && ch < BL)
+              Ls[ch * p.lplane + d_loff[j]] = (g[j] >= 0 && cl0 + ch < p.CL) ? lv[u][j] : 0.f;
         }
       }
     }
