@@ -68,6 +68,8 @@ class TrainingStep:
         self.pl_noise_scaler = 1.0 / math.sqrt(float(cfg.image_width) * float(cfg.char_height))
         self.pg = process_group
         self.use_graphs = use_graphs
+        self.overlap_ocr = True  # OCR branch on a second HIP stream (its small kernels fill gaps of the D passes)
+        self._ocr_stream = None
         self._graphs = {}
         self._warmed = set()
         self._static = None
@@ -183,6 +185,18 @@ class TrainingStep:
         fake_images = G((input_words, z), training=True, rand=rand)
         fake_images = mask_text_box(fake_images, input_words, cfg.char_width)
 
+        main_stream = torch.cuda.current_stream()
+        if self.overlap_ocr:
+            # fork: the frozen OCR (and, through autograd's stream tracking, its backward) runs on a side stream
+            if self._ocr_stream is None:
+                self._ocr_stream = torch.cuda.Stream()
+            side = self._ocr_stream
+            side.wait_stream(main_stream)
+            with torch.cuda.stream(side):
+                fake_images.record_stream(side)
+                ocr_loss = self._get_ocr_loss(fake_images, ocr_labels, ocr_images)
+                ocr_loss_w = ocr_loss_weight * ocr_loss
+
         fake_scores = D(fake_images)
         g_loss = generator_loss(fake_scores, self.batch_size)
         pl_penalty = self._path_length_reg(input_words, rand) if do_pl_reg else zero
@@ -196,8 +210,9 @@ class TrainingStep:
         d_loss = discriminator_loss(fake_scores, real_scores, self.batch_size)
         reg_d_loss = d_loss + r1_penalty
 
-        ocr_loss = self._get_ocr_loss(fake_images, ocr_labels, ocr_images)
-        ocr_loss_w = ocr_loss_weight * ocr_loss
+        if not self.overlap_ocr:
+            ocr_loss = self._get_ocr_loss(fake_images, ocr_labels, ocr_images)
+            ocr_loss_w = ocr_loss_weight * ocr_loss
 
         # --- three backward passes at the pre-update weights (training_step.py:194-213)
         ops.FLAGS.skip_d_wgrad = True
@@ -223,6 +238,8 @@ class TrainingStep:
         if handles is not None:
             handles.append(self._all_reduce_async(self.d_grad))
 
+        if self.overlap_ocr:
+            main_stream.wait_stream(self._ocr_stream)  # join
         return ((reg_g_loss.detach(), g_loss.detach(), pl_penalty.detach()),
                 (reg_d_loss.detach(), d_loss.detach(), r1_penalty.detach()),
                 (ocr_loss_w / ocr_loss_weight).detach())
