@@ -705,6 +705,15 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
     if (BM == 64) return launch_fprop<1, 4, 2, 2, 32, 1>(p, st, maxtaps, maxTilesN);
     return launch_fprop<2, 2, 2, 2, 32, 1>(p, st, maxtaps, maxTilesN);
   }
+  // few-tap launches (the parity classes of a stride-2 transposed 3x3: 1/2/2/4 taps): a deeper channel chunk keeps
+  // the MFMA count per barrier pair up (4 taps x 16 channels instead of 4 x 8)
+  static const int tck = getenv("TBG_CONV_T_CK") ? atoi(getenv("TBG_CONV_T_CK")) : 16;
+  if (maxtaps > 1 && maxtaps <= 4 && tck == 16) {
+    if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, 4>(p, st, maxtaps, maxTilesN);
+    if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 16, 4>(p, st, maxtaps, maxTilesN);
+    if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN);
+    if (BN == 128) return launch_fprop<2, 2, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN);
+  }
   if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
   if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
   if (BM == 64) return launch_fprop<1, 4, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);

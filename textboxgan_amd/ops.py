@@ -130,6 +130,9 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
     return y
 
 
+FORCE_KSPLIT = None  # experiment knob (tools/bench_ksplit.py)
+
+
 def _conv_tiles(M, npix):
     bm, bn, _ = _fprop_tile(M, npix)
     return math.ceil(M / bm) * math.ceil(npix / bn)
@@ -147,9 +150,11 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     ksplit = 1
     _npix = B * (math.ceil(Hout / stride[0]) * math.ceil(Wout / stride[1]) if transposed else Hout * Wout)
     if allow_split:
-        tiles = _conv_tiles(M, _npix)
-        if tiles < 192 and nchunks >= 8:
-            ksplit = max(1, min(nchunks // 4, math.ceil(384 / tiles)))
+        tiles = _conv_tiles(M, _npix) * (stride[0] * stride[1] if transposed else 1)  # one launch covers all classes
+        if tiles < 256 and nchunks >= 8:  # tools/bench_ksplit.py: ~300 blocks is the sweet spot (atomics cost ~ ksplit)
+            ksplit = max(1, min(nchunks // 4, math.ceil(288 / tiles)))
+        if FORCE_KSPLIT is not None:
+            ksplit = max(1, min(nchunks, FORCE_KSPLIT))
     d = N.ConvDesc(B, Cc, M, Hin, Win, Hout, Wout, KH, KW, stride[0], stride[1], pad[0], pad[1], int(transposed),
                    int(flip), ldw, ksplit)
     if epi is None:
