@@ -97,6 +97,9 @@ int tbg_upfirdn2d_ex_f32(const float *x, const float *k, float *y, int major, in
  * while staging x; the epilogue applies demodulation / noise / bias / activation.
  * ksplit > 1 splits the reduction over blocks that atomically add alpha*acc into a
  * PRE-ZEROED y (epilogue must then be alpha-only).
+ * `w` is the PACKED filter Wp[tap][ceil(C/4)][ldw][4] written by tbg_weight_pack_f32 (ldw = its M;
+ * 16-byte aligned): 4 consecutive reduction channels of one output channel per 16-byte unit, which is
+ * both the LDS-DMA granule and one ds_read_b128 MFMA operand.
  * ---------------------------------------------------------------------------------------- */
 typedef struct tbg_conv_desc {
   int B, C, M;
@@ -134,10 +137,15 @@ int tbg_conv2d_wgrad_f32(const tbg_wgrad_desc *d, const float *S, const float *L
                          const float *s_scale, const float *l_scale, float *workspace,
                          long long workspace_bytes, void *stream);
 
-/* dst[t'][o][ldo: i] = src[t][i][o]  with t' = flip ? T-1-t : t ; rows padded to ldo (zero). Turns
- * the HWIO parameter into the GEMM layout the data-gradient convolutions need. */
-int tbg_weight_transpose_f32(const float *src, float *dst, int T, int I, int O, int ldo,
-                             int flip, void *stream);
+/* Pack the HWIO parameter src[T][I][O] (the layout of the reference's conv kernels, layers/conv.py:30-41,
+ * modulated_conv2d.py:33-45) into the filter format of tbg_conv2d_f32:
+ *   transpose = 0 : C = I, M = O   (forward correlation)
+ *   transpose = 1 : C = O, M = I   (data gradient: the transposed filter)
+ * dst[t'][c/4][m][c%4] with t' = flip ? T-1-t : t, zero padded past C; dst holds
+ * tbg_weight_pack_floats(T, I, O, transpose) floats and must be 16-byte aligned. */
+long long tbg_weight_pack_floats(int T, int I, int O, int transpose);
+int tbg_weight_pack_f32(const float *src, float *dst, int T, int I, int O, int transpose, int flip,
+                        void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Thin 1x1 convolutions at the RGB ends (one side has O <= 4 channels): HBM-bound streaming kernels.

@@ -281,15 +281,22 @@ def test_bias_act_fwd_bwd(dev):
         assert rel_err(pdy.sum(dim=2) / dd, gd) < 1e-4
 
 
-def test_weight_transpose(dev):
+def test_weight_pack(dev):
+    """tbg_weight_pack_f32: Wp[t'][c/4][m][c%4], zero padded past C, for both orientations and tap orders."""
     from textboxgan_amd import ops
-    w = rnd(3, 3, 13, 20, seed=60).float().double()
-    for flip in (False, True):
-        out, ldo = ops.weight_transpose_raw(w.float().to(dev), flip)
-        ref = (torch.flip(w, (0, 1)) if flip else w).reshape(9, 13, 20).permute(0, 2, 1)
-        assert ldo == 16
-        assert rel_err(out[:, :, :13], ref) == 0.0
-        assert float(out[:, :, 13:].abs().max()) == 0.0
+    w = rnd(3, 3, 13, 20, seed=60).float()
+    for transpose in (False, True):
+        for flip in (False, True):
+            pf = ops.pack_filter(w.to(dev), transpose, flip)
+            src = (torch.flip(w, (0, 1)) if flip else w).reshape(9, 13, 20)
+            gemm = src.permute(0, 2, 1) if transpose else src        # [T, C, M]
+            T, Cc, M = gemm.shape
+            assert (pf.T, pf.C, pf.M) == (T, Cc, M)
+            C4 = (Cc + 3) // 4
+            ref = torch.zeros(T, C4 * 4, M)
+            ref[:, :Cc] = gemm
+            ref = ref.reshape(T, C4, 4, M).permute(0, 1, 3, 2).contiguous()
+            assert torch.equal(pf.data.cpu().reshape(T, C4, M, 4), ref)
 
 
 def test_adam_and_ema(dev):

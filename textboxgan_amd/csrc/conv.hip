@@ -59,13 +59,22 @@ static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF>
 __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
   constexpr int BM = WGM * WTM * 32;
+  constexpr int G4 = (CK + 3) / 4;          // channel quads per chunk
+  constexpr int CB = CK < 8 ? CK : 8;       // channels per halo load batch
+  constexpr int NB = PF ? 2 : 1;            // LDS buffers (PF > 0: software-pipelined K loop)
+  constexpr int NJC = PF ? PF : MAXNJ;      // halo positions per thread this instance can hold
+  static_assert(CK == 4 || CK % 8 == 0, "chunk = one quad (half-waves split it) or whole quad pairs");
+  static_assert(!PF || CK <= 8, "the pipelined variant prefetches one load batch");
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *As = smem;
-  float *Xs = smem + p.a_floats;
-  int *tabs = reinterpret_cast<int *>(Xs + CK * p.planeStride);  // [0..8] weight tap, [9..17] LDS tap offset
+  float *As = smem;                                    // [NB][tap][quad][BM][4]
+  float *Xs = smem + NB * p.a_floats;                  // [NB][quad][halo position][4]
+  float *Ss = Xs + NB * G4 * 4 * p.planeStride;        // [NSEG][C] style modulation of this block's images
+  const int xbuf_floats = G4 * 4 * p.planeStride;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -84,19 +93,11 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
   const int ntaps = ci.ntaps;
   const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTHs) - 1;
 
-  if (tid == 0) {
-    for (int t = 0; t < ntaps; ++t) {
-      const int khp = t / ci.KWc, kwp = t - khp * ci.KWc;
-      tabs[t] = ci.wtap[t];
-      tabs[MAXTAPS + t] = khp * p.IWp + (p.sx == 2 ? (kwp & 1) * p.HALFW + (kwp >> 1) : kwp);
-    }
-  }
-
   // ---- per-thread staging descriptors for the input halo tile (same for every chunk)
-  int goff[MAXNJ], loff[MAXNJ], sbc[MAXNJ];
+  int goff[NJC], loff[NJC], sseg[NJC];
 #pragma unroll
-  for (int j = 0; j < MAXNJ; ++j) {
-    goff[j] = -1; loff[j] = -1; sbc[j] = 0;
+  for (int j = 0; j < NJC; ++j) {
+    goff[j] = -1; loff[j] = -1; sseg[j] = 0;
     const int e = tid + 256 * j;
     if (j < p.NJ && e < p.ppc) {
       const int per = p.IHs * p.IWs;
@@ -109,21 +110,39 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
       const int ix = v0 * p.sx - ci.px + ixl;
       const bool ok = b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
       goff[j] = ok ? ((b * p.C) * p.Hin + iy) * p.Win + ix : -1;
-      sbc[j] = b * p.C;
+      sseg[j] = seg * p.C;
       const int col = (p.sx == 2) ? (ixl & 1) * p.HALFW + (ixl >> 1) : ixl;
       loff[j] = (seg * p.IHs + iyl) * p.IWp + col;
     }
   }
+  if (p.in_scale) {  // s[b, :] of the block's images -> LDS once (read back while storing the halo tile)
+    for (int e = tid; e < p.NSEG * p.C; e += 256) {
+      const int seg = e / p.C, b = bg * p.NSEG + seg;
+      Ss[e] = b < p.B ? p.in_scale[(size_t)b * p.C + (e - seg * p.C)] : 0.f;
+    }
+  }
 
   // ---- per-lane pixel decode for the B operand / epilogue
-  int bofs[WTN];
+  // MFMA 32x32x2: lanes 0-31 supply k = 0, lanes 32-63 k = 1.  CK >= 8: half-wave h reads channel quad 2*o + h, so one
+  // 16-byte read per operand sub-tile feeds 4 k-steps; CK == 4: the half-waves split the single quad (8-byte reads, 2
+  // k-steps).  The k order inside a chunk is free as long as A and B agree.
+  const int half = lane >> 5;
+  int bbytes[WTN];  // byte offset of this lane's B operand (tap 0) inside one X buffer
 #pragma unroll
   for (int j = 0; j < WTN; ++j) {
     const int n = (wn * WTN + j) * 32 + (lane & 31);
     const int q = n & TWm, rr = n >> p.logTW;
     const int seg = rr >> p.logTHs, r = rr & THm;
-    bofs[j] = (seg * p.IHs + r * p.sy) * p.IWp + q;
+    const int pos = (seg * p.IHs + r * p.sy) * p.IWp + q;
+    bbytes[j] = CK == 4 ? pos * 16 + half * 8 : (half * p.planeStride + pos) * 16;
   }
+  int tofft;  // lane t holds the LDS shift of tap t: fetched with v_readlane in the tap loop (no memory, no SALU chain)
+  {
+    const int khp = lane / ci.KWc, kwp = lane - khp * ci.KWc;
+    tofft = (khp * p.IWp + (p.sx == 2 ? (kwp & 1) * p.HALFW + (kwp >> 1) : kwp)) * 16;
+  }
+  const int abytes = CK == 4 ? (wm * (WTM * 32) + (lane & 31)) * 16 + half * 8
+                             : (half * BM + wm * (WTM * 32) + (lane & 31)) * 16;
 
   f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -137,117 +156,167 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
   const int kbeg = ks * p.cps;
   const int kend = min(kbeg + p.cps, p.nchunks);
 
-  // filter-DMA addressing, hoisted out of the K loop: the tap table lives in the kernarg segment and a scalar
-  // load per DMA piece cost ~500 cycles each (measured with s_memtime); wave-uniform -> stays in SGPRs
-  constexpr int RPI_ = 1024 / BM;  // filter rows (tap, c) covered by one 256-lane pass
-  constexpr int TPI_ = (CK >= RPI_) ? 1 : RPI_ / CK;
-  constexpr int A_IT_ = (CK >= RPI_) ? (MT * CK + RPI_ - 1) / RPI_ : (MT + TPI_ - 1) / TPI_;
-  static_assert((CK >= RPI_) ? (CK % RPI_ == 0) : (RPI_ % CK == 0 && TPI_ <= 4), "tile/chunk combination");
-  const int r_local = tid / (BM / 4);
-  const int m4 = tid - r_local * (BM / 4);
-  const int mmoff = min(m0 + 4 * m4, p.ldw - 4);
-  const int t_local = (CK >= RPI_) ? 0 : __builtin_amdgcn_readfirstlane(r_local / CK);
-  const int c_loc = r_local - (r_local / CK) * CK;
+  // filter-DMA addressing, hoisted out of the K loop.  The packed filter (tbg_weight_pack_f32) is
+  // Wp[tap][C/4][ldw][4]: one 16-byte DMA unit = 4 consecutive input channels of one output channel, so the LDS image
+  // As4[tap][quad][BM] is a linear copy and an MFMA A operand for 4 k-steps is ONE ds_read_b128.
+  // The tap table lives in the kernarg segment: a scalar load per DMA piece cost ~500 cycles each (s_memtime), so the
+  // per-pass tap base is hoisted (wave-uniform -> SGPRs).
+  constexpr int UPT = BM * G4;  // DMA units per tap
+  constexpr int PPT = UPT >= 256 ? UPT / 256 : 1, TPP = UPT >= 256 ? 1 : 256 / UPT;
+  constexpr int A_IT_ = UPT >= 256 ? MT * PPT : (MT + TPP - 1) / TPP;
+  static_assert(UPT >= 64 && (UPT >= 256 ? UPT % 256 == 0 : 256 % UPT == 0), "tile/chunk combination");
+  const int C4 = (p.C + 3) >> 2;
+  const int t_local = UPT >= 256 ? 0 : __builtin_amdgcn_readfirstlane(tid / UPT);
   int tapbase[A_IT_];
 #pragma unroll
   for (int it = 0; it < A_IT_; ++it) {
-    const int t = (CK >= RPI_) ? (it * RPI_) / CK : it * TPI_ + t_local;
-    tapbase[it] = (t < ntaps) ? ci.wtap[t] * p.C * p.ldw : 0;
+    const int t = UPT >= 256 ? it / PPT : it * TPP + t_local;
+    tapbase[it] = (t < ntaps) ? ci.wtap[t] * C4 * p.ldw * 4 : 0;
   }
-  for (int kc = kbeg; kc < kend; ++kc) {
-    const int c0 = kc * CK;
-    __syncthreads();
-    // halo positions 0..255 (batch j = 0; the only batch of the large stride-1 shapes): issue the 8 channel loads
-    // FIRST -- their round trip then hides under the ~4k-cycle issue phase of the filter DMA below
-    float xv0[8];
-    const bool ok0 = goff[0] >= 0;
-    {
-      const int gi = ok0 ? goff[0] : 0;
+
+  // stage the filter slice of chunk kc with the direct global->LDS DMA (global_load_lds, 16 B per lane, 1 KiB per wave
+  // instruction): no staging registers and every piece is in flight at once.  LDS destination = wave-uniform base +
+  // lane*16 (linear image); the per-lane SOURCE address carries the tap table / channel-quad / M-tail clamps.
+  auto issue_filter_dma = [&](int kc, float *Abuf) {
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) xv0[cc] = p.x[gi + min(c0 + cc, p.C - 1) * HWin];
-    }
-    // stage the filter slice As[tap][c][BM] with the direct global->LDS DMA (global_load_lds, 16 B per lane,
-    // 1 KiB per wave instruction): no staging registers and every row group is in flight at once, so the block
-    // pays ONE memory round trip per chunk.  LDS destination = wave-uniform base + lane*16 (linear image);
-    // the per-lane SOURCE address carries the tap table / channel / M-tail clamps.
-    {
-      if constexpr (CK >= RPI_) {
-#pragma unroll
-        for (int it = 0; it < A_IT_; ++it) {
-          const int t = (it * RPI_) / CK;            // compile-time per pass
-          const int c = (it * RPI_) % CK + r_local;
-          if (t < ntaps) {
-            const float *src = p.w + tapbase[it] + (min(c0 + c, p.C - 1) * p.ldw + mmoff);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
-                                             16, 0, 0);
-          }
-        }
-      } else {
-        const int laneoff = min(c0 + c_loc, p.C - 1) * p.ldw + mmoff;  // ONE per-lane offset
-#pragma unroll
-        for (int it = 0; it < A_IT_; ++it) {
-          if (it * TPI_ + t_local < ntaps) {
-            const float *src = p.w + tapbase[it] + laneoff;  // scalar base (hoisted) + lane offset
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
-                                             16, 0, 0);
-          }
-        }
+    for (int it = 0; it < A_IT_; ++it) {
+      const int t = UPT >= 256 ? it / PPT : it * TPP + t_local;
+      const int uu = UPT >= 256 ? (it % PPT) * 256 + tid : tid % UPT;
+      const int gq = uu / BM, mm = uu - gq * BM;
+      if (t < ntaps) {
+        const float *src = p.w + tapbase[it] + (min(kc * G4 + gq, C4 - 1) * p.ldw + min(m0 + mm, p.ldw - 1)) * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(Abuf + (size_t)(256 * it + (wave << 6)) * 4),
+                                         16, 0, 0);
       }
     }
-    // Branch-free: every lane always loads (address clamped to element 0 when the position is padding / out of
-    // range) and selects 0 afterwards, so the 8 channel loads of a position are in flight together instead of
-    // one memory round trip per `if (valid)` basic block.
-#pragma unroll 1
-    for (int cb = 0; cb < CK; cb += 8) {
+  };
+  // Halo loads are branch-free: every lane always loads (address clamped to element 0 when the position is padding /
+  // out of range) and the value is zeroed at store time, so the CB channel loads of a position are in flight together
+  // instead of one memory round trip per `if (valid)` basic block.
+  auto load_halo = [&](int c0, int j, float (&xv)[CB]) {
+    const int gi = goff[j] >= 0 ? goff[j] : 0;
 #pragma unroll
-      for (int j = 0; j < MAXNJ; ++j) {
-        if (j < p.NJ) {  // uniform
-          const bool lane_ok = goff[j] >= 0;
-          const int gi = lane_ok ? goff[j] : 0;
-          float xv[8];
-          if (j == 0 && cb == 0) {
+    for (int cc = 0; cc < CB; ++cc) xv[cc] = p.x[gi + min(c0 + cc, p.C - 1) * HWin];
+  };
+  auto store_halo = [&](int c0, int qb, int j, float (&xv)[CB], float *Xbuf) {  // Xs4[quad][position]: ds_write_b128
+    if (loff[j] >= 0) {
+      const bool lane_ok = goff[j] >= 0;
+      if (p.in_scale) {
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc) xv[cc] = xv0[cc];
-          } else {
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) {
-              const int ch = min(c0 + cb + cc, p.C - 1);
-              xv[cc] = p.x[gi + ch * HWin];
-            }
-          }
-          if (p.in_scale) {
-            const int si = lane_ok ? sbc[j] : 0;
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) xv[cc] *= p.in_scale[si + min(c0 + cb + cc, p.C - 1)];
-          }
-          if (loff[j] >= 0) {
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc)
-              Xs[(cb + cc) * p.planeStride + loff[j]] = (lane_ok && (c0 + cb + cc) < p.C) ? xv[cc] : 0.f;
-          }
-        }
+        for (int cc = 0; cc < CB; ++cc) xv[cc] *= Ss[sseg[j] + min(c0 + cc, p.C - 1)];
       }
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc) xv[cc] = (lane_ok && (c0 + cc) < p.C) ? xv[cc] : 0.f;
+      f32x4 *X4 = reinterpret_cast<f32x4 *>(Xbuf);
+      X4[qb * p.planeStride + loff[j]] = f32x4{xv[0], xv[1], xv[2], xv[3]};
+      if constexpr (CB == 8) X4[(qb + 1) * p.planeStride + loff[j]] = f32x4{xv[4], xv[5], xv[6], xv[7]};
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of the filter slice has landed (explicit, not left to the fence)
-    __syncthreads();
+  };
+  auto mfma_taps = [&](const float *Abuf, const float *Xbuf) {
+    const char *Ab = reinterpret_cast<const char *>(Abuf) + abytes;
+    const char *Xb = reinterpret_cast<const char *>(Xbuf);
     for (int t = 0; t < ntaps; ++t) {
-      const float *Ap = As + t * CK * BM + wm * (WTM * 32) + (lane & 31) + (lane >> 5) * BM;
-      const float *Bp = Xs + (lane >> 5) * p.planeStride + tabs[MAXTAPS + t];
-#pragma unroll 4
-      for (int cp = 0; cp < CK / 2; ++cp) {
-        float a[WTM], b[WTN];
+      const int toffb = __builtin_amdgcn_readlane(tofft, t);  // tap shift in bytes (lane t of the table)
+      if constexpr (CK == 4) {
+        f32x2 a[WTM], b[WTN];
 #pragma unroll
-        for (int i = 0; i < WTM; ++i) a[i] = Ap[cp * 2 * BM + i * 32];
+        for (int i = 0; i < WTM; ++i) a[i] = *reinterpret_cast<const f32x2 *>(Ab + (t * BM + i * 32) * 16);
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) b[j] = Bp[cp * 2 * p.planeStride + bofs[j]];
+        for (int j = 0; j < WTN; ++j) b[j] = *reinterpret_cast<const f32x2 *>(Xb + (bbytes[j] + toffb));
 #pragma unroll
-        for (int i = 0; i < WTM; ++i)
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int o = 0; o < CK / 8; ++o) {
+          f32x4 a[WTM], b[WTN];
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+            a[i] = *reinterpret_cast<const f32x4 *>(Ab + ((t * G4 + o * 2) * BM + i * 32) * 16);
 #pragma unroll
           for (int j = 0; j < WTN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            b[j] = *reinterpret_cast<const f32x4 *>(Xb + (bbytes[j] + toffb + o * 2 * p.planeStride * 16));
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+              for (int j = 0; j < WTN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
       }
+    }
+  };
+
+  if constexpr (PF > 0) {
+    // Software-pipelined K loop, ONE barrier per chunk: the filter DMA and the halo loads of chunk k+1 are issued
+    // before the MFMA work of chunk k (they land in the other LDS buffer / in registers while the matrix cores run),
+    // so no memory round trip is exposed.  Measured need: without it the staging of co-resident blocks did NOT overlap
+    // their MFMA phases (ablation: 0.70 ms full, 0.60 ms with the filter DMA removed, 0.50 ms pure MFMA time).
+    float xv[NJC][CB];
+    if (kbeg < kend) {
+      issue_filter_dma(kbeg, As);
+#pragma unroll
+      for (int j = 0; j < NJC; ++j)
+        if (j < p.NJ) load_halo(kbeg * CK, j, xv[j]);
+      if (p.in_scale) __syncthreads();  // Ss visible
+#pragma unroll
+      for (int j = 0; j < NJC; ++j)
+        if (j < p.NJ) store_halo(kbeg * CK, 0, j, xv[j], Xs);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    for (int kc = kbeg; kc < kend; ++kc) {
+      const int cur = (kc - kbeg) & 1;
+      const bool more = kc + 1 < kend;
+      if (more) {
+        issue_filter_dma(kc + 1, As + (cur ^ 1) * p.a_floats);
+#pragma unroll
+        for (int j = 0; j < NJC; ++j)
+          if (j < p.NJ) load_halo((kc + 1) * CK, j, xv[j]);
+      }
+      mfma_taps(As + cur * p.a_floats, Xs + cur * xbuf_floats);
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < NJC; ++j)
+          if (j < p.NJ) store_halo((kc + 1) * CK, 0, j, xv[j], Xs + (cur ^ 1) * xbuf_floats);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the filter DMA has landed (explicit, not left to the fence)
+      __syncthreads();
+    }
+  } else {
+    if (p.in_scale) __syncthreads();  // Ss visible
+    for (int kc = kbeg; kc < kend; ++kc) {
+      const int c0 = kc * CK;
+      if (kc > kbeg) __syncthreads();
+      // halo batch 0 first: its round trip hides under the issue phase of the filter DMA below
+      float xv0[CB];
+      load_halo(c0, 0, xv0);
+      issue_filter_dma(kc, As);
+#pragma unroll 1
+      for (int cb = 0; cb < CK; cb += CB) {
+#pragma unroll
+        for (int j = 0; j < NJC; ++j) {
+          if (j < p.NJ) {  // uniform
+            float xv[CB];
+            if (j == 0 && cb == 0) {
+#pragma unroll
+              for (int cc = 0; cc < CB; ++cc) xv[cc] = xv0[cc];
+            } else {
+              load_halo(c0 + cb, j, xv);
+            }
+            store_halo(c0 + cb, cb >> 2, j, xv, Xs);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the filter DMA has landed (explicit, not left to the fence)
+      __syncthreads();
+      mfma_taps(As, Xs);
     }
   }
 
@@ -309,18 +378,21 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
 }
 
 
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
   constexpr int BM = WGM * WTM * 32;
-  p.a_floats = maxtaps * CK * BM;
+  constexpr int G4 = (CK + 3) / 4;
+  if (PF > 0 && p.NJ > PF) return TBG_EUNSUPPORTED;
+  p.a_floats = maxtaps * G4 * 4 * BM;
   p.ck_rt = CK;
   p.nchunks = ceil_div(p.C, CK);
   if (p.ksplit > p.nchunks) p.ksplit = p.nchunks;
   p.cps = ceil_div(p.nchunks, p.ksplit);
-  const size_t lds = ((size_t)p.a_floats + (size_t)CK * p.planeStride + 2 * MAXTAPS + 2) * sizeof(float);
+  const size_t lds = ((size_t)(PF ? 2 : 1) * ((size_t)p.a_floats + (size_t)G4 * 4 * p.planeStride) +
+                      (p.in_scale ? (size_t)p.NSEG * p.C : 0)) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   if (maxtaps > MT) return TBG_EUNSUPPORTED;
-  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT>;
+  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF>;
   if (getenv("TBG_DEBUG_OCC")) {
     int nb = -1;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, lds);
@@ -349,246 +421,13 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
 }
 
 
-// ============================================================================================
-// 3x3 TRANSPOSED convolution with all sy*sx output-parity classes merged into one block:
-// the block stages ONE input halo tile + the 9-tap filter slice per chunk (exactly what the
-// forward 3x3 conv stages) and keeps one accumulator set per class -- tap (kh,kw) feeds class
-// (kh % sy, kw % sx) with input shift (kh / sy, kw / sx), all compile-time.  Versus one launch
-// per class this reads x once instead of 4x and turns the 1- and 2-tap classes (16/32 MFMAs per
-// barrier pair) into a 72-MFMA chunk.  Epilogue: alpha only (what every caller of the transposed
-// form needs); split-K via atomics.
-// ============================================================================================
-template <int SY, int SX, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv_tmerge_kernel(const ConvP p) {
-  constexpr int CK = 8, WTN = 2, NC = SY * SX, BM = WGM * 32;
-  constexpr int PY = 2 / SY, PX = 2 / SX;  // largest input shift per axis
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *As = smem;
-  float *Xs = smem + p.a_floats;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WGN, wn = wave - wm * WGN;
-  const ClassInfo &ci = p.cls[0];
-  const int ks = blockIdx.z;
-  const int tn = blockIdx.x;
-  const int tv = tn % ci.tilesV;
-  const int t2 = tn / ci.tilesV;
-  const int tu = t2 % ci.tilesU;
-  const int bg = t2 / ci.tilesU;
-  if (bg >= p.nBG) return;
-  const int m0 = blockIdx.y * BM;
-  const int u0 = tu << p.logTHs, v0 = tv << p.logTW;
-  const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTHs) - 1;
-
-  int goff[MAXNJ], loff[MAXNJ], sbc[MAXNJ];
-#pragma unroll
-  for (int j = 0; j < MAXNJ; ++j) {
-    goff[j] = -1; loff[j] = -1; sbc[j] = 0;
-    const int e = tid + 256 * j;
-    if (j < p.NJ && e < p.ppc) {
-      const int per = p.IHs * p.IWs;
-      const int seg = e / per;
-      const int rem = e - seg * per;
-      const int iyl = rem / p.IWs;
-      const int ixl = rem - iyl * p.IWs;
-      const int b = bg * p.NSEG + seg;
-      const int iy = u0 - PY + iyl, ix = v0 - PX + ixl;
-      const bool ok = b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-      goff[j] = ok ? ((b * p.C) * p.Hin + iy) * p.Win + ix : -1;
-      sbc[j] = b * p.C;
-      loff[j] = (seg * p.IHs + iyl) * p.IWp + ixl;
-    }
-  }
-  int bofs[WTN];
-#pragma unroll
-  for (int j = 0; j < WTN; ++j) {
-    const int n = (wn * WTN + j) * 32 + (lane & 31);
-    const int q = n & TWm, rr = n >> p.logTW;
-    const int seg = rr >> p.logTHs, r = rr & THm;
-    bofs[j] = (seg * p.IHs + r) * p.IWp + q;
-  }
-  f32x16 acc[NC][WTN];
-#pragma unroll
-  for (int c = 0; c < NC; ++c)
-#pragma unroll
-    for (int j = 0; j < WTN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
-
-  const int HWin = p.Hin * p.Win;
-  const int kbeg = ks * p.cps;
-  const int kend = min(kbeg + p.cps, p.nchunks);
-  for (int kc = kbeg; kc < kend; ++kc) {
-    const int c0 = kc * CK;
-    __syncthreads();
-    {  // 9-tap filter slice As[tap][c][BM] by LDS-DMA (same scheme as conv_fprop_kernel)
-      constexpr int RPI = 1024 / BM;
-      const int r_local = tid / (BM / 4);
-      const int m4 = tid - r_local * (BM / 4);
-      const int mmoff = min(m0 + 4 * m4, p.ldw - 4);
-      const size_t tapstride = (size_t)p.C * p.ldw;
-      if constexpr (RPI <= CK) {
-        constexpr int A_IT = 9 * CK / RPI;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-          const int t = (it * RPI) / CK;
-          const int c = (it * RPI) % CK + r_local;
-          const float *src = p.w + (size_t)ci.wtap[t] * tapstride + (min(c0 + c, p.C - 1) * p.ldw + mmoff);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                           (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
-                                           16, 0, 0);
-        }
-      } else {
-        constexpr int TPI = RPI / CK;
-        constexpr int A_IT = (9 + TPI - 1) / TPI;
-        const int t_local = __builtin_amdgcn_readfirstlane(r_local / CK);
-        const int c = r_local - (r_local / CK) * CK;
-        const int laneoff = min(c0 + c, p.C - 1) * p.ldw + mmoff;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-          const int t = it * TPI + t_local;
-          if (t < 9) {
-            const float *src = p.w + (size_t)ci.wtap[t] * tapstride + laneoff;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(As + (size_t)(256 * it + (wave << 6)) * 4),
-                                             16, 0, 0);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < CK; ++c) {
-      const bool cok = (c0 + c) < p.C;
-#pragma unroll
-      for (int j = 0; j < MAXNJ; ++j) {
-        if (j < p.NJ && loff[j] >= 0) {
-          float v = 0.f;
-          if (cok && goff[j] >= 0) {
-            v = p.x[goff[j] + (c0 + c) * HWin];
-            if (p.in_scale) v *= p.in_scale[sbc[j] + c0 + c];
-          }
-          Xs[c * p.planeStride + loff[j]] = v;
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // runtime tap loop + switch on the tap's class: accumulators stay statically indexed while operand
-    // loads are NOT hoisted nine taps deep (that cost 148 non-accumulator registers)
-#define TBG_TM_BODY(CLS)                                                                         \
-  {                                                                                              \
-    _Pragma("unroll") for (int cp = 0; cp < CK / 2; ++cp) {                                      \
-      const float a = Ap[cp * 2 * BM];                                                           \
-      _Pragma("unroll") for (int j = 0; j < WTN; ++j) {                                          \
-        const float b = Bp[cp * 2 * p.planeStride + bofs[j]];                                    \
-        acc[CLS][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[CLS][j], 0, 0, 0);          \
-      }                                                                                          \
-    }                                                                                            \
-  }
-#pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-      const int kh = t / 3, kw = t - kh * 3;
-      const int cls = (kh % SY) * SX + (kw % SX);
-      const int toff = (PY - kh / SY) * p.IWp + (PX - kw / SX);
-      const float *Ap = As + t * CK * BM + wm * 32 + (lane & 31) + (lane >> 5) * BM;
-      const float *Bp = Xs + (lane >> 5) * p.planeStride + toff;
-      switch (cls) {
-        case 0: TBG_TM_BODY(0) break;
-        case 1: if constexpr (NC > 1) TBG_TM_BODY(1) break;
-        case 2: if constexpr (NC > 2) TBG_TM_BODY(2) break;
-        default: if constexpr (NC > 3) TBG_TM_BODY(3) break;
-      }
-    }
-#undef TBG_TM_BODY
-  }
-  const int HWout = p.Hout * p.Wout;
-#pragma unroll
-  for (int j = 0; j < WTN; ++j) {
-    const int n = (wn * WTN + j) * 32 + (lane & 31);
-    const int q = n & TWm, rr = n >> p.logTW;
-    const int seg = rr >> p.logTHs, r = rr & THm;
-    const int b = bg * p.NSEG + seg, u = u0 + r, v = v0 + q;
-    if (b >= p.B) continue;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int Y = u * SY + c / SX, X = v * SX + c % SX;
-      if (Y >= p.Hout || X >= p.Wout) continue;
-      const int pix = Y * p.Wout + X;
-#pragma unroll
-      for (int r16 = 0; r16 < 16; ++r16) {
-        const int m = m0 + wm * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
-        if (m < p.M) {
-          const size_t idx = ((size_t)b * p.M + m) * HWout + pix;
-          const float val = acc[c][j][r16] * p.e.alpha;
-          if (p.ksplit > 1) atomicAdd(p.y + idx, val);
-          else p.y[idx] = val;
-        }
-      }
-    }
-  }
-}
-
-template <int SY, int SX, int WGM, int WGN>
-static int launch_tmerge(ConvP &p, hipStream_t st, int tilesN) {
-  constexpr int BM = WGM * 32, CK = 8;
-  p.a_floats = 9 * CK * BM;
-  p.nchunks = ceil_div(p.C, CK);
-  if (p.ksplit > p.nchunks) p.ksplit = p.nchunks;
-  p.cps = ceil_div(p.nchunks, p.ksplit);
-  const size_t lds = ((size_t)p.a_floats + (size_t)CK * p.planeStride) * sizeof(float);
-  if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
-  auto kern = conv_tmerge_kernel<SY, SX, WGM, WGN>;
-  if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return TBG_EHIP;
-  }
-  hipLaunchKernelGGL(kern, dim3(tilesN, ceil_div(p.M, BM), p.ksplit), dim3(256), lds, st, p);
-  TBG_LAUNCH_CHECK();
-  return TBG_OK;
-}
-
-// returns TBG_EUNSUPPORTED when the merged form does not apply (caller falls back to per-class launches)
-static int try_tmerge(const tbg_conv_desc *d, ConvP p, hipStream_t st) {
-  if (d->KH != 3 || d->KW != 3 || (d->sy == 1 && d->sx == 1)) return TBG_EUNSUPPORTED;
-  if (p.e.out_scale || p.e.bias || p.e.noise || p.e.residual || p.e.dot_aux || p.e.act != TBG_ACT_LINEAR) return TBG_EUNSUPPORTED;
-  const int T = 9;
-  ClassInfo &c = p.cls[0];
-  for (int t = 0; t < T; ++t) c.wtap[t] = d->flip ? T - 1 - t : t;
-  c.Ug = ceil_div(d->Hout, d->sy); c.Vg = ceil_div(d->Wout, d->sx);
-  const int BM = d->M <= 32 ? 32 : (d->M <= 64 ? 64 : 128);
-  const int BN = 256 * 32 / BM;  // 4 waves x (32 x 64)
-  const int PY = 2 / d->sy, PX = 2 / d->sx;
-  const int TW = pow2ceil(c.Vg) < 32 ? pow2ceil(c.Vg) : 32;
-  const int TR = BN / TW;
-  const int THs = pow2ceil(c.Ug) < TR ? pow2ceil(c.Ug) : TR;
-  p.logTW = ilog2(TW); p.logTHs = ilog2(THs); p.NSEG = TR / THs;
-  p.IHs = THs + PY; p.IWs = TW + PX; p.IWp = p.IWs; p.HALFW = 0;
-  p.planeStride = p.NSEG * p.IHs * p.IWp;
-  p.ppc = p.NSEG * p.IHs * p.IWs;
-  p.NJ = ceil_div(p.ppc, 256);
-  if (p.NJ > MAXNJ) return TBG_EUNSUPPORTED;
-  p.nBG = ceil_div(p.B, p.NSEG);
-  c.tilesU = ceil_div(c.Ug, THs); c.tilesV = ceil_div(c.Vg, TW);
-  const int tilesN = c.tilesU * c.tilesV * p.nBG;
-  p.ksplit = d->ksplit;
-  p.nclass = 1;
-#define TBG_TM(sy_, sx_)                                                         \
-  if (d->sy == sy_ && d->sx == sx_) {                                            \
-    if (BM == 32) return launch_tmerge<sy_, sx_, 1, 4>(p, st, tilesN);           \
-    if (BM == 64) return launch_tmerge<sy_, sx_, 2, 2>(p, st, tilesN);           \
-    return launch_tmerge<sy_, sx_, 4, 1>(p, st, tilesN);                         \
-  }
-  TBG_TM(2, 2) TBG_TM(1, 2) TBG_TM(2, 1)
-#undef TBG_TM
-  return TBG_EUNSUPPORTED;
-}
-
 extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                               const float *in_scale, const tbg_epilogue *epi, void *stream) {
   if (!d || !x || !w || !y || !epi_valid(epi)) return TBG_EINVAL;
   if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1 || d->Hout < 1 || d->Wout < 1) return TBG_EINVAL;
   if (d->KH < 1 || d->KW < 1 || d->KH * d->KW > MAXTAPS) return TBG_EUNSUPPORTED;
   if (d->sy < 1 || d->sy > 2 || d->sx < 1 || d->sx > 2) return TBG_EUNSUPPORTED;
-  if (d->ldw < d->M || (d->ldw & 3) != 0) return TBG_EINVAL;
+  if (d->ldw < d->M || (reinterpret_cast<uintptr_t>(w) & 15) != 0) return TBG_EINVAL;
   if ((((uintptr_t)w) & 15) != 0) return TBG_EINVAL;
   if (d->ksplit < 1) return TBG_EINVAL;
   if (d->ksplit > 1 && epi && (epi->out_scale || epi->bias || epi->noise || epi->residual || epi->dot_aux || epi->act != TBG_ACT_LINEAR))
@@ -609,12 +448,6 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
   p.ldw = d->ldw;
   p.e = make_epi(epi);
   const int T = d->KH * d->KW;
-  // merged-class kernel: opt-in experiment (TBG_TMERGE=1).  Measured on MI355X: 4 classes x 2 MFMA tiles = 128
-  // accumulators + operands = 276 registers -> 1 wave/SIMD, 16-48 TFLOP/s, i.e. no better than per-class launches.
-  if (d->transposed && getenv("TBG_TMERGE")) {
-    const int rc = try_tmerge(d, p, tbg_stream(stream));
-    if (rc != TBG_EUNSUPPORTED) return rc;
-  }
   int maxUg = 0, maxVg = 0, maxKH = 0, maxKW = 0, maxtaps = 0;
   if (!d->transposed) {
     p.sy = d->sy; p.sx = d->sx; p.osy = 1; p.osx = 1; p.nclass = 1;
@@ -666,7 +499,8 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
       else { BM = 128; BN = 128; }
     }
   }
-  const int TW = pow2ceil(maxVg) < 32 ? pow2ceil(maxVg) : 32;
+  static const int twmax = getenv("TBG_TW_MAX") ? atoi(getenv("TBG_TW_MAX")) : 32;
+  const int TW = pow2ceil(maxVg) < twmax ? pow2ceil(maxVg) : (twmax < BN ? twmax : BN);
   const int TR = BN / TW;
   const int THs = pow2ceil(maxUg) < TR ? pow2ceil(maxUg) : TR;
   p.logTW = ilog2(TW); p.logTHs = ilog2(THs); p.NSEG = TR / THs;
@@ -713,6 +547,18 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
     if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 16, 4>(p, st, maxtaps, maxTilesN);
     if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN);
     if (BN == 128) return launch_fprop<2, 2, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN);
+  }
+  // Software-pipelined variants (double-buffered LDS, one barrier per chunk).  Measured (tools/bench_conv.py): +12% on
+  // the 64x256 tile (76 -> 86 TFLOP/s), neutral on 128x128 (99-108 both ways), -5..10% on the small-spatial 64x64 tile
+  // -> default: 64x256 only.  TBG_CONV_PF=0 disables, =2 enables everywhere.
+  static const int pf = getenv("TBG_CONV_PF") ? atoi(getenv("TBG_CONV_PF")) : 1;
+  if (pf && p.NJ <= 3) {
+    if (BM == 64 && BN == 256) return launch_fprop<1, 4, 2, 2, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN);
+    if (pf >= 2) {
+      if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS, 3>(p, st, maxtaps, maxTilesN);
+      if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN);
+      if (BN == 128) return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN);
+    }
   }
   if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
   if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);

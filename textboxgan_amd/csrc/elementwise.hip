@@ -333,31 +333,45 @@ extern "C" int tbg_bias_act_bwd_f32(const float *dout, const float *out_act, flo
 }
 
 // ============================================================================================
-// weight transpose  dst[t'][o][i (ldo)] = src[t][i][o]
+// filter packing for the MFMA convolutions: HWIO parameter [T][I][O] -> Wp[T][C/4][M][4]
+//   transpose = 0: C = I (reduction), M = O  -- forward correlation
+//   transpose = 1: C = O, M = I              -- data gradient (the transposed filter); flip reverses the taps
+// A 16-byte unit holds 4 consecutive reduction channels of one output channel (zero padded past C): the conv
+// kernel DMAs units straight into LDS and reads an MFMA A operand for 4 k-steps with one ds_read_b128.
 // ============================================================================================
-__global__ __launch_bounds__(256) void weight_transpose_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                               int T, int I, int O, int ldo, int flip) {
-  __shared__ float tile[32][33];
+__global__ __launch_bounds__(256) void weight_pack_kernel(const float *__restrict__ src, float4 *__restrict__ dst,
+                                                          int T, int I, int O, int transpose, int flip) {
   const int t = blockIdx.z;
   const int td = flip ? T - 1 - t : t;
-  const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int r = ty; r < 32; r += 8) {
-    const int i = i0 + r, o = o0 + tx;
-    tile[r][tx] = (i < I && o < O) ? src[((size_t)t * I + i) * O + o] : 0.f;
+  const int C = transpose ? O : I, M = transpose ? I : O;
+  const int C4 = (C + 3) >> 2;
+  const int c4 = blockIdx.y;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * c4 + e;
+    const int i = transpose ? m : c, o = transpose ? c : m;
+    v[e] = (c < C) ? src[((size_t)t * I + i) * O + o] : 0.f;
   }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int o = o0 + r, i = i0 + tx;
-    if (o < O && i < ldo) dst[((size_t)td * O + o) * ldo + i] = tile[tx][r];
-  }
+  dst[((size_t)td * C4 + c4) * M + m] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-extern "C" int tbg_weight_transpose_f32(const float *src, float *dst, int T, int I, int O, int ldo, int flip,
-                                        void *stream) {
-  if (!src || !dst || T < 1 || I < 1 || O < 1 || ldo < I) return TBG_EINVAL;
-  dim3 grid((ldo + 31) / 32, (O + 31) / 32, T);
-  hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, tbg_stream(stream), src, dst, T, I, O, ldo, flip);
+extern "C" long long tbg_weight_pack_floats(int T, int I, int O, int transpose) {
+  if (T < 1 || I < 1 || O < 1) return -1;
+  const long long C = transpose ? O : I, M = transpose ? I : O;
+  return (long long)T * ((C + 3) / 4) * M * 4;
+}
+
+extern "C" int tbg_weight_pack_f32(const float *src, float *dst, int T, int I, int O, int transpose, int flip,
+                                   void *stream) {
+  if (!src || !dst || T < 1 || I < 1 || O < 1) return TBG_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) != 0) return TBG_EINVAL;
+  const int C = transpose ? O : I, M = transpose ? I : O;
+  dim3 grid((M + 255) / 256, (C + 3) / 4, T);
+  hipLaunchKernelGGL(weight_pack_kernel, grid, dim3(256), 0, tbg_stream(stream), src, reinterpret_cast<float4 *>(dst), T, I,
+                     O, transpose, flip);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }

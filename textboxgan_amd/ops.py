@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Optional, Tuple
+from typing import NamedTuple, Optional, Tuple
 
 import numpy as np
 import torch
@@ -141,10 +141,16 @@ def _conv_tiles(M, npix):
 def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_hw: Tuple[int, int], stride=(1, 1),
                pad=(0, 0), transposed=False, flip=False, in_scale=None, epi: Optional[N.Epilogue] = None,
                ldw: Optional[int] = None, allow_split=True, dot=None) -> torch.Tensor:
-    """w: GEMM layout [KH*KW, C, ldw] (any view with that memory layout, e.g. the HWIO parameter).
+    """w: a PackedFilter (pack_filter), or a tensor in GEMM layout [KH*KW, C, ldw] (any view with that memory layout,
+    e.g. the HWIO parameter) which is packed here.
     dot = (aux, out): out[b,m] = sum_p (alpha*acc)[b,m,p] * aux[b,m,p]  (fused when K is not split)."""
     B, Cc, Hin, Win = x.shape
-    ldw = M if ldw is None else ldw
+    if not isinstance(w, PackedFilter):
+        ldw = M if ldw is None else ldw
+        w = pack_filter(w.reshape(KH * KW, Cc, ldw), transpose=False, flip=False)
+    assert w.C == Cc and w.M >= M and w.T == KH * KW, "packed filter does not match the convolution"
+    ldw = w.M
+    w = w.data
     Hout, Wout = out_hw
     nchunks = math.ceil(Cc / 8)
     ksplit = 1
@@ -219,14 +225,58 @@ def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, o
     return out
 
 
-def weight_transpose_raw(w: torch.Tensor, flip: bool) -> Tuple[torch.Tensor, int]:
-    """HWIO [k,k,I,O] -> GEMM layout for the data gradient [T][O][ldo>=I]."""
-    KH, KW, I, O = w.shape
-    ldo = (I + 3) // 4 * 4
-    out = torch.empty((KH * KW, O, ldo), device=w.device, dtype=torch.float32)
-    N.check(N.lib().tbg_weight_transpose_f32(N.ptr(w), N.ptr(out), KH * KW, I, O, ldo, int(flip), N.stream()),
-            "tbg_weight_transpose")
-    return out, ldo
+class PackedFilter(NamedTuple):
+    """Wp[T][ceil(C/4)][M][4] (tbg_weight_pack_f32): the filter format of tbg_conv2d_f32."""
+    data: torch.Tensor
+    T: int
+    C: int
+    M: int
+
+
+_PACK_STEP: Optional[dict] = None  # live only inside filter_cache(): weights are constant within one step's passes
+_PACK_FROZEN: dict = {}            # frozen networks (OCR): packed once per weight version
+
+
+class filter_cache:
+    """Scope in which packed filters of PARAMETERS are reused (forward, and the data gradients of the three backward
+    passes, see the same weights).  Nothing outlives the scope, so an optimiser update can never meet a stale pack."""
+
+    def __enter__(self):
+        global _PACK_STEP
+        self._outer = _PACK_STEP
+        if _PACK_STEP is None:
+            _PACK_STEP = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _PACK_STEP
+        _PACK_STEP = self._outer
+        return False
+
+
+def pack_filter(w: torch.Tensor, transpose: bool, flip: bool, frozen: bool = False) -> PackedFilter:
+    """HWIO [KH,KW,I,O] / [T,I,O] parameter -> PackedFilter.  transpose: C = O, M = I (data gradient)."""
+    if w.dim() == 4:
+        T, I, O = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
+    else:
+        T, I, O = w.shape
+    cache = None
+    if frozen:
+        cache = _PACK_FROZEN
+    elif _PACK_STEP is not None and w.is_leaf and w.requires_grad:
+        cache = _PACK_STEP
+    key = (w.data_ptr(), T, I, O, bool(transpose), bool(flip), w._version)
+    if cache is not None and key in cache:
+        return cache[key]
+    w = w.contiguous()
+    n = N.lib().tbg_weight_pack_floats(T, I, O, int(transpose))
+    out = torch.empty(n, device=w.device, dtype=torch.float32)
+    N.check(N.lib().tbg_weight_pack_f32(N.ptr(w), N.ptr(out), T, I, O, int(transpose), int(flip), N.stream()),
+            "tbg_weight_pack")
+    pf = PackedFilter(out, T, O if transpose else I, I if transpose else O)
+    if cache is not None:
+        cache[key] = pf
+    return pf
 
 
 def bias_act_bwd_raw(dout, out_act, epi: N.Epilogue, want_dx=False, want_dpre=True, want_db=True, want_dn=False,
@@ -322,11 +372,7 @@ class _Geom:
 
 def _fwd_launch(x, w, g: _Geom, alpha=1.0):
     O = w.shape[3]
-    ldw = O
-    if O % 4:  # 16-byte filter rows (toRGB: O = 3)
-        ldw = (O + 3) // 4 * 4
-        w = torch.nn.functional.pad(w, (0, ldw - O)).contiguous()
-    return conv2d_raw(x, w, O, g.KH, g.KW, g.yhw, g.stride, g.pad, epi=N.epilogue(alpha=alpha), ldw=ldw)
+    return conv2d_raw(x, pack_filter(w, False, False), O, g.KH, g.KW, g.yhw, g.stride, g.pad, epi=N.epilogue(alpha=alpha))
 
 
 def _bwd_data_launch(dy, w, g: _Geom, alpha=1.0, in_scale=None, epi=None, dot=None):
@@ -334,13 +380,13 @@ def _bwd_data_launch(dy, w, g: _Geom, alpha=1.0, in_scale=None, epi=None, dot=No
     I = w.shape[2]
     epi = epi if epi is not None else N.epilogue(alpha=alpha)
     if g.stride == (1, 1):
-        wt, ldo = weight_transpose_raw(w, flip=True)
+        wt = pack_filter(w, transpose=True, flip=True)
         return conv2d_raw(dy, wt, I, g.KH, g.KW, g.xhw, (1, 1), (g.KH - 1 - g.pad[0], g.KW - 1 - g.pad[1]),
-                          in_scale=in_scale, epi=epi, ldw=ldo, dot=dot)
+                          in_scale=in_scale, epi=epi, dot=dot)
     assert g.pad == (0, 0), "strided convolutions on this path are VALID"
-    wt, ldo = weight_transpose_raw(w, flip=False)
+    wt = pack_filter(w, transpose=True, flip=False)
     return conv2d_raw(dy, wt, I, g.KH, g.KW, g.xhw, g.stride, (0, 0), transposed=True, in_scale=in_scale, epi=epi,
-                      ldw=ldo, dot=dot)
+                      dot=dot)
 
 
 def _bwd_weight_launch(x, dy, g: _Geom, I, O, alpha=1.0, x_scale=None, dy_scale=None):
@@ -432,7 +478,8 @@ class _ModConvFused(torch.autograd.Function):
         coef = 1.0 / math.sqrt(KH * KW * I)
         x = x.contiguous()
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=coef)
-        out = conv2d_raw(x, w, O, KH, KW, (x.shape[2], x.shape[3]), (1, 1), (KH // 2, KW // 2), in_scale=s, epi=epi)
+        out = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (x.shape[2], x.shape[3]), (1, 1), (KH // 2, KW // 2),
+                         in_scale=s, epi=epi)
         ctx.save_for_backward(x, w, s, d, noise, strength, b, out)
         ctx.coef = coef
         return out
@@ -465,7 +512,7 @@ class _ModConvUpFused(torch.autograd.Function):
         coef = 1.0 / math.sqrt(KH * KW * I)
         x = x.contiguous()
         H, W = x.shape[2], x.shape[3]
-        y_up = conv2d_raw(x, w, O, KH, KW, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, flip=True,
+        y_up = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, flip=True,
                           in_scale=s, epi=N.epilogue(alpha=coef))
         k = fir_kernel(x.device, gain=4.0)
         epi = _lrelu_epi(out_scale=d.reshape(-1), bias=b, noise=noise, strength=strength, alpha=1.0)
@@ -488,9 +535,9 @@ class _ModConvUpFused(torch.autograd.Function):
         dd = pdy.sum(dim=2) / d
         k = fir_kernel(x.device, gain=4.0)  # symmetric: flipped == itself
         dy_up = upfirdn2d_raw(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))  # [B,O,2H+1,2W+1]
-        wt, ldo = weight_transpose_raw(w, flip=True)
+        wt = pack_filter(w, transpose=True, flip=True)
         ds = torch.zeros_like(s)
-        dx = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0), ldw=ldo,
+        dx = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0),
                         epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds))
         dw = torch.empty_like(w)
         T = KH * KW
@@ -540,7 +587,7 @@ class _ConvBiasActFused(torch.autograd.Function):
         H, W = x.shape[2], x.shape[3]
         yhw = ((H + 2 * pad[0] - KH) // stride[0] + 1, (W + 2 * pad[1] - KW) // stride[1] + 1)
         epi = N.epilogue(alpha=coef, bias=b, act=act, residual=residual, res_scale=res_scale)
-        out = conv2d_raw(x, w, O, KH, KW, yhw, stride, pad, epi=epi)
+        out = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, yhw, stride, pad, epi=epi)
         ctx.save_for_backward(x, w, b, out if act == ACT_LRELU else None)
         ctx.cfgv = (stride, pad, act, res_scale, coef, residual is not None, yhw)
         return out
@@ -652,7 +699,7 @@ class _FrozenConv(torch.autograd.Function):
             residual = residual.contiguous()
         epi = N.epilogue(bias=b, residual=residual, res_first=1, act=ACT_LRELU if relu else ACT_LINEAR, slope=0.0,
                          gain=1.0)
-        y = conv2d_raw(x, w, O, KH, KW, yhw, stride, pad, epi=epi)
+        y = conv2d_raw(x, pack_filter(w, False, False, frozen=True), O, KH, KW, yhw, stride, pad, epi=epi)
         ctx.save_for_backward(w, y if relu else None)
         ctx.cfgv = (stride, pad, relu, residual is not None, (H, W), yhw)
         return y
@@ -669,12 +716,12 @@ class _FrozenConv(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if stride == (1, 1):
-                wt, ldo = weight_transpose_raw(w, flip=True)
-                dx = conv2d_raw(dy, wt, I, KH, KW, xhw, (1, 1), (KH - 1 - pad[0], KW - 1 - pad[1]), ldw=ldo)
+                wt = pack_filter(w, transpose=True, flip=True, frozen=True)
+                dx = conv2d_raw(dy, wt, I, KH, KW, xhw, (1, 1), (KH - 1 - pad[0], KW - 1 - pad[1]))
             else:
                 assert KH == 1 and KW == 1 and pad == (0, 0), "strided OCR convolutions are 1x1"
-                wt, ldo = weight_transpose_raw(w, flip=False)
-                dx = conv2d_raw(dy, wt, I, 1, 1, xhw, stride, (0, 0), transposed=True, ldw=ldo)
+                wt = pack_filter(w, transpose=True, flip=False, frozen=True)
+                dx = conv2d_raw(dy, wt, I, 1, 1, xhw, stride, (0, 0), transposed=True)
         return dx, None, None, None, None, None, (dy if has_res else None)
 
 

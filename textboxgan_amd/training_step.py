@@ -175,8 +175,12 @@ class TrainingStep:
         self._apply_updates(handles)
         return outs
 
-    def _compute_grads(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg, do_pl_reg, ocr_loss_weight,
-                       rand, handles=None):
+    def _compute_grads(self, *args, **kw):
+        with ops.filter_cache():  # packed filters are shared by the forward and the three backward passes
+            return self._compute_grads_impl(*args, **kw)
+
+    def _compute_grads_impl(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg, do_pl_reg,
+                            ocr_loss_weight, rand, handles=None):
         cfg, G, D = self.cfg, self.generator, self.discriminator
         dev = real_images.device
         zero = torch.zeros((), device=dev)

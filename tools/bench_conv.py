@@ -28,13 +28,10 @@ tot = [0, 0, 0]
 for name, C, M, H, W, k, kind in L:
     x = torch.randn(B, C, H, W, device=dev)
     w = torch.randn(k, k, C, M, device=dev)
-    if M % 4:
-        wp = torch.zeros(k * k, C, 4, device=dev); wp[:, :, :M] = w.reshape(k * k, C, M); ldw = 4
-    else:
-        wp, ldw = w, M
+    wp = ops.pack_filter(w, False, False)   # packed once: the timings below are the conv kernels alone
     if kind == "s1":
         ohw = (H, W); g = ops._Geom((1, 1), (k // 2, k // 2), k, k, (H, W), ohw)
-        fwd = lambda: ops.conv2d_raw(x, wp, M, k, k, ohw, (1, 1), (k // 2, k // 2), ldw=ldw)
+        fwd = lambda: ops.conv2d_raw(x, wp, M, k, k, ohw, (1, 1), (k // 2, k // 2))
         flops = 2 * B * C * M * k * k * H * W
     elif kind == "up":
         ohw = (2 * H + 1, 2 * W + 1); g = ops._Geom((2, 2), (0, 0), k, k, ohw, (H, W))
@@ -47,12 +44,17 @@ for name, C, M, H, W, k, kind in L:
     y = fwd()
     dy = torch.randn_like(y)
     if kind == "up":   # bwd-data of the transposed conv = strided conv of dy ; wgrad: S = x, L = dy
-        wt, ldo = ops.weight_transpose_raw(w, True)
-        bwd = lambda: ops.conv2d_raw(dy, wt, C, k, k, (H, W), (2, 2), (0, 0), ldw=ldo)
+        wt = ops.pack_filter(w, True, True)
+        bwd = lambda: ops.conv2d_raw(dy, wt, C, k, k, (H, W), (2, 2), (0, 0))
         dw = torch.empty_like(w)
         wg = lambda: ops.wgrad_raw(x, dy, k, k, (2, 2), (0, 0), dw, -C * M, 1, M, 1.0, out_offset=(k * k - 1) * C * M)
     else:
-        bwd = lambda: ops._bwd_data_launch(dy, w, g)
+        if kind == "s1":
+            wt = ops.pack_filter(w, True, True)
+            bwd = lambda: ops.conv2d_raw(dy, wt, C, k, k, (H, W), (1, 1), (k - 1 - k // 2, k - 1 - k // 2))
+        else:
+            wt = ops.pack_filter(w, True, False)
+            bwd = lambda: ops.conv2d_raw(dy, wt, C, k, k, (H, W), (2, 2), (0, 0), transposed=True)
         wg = lambda: ops._bwd_weight_launch(x, dy, g, C, M)
     t = [timeit(fwd), timeit(bwd), timeit(wg)]
     for i in range(3): tot[i] += t[i]

@@ -7,14 +7,15 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 B, C, M, H, W = 16, 128, 128, 64, 256
 x = torch.randn(B, C, H, W, device=dev); w = torch.randn(3, 3, C, M, device=dev)
+wp = ops.pack_filter(w, False, False)
 g = ops._Geom((1, 1), (1, 1), 3, 3, (H, W), (H, W))
 if kind == "fwd":
-    fn = lambda: ops.conv2d_raw(x, w, M, 3, 3, (H, W), (1, 1), (1, 1))
+    fn = lambda: ops.conv2d_raw(x, wp, M, 3, 3, (H, W), (1, 1), (1, 1))
 elif kind == "fwdmod":
     s = torch.rand(B, C, device=dev) + 0.5; d = torch.rand(B, M, device=dev) + 0.5
     nz = torch.randn(B, 1, H, W, device=dev); st = torch.tensor(0.1, device=dev); b = torch.randn(M, device=dev)
     epi = N.epilogue(out_scale=d, bias=b, noise=nz, strength=st, act=N.ACT_LRELU, alpha=0.03)
-    fn = lambda: ops.conv2d_raw(x, w, M, 3, 3, (H, W), (1, 1), (1, 1), in_scale=s, epi=epi)
+    fn = lambda: ops.conv2d_raw(x, wp, M, 3, 3, (H, W), (1, 1), (1, 1), in_scale=s, epi=epi)
 elif kind == "wgrad":
     dy = torch.randn(B, M, H, W, device=dev)
     fn = lambda: ops._bwd_weight_launch(x, dy, g, C, M)
