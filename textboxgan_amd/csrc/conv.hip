@@ -581,10 +581,12 @@ struct WgradP {
   int logTW, logTHs, NSEG, IHs, IWs, IWp, HALFW, lplane, ppc, NJ, nBG, tilesU, tilesV, nchunks, ksplit;
 };
 
-template <int WGS, int WGL, int NT, int PIX>
+template <int WGS, int WGL, int NT, int PIX, bool GRP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
-  constexpr int BS = WGS * 32, BL = WGL * 32, SP = PIX + 1;
+  constexpr int BS = WGS * 32, BL = WGL * 32, SP = PIX + 4;  // 16-byte aligned S rows; 68 words = conflict-free b128
   constexpr int KWt = (NT == 9) ? 3 : 1;
+  constexpr int NJC = (NT == 1) ? 1 : WG_MAXNJ;  // halo positions per lane (compile-time trip count: no guards)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *Ss = smem;            // [BS][SP]
   float *Ls = smem + BS * SP;  // [BL][lplane]
@@ -595,10 +597,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTHs) - 1;
 
   // position descriptors inside one L channel plane: a wave stages one channel at a time
-  int d_seg[WG_MAXNJ], d_iyl[WG_MAXNJ], d_ixl[WG_MAXNJ], d_loff[WG_MAXNJ];
+  int d_pos[NJC], d_loff[NJC];  // d_pos = seg << 16 | iyl << 8 | ixl, or -1
 #pragma unroll
-  for (int j = 0; j < WG_MAXNJ; ++j) {
-    d_seg[j] = -1; d_iyl[j] = 0; d_ixl[j] = 0; d_loff[j] = 0;
+  for (int j = 0; j < NJC; ++j) {
+    d_pos[j] = -1; d_loff[j] = 0;
     const int e = lane + 64 * j;
     if (j < p.NJ && e < p.ppc) {
       const int per = p.IHs * p.IWs;
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
       const int rem = e - seg * per;
       const int iyl = rem / p.IWs;
       const int ixl = rem - iyl * p.IWs;
-      d_seg[j] = seg; d_iyl[j] = iyl; d_ixl[j] = ixl;
+      d_pos[j] = (seg << 16) | (iyl << 8) | ixl;
       const int col = (p.sx == 2) ? (ixl & 1) * p.HALFW + (ixl >> 1) : ixl;
       d_loff[j] = (seg * p.IHs + iyl) * p.IWp + col;
     }
@@ -631,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int HWs = p.Hs * p.Ws, HWl = p.Hl * p.Wl;
+  const int half = lane >> 5;
 
   for (int chunk = blockIdx.z; chunk < p.nchunks; chunk += p.ksplit) {
     const int tv = chunk % p.tilesV;
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     const int u0 = tu << p.logTHs, v0 = tv << p.logTW;
     __syncthreads();
     // Branch-free staging (same lesson as conv_fprop_kernel): clamp the address, always load, select 0 -- the loads
-    // of a batch are then in flight together instead of one round trip per `if (valid)` block.
+    // of a batch (and their scale factors) are then in flight together instead of one round trip per `if` block.
     {  // S tile
       const int b = bg * p.NSEG + sseg, u = u0 + sr, v = v0 + sq;
       const bool ok = b < p.B && u < p.Hs && v < p.Ws;
@@ -649,82 +652,107 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
       constexpr int S_IT = BS / (256 / PIX), S_B = 8;
 #pragma unroll
       for (int it0 = 0; it0 < S_IT; it0 += S_B) {
-        float sv[S_B];
+        float sv[S_B], sc[S_B];
 #pragma unroll
         for (int u = 0; u < S_B; ++u) {
           const int chc = min(cs0 + sch0 + (it0 + u) * (256 / PIX), p.CS - 1);
           sv[u] = p.S[base + chc * HWs];
-        }
-        if (p.s_scale) {
-#pragma unroll
-          for (int u = 0; u < S_B; ++u) sv[u] *= p.s_scale[sb + min(cs0 + sch0 + (it0 + u) * (256 / PIX), p.CS - 1)];
+          sc[u] = p.s_scale ? p.s_scale[sb + chc] : 1.f;
         }
 #pragma unroll
         for (int u = 0; u < S_B; ++u) {
           const int ch = sch0 + (it0 + u) * (256 / PIX);
-          Ss[ch * SP + spix] = (ok && cs0 + ch < p.CS) ? sv[u] : 0.f;
+          Ss[ch * SP + spix] = (ok && cs0 + ch < p.CS) ? sv[u] * sc[u] : 0.f;
         }
       }
     }
     {  // L halo tile: wave w stages channels w, w+4, ...
-      int g[WG_MAXNJ], bb[WG_MAXNJ];
+      int g[NJC], bb[NJC];
 #pragma unroll
-      for (int j = 0; j < WG_MAXNJ; ++j) {
-        g[j] = -1; bb[j] = 0;
-        if (j < p.NJ && d_seg[j] >= 0) {
-          const int b = bg * p.NSEG + d_seg[j];
-          const int iy = u0 * p.sy - p.py + d_iyl[j];
-          const int ix = v0 * p.sx - p.px + d_ixl[j];
-          const bool ok = b < p.B && iy >= 0 && iy < p.Hl && ix >= 0 && ix < p.Wl;
-          g[j] = ok ? (b * p.CL) * HWl + iy * p.Wl + ix : -1;
-          bb[j] = ok ? b * p.CL : 0;
-        }
+      for (int j = 0; j < NJC; ++j) {
+        const int seg = d_pos[j] >> 16, iyl = (d_pos[j] >> 8) & 255, ixl = d_pos[j] & 255;
+        const int b = bg * p.NSEG + seg;
+        const int iy = u0 * p.sy - p.py + iyl;
+        const int ix = v0 * p.sx - p.px + ixl;
+        const bool ok = d_pos[j] >= 0 && b < p.B && iy >= 0 && iy < p.Hl && ix >= 0 && ix < p.Wl;
+        g[j] = ok ? (b * p.CL) * HWl + iy * p.Wl + ix : -1;
+        bb[j] = ok ? b * p.CL : 0;
       }
-      constexpr int LB = 4;  // channels per batch: LB * NJ loads in flight per lane
+      constexpr int LB = 4;  // channels per batch: LB * NJC loads (+ scales) in flight per lane
       for (int ch0 = wave; ch0 < BL; ch0 += 4 * LB) {
-        float lv[LB][WG_MAXNJ];
+        float lv[LB][NJC];
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
           const int chc = min(cl0 + ch0 + 4 * u, p.CL - 1);
 #pragma unroll
-          for (int j = 0; j < WG_MAXNJ; ++j) {
-            lv[u][j] = 0.f;
-            if (j < p.NJ) lv[u][j] = p.L[(g[j] >= 0 ? g[j] : 0) + chc * HWl];  // uniform guard only
-          }
+          for (int j = 0; j < NJC; ++j) lv[u][j] = p.L[(g[j] >= 0 ? g[j] : 0) + chc * HWl];
         }
-        if (p.l_scale) {
+        if (p.l_scale) {  // uniform
+          float lsc[LB][NJC];
 #pragma unroll
           for (int u = 0; u < LB; ++u) {
             const int chc = min(cl0 + ch0 + 4 * u, p.CL - 1);
 #pragma unroll
-            for (int j = 0; j < WG_MAXNJ; ++j)
-              if (j < p.NJ) lv[u][j] *= p.l_scale[bb[j] + chc];
+            for (int j = 0; j < NJC; ++j) lsc[u][j] = p.l_scale[bb[j] + chc];
           }
+#pragma unroll
+          for (int u = 0; u < LB; ++u)
+#pragma unroll
+            for (int j = 0; j < NJC; ++j) lv[u][j] *= lsc[u][j];
         }
 #pragma unroll
         for (int u = 0; u < LB; ++u) {
           const int ch = ch0 + 4 * u;
 #pragma unroll
-          for (int j = 0; j < WG_MAXNJ; ++j)
-            if (j < p.NJ && d_seg[j] >= 0 && ch < BL)
+          for (int j = 0; j < NJC; ++j)
+            if (d_pos[j] >= 0 && ch < BL)
               Ls[ch * p.lplane + d_loff[j]] = (g[j] >= 0 && cl0 + ch < p.CL) ? lv[u][j] : 0.f;
         }
       }
     }
     __syncthreads();
-    const float *Sp = Ss + (ws * 32 + (lane & 31)) * SP + (lane >> 5);
-    const float *Lp = Ls + (wl * 32 + (lane & 31)) * p.lplane;
+    if constexpr (GRP) {
+      // (tile rows of >= 4 pixels)  K (= pixels) is walked in groups of 8: half-wave h takes pixels 8g+4h .. 8g+4h+3, so
+      // the A operand of 4 k-steps is ONE aligned ds_read_b128 and the B operands are immediate-offset reads from one
+      // base address per tap; the reads of k-step i+1 are issued before the MFMAs of k-step i.
+      const float *Sp = Ss + (ws * 32 + (lane & 31)) * SP + 4 * half;
+      const float *Lp = Ls + (wl * 32 + (lane & 31)) * p.lplane;
 #pragma unroll 2
-    for (int kp = 0; kp < PIX / 2; ++kp) {
-      const int pp = 2 * kp + (lane >> 5);
-      const int q = pp & TWm, rr = pp >> p.logTW;
-      const int seg = rr >> p.logTHs, r = rr & THm;
-      const int poff = (seg * p.IHs + r * p.sy) * p.IWp + q;
-      const float a = Sp[2 * kp];
+      for (int gp = 0; gp < PIX / 8; ++gp) {
+        const int pp = 8 * gp + 4 * half;
+        const int q = pp & TWm, rr = pp >> p.logTW;
+        const int seg = rr >> p.logTHs, r = rr & THm;
+        const float *Lg = Lp + (seg * p.IHs + r * p.sy) * p.IWp + q;
+        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(Sp + 8 * gp);
+        float bq[2][NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float bv = Lp[poff + toff[t]];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) bq[0][t] = Lg[toff[t]];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < 3) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bq[(i + 1) & 1][t] = Lg[toff[t] + i + 1];
+          }
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], bq[i & 1][t], acc[t], 0, 0, 0);
+        }
+      }
+    } else {  // narrow tiles (Ws <= 2): generic pixel walk
+      const float *Sp = Ss + (ws * 32 + (lane & 31)) * SP + half;
+      const float *Lp = Ls + (wl * 32 + (lane & 31)) * p.lplane;
+#pragma unroll 1
+      for (int kp = 0; kp < PIX / 2; ++kp) {
+        const int pp = 2 * kp + half;
+        const int q = pp & TWm, rr = pp >> p.logTW;
+        const int seg = rr >> p.logTHs, r = rr & THm;
+        const int poff = (seg * p.IHs + r * p.sy) * p.IWp + q;
+        const float a = Sp[2 * kp];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float bv = Lp[poff + toff[t]];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+        }
       }
     }
   }
@@ -764,12 +792,13 @@ static int wgrad_ksplit(int tiles, int nchunks) {
   return ksplit;
 }
 
-template <int WGS, int WGL, int NT, int PIX>
-static int launch_wgrad(WgradP &p, hipStream_t st, size_t ws_bytes) {
+template <int WGS, int WGL, int NT, int PIX, bool GRP>
+static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes) {
   constexpr int BS = WGS * 32, BL = WGL * 32;
-  const size_t lds = ((size_t)BS * (PIX + 1) + (size_t)BL * p.lplane) * sizeof(float);
+  const size_t lds = ((size_t)BS * (PIX + 4) + (size_t)BL * p.lplane) * sizeof(float);
+  if (p.NJ > (NT == 1 ? 1 : WG_MAXNJ)) return TBG_EUNSUPPORTED;
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
-  auto kern = conv_wgrad_kernel<WGS, WGL, NT, PIX>;
+  auto kern = conv_wgrad_kernel<WGS, WGL, NT, PIX, GRP>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TBG_EHIP;
@@ -782,6 +811,12 @@ static int launch_wgrad(WgradP &p, hipStream_t st, size_t ws_bytes) {
   hipLaunchKernelGGL((conv_wgrad_reduce_kernel<WGS, WGL, NT>), dim3(tx, ty, NT * 16), dim3(256), 0, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
+}
+
+template <int WGS, int WGL, int NT, int PIX>
+static int launch_wgrad(WgradP &p, hipStream_t st, size_t ws_bytes) {
+  if (p.logTW >= 2) return launch_wgrad_impl<WGS, WGL, NT, PIX, true>(p, st, ws_bytes);
+  return launch_wgrad_impl<WGS, WGL, NT, PIX, false>(p, st, ws_bytes);
 }
 
 // geometry shared by the launcher and the workspace query
