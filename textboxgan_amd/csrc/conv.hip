@@ -766,9 +766,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     for (int r16 = 0; r16 < 16; ++r16) wsp[(t * 16 + r16) * 256 + tid] = acc[t][r16];
 }
 
-// sum the ksplit partial tiles of every output tile and scatter into dW (alpha applied once)
+// few output tiles, many partials: one block per (tile, tap, accumulator register) -- 16x more blocks than the
+// transposing kernel below, scattered 4-byte stores
 template <int WGS, int WGL, int NT>
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradP p) {
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_wide_kernel(const WgradP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ws_ = wave / WGL, wl = wave - ws_ * WGL;
   const int cs0 = blockIdx.x * (WGS * 32), cl0 = blockIdx.y * (WGL * 32);
@@ -783,6 +784,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradP p) 
   const int cs = cs0 + ws_ * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
   if (cl < p.CL && cs < p.CS)
     p.dW[(long long)t * p.st_t + (long long)cl * p.st_l + (long long)cs * p.st_s] = a * p.alpha;
+}
+
+// sum the ksplit partial tiles of one (output tile, tap) and write dW (alpha applied once).  The 64x64 tile is
+// transposed through LDS so that the dW rows are written as contiguous runs along whichever of (cs, cl) has unit stride.
+template <int WGS, int WGL, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradP p) {
+  constexpr int BS = WGS * 32, BL = WGL * 32;
+  __shared__ float tile[BL][BS + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ws_ = wave / WGL, wl = wave - ws_ * WGL;
+  const int cs0 = blockIdx.x * BS, cl0 = blockIdx.y * BL;
+  const int t = blockIdx.z;
+  const size_t tl = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const size_t per_split = (size_t)gridDim.x * gridDim.y;
+  float a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+  for (int kz = 0; kz < p.ksplit; ++kz) {
+    const float *src = p.ws + ((size_t)kz * per_split + tl) * (size_t)(NT * 16 * 256) + (size_t)t * 16 * 256 + tid;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] += src[r * 256];  // 16 independent coalesced loads in flight
+  }
+  const int cl_l = wl * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[cl_l][ws_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = a[r];
+  __syncthreads();
+  const bool s_fast = p.st_s == 1 || p.st_l != 1;
+  for (int idx = tid; idx < BS * BL; idx += 256) {
+    const int cl = s_fast ? idx / BS : idx % BL;
+    const int cs = s_fast ? idx % BS : idx / BL;
+    if (cl0 + cl < p.CL && cs0 + cs < p.CS)
+      p.dW[(long long)t * p.st_t + (long long)(cl0 + cl) * p.st_l + (long long)(cs0 + cs) * p.st_s] = tile[cl][cs] * p.alpha;
+  }
 }
 
 static int wgrad_ksplit(int tiles, int nchunks) {
@@ -808,7 +842,10 @@ static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes) {
   if ((size_t)p.ksplit * tx * ty * NT * 16 * 256 * sizeof(float) > ws_bytes) return TBG_EINVAL;
   hipLaunchKernelGGL(kern, dim3(tx, ty, p.ksplit), dim3(256), lds, st, p);
   TBG_LAUNCH_CHECK();
-  hipLaunchKernelGGL((conv_wgrad_reduce_kernel<WGS, WGL, NT>), dim3(tx, ty, NT * 16), dim3(256), 0, st, p);
+  if (tx * ty * NT >= 256)
+    hipLaunchKernelGGL((conv_wgrad_reduce_kernel<WGS, WGL, NT>), dim3(tx, ty, NT), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_reduce_wide_kernel<WGS, WGL, NT>), dim3(tx, ty, NT * 16), dim3(256), 0, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
