@@ -116,6 +116,10 @@ typedef struct tbg_conv_desc {
 int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                    const float *in_scale, const tbg_epilogue *epi, void *stream);
 
+/* Kernel instantiation (rocprofv3 spelling) launched by the calling thread's last tbg_conv2d_f32 /
+ * tbg_conv2d_wgrad_f32 call; profiling aid (bench.py attributes HIP-event timings with it). */
+const char *tbg_last_conv_kernel(void);
+
 /* Weight gradient:  dW[t*st_t + cl*st_l + cs*st_s] = alpha * sum_{b,u,v}
  *     S[b,cs,u,v]*s_scale[b,cs] * L[b,cl,u*sy-py+kh,v*sx-px+kw]*l_scale[b,cl]
  * S is the tensor on the (small) output grid, L the tensor on the input grid.  Every element of dW

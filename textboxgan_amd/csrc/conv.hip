@@ -378,6 +378,12 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
 }
 
 
+static thread_local char g_last_kernel[96] = "";
+
+// name of the kernel instantiation the calling thread's last tbg_conv2d_f32 / tbg_conv2d_wgrad_f32 launched (as rocprofv3
+// prints it) -- lets a profiler attribute event timings to the exact instantiation
+extern "C" const char *tbg_last_conv_kernel(void) { return g_last_kernel; }
+
 template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
   constexpr int BM = WGM * WTM * 32;
@@ -415,6 +421,7 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
       return TBG_EHIP;
   }
   dim3 grid(maxTilesN, ceil_div(p.M, BM), p.nclass * p.ksplit);
+  snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
@@ -840,6 +847,7 @@ static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes) {
   const int tx = ceil_div(p.CS, BS), ty = ceil_div(p.CL, BL);
   p.ksplit = wgrad_ksplit(tx * ty, p.nchunks);
   if ((size_t)p.ksplit * tx * ty * NT * 16 * 256 * sizeof(float) > ws_bytes) return TBG_EINVAL;
+  snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_wgrad_kernel<%d, %d, %d, %d, %s>", WGS, WGL, NT, PIX, GRP ? "true" : "false");
   hipLaunchKernelGGL(kern, dim3(tx, ty, p.ksplit), dim3(256), lds, st, p);
   TBG_LAUNCH_CHECK();
   if (tx * ty * NT >= 256)

@@ -56,12 +56,16 @@ class _Profile:
     def launch(self, name, flops, fn, shape=None):
         if not self.on:
             return fn()
-        if self.by_shape and shape is not None:
+        if name is not None and self.by_shape and shape is not None:
             name = name + " " + shape
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn()
         e1.record()
+        if name is None:  # the instantiation the library actually launched (rocprofv3 spelling)
+            name = N.lib().tbg_last_conv_kernel().decode()
+            if self.by_shape and shape is not None:
+                name = name + " " + shape
         self.recs.append((name, flops, e0, e1))
         return rc
 
@@ -168,7 +172,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     _what = (f"tbg_conv2d[B={B} C={Cc} M={M} in={Hin}x{Win} out={Hout}x{Wout} k={KH}x{KW} s={tuple(stride)} "
              f"p={tuple(pad)} T={int(transposed)} ldw={ldw} ksplit={ksplit}]")
     _flops = 2.0 * B * M * Cc * KH * KW * (Hin * Win if transposed else Hout * Wout)
-    _kname = f"conv_fprop_kernel<{_fprop_tile(M, _npix)[2]}>"
+    _kname = None  # resolved from tbg_last_conv_kernel()
     trivial = not (epi.out_scale or epi.bias or epi.noise or epi.residual or epi.act != ACT_LINEAR or dot is not None)
     if ksplit > 1 and not trivial:
         tmp = torch.zeros((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
@@ -217,7 +221,7 @@ def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, o
         raise N.TbgError("tbg_conv2d_wgrad: unsupported geometry")
     ws = _workspace(S.device, nbytes)
     _flops = 2.0 * B * CS * CL * Hs * Ws * KH * KW
-    _kname = f"conv_wgrad_kernel<2,2,{KH * KW},{32 if (stride[0] == 2 or stride[1] == 2) else 64}>"
+    _kname = None
     N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_wgrad_f32(
         C.byref(d), N.ptr(S), N.ptr(L), N.ptr(out) + 4 * out_offset, N.ptr(s_scale), N.ptr(l_scale), N.ptr(ws),
         ws.numel() * 4, N.stream()), f"wgrad[B={B} CS={CS} CL={CL} S={Hs}x{Ws} L={Hl}x{Wl} k={KH} s={tuple(stride)}]"),
