@@ -140,6 +140,13 @@ long long tbg_conv2d_wgrad_workspace_bytes(const tbg_wgrad_desc *d);
 int tbg_conv2d_wgrad_f32(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
                          const float *s_scale, const float *l_scale, float *workspace,
                          long long workspace_bytes, void *stream);
+/* _ex: dW[idx] = alpha*sum + gamma * addw[idx] * addq[cl*st_l + cs*st_s]  (addw laid out like dW, addq one
+ * [CL x CS] plane).  Folds the demodulation term of the filter gradient (modulated_conv2d.py:78-82:
+ * d(dem)/dw = 2 coef^2 w * dwsq[i,o]) into the write of the convolution's filter gradient. */
+int tbg_conv2d_wgrad_ex_f32(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
+                            const float *s_scale, const float *l_scale, const float *addw,
+                            const float *addq, float gamma, float *workspace,
+                            long long workspace_bytes, void *stream);
 
 /* Pack the HWIO parameter src[T][I][O] (the layout of the reference's conv kernels, layers/conv.py:30-41,
  * modulated_conv2d.py:33-45) into the filter format of tbg_conv2d_f32:

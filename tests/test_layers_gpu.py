@@ -61,14 +61,32 @@ def test_modconv_fused_fwd_bwd(dev, up, shape):
     f = lambda t: t.detach().float().to(dev).contiguous()
     xd, wd, nd, std, bd = f(x).requires_grad_(True), f(w).requires_grad_(True), f(noise), f(strength).requires_grad_(True), f(bias).requires_grad_(True)
     mwd, mbd = f(mw).requires_grad_(True), f(mb).requires_grad_(True)
-    s = torch.addmm(mbd + 1.0, f(style), mwd / math.sqrt(sd))
-    d = ops.demod_coefs(s, wd)
+    s = ops.dense_bias_act(f(style), mwd, mbd, 1.0 / math.sqrt(sd), 1.0, lrelu=False, offset=1.0)  # style dense (fused mode)
     fn = ops.modconv_up_fused if up else ops.modconv_fused
-    outd = fn(xd, wd, s, d, nd, std, bd)
+    outd = fn(xd, wd, s, nd, std, bd)  # demodulation inside the node
     assert rel_err(outd, out) < 3e-5
     gd = torch.autograd.grad(outd, (xd, wd, mwd, mbd, std, bd), f(dout))
     for name, a, b in zip(("dx", "dw", "dmod_w", "dmod_b", "dstrength", "dbias"), gd, grads):
         assert rel_err(a, b) < 2e-4, name
+
+
+def test_dense_bias_act(dev):
+    """equalised-LR dense + bias (+lrelu*sqrt2 / +offset): forward and the three gradients vs the oracle layers."""
+    from textboxgan_amd import ops
+    B, I, O, lrmul = 5, 24, 40, 0.01
+    x, w, b = rnd(B, I, seed=21), rnd(I, O, seed=22) / lrmul, rnd(O, seed=23) / lrmul
+    leaves = [t.requires_grad_(True) for t in (x, w, b)]
+    f = lambda t: t.detach().float().to(dev).contiguous().requires_grad_(True)
+    for lrelu, offset in ((True, 0.0), (False, 1.0), (False, 0.0)):
+        ref = R.t_bias_act(R.t_dense(x, w, lrmul=lrmul), b, "lrelu" if lrelu else "linear", lrmul=lrmul) + offset
+        dout = rnd(*ref.shape, seed=24)
+        grads = torch.autograd.grad(ref, leaves, dout)
+        xd, wd, bd = f(x), f(w), f(b)
+        out = ops.dense_bias_act(xd, wd, bd, lrmul / math.sqrt(I), lrmul, lrelu=lrelu, offset=offset)
+        assert rel_err(out, ref) < 1e-5
+        gd = torch.autograd.grad(out, (xd, wd, bd), dout.float().to(dev))
+        for name, a, b_ in zip(("dx", "dw", "db"), gd, grads):
+            assert rel_err(a, b_) < 1e-5, (lrelu, offset, name)
 
 
 def test_torgb_fused(dev):

@@ -580,8 +580,9 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
 #define WG_MAXNJ 4
 
 struct WgradP {
-  const float *S, *L, *s_scale, *l_scale;
+  const float *S, *L, *s_scale, *l_scale, *addw, *addq;
   float *dW, *ws;
+  float gamma;
   int B, CS, CL, Hs, Ws, Hl, Wl, KW, sy, sx, py, px;
   int st_t, st_l, st_s;
   float alpha;
@@ -790,7 +791,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_wide_kernel(const Wgrad
   const int cl = cl0 + wl * 32 + (lane & 31);
   const int cs = cs0 + ws_ * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
   if (cl < p.CL && cs < p.CS)
-    p.dW[(long long)t * p.st_t + (long long)cl * p.st_l + (long long)cs * p.st_s] = a * p.alpha;
+  {
+    const long long iq = (long long)cl * p.st_l + (long long)cs * p.st_s, idx = (long long)t * p.st_t + iq;
+    float v = a * p.alpha;
+    if (p.addw) v += p.gamma * p.addw[idx] * p.addq[iq];
+    p.dW[idx] = v;
+  }
 }
 
 // sum the ksplit partial tiles of one (output tile, tap) and write dW (alpha applied once).  The 64x64 tile is
@@ -822,7 +828,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradP p) 
     const int cl = s_fast ? idx / BS : idx % BL;
     const int cs = s_fast ? idx % BS : idx / BL;
     if (cl0 + cl < p.CL && cs0 + cs < p.CS)
-      p.dW[(long long)t * p.st_t + (long long)(cl0 + cl) * p.st_l + (long long)(cs0 + cs) * p.st_s] = tile[cl][cs] * p.alpha;
+    {
+      const long long iq = (long long)(cl0 + cl) * p.st_l + (long long)(cs0 + cs) * p.st_s, idx = (long long)t * p.st_t + iq;
+      float v = tile[cl][cs] * p.alpha;
+      if (p.addw) v += p.gamma * p.addw[idx] * p.addq[iq];
+      p.dW[idx] = v;
+    }
   }
 }
 
@@ -908,12 +919,19 @@ extern "C" long long tbg_conv2d_wgrad_workspace_bytes(const tbg_wgrad_desc *d) {
 extern "C" int tbg_conv2d_wgrad_f32(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
                                     const float *s_scale, const float *l_scale, float *workspace,
                                     long long workspace_bytes, void *stream) {
-  if (!d || !S || !L || !dW || !workspace) return TBG_EINVAL;
+  return tbg_conv2d_wgrad_ex_f32(d, S, L, dW, s_scale, l_scale, nullptr, nullptr, 0.f, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tbg_conv2d_wgrad_ex_f32(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
+                                       const float *s_scale, const float *l_scale, const float *addw, const float *addq,
+                                       float gamma, float *workspace, long long workspace_bytes, void *stream) {
+  if (!d || !S || !L || !dW || !workspace || ((addw == nullptr) != (addq == nullptr))) return TBG_EINVAL;
   WgradP p;
   int PIX;
   const int rc = wgrad_geometry(d, p, PIX);
   if (rc != TBG_OK) return rc;
   p.S = S; p.L = L; p.s_scale = s_scale; p.l_scale = l_scale; p.dW = dW; p.ws = workspace;
+  p.addw = addw; p.addq = addq; p.gamma = gamma;
   const int NT = d->KH * d->KW;
   hipStream_t st = tbg_stream(stream);
   const size_t wsb = workspace_bytes < 0 ? 0 : (size_t)workspace_bytes;

@@ -82,7 +82,11 @@ class Mapping(nn.Module):
     def forward(self, z):
         x = z * torch.rsqrt(z.square().mean(dim=1, keepdim=True) + 1e-8)
         for dense, ba in zip(self.dense_layers, self.bias_act_layers):
-            x = ba(dense(x))
+            if x.is_cuda:  # one GEMM + one activation launch per layer
+                x = ops.dense_bias_act(x, dense.w, ba.b, _coef(dense.w.shape, dense.gain, dense.lrmul), ba.lrmul,
+                                       lrelu=True)
+            else:
+                x = ba(dense(x))
         return x
 
 
@@ -98,22 +102,23 @@ class LatentEncoder(nn.Module):
 
     def forward(self, z, training: bool, truncation_psi=1.0, rand: Optional[dict] = None):
         ns = self.n_broadcast
-        w = self.g_mapping(z)
-        wb = w[:, None, :].expand(-1, ns, -1)
         if training:
-            with torch.no_grad():  # :39-45
-                batch_avg = w.mean(dim=0)
-                self.w_avg.copy_(batch_avg + (self.w_avg - batch_avg) * self.w_ema_decay)
             if rand is not None and "z2" in rand:
                 z2, cutoff = rand["z2"], int(rand["mix_cutoff"])
             else:  # :47-60 -- drawn on the device, no host sync (the step is HIP-graph capturable)
                 z2 = torch.randn_like(z)
                 cutoff = torch.where(torch.rand((), device=z.device) < self.style_mixing_prob,
                                      torch.randint(1, ns, (), device=z.device), torch.full((), ns, device=z.device))
-            w2 = self.g_mapping(z2)
+            # the mapping network is row-wise: z and the style-mixing z2 (:47-60) go through it as one 2B-row batch
+            w, w2 = self.g_mapping(torch.cat([z, z2], dim=0)).chunk(2, dim=0)
+            wb = w[:, None, :].expand(-1, ns, -1)
+            with torch.no_grad():  # :39-45
+                batch_avg = w.mean(dim=0)
+                self.w_avg.copy_(batch_avg + (self.w_avg - batch_avg) * self.w_ema_decay)
             idx = torch.arange(ns, device=z.device)[None, :, None]
             wb = torch.where(idx < cutoff, wb, w2[:, None, :].expand(-1, ns, -1))
         else:  # :73-78
+            wb = self.g_mapping(z)[:, None, :].expand(-1, ns, -1)
             wb = self.w_avg + (wb - self.w_avg) * truncation_psi
         return wb
 
@@ -161,8 +166,11 @@ class ModulatedConv2D(nn.Module):
         self.mod_dense = Dense(cfg.style_dim, in_fmaps, 1.0, 1.0)
         self.mod_bias = BiasAct(in_fmaps, 1.0, "linear")
 
-    def style(self, y):
+    def style(self, y, mode="composable"):
         """s = mod_dense(y) + b + 1   (:74-76)."""
+        if mode == "fused":
+            return ops.dense_bias_act(y, self.mod_dense.w, self.mod_bias.b, _coef(self.mod_dense.w.shape), 1.0,
+                                      lrelu=False, offset=1.0)
         return torch.addmm(self.mod_bias.b + 1.0, y, self.mod_dense.w * _coef(self.mod_dense.w.shape))
 
     def demod(self, s, mode):
@@ -196,7 +204,7 @@ class ToRGB(nn.Module):
         self.apply_bias = BiasAct(3, 1.0, "linear")
 
     def forward(self, x, style, skip=None, mode="fused"):
-        s = self.conv.style(style)
+        s = self.conv.style(style, mode)
         if mode == "fused":
             return ops.torgb_fused(x, self.conv.w, s, self.apply_bias.b, skip)
         y = self.apply_bias(self.conv.conv_composable(x, s, None))
@@ -218,13 +226,12 @@ class SynthesisBlock(nn.Module):
     def forward(self, x, w0, w1, noise0, noise1, mode="fused"):
         for conv, nz, ba, style, noise in ((self.conv_0, self.apply_noise_0, self.apply_bias_act_0, w0, noise0),
                                            (self.conv_1, self.apply_noise_1, self.apply_bias_act_1, w1, noise1)):
-            s = conv.style(style)
-            d = conv.demod(s, mode)
+            s = conv.style(style, mode)
             if mode == "fused":
                 fn = ops.modconv_up_fused if conv.up else ops.modconv_fused
-                x = fn(x, conv.w, s, d, noise, nz.noise_strength, ba.b)
+                x = fn(x, conv.w, s, noise, nz.noise_strength, ba.b)
             else:
-                x = ba(conv.conv_composable(x, s, d) + noise * nz.noise_strength)
+                x = ba(conv.conv_composable(x, s, conv.demod(s, mode)) + noise * nz.noise_strength)
         return x
 
 

@@ -21,7 +21,7 @@ SQRT2 = 1.4142135623730951
 
 EXPORTS = [
     "tbg_version", "tbg_strerror", "tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_conv2d_f32",
-    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_last_conv_kernel", "tbg_bias_act_fwd_f32", "tbg_bias_act_bwd_chunks",
+    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_last_conv_kernel", "tbg_bias_act_fwd_f32", "tbg_bias_act_bwd_chunks",
     "tbg_bias_act_bwd_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -66,6 +66,7 @@ def lib():
         l.tbg_upfirdn2d_ex_f32.argtypes = [vp, vp, vp] + [ci] * 13 + [vp, ci, C.POINTER(Epilogue), vp]
         l.tbg_conv2d_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(Epilogue), vp]
         l.tbg_conv2d_wgrad_f32.argtypes = [C.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, ll, vp]
+        l.tbg_conv2d_wgrad_ex_f32.argtypes = [C.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, vp, cf, vp, ll, vp]
         l.tbg_conv2d_wgrad_workspace_bytes.restype = ll
         l.tbg_conv2d_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
         l.tbg_weight_pack_f32.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]

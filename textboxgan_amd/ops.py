@@ -211,8 +211,9 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
 
 
 def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, out: torch.Tensor, st_t: int, st_l: int,
-              st_s: int, alpha: float, s_scale=None, l_scale=None, out_offset: int = 0):
-    """Overwrites ``out`` (every in-range element written exactly once)."""
+              st_s: int, alpha: float, s_scale=None, l_scale=None, out_offset: int = 0, add=None):
+    """Overwrites ``out`` (every in-range element written exactly once).
+    add = (addw, addq, gamma): out += gamma * addw (laid out like out) * addq[CL x CS plane]."""
     B, CS, Hs, Ws = S.shape
     _, CL, Hl, Wl = L.shape
     d = N.WgradDesc(B, CS, CL, Hs, Ws, Hl, Wl, KH, KW, stride[0], stride[1], pad[0], pad[1], st_t, st_l, st_s, alpha)
@@ -222,8 +223,10 @@ def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, o
     ws = _workspace(S.device, nbytes)
     _flops = 2.0 * B * CS * CL * Hs * Ws * KH * KW
     _kname = None
-    N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_wgrad_f32(
-        C.byref(d), N.ptr(S), N.ptr(L), N.ptr(out) + 4 * out_offset, N.ptr(s_scale), N.ptr(l_scale), N.ptr(ws),
+    addw, addq, gamma = add if add is not None else (None, None, 0.0)
+    N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_wgrad_ex_f32(
+        C.byref(d), N.ptr(S), N.ptr(L), N.ptr(out) + 4 * out_offset, N.ptr(s_scale), N.ptr(l_scale),
+        (N.ptr(addw) + 4 * out_offset) if addw is not None else None, N.ptr(addq), gamma, N.ptr(ws),
         ws.numel() * 4, N.stream()), f"wgrad[B={B} CS={CS} CL={CL} S={Hs}x{Ws} L={Hl}x{Wl} k={KH} s={tuple(stride)}]"),
         "tbg_conv2d_wgrad")
     return out
@@ -393,9 +396,9 @@ def _bwd_data_launch(dy, w, g: _Geom, alpha=1.0, in_scale=None, epi=None, dot=No
                       dot=dot)
 
 
-def _bwd_weight_launch(x, dy, g: _Geom, I, O, alpha=1.0, x_scale=None, dy_scale=None):
+def _bwd_weight_launch(x, dy, g: _Geom, I, O, alpha=1.0, x_scale=None, dy_scale=None, add=None):
     dw = torch.empty((g.KH, g.KW, I, O), device=x.device, dtype=torch.float32)
-    wgrad_raw(dy, x, g.KH, g.KW, g.stride, g.pad, dw, I * O, O, 1, alpha, s_scale=dy_scale, l_scale=x_scale)
+    wgrad_raw(dy, x, g.KH, g.KW, g.stride, g.pad, dw, I * O, O, 1, alpha, s_scale=dy_scale, l_scale=x_scale, add=add)
     return dw
 
 
@@ -472,63 +475,77 @@ def _lrelu_epi(**kw):
     return N.epilogue(act=ACT_LRELU, slope=0.2, gain=SQRT2, **kw)
 
 
+def _demod_backward(pdy, d, s, wsq, ds_conv):
+    """Shared tail of the two modulated-conv backward passes (modulated_conv2d.py:78-82).
+    d = rsqrt(s^2 @ wsq + eps);  dd = sum_p(dy*yy)/d;  t = dd d^3 = P d^2
+    returns ds_total = ds_conv - s * (t @ wsq^T)   and   dwsq' = (s^2)^T @ t   (the -1/2 is folded into gamma)."""
+    t = pdy.sum(dim=2) * d.square()
+    ds = torch.addcmul(ds_conv, s, t @ wsq.t(), value=-1.0)
+    return ds, s.square().t() @ t
+
+
 class _ModConvFused(torch.autograd.Function):
-    """out = lrelu(d * coef*conv(s*x, w) + noise*strength + b) * sqrt2   (3x3, SAME).
-    modulated_conv2d.py:66-122 (activation-scaling form :94-96,:119-121) + noise.py + bias_act.py."""
+    """out = lrelu(d * coef*conv(s*x, w) + noise*strength + b) * sqrt2   (3x3, SAME), d = demodulation of (s, w).
+    modulated_conv2d.py:66-122 (activation-scaling form :94-96,:119-121) + noise.py + bias_act.py.  The demodulation
+    coefficients and their gradient live inside the node: the filter-gradient launch adds the demodulation term
+    2 coef^2 w * dwsq while it writes dW (tbg_conv2d_wgrad_ex_f32), so no extra pass over the filter is needed."""
 
     @staticmethod
-    def forward(ctx, x, w, s, d, noise, strength, b):
+    def forward(ctx, x, w, s, noise, strength, b):
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
-        x = x.contiguous()
+        x = x.contiguous(); s = s.contiguous()
+        d, wsq = demod_coefs_raw(s, w.contiguous(), coef)
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=coef)
         out = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (x.shape[2], x.shape[3]), (1, 1), (KH // 2, KW // 2),
                          in_scale=s, epi=epi)
-        ctx.save_for_backward(x, w, s, d, noise, strength, b, out)
+        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out)
         ctx.coef = coef
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
-        x, w, s, d, noise, strength, b, out = ctx.saved_tensors
+        x, w, s, d, wsq, noise, strength, b, out = ctx.saved_tensors
         KH, KW, I, O = w.shape
         coef = ctx.coef
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
         _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
         db = pdb.sum(dim=(0, 2))
         dstrength = pdn.sum()
-        dd = pdy.sum(dim=2) / d
         g = _Geom((1, 1), (KH // 2, KW // 2), KH, KW, (x.shape[2], x.shape[3]), (out.shape[2], out.shape[3]))
         ds = torch.zeros_like(s)
         dx = _bwd_data_launch(dpre, w, g, in_scale=d, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds))
-        dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef, x_scale=s, dy_scale=d)
-        return dx, dw, ds, dd, None, dstrength, db
+        ds, dwsq = _demod_backward(pdy, d, s, wsq, ds)
+        dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef, x_scale=s, dy_scale=d, add=(w, dwsq, -coef * coef))
+        return dx, dw, ds, None, dstrength, db
 
 
 class _ModConvUpFused(torch.autograd.Function):
     """out = lrelu(d * FIR(coef*convT_s2(s*x, flip w)) + noise*strength + b) * sqrt2.
-    upfirdn_2d_v2.py:65-103 (upsample_conv_2d) + the same epilogue, the FIR pass carries the epilogue."""
+    upfirdn_2d_v2.py:65-103 (upsample_conv_2d) + the same epilogue, the FIR pass carries the epilogue;
+    demodulation inside the node as in _ModConvFused."""
 
     @staticmethod
-    def forward(ctx, x, w, s, d, noise, strength, b):
+    def forward(ctx, x, w, s, noise, strength, b):
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
-        x = x.contiguous()
+        x = x.contiguous(); s = s.contiguous()
+        d, wsq = demod_coefs_raw(s, w.contiguous(), coef)
         H, W = x.shape[2], x.shape[3]
-        y_up = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, flip=True,
-                          in_scale=s, epi=N.epilogue(alpha=coef))
+        y_up = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True,
+                          flip=True, in_scale=s, epi=N.epilogue(alpha=coef))
         k = fir_kernel(x.device, gain=4.0)
         epi = _lrelu_epi(out_scale=d.reshape(-1), bias=b, noise=noise, strength=strength, alpha=1.0)
         out = upfirdn2d_raw(y_up, k, pad=(1, 1, 1, 1), epi=epi)
-        ctx.save_for_backward(x, w, s, d, noise, strength, b, out)
+        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out)
         ctx.coef = coef
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
-        x, w, s, d, noise, strength, b, out = ctx.saved_tensors
+        x, w, s, d, wsq, noise, strength, b, out = ctx.saved_tensors
         KH, KW, I, O = w.shape
         coef = ctx.coef
         H, W = x.shape[2], x.shape[3]
@@ -536,18 +553,19 @@ class _ModConvUpFused(torch.autograd.Function):
         _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
         db = pdb.sum(dim=(0, 2))
         dstrength = pdn.sum()
-        dd = pdy.sum(dim=2) / d
         k = fir_kernel(x.device, gain=4.0)  # symmetric: flipped == itself
         dy_up = upfirdn2d_raw(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))  # [B,O,2H+1,2W+1]
         wt = pack_filter(w, transpose=True, flip=True)
         ds = torch.zeros_like(s)
         dx = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0),
                         epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds))
+        ds, dwsq = _demod_backward(pdy, d, s, wsq, ds)
         dw = torch.empty_like(w)
         T = KH * KW
         # dW_t[t][i][o] = sum x*s . dy_up shifted;  w = flip(w_t)  -> write tap t at T-1-t
-        wgrad_raw(x, dy_up, KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O)
-        return dx, dw, ds, dd, None, dstrength, db
+        wgrad_raw(x, dy_up, KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O,
+                  add=(w, dwsq, -coef * coef))
+        return dx, dw, ds, None, dstrength, db
 
 
 class _ToRGBFused(torch.autograd.Function):
@@ -632,12 +650,13 @@ class _ConvBiasActFused(torch.autograd.Function):
         return dx, dw, db, dres, None, None, None, None
 
 
-def modconv_fused(x, w, s, d, noise, strength, b):
-    return _ModConvFused.apply(x, w, s, d, noise, strength, b)
+def modconv_fused(x, w, s, noise, strength, b):
+    """demodulated 3x3 modulated conv + noise + bias + lrelu (demodulation computed inside the node)."""
+    return _ModConvFused.apply(x, w, s, noise, strength, b)
 
 
-def modconv_up_fused(x, w, s, d, noise, strength, b):
-    return _ModConvUpFused.apply(x, w, s, d, noise, strength, b)
+def modconv_up_fused(x, w, s, noise, strength, b):
+    return _ModConvUpFused.apply(x, w, s, noise, strength, b)
 
 
 def torgb_fused(x, w, s, b, skip=None):
@@ -673,6 +692,53 @@ class _DemodCoefs(torch.autograd.Function):
 
 def demod_coefs(s, w):
     return _DemodCoefs.apply(s, w)
+
+
+# ----------------------------------------------------------------------------------------
+# equalised-LR dense layers (torch GEMMs; the Functions only remove the elementwise launches around them)
+# ----------------------------------------------------------------------------------------
+class _DenseBiasAct(torch.autograd.Function):
+    """out = act(coef * x @ w + lrmul * b) [* sqrt2 if lrelu] + offset   (dense.py:23-29 + bias_act.py:25-34).
+    lrelu is positively homogeneous, so the sqrt2 gain is folded into the GEMM's alpha/beta: forward = addmm +
+    leaky_relu, backward = mask + 2 GEMMs + 1 GEMV."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, coef, lrmul, lrelu, offset):
+        g = math.sqrt(2.0) if lrelu else 1.0
+        out = torch.addmm(b, x, w, beta=lrmul * g, alpha=coef * g)
+        if lrelu:
+            out = torch.nn.functional.leaky_relu(out, 0.2)
+        if offset != 0.0:
+            out = out.add_(offset) if not lrelu else out + offset
+        ctx.save_for_backward(x, w, out if lrelu else None)
+        ctx.cfgv = (coef * g, lrmul * g, lrelu, offset)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x, w, out = ctx.saved_tensors
+        alpha, beta, lrelu, offset = ctx.cfgv
+        dout = dout.contiguous()
+        if lrelu:  # sign(out - offset) = sign(pre-activation)
+            dout = torch.ops.aten.leaky_relu_backward(dout, out if offset == 0.0 else out - offset, 0.2, True)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.addmm(x, dout, w.t(), beta=0.0, alpha=alpha)
+        if ctx.needs_input_grad[1]:
+            dw = torch.addmm(w, x.t(), dout, beta=0.0, alpha=alpha)
+        if ctx.needs_input_grad[2]:
+            ones = dout.new_ones(dout.shape[0])
+            db = torch.addmv(b_like(dout), dout.t(), ones, beta=0.0, alpha=beta)
+        return dx, dw, db, None, None, None, None
+
+
+def b_like(dout):
+    return dout.new_empty(dout.shape[1])
+
+
+def dense_bias_act(x, w, b, coef, lrmul=1.0, lrelu=False, offset=0.0):
+    return _DenseBiasAct.apply(x, w, b, float(coef), float(lrmul), bool(lrelu), float(offset))
 
 
 # ----------------------------------------------------------------------------------------
