@@ -68,7 +68,10 @@ class TrainingStep:
         self.pl_noise_scaler = 1.0 / math.sqrt(float(cfg.image_width) * float(cfg.char_height))
         self.pg = process_group
         self.use_graphs = use_graphs
-        self.overlap_ocr = True  # OCR branch on a second HIP stream (its small kernels fill gaps of the D passes)
+        # OCR branch (forward + its own backward) on a second HIP stream.  Worth ~1% only (415 -> 418-420 text-boxes/s):
+        # tools/graph_branch_test.py shows that on MI355X / ROCm 7.2 neither eager streams nor captured fork/join branches
+        # overlap a chain of small kernels with a large kernel to any useful degree (7.67 vs 7.96 ms).
+        self.overlap_ocr = True
         self._ocr_stream = None
         self._graphs = {}
         self._warmed = set()
@@ -200,6 +203,10 @@ class TrainingStep:
                 fake_images.record_stream(side)
                 ocr_loss = self._get_ocr_loss(fake_images, ocr_labels, ocr_images)
                 ocr_loss_w = ocr_loss_weight * ocr_loss
+                # the OCR network's own backward (hundreds of small kernels) is issued HERE, from the side stream, so
+                # that it runs beside the discriminator passes and the g-pass backward of the main stream instead of
+                # in front of the generator's ocr-pass backward; only d(ocr_loss)/d(fake_images) crosses back
+                (dfake_ocr,) = torch.autograd.grad(ocr_loss_w, fake_images, retain_graph=False)
 
         fake_scores = D(fake_images)
         g_loss = generator_loss(fake_scores, self.batch_size)
@@ -228,7 +235,13 @@ class TrainingStep:
         if handles is not None:
             handles.append(self._all_reduce_async(self.g_grad))
 
-        grads = torch.autograd.grad(ocr_loss_w, self.o_params, retain_graph=True, allow_unused=True)
+        if self.overlap_ocr:
+            main_stream.wait_stream(self._ocr_stream)
+            dfake_ocr.record_stream(main_stream)
+            grads = torch.autograd.grad(fake_images, self.o_params, grad_outputs=dfake_ocr, retain_graph=True,
+                                        allow_unused=True)
+        else:
+            grads = torch.autograd.grad(ocr_loss_w, self.o_params, retain_graph=True, allow_unused=True)
         write_grads(self.o_views, grads)
         if handles is not None:
             handles.append(self._all_reduce_async(self.o_grad))
