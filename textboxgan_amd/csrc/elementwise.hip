@@ -66,18 +66,60 @@ __global__ __launch_bounds__(256) void upfirdn2d_small_kernel(const UpfirdnP p) 
   const int relOutY = tid / (TOW / 4);
   const int relOutX0 = (tid - relOutY * (TOW / 4)) * 4;
 
-  for (int major = blockIdx.z; major < p.major; major += gridDim.z) {
-    const float isc = p.in_scale ? p.in_scale[major] : 1.f;
-    const float *xin = p.x + (size_t)major * p.inH * p.inW;
-    __syncthreads();
-    for (int idx = tid; idx < TIH * TIW; idx += 256) {
+  // input-tile descriptors are plane-independent: decode once; when the tile is small enough (<= 8 elements per
+  // lane: the up=1/down=1 blur and the up-sampling forms) the tile of plane k+1 is prefetched into registers while
+  // plane k is filtered -- one exposed HBM round trip per block instead of one per plane (blur 3.0 -> 3.7 TB/s).
+  // The down-sampling forms (18 elements per lane) keep the plain loop: the extra registers cost more than they hide.
+  constexpr int NLD = (TIH * TIW + 255) / 256;
+  constexpr bool PREFETCH = NLD <= 8;
+  constexpr int NLR = PREFETCH ? NLD : 1;
+  int l_goff[NLR], l_soff[NLR];
+  bool l_any[NLR];  // wave-uniform
+  float pre[NLR];
+  const size_t plane = (size_t)p.inH * p.inW;
+  if constexpr (PREFETCH) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + 256 * i;
       const int ry = idx / TIW, rx = idx - ry * TIW;
       const int ix = rx + tileInX, iy = ry + tileInY;
-      float v = 0.f;
-      if (ix >= 0 && iy >= 0 && ix < p.inW && iy < p.inH) v = xin[(size_t)iy * p.inW + ix] * isc;
-      sx[ry][rx] = v;
+      l_soff[i] = idx < TIH * TIW ? ry * TIWP + rx : -1;
+      l_goff[i] = (idx < TIH * TIW && ix >= 0 && iy >= 0 && ix < p.inW && iy < p.inH) ? iy * p.inW + ix : -1;
+      l_any[i] = __builtin_amdgcn_ballot_w64(l_goff[i] >= 0) != 0;
+      pre[i] = 0.f;
     }
+    if ((int)blockIdx.z < p.major) {
+      const float *xin = p.x + (size_t)blockIdx.z * plane;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)  // clamp + select below; a wave skips pieces that are entirely outside the plane
+        if (l_any[i]) pre[i] = xin[l_goff[i] >= 0 ? l_goff[i] : 0];
+    }
+  }
+  for (int major = blockIdx.z; major < p.major; major += gridDim.z) {
+    const float isc = p.in_scale ? p.in_scale[major] : 1.f;
     __syncthreads();
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        if (l_soff[i] >= 0) (&sx[0][0])[l_soff[i]] = l_goff[i] >= 0 ? pre[i] * isc : 0.f;
+      __syncthreads();
+      if (major + (int)gridDim.z < p.major) {
+        const float *xin = p.x + (size_t)(major + gridDim.z) * plane;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+          if (l_any[i]) pre[i] = xin[l_goff[i] >= 0 ? l_goff[i] : 0];
+      }
+    } else {
+      const float *xin = p.x + (size_t)major * plane;
+      for (int idx = tid; idx < TIH * TIW; idx += 256) {
+        const int ry = idx / TIW, rx = idx - ry * TIW;
+        const int ix = rx + tileInX, iy = ry + tileInY;
+        float v = 0.f;
+        if (ix >= 0 && iy >= 0 && ix < p.inW && iy < p.inH) v = xin[(size_t)iy * p.inW + ix] * isc;
+        sx[ry][rx] = v;
+      }
+      __syncthreads();
+    }
 
     const int outY = tileOutY + relOutY;
     const int relY = remY + relOutY * DNY;
