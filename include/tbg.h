@@ -159,6 +159,21 @@ int tbg_weight_pack_f32(const float *src, float *dst, int T, int I, int O, int t
                         void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One time step of a frozen (bi)directional LSTM layer, pointwise part for all directions in one launch -- the
+ * recurrent encoder of the OCR branch (aster_inferer.py:28-190 runs the ASTER SavedModel: 2x BiLSTM).  The step's
+ * GEMMs (h @ Whh^T forward, dgates @ Whh backward) stay library GEMMs batched over the directions.
+ * Direction d works on time t = d == 0 ? s : T-1-s.  Gate order i,f,g,o (PyTorch / cuDNN).
+ *   gx, dg [D][T][B][4H] time-major input projections (+biases) / their gradients;  hw [D][B][4H] (NULL at s = 0)
+ *   act [D][S][B][4H], cs [D][S][B][H] saved activations / cell states;  h [D][B][H];  seq, dseq [B][T][D*H]
+ * bwd: `first` = 1 for the first step processed (s = T-1): no recurrent gradient, dc is initialised.
+ * ---------------------------------------------------------------------------------------- */
+int tbg_lstm_step_fwd_f32(const float *gx, const float *hw, float *act, float *cs, float *h, float *seq,
+                          int D, int T, int B, int H, int s, void *stream);
+int tbg_lstm_step_bwd_f32(const float *dseq, const float *dh_rec, float *dc, const float *act,
+                          const float *cs, float *dg, float *dgates, int D, int T, int B, int H, int s,
+                          int first, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Thin 1x1 convolutions at the RGB ends (one side has O <= 4 channels): HBM-bound streaming kernels.
  * project:      y[b,o,p] = alpha * sum_c x[b,c,p] * w[c*ldw+o] * (scale ? scale[b*C+c] : 1)
  *                          + (bias ? bias[o]*bias_mul : 0) + (skip ? skip[b,o,p] : 0)

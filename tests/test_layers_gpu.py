@@ -89,6 +89,25 @@ def test_dense_bias_act(dev):
             assert rel_err(a, b_) < 1e-5, (lrelu, offset, name)
 
 
+@pytest.mark.parametrize("dims", [(3, 7, 12, 8), (16, 25, 512, 256)], ids=["small", "ocr-encoder"])
+def test_frozen_bilstm_layer(dev, dims):
+    """batched-GEMM + pointwise-kernel BiLSTM layer vs torch.nn.LSTM (float64 CPU): output and input gradient."""
+    from textboxgan_amd import ops
+    B, T, In, H = dims
+    torch.manual_seed(5)
+    ref = torch.nn.LSTM(In, H, num_layers=1, bidirectional=True, batch_first=True).double()
+    x = rnd(B, T, In, seed=31).requires_grad_(True)
+    y = ref(x)[0]
+    dy = rnd(*y.shape, seed=32)
+    (gx,) = torch.autograd.grad(y, x, dy)
+    g = lambda n: torch.stack([getattr(ref, f"{n}_l0"), getattr(ref, f"{n}_l0_reverse")]).detach().float().to(dev).contiguous()
+    xd = x.detach().float().to(dev).requires_grad_(True)
+    yd = ops.frozen_bilstm_layer(xd, g("weight_ih"), g("weight_hh"), (g("bias_ih") + g("bias_hh")).contiguous())
+    assert rel_err(yd, y) < 1e-5
+    (gxd,) = torch.autograd.grad(yd, xd, dy.float().to(dev))
+    assert rel_err(gxd, gx) < 2e-5
+
+
 def test_torgb_fused(dev):
     from textboxgan_amd import ops
     B, I, H, W, sd = 3, 24, 8, 32, 16

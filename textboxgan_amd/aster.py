@@ -272,6 +272,10 @@ class AsterLikeOCR(nn.Module):
         grid = (src * 2.0 - 1.0).reshape(B, self.rect_hw[0], self.rect_hw[1], 2)
         return F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=False)
 
+    def _encode_rnn(self, seq):
+        """2x BiLSTM (overridden by the HIP subclass)."""
+        return self.rnn(seq)[0]
+
     def encode(self, x):
         x = self._run(self.stem, x)
         for u in self.resnet:
@@ -283,7 +287,7 @@ class AsterLikeOCR(nn.Module):
         """[B,3,64,256] in [-1,1] -> forward logits [B, max_steps, num_classes]."""
         x = self.encode(self.rectify(img_nchw))  # [B,512,1,25]
         seq = x.squeeze(2).permute(0, 2, 1)
-        enc, _ = self.rnn(seq)  # [B,25,512]
+        enc = self._encode_rnn(seq)  # [B,25,512]
         B = enc.shape[0]
         enc_proj = self.att_enc(enc)
         h = enc.new_zeros(B, self.hidden)
@@ -317,6 +321,22 @@ class AsterLikeOCRHip(AsterLikeOCR):
         self._cache = {}
         return super()._apply(fn, *a, **kw)
 
+    def _encode_rnn(self, seq):
+        """The frozen BiLSTM stack on batched GEMMs + one pointwise launch per step (ops.frozen_bilstm_layer) instead of
+        MIOpen's per-direction per-step GEMM + pointwise pairs."""
+        from . import ops
+        if "rnn" not in self._cache:
+            with torch.no_grad():
+                layers = []
+                for l in range(self.rnn.num_layers):
+                    g = lambda n: torch.stack([getattr(self.rnn, f"{n}_l{l}"), getattr(self.rnn, f"{n}_l{l}_reverse")])
+                    layers.append((g("weight_ih").contiguous(), g("weight_hh").contiguous(),
+                                   (g("bias_ih") + g("bias_hh")).contiguous()))
+                self._cache["rnn"] = layers
+        for w_ih, w_hh, b in self._cache["rnn"]:
+            seq = ops.frozen_bilstm_layer(seq, w_ih, w_hh, b)
+        return seq
+
     def _run(self, blk: _ConvBN, x, residual=None):
         from . import ops
         if not x.is_cuda:
@@ -324,6 +344,7 @@ class AsterLikeOCRHip(AsterLikeOCR):
         key = id(blk)
         if key not in self._cache:
             with torch.no_grad():
-                self._cache[key] = blk.folded()
-        w, b = self._cache[key]
-        return ops.frozen_conv(x, w, b, tuple(blk.conv.stride), tuple(blk.conv.padding), blk.relu, residual)
+                w, b = blk.folded()
+                self._cache[key] = (w, b, ops.frozen_conv_packs(w, blk.conv.stride))  # packed once: the net is frozen
+        w, b, packs = self._cache[key]
+        return ops.frozen_conv(x, w, b, tuple(blk.conv.stride), tuple(blk.conv.padding), blk.relu, residual, packs)

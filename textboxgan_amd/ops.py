@@ -241,7 +241,6 @@ class PackedFilter(NamedTuple):
 
 
 _PACK_STEP: Optional[dict] = None  # live only inside filter_cache(): weights are constant within one step's passes
-_PACK_FROZEN: dict = {}            # frozen networks (OCR): packed once per weight version
 
 
 class filter_cache:
@@ -261,16 +260,14 @@ class filter_cache:
         return False
 
 
-def pack_filter(w: torch.Tensor, transpose: bool, flip: bool, frozen: bool = False) -> PackedFilter:
+def pack_filter(w: torch.Tensor, transpose: bool, flip: bool) -> PackedFilter:
     """HWIO [KH,KW,I,O] / [T,I,O] parameter -> PackedFilter.  transpose: C = O, M = I (data gradient)."""
     if w.dim() == 4:
         T, I, O = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
     else:
         T, I, O = w.shape
     cache = None
-    if frozen:
-        cache = _PACK_FROZEN
-    elif _PACK_STEP is not None and w.is_leaf and w.requires_grad:
+    if _PACK_STEP is not None and w.is_leaf and w.requires_grad:  # live parameters only: the key is an address
         cache = _PACK_STEP
     key = (w.data_ptr(), T, I, O, bool(transpose), bool(flip), w._version)
     if cache is not None and key in cache:
@@ -742,6 +739,60 @@ def dense_bias_act(x, w, b, coef, lrmul=1.0, lrelu=False, offset=0.0):
 
 
 # ----------------------------------------------------------------------------------------
+# frozen bidirectional LSTM layer (OCR encoder): batched GEMMs + one pointwise launch per step
+# ----------------------------------------------------------------------------------------
+class _FrozenBiLSTMLayer(torch.autograd.Function):
+    """x [B,T,In] -> [B,T,D*H]; w_ih [D,4H,In], w_hh [D,4H,H], bias [D,4H] (= b_ih + b_hh); gradient w.r.t. x only
+    (the OCR network is frozen).  Per step: ONE bmm over the directions + ONE pointwise launch (tbg_lstm_step_*)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, bias):
+        B, T, In = x.shape
+        D, H = w_hh.shape[0], w_hh.shape[2]
+        dev = x.device
+        x_tm = x.transpose(0, 1).reshape(T * B, In)  # time-major
+        gx = torch.baddbmm(bias[:, None, :], x_tm.expand(D, T * B, In), w_ih.transpose(1, 2))  # [D, T*B, 4H]
+        act = torch.empty((D, T, B, 4 * H), device=dev, dtype=torch.float32)
+        cs = torch.empty((D, T, B, H), device=dev, dtype=torch.float32)
+        h = torch.empty((D, B, H), device=dev, dtype=torch.float32)
+        seq = torch.empty((B, T, D * H), device=dev, dtype=torch.float32)
+        w_hhT = w_hh.transpose(1, 2)
+        hw = None
+        for s in range(T):
+            if s > 0:
+                hw = torch.bmm(h, w_hhT)
+            N.check(N.lib().tbg_lstm_step_fwd_f32(N.ptr(gx), N.ptr(hw), N.ptr(act), N.ptr(cs), N.ptr(h), N.ptr(seq), D, T, B,
+                                                  H, s, N.stream()), "tbg_lstm_step_fwd")
+        ctx.save_for_backward(act, cs, w_ih, w_hh)
+        ctx.dims = (B, T, In, D, H)
+        return seq
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        act, cs, w_ih, w_hh = ctx.saved_tensors
+        B, T, In, D, H = ctx.dims
+        dev = dout.device
+        dseq = dout.contiguous()
+        dg = torch.empty((D, T, B, 4 * H), device=dev, dtype=torch.float32)
+        dgates = torch.empty((D, B, 4 * H), device=dev, dtype=torch.float32)
+        dc = torch.empty((D, B, H), device=dev, dtype=torch.float32)
+        dh_rec = None
+        for s in range(T - 1, -1, -1):
+            N.check(N.lib().tbg_lstm_step_bwd_f32(N.ptr(dseq), N.ptr(dh_rec), N.ptr(dc), N.ptr(act), N.ptr(cs), N.ptr(dg),
+                                                  N.ptr(dgates), D, T, B, H, s, int(s == T - 1), N.stream()),
+                    "tbg_lstm_step_bwd")
+            if s > 0:
+                dh_rec = torch.bmm(dgates, w_hh)
+        dx_tm = torch.bmm(dg.view(D, T * B, 4 * H), w_ih).sum(dim=0)  # [T*B, In]
+        return dx_tm.view(T, B, In).transpose(0, 1), None, None, None
+
+
+def frozen_bilstm_layer(x, w_ih, w_hh, bias):
+    return _FrozenBiLSTMLayer.apply(x.contiguous(), w_ih, w_hh, bias)
+
+
+# ----------------------------------------------------------------------------------------
 # optimiser / EMA over flat buffers
 # ----------------------------------------------------------------------------------------
 def adam_tf_(theta, m, v, g, step, lr, beta1, beta2, eps):
@@ -760,7 +811,7 @@ class _FrozenConv(torch.autograd.Function):
     """y = [relu]( conv(x, w) + b [+ residual] ) with constant (w, b); only d/dx and d/dresidual exist."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, relu, residual):
+    def forward(ctx, x, w, b, stride, pad, relu, residual, packs):
         KH, KW, I, O = w.shape
         x = x.contiguous()
         H, W = x.shape[2], x.shape[3]
@@ -769,9 +820,11 @@ class _FrozenConv(torch.autograd.Function):
             residual = residual.contiguous()
         epi = N.epilogue(bias=b, residual=residual, res_first=1, act=ACT_LRELU if relu else ACT_LINEAR, slope=0.0,
                          gain=1.0)
-        y = conv2d_raw(x, pack_filter(w, False, False, frozen=True), O, KH, KW, yhw, stride, pad, epi=epi)
+        pf_fwd, pf_bwd = packs if packs is not None else frozen_conv_packs(w, stride)
+        y = conv2d_raw(x, pf_fwd, O, KH, KW, yhw, stride, pad, epi=epi)
         ctx.save_for_backward(w, y if relu else None)
         ctx.cfgv = (stride, pad, relu, residual is not None, (H, W), yhw)
+        ctx.pf_bwd = pf_bwd
         return y
 
     @staticmethod
@@ -786,14 +839,19 @@ class _FrozenConv(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if stride == (1, 1):
-                wt = pack_filter(w, transpose=True, flip=True, frozen=True)
-                dx = conv2d_raw(dy, wt, I, KH, KW, xhw, (1, 1), (KH - 1 - pad[0], KW - 1 - pad[1]))
+                dx = conv2d_raw(dy, ctx.pf_bwd, I, KH, KW, xhw, (1, 1), (KH - 1 - pad[0], KW - 1 - pad[1]))
             else:
                 assert KH == 1 and KW == 1 and pad == (0, 0), "strided OCR convolutions are 1x1"
-                wt = pack_filter(w, transpose=True, flip=False, frozen=True)
-                dx = conv2d_raw(dy, wt, I, 1, 1, xhw, stride, (0, 0), transposed=True)
-        return dx, None, None, None, None, None, (dy if has_res else None)
+                dx = conv2d_raw(dy, ctx.pf_bwd, I, 1, 1, xhw, stride, (0, 0), transposed=True)
+        return dx, None, None, None, None, None, (dy if has_res else None), None
 
 
-def frozen_conv(x, w, b, stride=(1, 1), pad=(0, 0), relu=True, residual=None):
-    return _FrozenConv.apply(x, w, b, tuple(stride), tuple(pad), relu, residual)
+def frozen_conv_packs(w, stride):
+    """(forward, data-gradient) packed filters of a frozen convolution.  The caller that owns the constant weight keeps
+    them (AsterLikeOCRHip caches them per layer) -- there is deliberately no global cache keyed by address."""
+    stride = tuple(stride)
+    return pack_filter(w, False, False), pack_filter(w, transpose=True, flip=(stride == (1, 1)))
+
+
+def frozen_conv(x, w, b, stride=(1, 1), pad=(0, 0), relu=True, residual=None, packs=None):
+    return _FrozenConv.apply(x, w, b, tuple(stride), tuple(pad), relu, residual, packs)
