@@ -59,8 +59,8 @@ static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF>
-__global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvP p) {
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   constexpr int BM = WGM * WTM * 32;
   constexpr int G4 = (CK + 3) / 4;          // channel quads per chunk
   constexpr int CB = CK < 8 ? CK : 8;       // channels per halo load batch
@@ -384,7 +384,7 @@ static thread_local char g_last_kernel[96] = "";
 // prints it) -- lets a profiler attribute event timings to the exact instantiation
 extern "C" const char *tbg_last_conv_kernel(void) { return g_last_kernel; }
 
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 1>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
   constexpr int BM = WGM * WTM * 32;
   constexpr int G4 = (CK + 3) / 4;
@@ -398,7 +398,7 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
                       (p.in_scale ? (size_t)p.NSEG * p.C : 0)) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   if (maxtaps > MT) return TBG_EUNSUPPORTED;
-  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF>;
+  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF, OCC>;
   if (getenv("TBG_DEBUG_OCC")) {
     int nb = -1;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, lds);
@@ -421,7 +421,8 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
       return TBG_EHIP;
   }
   dim3 grid(maxTilesN, ceil_div(p.M, BM), p.nclass * p.ksplit);
-  snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF);
+  if (OCC == 1) snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF);
+  else snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
@@ -570,6 +571,13 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
   if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
   if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
   if (BM == 64) return launch_fprop<1, 4, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
+  // Largest launches (>= 1.5 waves of the 1024 block slots that 4 blocks/CU give): CK=4 chunks need 22 KB of LDS and
+  // 109 registers -> 4 waves/SIMD and a grid that fills whole rounds: 98 -> 104 TFLOP/s on 64x256 128->128
+  // (tools/bench_conv.py).  Smaller launches lose (more barriers per FLOP), so they keep CK=8 at 3 waves/SIMD.
+  static const int occ4 = getenv("TBG_CONV_OCC4") ? atoi(getenv("TBG_CONV_OCC4")) : 1;
+  if (occ4 && BM == 128 && BN == 128 && maxtaps == 9 && p.NJ <= 3 &&
+      (long long)maxTilesN * ceil_div(p.M, BM) * p.nclass >= 1536 && p.ksplit == 1)
+    return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 0, 4>(p, st, maxtaps, maxTilesN);
   if (BN == 256) return launch_fprop<2, 2, 2, 4, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
   return launch_fprop<2, 2, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
 }
