@@ -95,8 +95,10 @@ int tbg_upfirdn2d_ex_f32(const float *x, const float *k, float *y, int major, in
  * layers/conv.py:51-73, layers/modulated_conv2d.py:85-121, upfirdn_2d_v2.py:65-113 and
  * their gradients.  in_scale [B*C] (style modulation, modulated_conv2d.py:94-96) is applied
  * while staging x; the epilogue applies demodulation / noise / bias / activation.
- * ksplit > 1 splits the reduction over blocks that atomically add alpha*acc into a
- * PRE-ZEROED y (epilogue must then be alpha-only).
+ * ksplit > 1 splits the reduction: y must then hold ksplit SLABS [ksplit][B,M,Hout,Wout]; split k
+ * stores alpha*acc of its channel range into slab k with plain stores (every slab is fully written; no
+ * zero-fill, no atomics; the epilogue must be alpha-only) and tbg_slab_epilogue_f32 sums the slabs
+ * and applies the real epilogue.
  * `w` is the PACKED filter Wp[tap][ceil(C/4)][ldw][4] written by tbg_weight_pack_f32 (ldw = its M;
  * 16-byte aligned): 4 consecutive reduction channels of one output channel per 16-byte unit, which is
  * both the LDS-DMA granule and one ds_read_b128 MFMA operand.
@@ -206,6 +208,11 @@ int tbg_rgb_backproject_f32(const float *x, const float *dy, const float *w, con
 int tbg_bias_act_fwd_f32(const float *x, float *y, int B, int M, int HW, const tbg_epilogue *epi,
                          void *stream);
 int tbg_bias_act_bwd_chunks(int HW);
+/* y[i] = epilogue(sum_{s<nslab} x[s*B*M*HW + i]) -- the second half of a split-K convolution (nslab =
+ * ksplit), and the small-plane form of tbg_bias_act_fwd_f32 (nslab = 1): one flat pass. */
+int tbg_slab_epilogue_f32(const float *x, float *y, int B, int M, int HW, int nslab,
+                          const tbg_epilogue *epi, void *stream);
+
 int tbg_bias_act_bwd_f32(const float *dout, const float *out_act, float *dx, float *dpre_out,
                          float *part_db, float *part_dn, float *part_dyy, int B, int M, int HW,
                          const tbg_epilogue *epi, void *stream);

@@ -50,6 +50,7 @@ struct ConvP {
   int ldw;
   int logTW, logTHs, NSEG, IHs, IWs, IWp, HALFW, planeStride, ppc, NJ, nBG;
   int nclass, ksplit, nchunks, cps;
+  long long slab;  // elements per split-K slab (= B*M*Hout*Wout)
   int a_floats, ck_rt;
   ClassInfo cls[MAXCLS];
   EpiK e;
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
           const size_t idx = ((size_t)e_b[j] * p.M + m) * HWout + e_pix[j];
           float val = acc[i][j][r16] * p.e.alpha;
           if (p.ksplit > 1) {
-            atomicAdd(p.y + idx, val);
+            p.y[(size_t)ks * p.slab + idx] = val;  // split-K: plain stores into this split's slab, summed by the epilogue pass
           } else {
             if (do_dot) {
               const float pv = val * p.e.dot_aux[idx];
@@ -392,8 +393,7 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
   p.a_floats = maxtaps * G4 * 4 * BM;
   p.ck_rt = CK;
   p.nchunks = ceil_div(p.C, CK);
-  if (p.ksplit > p.nchunks) p.ksplit = p.nchunks;
-  p.cps = ceil_div(p.nchunks, p.ksplit);
+  p.cps = ceil_div(p.nchunks, p.ksplit);  // splits past the last chunk run no K loop and store zeros: every slab is fully written
   const size_t lds = ((size_t)(PF ? 2 : 1) * ((size_t)p.a_floats + (size_t)G4 * 4 * p.planeStride) +
                       (p.in_scale ? (size_t)p.NSEG * p.C : 0)) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
@@ -535,10 +535,8 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
     const int tiles = c.tilesU * c.tilesV * p.nBG;
     if (tiles > maxTilesN) maxTilesN = tiles;
   }
-  p.ksplit = d->ksplit;  // clamped to the chunk count in launch_fprop
-  if (d->ksplit > 1 && p.ksplit == 1) {
-    // caller promised a zeroed buffer + alpha-only epilogue; plain stores give the same result
-  }
+  p.ksplit = d->ksplit;
+  p.slab = (long long)d->B * d->M * d->Hout * d->Wout;
   hipStream_t st = tbg_stream(stream);
   static const bool ck32 = getenv("TBG_CONV_1X1_CK32") != nullptr;  // experiment knob: measured no gain (1x1 is HBM/latency bound)
   if (maxtaps == 1 && ck32) {

@@ -314,6 +314,68 @@ extern "C" int tbg_bias_act_fwd_f32(const float *x, float *y, int B, int M, int 
   return TBG_OK;
 }
 
+// Split-K epilogue / small-plane forward: y[i] = epilogue(sum_s x[s*slab + i]) as ONE flat grid-stride pass (a block per
+// (plane, chunk) is wasteful when planes hold a few hundred elements -- exactly the layers that split K).
+struct SlabEpiP {
+  const float *x;
+  float *y;
+  int B, M, HW, nslab;
+  long long slab, total;
+  EpiK e;
+};
+
+__global__ __launch_bounds__(256) void slab_epilogue_kernel(const SlabEpiP p) {
+  const float str = p.e.noise ? p.e.strength[0] : 0.f;
+  const bool rf = p.e.residual && p.e.res_first;
+  const bool vec = (p.HW & 3) == 0;
+  const long long n = vec ? p.total >> 2 : p.total;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long long)gridDim.x * 256) {
+    const long long i = vec ? q << 2 : q;
+    const int plane = (int)(i / p.HW), pix = (int)(i - (long long)plane * p.HW);
+    const int b = plane / p.M, m = plane - b * p.M;
+    const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[plane] : 1.f);
+    const float bias = p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int w = vec ? 4 : 1;
+    for (int s = 0; s < p.nslab; ++s) {
+      const float *src = p.x + (size_t)s * p.slab + i;
+      if (vec) {
+        const float4 t = *reinterpret_cast<const float4 *>(src);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      } else {
+        v[0] += src[0];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < w) {
+        float o = v[k] * sc + bias;
+        if (p.e.noise) o += p.e.noise[(size_t)b * p.HW + pix + k] * str;
+        if (rf) o += p.e.residual[i + k];
+        o = epi_act(p.e, o);
+        if (p.e.residual && !rf) o = (o + p.e.residual[i + k]) * p.e.res_scale;
+        v[k] = o;
+      }
+    }
+    if (vec) *reinterpret_cast<float4 *>(p.y + i) = make_float4(v[0], v[1], v[2], v[3]);
+    else p.y[i] = v[0];
+  }
+}
+
+extern "C" int tbg_slab_epilogue_f32(const float *x, float *y, int B, int M, int HW, int nslab, const tbg_epilogue *epi,
+                                     void *stream) {
+  if (!x || !y || B < 1 || M < 1 || HW < 1 || nslab < 1 || !epi_valid(epi) || (epi && epi->dot_aux)) return TBG_EINVAL;
+  if ((double)B * M * HW > 2147483647.0) return TBG_ERANGE;
+  if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return TBG_EINVAL;
+  SlabEpiP p{x, y, B, M, HW, nslab, (long long)B * M * HW, (long long)B * M * HW, make_epi(epi)};
+  const long long work = (HW & 3) == 0 ? p.total >> 2 : p.total;
+  long long blocks = (work + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(slab_epilogue_kernel, dim3((int)blocks), dim3(256), 0, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
 struct BiasActBwdP {
   const float *dout, *out_act;
   float *dx, *dpre_out, *part_db, *part_dn, *part_dyy;

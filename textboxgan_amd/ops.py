@@ -161,8 +161,11 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     _npix = B * (math.ceil(Hout / stride[0]) * math.ceil(Wout / stride[1]) if transposed else Hout * Wout)
     if allow_split:
         tiles = _conv_tiles(M, _npix) * (stride[0] * stride[1] if transposed else 1)  # one launch covers all classes
-        if tiles < 256 and nchunks >= 8:  # tools/bench_ksplit.py: ~300 blocks is the sweet spot (atomics cost ~ ksplit)
-            ksplit = max(1, min(nchunks // 4, math.ceil(288 / tiles)))
+        if tiles < 256 and nchunks >= 8:  # tools/bench_ksplit.py: ~300 blocks is the sweet spot (slab traffic ~ ksplit)
+            target = max(1, min(nchunks // 4, math.ceil(288 / tiles)))
+            # a split that divides the chunk count keeps the splits even (32 chunks: 6 splits = 6,6,6,6,6,2 ran slower than 4)
+            divs = [k for k in range(1, nchunks // 2 + 1) if nchunks % k == 0]
+            ksplit = min(divs, key=lambda k: abs(math.log(k / target)))
         if FORCE_KSPLIT is not None:
             ksplit = max(1, min(nchunks, FORCE_KSPLIT))
     d = N.ConvDesc(B, Cc, M, Hin, Win, Hout, Wout, KH, KW, stride[0], stride[1], pad[0], pad[1], int(transposed),
@@ -173,25 +176,32 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
              f"p={tuple(pad)} T={int(transposed)} ldw={ldw} ksplit={ksplit}]")
     _flops = 2.0 * B * M * Cc * KH * KW * (Hin * Win if transposed else Hout * Wout)
     _kname = None  # resolved from tbg_last_conv_kernel()
-    trivial = not (epi.out_scale or epi.bias or epi.noise or epi.residual or epi.act != ACT_LINEAR or dot is not None)
-    if ksplit > 1 and not trivial:
-        tmp = torch.zeros((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
+    if ksplit > 1:
+        # split-K: every split stores alpha*acc into its own slab (no zero-fill, no atomics); one flat pass sums the
+        # slabs and applies the real epilogue
+        slabs = torch.empty((ksplit, B, M, Hout, Wout), device=x.device, dtype=torch.float32)
         e0 = N.epilogue(alpha=epi.alpha)
         N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
-            C.byref(d), N.ptr(x), N.ptr(w), N.ptr(tmp), N.ptr(in_scale), C.byref(e0), N.stream()), _what), _what)
-        if dot is not None:
-            dot[1].copy_((tmp * dot[0]).sum(dim=(2, 3)))
+            C.byref(d), N.ptr(x), N.ptr(w), N.ptr(slabs), N.ptr(in_scale), C.byref(e0), N.stream()), _what), _what)
         e1 = N.Epilogue.from_buffer_copy(epi)
         e1.alpha = 1.0
-        y = torch.empty_like(tmp)
-        N.check(N.lib().tbg_bias_act_fwd_f32(N.ptr(tmp), N.ptr(y), B, M, Hout * Wout, C.byref(e1), N.stream()),
-                "tbg_bias_act_fwd")
+        if dot is not None:  # the fused dot needs the complete sum: reduce first (rare: the smallest G layers' backward)
+            e1.dot_aux, e1.dot_out = None, None
+            tmp = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
+            N.check(N.lib().tbg_slab_epilogue_f32(N.ptr(slabs), N.ptr(tmp), B, M, Hout * Wout, ksplit,
+                                                  C.byref(N.epilogue()), N.stream()), "tbg_slab_epilogue")
+            dot[1].copy_((tmp * dot[0]).sum(dim=(2, 3)))
+            slabs, nslab = tmp, 1
+        else:
+            nslab = ksplit
+        y = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
+        N.check(N.lib().tbg_slab_epilogue_f32(N.ptr(slabs), N.ptr(y), B, M, Hout * Wout, nslab, C.byref(e1), N.stream()),
+                "tbg_slab_epilogue")
         return y
     if dot is not None:
         epi = N.Epilogue.from_buffer_copy(epi)
         epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(dot[1])
-    alloc = torch.zeros if ksplit > 1 else torch.empty
-    y = alloc((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
+    y = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
     N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
         C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream()), _what), _what)
     return y
