@@ -844,8 +844,8 @@ class _FrozenConv(torch.autograd.Function):
         stride, pad, relu, has_res, xhw, yhw = ctx.cfgv
         KH, KW, I, O = w.shape
         dy = dy.contiguous()
-        if relu:
-            _, dy, _, _, _ = bias_act_bwd_raw(dy, y, N.epilogue(act=ACT_LRELU, slope=0.0, gain=1.0), want_db=False)
+        if relu:  # mask only (no bias gradient: frozen) -> one flat elementwise pass; sign(y) = sign(pre-activation)
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)
         dx = None
         if ctx.needs_input_grad[0]:
             if stride == (1, 1):
