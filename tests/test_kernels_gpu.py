@@ -201,6 +201,8 @@ WG_CASES = [
     (2, 32, 48, 10, 34, 3, (1, 2), (0, 0), "3x3 s(1,2) VALID"),
     (2, 3, 64, 16, 64, 1, (1, 1), (0, 0), "1x1 fromRGB"),
     (4, 513, 512, 4, 4, 3, (1, 1), (1, 1), "513->512 4x4"),
+    (3, 40, 72, 9, 17, 1, (2, 2), (0, 0), "1x1 s2 (strided shortcut)"),
+    (2, 24, 40, 5, 3, 3, (1, 1), (1, 1), "3x3 on a 3-wide map (narrow-tile path)"),
 ]
 
 

@@ -599,7 +599,7 @@ template <int WGS, int WGL, int NT, int PIX, bool GRP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   constexpr int BS = WGS * 32, BL = WGL * 32, SP = PIX + 4;  // 16-byte aligned S rows; 68 words = conflict-free b128
   constexpr int KWt = (NT == 9) ? 3 : 1;
-  constexpr int NJC = (NT == 1) ? 1 : WG_MAXNJ;  // halo positions per lane (compile-time trip count: no guards)
+  constexpr int NJC = (NT == 1 && PIX == 64) ? 1 : WG_MAXNJ;  // halo positions per lane (compile-time trip count: no guards)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *Ss = smem;            // [BS][SP]
@@ -854,7 +854,7 @@ template <int WGS, int WGL, int NT, int PIX, bool GRP>
 static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes) {
   constexpr int BS = WGS * 32, BL = WGL * 32;
   const size_t lds = ((size_t)BS * (PIX + 4) + (size_t)BL * p.lplane) * sizeof(float);
-  if (p.NJ > (NT == 1 ? 1 : WG_MAXNJ)) return TBG_EUNSUPPORTED;
+  if (p.NJ > ((NT == 1 && PIX == 64) ? 1 : WG_MAXNJ)) return TBG_EUNSUPPORTED;
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   auto kern = conv_wgrad_kernel<WGS, WGL, NT, PIX, GRP>;
   if (lds > 64 * 1024) {
