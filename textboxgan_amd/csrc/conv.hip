@@ -60,7 +60,7 @@ static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF, int OCC = 1>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF, int OCC = 3>
 __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   constexpr int BM = WGM * WTM * 32;
   constexpr int G4 = (CK + 3) / 4;          // channel quads per chunk
@@ -321,10 +321,21 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     }
   }
 
-  // ---- epilogue (m outer, pixel sub-tile inner: the fused dot needs only one running scalar)
+  // ---- epilogue.  Every pointer / scalar of the epilogue descriptor is hoisted into locals first, and the loads a row
+  // group needs (demodulation, residual, dot operand) are issued together before any arithmetic or store: the first
+  // version interleaved kernarg reloads, loads and stores element by element (521 s_waitcnt in 6.8k instructions) and
+  // cost 45-80 us per large launch -- more than the output write itself (a 134 MB fill takes 21 us).
   const int HWout = p.Hout * p.Wout;
+  const float *const e_os = p.e.out_scale, *const e_bias = p.e.bias, *const e_res = p.e.residual, *const e_aux = p.e.dot_aux;
+  float *const e_dot = p.e.dot_out;
+  const float e_alpha = p.e.alpha, e_bmul = p.e.bias_mul, e_slope = p.e.slope, e_gain = p.e.gain, e_rscale = p.e.res_scale;
+  const bool e_lrelu = p.e.act == TBG_ACT_LRELU, e_rfirst = p.e.res_first != 0;
   const float str = p.e.noise ? p.e.strength[0] : 0.f;
-  const bool do_dot = p.e.dot_aux != nullptr && p.ksplit == 1;
+  const bool split = p.ksplit > 1;
+  const bool do_dot = e_aux != nullptr && !split;
+  const bool plain = !e_os && !e_bias && !p.e.noise && !e_res && !e_aux && !e_lrelu && e_gain == 1.f;
+  const int M = p.M, NSEGr = p.NSEG;
+  float *const ybase = split ? p.y + (size_t)ks * p.slab : p.y;
   int e_pix[WTN], e_b[WTN];
   float e_nz[WTN];
 #pragma unroll
@@ -336,48 +347,88 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     const bool okpix = b < p.B && u < ci.Ug && v < ci.Vg;
     const int Y = u * p.osy + ci.ooy, X = v * p.osx + ci.oox;
     e_pix[j] = okpix ? Y * p.Wout + X : -1;
-    e_b[j] = b;
+    e_b[j] = okpix ? b : 0;
     e_nz[j] = (okpix && p.e.noise) ? p.e.noise[(size_t)b * HWout + e_pix[j]] * str : 0.f;
   }
+  if (split || plain) {  // store-only: alpha * acc (split-K slabs, plain data gradients)
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+          if (m < M && e_pix[j] >= 0) ybase[(e_b[j] * M + m) * HWout + e_pix[j]] = acc[i][j][r16] * e_alpha;
+      }
+    return;
+  }
+  constexpr int RG = 2;  // rows per load batch (register budget: the epilogue must not raise the kernel's allocation)
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
 #pragma unroll
-    for (int r16 = 0; r16 < 16; ++r16) {
-      const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
-      const bool okm = m < p.M;
-      const float bias = (okm && p.e.bias) ? p.e.bias[m] * p.e.bias_mul : 0.f;
-      float dsum = 0.f;
+    for (int r0 = 0; r0 < 16; r0 += RG) {  // accumulator rows r0 .. r0+RG-1
+      int idx[RG][WTN];  // output offsets fit 31 bits (checked on the host)
+      int mrow[RG];
+      float bias4[RG], osv[RG][WTN], rsv[RG][WTN], axv[RG][WTN];
 #pragma unroll
-      for (int j = 0; j < WTN; ++j) {
-        if (okm && e_pix[j] >= 0) {
-          const size_t idx = ((size_t)e_b[j] * p.M + m) * HWout + e_pix[j];
-          float val = acc[i][j][r16] * p.e.alpha;
-          if (p.ksplit > 1) {
-            p.y[(size_t)ks * p.slab + idx] = val;  // split-K: plain stores into this split's slab, summed by the epilogue pass
-          } else {
-            if (do_dot) {
-              const float pv = val * p.e.dot_aux[idx];
-              if (p.NSEG == 1) dsum += pv;
-              else atomicAdd(p.e.dot_out + e_b[j] * p.M + m, pv);
-            }
-            if (p.e.out_scale) val *= p.e.out_scale[e_b[j] * p.M + m];
-            val += e_nz[j] + bias;
-            if (p.e.residual && p.e.res_first) val += p.e.residual[idx];
-            val = epi_act(p.e, val);
-            if (p.e.residual && !p.e.res_first) val = (val + p.e.residual[idx]) * p.e.res_scale;
-            p.y[idx] = val;
-          }
+      for (int q = 0; q < RG; ++q) {
+        const int r16 = r0 + q;
+        const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+        mrow[q] = m;
+        const bool okm = m < M;
+        bias4[q] = (okm && e_bias) ? e_bias[m] * e_bmul : 0.f;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+          idx[q][j] = (okm && e_pix[j] >= 0) ? (e_b[j] * M + m) * HWout + e_pix[j] : -1;
+          osv[q][j] = 1.f; rsv[q][j] = 0.f; axv[q][j] = 0.f;
         }
       }
-      if (do_dot && p.NSEG == 1) {  // one image per tile: reduce the 32 pixel lanes of each half-wave
+      if (e_os) {
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
-        if ((lane & 31) == 0 && okm && bg < p.B) atomicAdd(p.e.dot_out + bg * p.M + m, dsum);
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) osv[q][j] = e_os[idx[q][j] >= 0 ? e_b[j] * M + mrow[q] : 0];
+      }
+      if (e_res) {
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) rsv[q][j] = e_res[max(idx[q][j], 0)];  // clamped: branch-free
+      }
+      if (do_dot) {
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) axv[q][j] = e_aux[max(idx[q][j], 0)];
+      }
+#pragma unroll
+      for (int q = 0; q < RG; ++q) {
+        const int m = mrow[q];
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+          const bool okq = idx[q][j] >= 0;
+          float val = acc[i][j][r0 + q] * e_alpha;
+          if (do_dot) {
+            const float pv = okq ? val * axv[q][j] : 0.f;
+            if (NSEGr == 1) dsum += pv;
+            else if (okq) atomicAdd(e_dot + e_b[j] * M + m, pv);
+          }
+          val = val * osv[q][j] + e_nz[j] + bias4[q];
+          if (e_rfirst) val += rsv[q][j];
+          val = (e_lrelu ? (val > 0.f ? val : val * e_slope) : val) * e_gain;
+          if (e_res && !e_rfirst) val = (val + rsv[q][j]) * e_rscale;
+          if (okq) p.y[idx[q][j]] = val;
+        }
+        if (do_dot && NSEGr == 1) {  // one image per tile: reduce the 32 pixel lanes of each half-wave
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+          if ((lane & 31) == 0 && m < M && bg < p.B) atomicAdd(e_dot + bg * M + m, dsum);
+        }
       }
     }
   }
 }
-
 
 static thread_local char g_last_kernel[96] = "";
 
@@ -385,7 +436,7 @@ static thread_local char g_last_kernel[96] = "";
 // prints it) -- lets a profiler attribute event timings to the exact instantiation
 extern "C" const char *tbg_last_conv_kernel(void) { return g_last_kernel; }
 
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 1>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
   constexpr int BM = WGM * WTM * 32;
   constexpr int G4 = (CK + 3) / 4;
@@ -421,7 +472,7 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
       return TBG_EHIP;
   }
   dim3 grid(maxTilesN, ceil_div(p.M, BM), p.nclass * p.ksplit);
-  if (OCC == 1) snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF);
+  if (OCC == 3) snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF);
   else snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   TBG_LAUNCH_CHECK();
@@ -576,7 +627,7 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
   if (occ4 && BM == 128 && BN == 128 && maxtaps == 9 && p.NJ <= 3 &&
       (long long)maxTilesN * ceil_div(p.M, BM) * p.nclass >= 1536 && p.ksplit == 1)
     return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 0, 4>(p, st, maxtaps, maxTilesN);
-  if (BN == 256) return launch_fprop<2, 2, 2, 4, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
+  if (BN == 256) return launch_fprop<2, 2, 2, 4, 8, MAXTAPS, 0, 1>(p, st, maxtaps, maxTilesN);
   return launch_fprop<2, 2, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
 }
 

@@ -1,4 +1,5 @@
-"""How long do prologue + epilogue of the fprop kernel take?  C = 8 (one chunk) vs a plain fill of the same output."""
+"""Fixed cost (prologue + epilogue + launch) of the fprop kernel: time vs C at constant output, and a plain fill of
+the same output for reference."""
 import sys; sys.path.insert(0, '.')
 import torch
 from textboxgan_amd import ops
@@ -10,12 +11,15 @@ def timeit(f, n=50):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-B, M, H, W = 16, 128, 64, 256
-y = torch.empty(B, M, H, W, device=dev)
-print("fill 134 MB: %.1f us" % timeit(lambda: y.fill_(1.0)))
-src = torch.randn(B, M, H, W, device=dev)
-print("copy 134 MB: %.1f us" % timeit(lambda: y.copy_(src)))
-for C in (4, 8, 16, 32, 64, 128):
-    x = torch.randn(B, C, H, W, device=dev); w = ops.pack_filter(torch.randn(9, C, M, device=dev), False, False)
-    t = timeit(lambda: ops.conv2d_raw(x, w, M, 3, 3, (H, W), (1, 1), (1, 1)))
-    print(f"conv C={C:3d}: {t:7.1f} us   ({2*B*C*M*9*H*W/t/1e6:6.1f} TF)")
+B = 16
+for (M, H, W) in ((128, 64, 256), (128, 32, 128), (256, 16, 64), (256, 8, 32)):
+    y = torch.empty(B, M, H, W, device=dev)
+    tf = timeit(lambda: y.fill_(1.0))
+    ts = {}
+    for C in (8, 64, 128):
+        x = torch.randn(B, C, H, W, device=dev); w = ops.pack_filter(torch.randn(9, C, M, device=dev), False, False)
+        ops.FORCE_KSPLIT = 1
+        ts[C] = timeit(lambda: ops.conv2d_raw(x, w, M, 3, 3, (H, W), (1, 1), (1, 1)))
+    slope = (ts[128] - ts[64]) / 64
+    print(f"M={M} {H}x{W}: fill {tf:6.1f} us | C=8 {ts[8]:6.1f}  C=64 {ts[64]:6.1f}  C=128 {ts[128]:6.1f} us | "
+          f"marginal {2*B*M*9*H*W/slope/1e6:6.1f} TF  intercept {ts[128]-128*slope:6.1f} us")
