@@ -142,10 +142,35 @@ __global__ __launch_bounds__(256) void upfirdn2d_small_kernel(const UpfirdnP p) 
     if (outY < p.outH) {
       const int outX0 = tileOutX + relOutX0;
       float *yo = p.y + ((size_t)major * p.outH + outY) * p.outW + outX0;
+      const bool vec = (p.outW & 3) == 0 && outX0 + 3 < p.outW;
+      if (p.has_epi) {
+        // per-plane epilogue terms once per thread, the four noise values as one 16-byte load (the per-element
+        // upfirdn_epilogue() re-read the descriptor and every operand for each output: +70% on the blur)
+        const int b = major / p.M, m = major - b * p.M;
+        const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[major] : 1.f);
+        const float bias = p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f;
+        const float str = p.e.noise ? p.e.strength[0] : 0.f;
+        const bool lrelu = p.e.act == TBG_ACT_LRELU;
+        const float slope = p.e.slope, gain = p.e.gain;
+        float nz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.e.noise) {
+          const float *np = p.e.noise + (size_t)b * p.outH * p.outW + (size_t)outY * p.outW + outX0;
+          if (vec) {
+            const float4 t = *reinterpret_cast<const float4 *>(np);
+            nz[0] = t.x; nz[1] = t.y; nz[2] = t.z; nz[3] = t.w;
+          } else {
 #pragma unroll
-      for (int o = 0; o < 4; ++o)
-        if (outX0 + o < p.outW) res[o] = upfirdn_epilogue(p, res[o], major, outY, outX0 + o);
-      if ((p.outW & 3) == 0 && outX0 + 3 < p.outW) {
+            for (int o = 0; o < 4; ++o)
+              if (outX0 + o < p.outW) nz[o] = np[o];
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const float pre = res[o] * sc + nz[o] * str + bias;
+          res[o] = (lrelu ? (pre > 0.f ? pre : pre * slope) : pre) * gain;
+        }
+      }
+      if (vec) {
         *reinterpret_cast<float4 *>(yo) = make_float4(res[0], res[1], res[2], res[3]);
       } else {
 #pragma unroll

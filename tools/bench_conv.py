@@ -5,8 +5,9 @@ from textboxgan_amd import ops, native as N
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 
-def timeit(fn, n=5):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=30):
+    for _ in range(10): fn()  # clocks ramp from idle over the first launches: 5 timed calls under-reported by ~20%
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()

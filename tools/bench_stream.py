@@ -25,6 +25,9 @@ for (C, H, W) in ((128, 64, 256), (64, 64, 256), (128, 32, 128), (256, 16, 64), 
     k = ops.fir_kernel(dev, 1.0)
     t = timeit(lambda: ops.upfirdn2d_raw(x, k, pad=(2, 1, 2, 1)))
     print(f"blur {t:7.1f} us  {2*nb/t/1e3:6.0f} GB/s", end="   ")
+    xe = torch.randn(B, C, H + 1, W + 1, device=dev)
+    t2 = timeit(lambda: ops.upfirdn2d_raw(xe, k, pad=(1, 1, 1, 1), epi=epi))
+    print(f"blur+epi {t2:7.1f} us  {2*nb/t2/1e3:6.0f} GB/s", end="   ")
     t = timeit(lambda: ops.upfirdn2d_raw(x, k, down=(2, 2), pad=(2, 1, 2, 1)))
     print(f"blur/2 {t:7.1f} us  {1.25*nb/t/1e3:6.0f} GB/s", end="   ")
     y = torch.empty_like(x)
