@@ -107,16 +107,17 @@ def roofline_record(recs):
     achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
     # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 --pmc passes over
     # `bench.py --roofline-only` (tools/pmc_traffic.sh), matched by kernel instantiation; null if none is committed
-    traffic, traffic_src = None, None
+    traffic, traffic_src, mfma_busy = None, None, None
     try:
         tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "latest_traffic.json")))
         if name in tj["kernels"]:
             traffic, traffic_src = tj["kernels"][name]["hbm_bytes_per_launch"], tj["source"]
+            mfma_busy = tj["kernels"][name].get("mfma_busy")
     except (OSError, ValueError, KeyError):
         pass
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_src,
+            "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_src, "mfma_busy_pmc": mfma_busy,
             "launches": r["n"], "avg_launch_us": round(1e3 * r["ms"] / r["n"], 2),
             "gflop_per_launch": round(r["flops"] / r["n"] / 1e9, 3),
             "all_kernels": {k: {"n": v["n"], "ms": round(v["ms"], 3),

@@ -472,8 +472,7 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
       return TBG_EHIP;
   }
   dim3 grid(maxTilesN, ceil_div(p.M, BM), p.nclass * p.ksplit);
-  if (OCC == 3) snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF);
-  else snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC);
+  snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
