@@ -350,6 +350,24 @@ def demod_coefs_raw(s: torch.Tensor, w: torch.Tensor, coef: float):
 # ----------------------------------------------------------------------------------------
 # composable primitives (gradients of any order)
 # ----------------------------------------------------------------------------------------
+_FLIP_CACHE = {}
+
+
+def _flipped_fir(k: torch.Tensor) -> torch.Tensor:
+    """flip(k) for the cached FIR constants (fir_kernel): one flip per filter instead of one per backward call.  Only
+    tensors owned by _FIR_CACHE are memoised (they live for the process, so their address is a safe key)."""
+    key = k.data_ptr()
+    if any(v is k for v in _FIR_CACHE.values()) or key in _FLIP_CACHE and _FLIP_CACHE[key][0] is k:
+        hit = _FLIP_CACHE.get(key)
+        if hit is None or hit[0] is not k:
+            kf = torch.flip(k, (0, 1)).contiguous()
+            _FLIP_CACHE[key] = (k, kf)
+            _FLIP_CACHE[kf.data_ptr()] = (kf, k)  # flip(flip(k)) = k: gradients of gradients bounce between the two
+            return kf
+        return hit[1]
+    return torch.flip(k, (0, 1)).contiguous()
+
+
 class _UpFirDn2D(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k, up, down, pad):
@@ -367,8 +385,7 @@ class _UpFirDn2D(torch.autograd.Function):
         # upfirdn_2d_v2.py:204-209
         gpad = (kW - pad[0] - 1, inW * up[0] - outW * down[0] + pad[0] - up[0] + 1,
                 kH - pad[2] - 1, inH * up[1] - outH * down[1] + pad[2] - up[1] + 1)
-        kf = torch.flip(k, (0, 1)).contiguous()
-        return _UpFirDn2D.apply(dy, kf, down, up, gpad), None, None, None, None
+        return _UpFirDn2D.apply(dy, _flipped_fir(k), down, up, gpad), None, None, None, None
 
 
 def upfirdn2d(x, k, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0)):
