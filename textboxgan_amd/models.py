@@ -259,11 +259,13 @@ class Synthesis(nn.Module):
         if noises is None:  # fresh noise on every call, also at inference (noise.py:16-19)
             noises = [torch.randn(s, device=x.device) for s in self.noise_shapes(B)]
         k_up = ops.fir_kernel(x.device, 4.0)
-        y = self.initial_torgb(x, style[:, 0], None, mode)
+        ws = style.unbind(dim=1)  # one node: its backward is ONE stack of the per-layer latent gradients (16 selects
+        # would each zero-fill a [B, n, 512] tensor and be summed pairwise by the autograd engine)
+        y = self.initial_torgb(x, ws[0], None, mode)
         for i, (block, torgb) in enumerate(zip(self.synth_blocks, self.torgbs)):
-            x = block(x, style[:, 3 * i], style[:, 3 * i + 1], noises[2 * i], noises[2 * i + 1], mode)
+            x = block(x, ws[3 * i], ws[3 * i + 1], noises[2 * i], noises[2 * i + 1], mode)
             y = ops.upfirdn2d(y, k_up, up=(2, 2), pad=(2, 1, 2, 1))  # upsample_2d, :152
-            y = torgb(x, style[:, 3 * i + 2], y, mode)
+            y = torgb(x, ws[3 * i + 2], y, mode)
         return y
 
 
