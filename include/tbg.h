@@ -167,13 +167,23 @@ int tbg_weight_pack_f32(const float *src, float *dst, int T, int I, int O, int t
  * Direction d works on time t = d == 0 ? s : T-1-s.  Gate order i,f,g,o (PyTorch / cuDNN).
  *   gx, dg [D][T][B][4H] time-major input projections (+biases) / their gradients;  hw [D][B][4H] (NULL at s = 0)
  *   act [D][S][B][4H], cs [D][S][B][H] saved activations / cell states;  h [D][B][H];  seq, dseq [B][T][D*H]
- * bwd: `first` = 1 for the first step processed (s = T-1): no recurrent gradient, dc is initialised.
+ * bwd: `first` = 1 for the first step processed: dc is initialised.  Optional (NULL) operands: hw (gates already complete),
+ * seq, dseq (then dh = dh_rec), dh_rec, dg -- the attention decoder's LSTM cell uses the same kernels with D = 1.
  * ---------------------------------------------------------------------------------------- */
 int tbg_lstm_step_fwd_f32(const float *gx, const float *hw, float *act, float *cs, float *h, float *seq,
                           int D, int T, int B, int H, int s, void *stream);
 int tbg_lstm_step_bwd_f32(const float *dseq, const float *dh_rec, float *dc, const float *act,
                           const float *cs, float *dg, float *dgates, int D, int T, int B, int H, int s,
                           int first, void *stream);
+
+/* Bahdanau attention context of the OCR decoder (frozen weights), one launch per decoder step:
+ *   e[t] = sum_k v[k] tanh(enc_proj[b,t,k] + q[b,k]);  a = softmax_t(e) -> a [B][T];  ctx[b,:] = sum_t a[t] enc[b,t,:]
+ * bwd: dq [B][H] written; denc_proj [B][T][H] and denc [B][T][E] ACCUMULATED (+=).  T <= 64. */
+int tbg_attn_ctx_fwd_f32(const float *q, const float *enc_proj, const float *enc, const float *v, float *ctx,
+                         float *a, int B, int T, int H, int E, void *stream);
+int tbg_attn_ctx_bwd_f32(const float *dctx, const float *a, const float *q, const float *enc_proj,
+                         const float *enc, const float *v, float *dq, float *denc_proj, float *denc, int B,
+                         int T, int H, int E, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Thin 1x1 convolutions at the RGB ends (one side has O <= 4 channels): HBM-bound streaming kernels.

@@ -108,6 +108,26 @@ def test_frozen_bilstm_layer(dev, dims):
     assert rel_err(gxd, gx) < 2e-5
 
 
+def test_frozen_attn_decoder(dev):
+    """one-node attention decoder (HIP attention context + LSTM-cell launches) vs the torch definition in float64:
+    logits and d/d(encoder output) for a gradient that reaches every step."""
+    from textboxgan_amd.aster import AsterLikeOCR, AsterLikeOCRHip
+    ref = AsterLikeOCR().double()
+    hip = AsterLikeOCRHip().to(dev)
+    hip.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    enc = (rnd(5, 25, 512, seed=41) * 0.5).requires_grad_(True)
+    lg = ref._decode(enc)
+    dl = rnd(*lg.shape, seed=42)
+    (g,) = torch.autograd.grad(lg, enc, dl)
+    encd = enc.detach().float().to(dev).requires_grad_(True)
+    lgd = hip._decode(encd)
+    # greedy feedback: the comparison is only meaningful while both decoders pick the same symbols
+    assert torch.equal(lgd.argmax(-1).cpu(), lg.argmax(-1))
+    assert rel_err(lgd, lg) < 1e-4
+    (gd,) = torch.autograd.grad(lgd, encd, dl.float().to(dev))
+    assert rel_err(gd, g) < 1e-4
+
+
 def test_torgb_fused(dev):
     from textboxgan_amd import ops
     B, I, H, W, sd = 3, 24, 8, 32, 16

@@ -288,6 +288,10 @@ class AsterLikeOCR(nn.Module):
         x = self.encode(self.rectify(img_nchw))  # [B,512,1,25]
         seq = x.squeeze(2).permute(0, 2, 1)
         enc = self._encode_rnn(seq)  # [B,25,512]
+        return self._decode(enc)
+
+    def _decode(self, enc):
+        """Bahdanau-attention LSTM decoder, greedy feedback (overridden by the HIP subclass)."""
         B = enc.shape[0]
         enc_proj = self.att_enc(enc)
         h = enc.new_zeros(B, self.hidden)
@@ -336,6 +340,23 @@ class AsterLikeOCRHip(AsterLikeOCR):
         for w_ih, w_hh, b in self._cache["rnn"]:
             seq = ops.frozen_bilstm_layer(seq, w_ih, w_hh, b)
         return seq
+
+    def _decode(self, enc):
+        """The frozen decoder as one autograd node (ops.frozen_attn_decoder): attention context and LSTM-cell pointwise are
+        single HIP launches per step; ~100 launches per forward+backward instead of ~350 torch kernels."""
+        from . import ops
+        if "dec" not in self._cache:
+            with torch.no_grad():
+                E = self.att_enc.weight.shape[1]
+                w_ih, w_hh = self.cell.weight_ih, self.cell.weight_hh
+                c = lambda t: t.detach().contiguous()
+                self._cache["dec"] = ops.FrozenDecoderWeights(
+                    w_enc=c(self.att_enc.weight), w_dT=c(self.att_dec.weight.t()), b_d=c(self.att_dec.bias),
+                    w_d=c(self.att_dec.weight), v=c(self.att_v.weight.reshape(-1)),
+                    etab=c(self.emb.weight @ w_ih[:, E:].t() + self.cell.bias_ih + self.cell.bias_hh),
+                    w_ctx=c(w_ih[:, :E]), w_ctxT=c(w_ih[:, :E].t()), w_hh=c(w_hh), w_hhT=c(w_hh.t()),
+                    w_o=c(self.out.weight), w_oT=c(self.out.weight.t()), b_o=c(self.out.bias))
+        return ops.frozen_attn_decoder(enc, self._cache["dec"], self.max_steps, self.num_classes)
 
     def _run(self, blk: _ConvBN, x, residual=None):
         from . import ops

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const float *__restr
     a[u] = i; a[H + u] = f; a[2 * H + u] = gg; a[3 * H + u] = o;
     cs[(((size_t)d * T + s) * B + b) * H + u] = c;
     h[((size_t)d * B + b) * H + u] = hh;
-    seq[((size_t)b * T + t) * (D * H) + d * H + u] = hh;
+    if (seq) seq[((size_t)b * T + t) * (D * H) + d * H + u] = hh;
   }
 }
 
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float *__restr
   for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const int u = e % H, b = (e / H) % B, d = e / (H * B);
     const int t = d == 0 ? s : T - 1 - s;
-    float dh = dseq[((size_t)b * T + t) * (D * H) + d * H + u];
+    float dh = dseq ? dseq[((size_t)b * T + t) * (D * H) + d * H + u] : 0.f;
     if (dh_rec) dh += dh_rec[((size_t)d * B + b) * H + u];
     const float *a = act + (((size_t)d * T + s) * B + b) * 4 * H;
     const float i = a[u], f = a[H + u], gg = a[2 * H + u], o = a[3 * H + u];
@@ -69,8 +69,10 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float *__restr
     dc[ic] = dcc * f;
     float *q = dgates + ((size_t)d * B + b) * 4 * H;
     q[u] = d_i; q[H + u] = d_f; q[2 * H + u] = d_g; q[3 * H + u] = d_o;
-    float *w = dg + (((size_t)d * T + t) * B + b) * 4 * H;
-    w[u] = d_i; w[H + u] = d_f; w[2 * H + u] = d_g; w[3 * H + u] = d_o;
+    if (dg) {
+      float *w = dg + (((size_t)d * T + t) * B + b) * 4 * H;
+      w[u] = d_i; w[H + u] = d_f; w[2 * H + u] = d_g; w[3 * H + u] = d_o;
+    }
   }
 }
 
@@ -80,22 +82,130 @@ static int lstm_args_ok(int D, int T, int B, int H, int s) {
 
 extern "C" int tbg_lstm_step_fwd_f32(const float *gx, const float *hw, float *act, float *cs, float *h, float *seq, int D,
                                      int T, int B, int H, int s, void *stream) {
-  if (!gx || !act || !cs || !h || !seq || !lstm_args_ok(D, T, B, H, s)) return TBG_EINVAL;
-  if (s > 0 && !hw) return TBG_EINVAL;
+  if (!gx || !act || !cs || !h || !lstm_args_ok(D, T, B, H, s)) return TBG_EINVAL;
   const int n = D * B * H;
-  hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, tbg_stream(stream), gx, s > 0 ? hw : nullptr,
-                     act, cs, h, seq, D, T, B, H, s);
+  hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, tbg_stream(stream), gx, hw, act, cs, h, seq, D, T,
+                     B, H, s);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
 
 extern "C" int tbg_lstm_step_bwd_f32(const float *dseq, const float *dh_rec, float *dc, const float *act, const float *cs,
                                      float *dg, float *dgates, int D, int T, int B, int H, int s, int first, void *stream) {
-  if (!dseq || !dc || !act || !cs || !dg || !dgates || !lstm_args_ok(D, T, B, H, s)) return TBG_EINVAL;
-  if (!first && !dh_rec) return TBG_EINVAL;
+  if (!dc || !act || !cs || !dgates || !lstm_args_ok(D, T, B, H, s)) return TBG_EINVAL;
+  if (!dseq && !dh_rec) return TBG_EINVAL;
   const int n = D * B * H;
-  hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, tbg_stream(stream), dseq,
-                     first ? nullptr : dh_rec, dc, act, cs, dg, dgates, D, T, B, H, s, first);
+  hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, tbg_stream(stream), dseq, dh_rec, dc, act, cs, dg,
+                     dgates, D, T, B, H, s, first);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// ============================================================================================
+// Bahdanau attention context of the OCR decoder (one block per image), frozen weights:
+//   e[t] = sum_k v[k] * tanh(enc_proj[b,t,k] + q[b,k]);  a = softmax_t(e);  ctx[b,:] = sum_t a[t] * enc[b,t,:]
+// forward saves a; backward recomputes tanh and ACCUMULATES into denc_proj / denc (the decoder runs max_steps steps over the
+// same encoder output), writes dq.  T <= 64 (one wavefront does the softmax).
+// ============================================================================================
+#define ATT_MAXT 64
+
+__global__ __launch_bounds__(256) void attn_ctx_fwd_kernel(const float *__restrict__ q, const float *__restrict__ ep,
+                                                           const float *__restrict__ enc, const float *__restrict__ v,
+                                                           float *__restrict__ ctx, float *__restrict__ a_out, int T, int H,
+                                                           int E) {
+  __shared__ float part[4][ATT_MAXT];
+  __shared__ float a_s[ATT_MAXT];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *epb = ep + (size_t)b * T * H;
+  for (int t = 0; t < T; ++t) {
+    float s = 0.f;
+    for (int k = tid; k < H; k += 256) s += v[k] * tanhf(epb[(size_t)t * H + k] + q[(size_t)b * H + k]);
+    s = wave_sum(s);
+    if (lane == 0) part[wave][t] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float e = lane < T ? part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane] : -3.0e38f;
+    float mx = e;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float ex = lane < T ? expf(e - mx) : 0.f;
+    const float den = wave_sum(ex);
+    if (lane < T) {
+      const float a = ex / den;
+      a_s[lane] = a;
+      a_out[(size_t)b * T + lane] = a;
+    }
+  }
+  __syncthreads();
+  const float *eb = enc + (size_t)b * T * E;
+  for (int j = tid; j < E; j += 256) {
+    float c = 0.f;
+    for (int t = 0; t < T; ++t) c += a_s[t] * eb[(size_t)t * E + j];
+    ctx[(size_t)b * E + j] = c;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const float *__restrict__ dctx, const float *__restrict__ a_in,
+                                                           const float *__restrict__ q, const float *__restrict__ ep,
+                                                           const float *__restrict__ enc, const float *__restrict__ v,
+                                                           float *__restrict__ dq, float *__restrict__ dep,
+                                                           float *__restrict__ denc, int T, int H, int E) {
+  __shared__ float part[4][ATT_MAXT];
+  __shared__ float de_s[ATT_MAXT], a_s[ATT_MAXT];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *eb = enc + (size_t)b * T * E;
+  const float *dcb = dctx + (size_t)b * E;
+  if (tid < T) a_s[tid] = a_in[(size_t)b * T + tid];
+  for (int t = 0; t < T; ++t) {  // da[t] = <dctx, enc[t]>
+    float s = 0.f;
+    for (int j = tid; j < E; j += 256) s += dcb[j] * eb[(size_t)t * E + j];
+    s = wave_sum(s);
+    if (lane == 0) part[wave][t] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float da = lane < T ? part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane] : 0.f;
+    const float a = lane < T ? a_s[lane] : 0.f;
+    const float dot = wave_sum(a * da);
+    if (lane < T) de_s[lane] = a * (da - dot);
+  }
+  __syncthreads();
+  for (int j = tid; j < E; j += 256) {  // denc[t, j] += a[t] * dctx[j]
+    const float d = dcb[j];
+    for (int t = 0; t < T; ++t) denc[((size_t)b * T + t) * E + j] += a_s[t] * d;
+  }
+  const float *epb = ep + (size_t)b * T * H;
+  for (int k = tid; k < H; k += 256) {
+    const float qk = q[(size_t)b * H + k], vk = v[k];
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float th = tanhf(epb[(size_t)t * H + k] + qk);
+      const float dp = de_s[t] * vk * (1.f - th * th);
+      dep[((size_t)b * T + t) * H + k] += dp;
+      acc += dp;
+    }
+    dq[(size_t)b * H + k] = acc;
+  }
+}
+
+extern "C" int tbg_attn_ctx_fwd_f32(const float *q, const float *enc_proj, const float *enc, const float *v, float *ctx, float *a,
+                                    int B, int T, int H, int E, void *stream) {
+  if (!q || !enc_proj || !enc || !v || !ctx || !a || B < 1 || T < 1 || H < 1 || E < 1) return TBG_EINVAL;
+  if (T > ATT_MAXT) return TBG_EUNSUPPORTED;
+  hipLaunchKernelGGL(attn_ctx_fwd_kernel, dim3(B), dim3(256), 0, tbg_stream(stream), q, enc_proj, enc, v, ctx, a, T, H, E);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_attn_ctx_bwd_f32(const float *dctx, const float *a, const float *q, const float *enc_proj, const float *enc,
+                                    const float *v, float *dq, float *denc_proj, float *denc, int B, int T, int H, int E,
+                                    void *stream) {
+  if (!dctx || !a || !q || !enc_proj || !enc || !v || !dq || !denc_proj || !denc || B < 1 || T < 1 || H < 1 || E < 1)
+    return TBG_EINVAL;
+  if (T > ATT_MAXT) return TBG_EUNSUPPORTED;
+  hipLaunchKernelGGL(attn_ctx_bwd_kernel, dim3(B), dim3(256), 0, tbg_stream(stream), dctx, a, q, enc_proj, enc, v, dq, denc_proj,
+                     denc, T, H, E);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }

@@ -21,7 +21,7 @@ SQRT2 = 1.4142135623730951
 
 EXPORTS = [
     "tbg_version", "tbg_strerror", "tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_conv2d_f32",
-    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_last_conv_kernel", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
+    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_last_conv_kernel", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_attn_ctx_fwd_f32", "tbg_attn_ctx_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
     "tbg_bias_act_bwd_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -74,6 +74,8 @@ def lib():
         l.tbg_weight_pack_floats.restype = C.c_longlong
         l.tbg_lstm_step_fwd_f32.argtypes = [vp] * 6 + [ci] * 5 + [vp]
         l.tbg_lstm_step_bwd_f32.argtypes = [vp] * 7 + [ci] * 6 + [vp]
+        l.tbg_attn_ctx_fwd_f32.argtypes = [vp] * 6 + [ci] * 4 + [vp]
+        l.tbg_attn_ctx_bwd_f32.argtypes = [vp] * 9 + [ci] * 4 + [vp]
         l.tbg_last_conv_kernel.restype = C.c_char_p
         l.tbg_last_conv_kernel.argtypes = []
         l.tbg_bias_act_fwd_f32.argtypes = [vp, vp, ci, ci, ci, C.POINTER(Epilogue), vp]

@@ -820,6 +820,104 @@ def frozen_bilstm_layer(x, w_ih, w_hh, bias):
 
 
 # ----------------------------------------------------------------------------------------
+# frozen attention decoder of the OCR branch (greedy feedback): 8 launches per step forward, 6 backward
+# ----------------------------------------------------------------------------------------
+class FrozenDecoderWeights(NamedTuple):
+    """constants of the decoder, prepared once by the owner (AsterLikeOCRHip):
+    w_enc [H,E] (att_enc), w_dT [H,H] = att_dec.weight^T, b_d [H], w_d [H,H] = att_dec.weight, v [H],
+    etab [C+1,4H] = emb @ W_ih[:, E:]^T + b_ih + b_hh, w_ctx [4H,E], w_ctxT [E,4H], w_hh [4H,H], w_hhT [H,4H],
+    w_o [C,H], w_oT [H,C], b_o [C]."""
+    w_enc: torch.Tensor
+    w_dT: torch.Tensor
+    b_d: torch.Tensor
+    w_d: torch.Tensor
+    v: torch.Tensor
+    etab: torch.Tensor
+    w_ctx: torch.Tensor
+    w_ctxT: torch.Tensor
+    w_hh: torch.Tensor
+    w_hhT: torch.Tensor
+    w_o: torch.Tensor
+    w_oT: torch.Tensor
+    b_o: torch.Tensor
+
+
+class _FrozenAttnDecoder(torch.autograd.Function):
+    """enc [B,T,E] -> logits [B,S,C] of the Bahdanau-attention LSTM decoder with greedy (argmax) feedback; gradient w.r.t.
+    enc only.  Attention context and the LSTM cell's pointwise half are one HIP launch each per step
+    (tbg_attn_ctx_*, tbg_lstm_step_* with D = 1); the dense parts stay library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, enc, W: FrozenDecoderWeights, steps: int, go: int):
+        enc = enc.contiguous()
+        B, T, E = enc.shape
+        H = W.w_d.shape[0]
+        Cn = W.w_o.shape[0]
+        dev = enc.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        ep = torch.matmul(enc, W.w_enc.t())  # [B,T,H]
+        qs = torch.empty((steps, B, H), **f32)
+        a_all = torch.empty((steps, B, T), **f32)
+        ctxs = torch.empty((steps, B, E), **f32)
+        gbuf = torch.empty((1, steps, B, 4 * H), **f32)   # gate pre-activations, the layout tbg_lstm_step_fwd reads
+        act = torch.empty((1, steps, B, 4 * H), **f32)
+        cs = torch.empty((1, steps, B, H), **f32)
+        h = torch.zeros((1, B, H), **f32)
+        lbuf = torch.empty((steps, B, Cn), **f32)
+        prev = torch.full((B,), go, dtype=torch.long, device=dev)
+        for s in range(steps):
+            torch.addmm(W.b_d, h[0], W.w_dT, out=qs[s])
+            N.check(N.lib().tbg_attn_ctx_fwd_f32(N.ptr(qs[s]), N.ptr(ep), N.ptr(enc), N.ptr(W.v), N.ptr(ctxs[s]),
+                                                 N.ptr(a_all[s]), B, T, H, E, N.stream()), "tbg_attn_ctx_fwd")
+            g = torch.addmm(W.etab.index_select(0, prev), ctxs[s], W.w_ctxT)
+            torch.addmm(g, h[0], W.w_hhT, out=gbuf[0, s])
+            N.check(N.lib().tbg_lstm_step_fwd_f32(N.ptr(gbuf), None, N.ptr(act), N.ptr(cs), N.ptr(h), None, 1, steps, B, H, s,
+                                                  N.stream()), "tbg_lstm_step_fwd")
+            torch.addmm(W.b_o, h[0], W.w_oT, out=lbuf[s])
+            prev = lbuf[s].argmax(dim=1)  # greedy feedback (non-differentiable, as in the TF decoder)
+        ctx.save_for_backward(enc, ep, qs, a_all, act, cs)
+        ctx.W, ctx.dims = W, (B, T, E, H, Cn, steps)
+        return lbuf.transpose(0, 1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dlogits):
+        enc, ep, qs, a_all, act, cs = ctx.saved_tensors
+        W = ctx.W
+        B, T, E, H, Cn, steps = ctx.dims
+        dev = enc.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        dl = dlogits.transpose(0, 1).contiguous()  # [S,B,C]
+        denc = torch.zeros((B, T, E), **f32)
+        dep = torch.zeros((B, T, H), **f32)
+        dgates = torch.empty((1, B, 4 * H), **f32)
+        dc = torch.empty((1, B, H), **f32)
+        dq = torch.empty((B, H), **f32)
+        dctx = torch.empty((B, E), **f32)
+        dh = torch.empty((1, B, H), **f32)
+        dh_next = None
+        for s in range(steps - 1, -1, -1):
+            if dh_next is None:
+                torch.mm(dl[s], W.w_o, out=dh[0])
+            else:
+                torch.addmm(dh_next, dl[s], W.w_o, out=dh[0])
+            N.check(N.lib().tbg_lstm_step_bwd_f32(None, N.ptr(dh), N.ptr(dc), N.ptr(act), N.ptr(cs), None, N.ptr(dgates), 1,
+                                                  steps, B, H, s, int(s == steps - 1), N.stream()), "tbg_lstm_step_bwd")
+            torch.mm(dgates[0], W.w_ctx, out=dctx)
+            N.check(N.lib().tbg_attn_ctx_bwd_f32(N.ptr(dctx), N.ptr(a_all[s]), N.ptr(qs[s]), N.ptr(ep), N.ptr(enc), N.ptr(W.v),
+                                                 N.ptr(dq), N.ptr(dep), N.ptr(denc), B, T, H, E, N.stream()),
+                    "tbg_attn_ctx_bwd")
+            if s > 0:  # h_{s-1} feeds the cell (W_hh) and the attention query (att_dec)
+                dh_next = torch.addmm(torch.mm(dgates[0], W.w_hh), dq, W.w_d)
+        denc.view(B * T, E).addmm_(dep.view(B * T, H), W.w_enc)
+        return denc, None, None, None
+
+
+def frozen_attn_decoder(enc, W: FrozenDecoderWeights, steps: int, go: int):
+    return _FrozenAttnDecoder.apply(enc, W, steps, go)
+
+
+# ----------------------------------------------------------------------------------------
 # optimiser / EMA over flat buffers
 # ----------------------------------------------------------------------------------------
 def adam_tf_(theta, m, v, g, step, lr, beta1, beta2, eps):
