@@ -842,8 +842,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_wide_kernel(const Wgrad
   const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   const size_t per_split = (size_t)gridDim.x * gridDim.y;
   float a = 0.f;
-  for (int kz = 0; kz < p.ksplit; ++kz)
-    a += p.ws[((size_t)kz * per_split + tile) * (size_t)(NT * 16 * 256) + (size_t)tr * 256 + tid];
+  const float *src = p.ws + tile * (size_t)(NT * 16 * 256) + (size_t)tr * 256 + tid;
+  const size_t kstride = per_split * (size_t)(NT * 16 * 256);
+  int kz = 0;
+  for (; kz + 8 <= p.ksplit; kz += 8) {  // 8 partial tiles in flight per lane; summed in split order (deterministic)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(kz + u) * kstride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
+  }
+  for (; kz < p.ksplit; ++kz) a += src[(size_t)kz * kstride];
   const int cl = cl0 + wl * 32 + (lane & 31);
   const int cs = cs0 + ws_ * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
   if (cl < p.CL && cs < p.CS)
