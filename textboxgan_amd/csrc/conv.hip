@@ -845,12 +845,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_wide_kernel(const Wgrad
   const float *src = p.ws + tile * (size_t)(NT * 16 * 256) + (size_t)tr * 256 + tid;
   const size_t kstride = per_split * (size_t)(NT * 16 * 256);
   int kz = 0;
-  for (; kz + 8 <= p.ksplit; kz += 8) {  // 8 partial tiles in flight per lane; summed in split order (deterministic)
-    float v[8];
+  for (; kz + 16 <= p.ksplit; kz += 16) {  // 16 partial tiles in flight per lane; summed in split order (deterministic)
+    float v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(kz + u) * kstride];
+    for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(kz + u) * kstride];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a += v[u];
+    for (int u = 0; u < 16; ++u) a += v[u];
+  }
+  for (; kz + 4 <= p.ksplit; kz += 4) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(kz + u) * kstride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a += v[u];
   }
   for (; kz < p.ksplit; ++kz) a += src[(size_t)kz * kstride];
   const int cl = cl0 + wl * 32 + (lane & 31);
@@ -879,10 +886,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradP p) 
   float a[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
-  for (int kz = 0; kz < p.ksplit; ++kz) {
+  int kz = 0;
+  for (; kz + 2 <= p.ksplit; kz += 2) {  // 32 independent coalesced loads in flight
+    const float *s0 = p.ws + ((size_t)kz * per_split + tl) * (size_t)(NT * 16 * 256) + (size_t)t * 16 * 256 + tid;
+    const float *s1 = s0 + per_split * (size_t)(NT * 16 * 256);
+    float v0[16], v1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { v0[r] = s0[r * 256]; v1[r] = s1[r * 256]; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a[r] += v0[r]; a[r] += v1[r]; }
+  }
+  for (; kz < p.ksplit; ++kz) {
     const float *src = p.ws + ((size_t)kz * per_split + tl) * (size_t)(NT * 16 * 256) + (size_t)t * 16 * 256 + tid;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] += src[r * 256];  // 16 independent coalesced loads in flight
+    for (int r = 0; r < 16; ++r) a[r] += src[r * 256];
   }
   const int cl_l = wl * 32 + (lane & 31);
 #pragma unroll

@@ -364,14 +364,21 @@ __global__ __launch_bounds__(256) void slab_epilogue_kernel(const SlabEpiP p) {
     const float bias = p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     const int w = vec ? 4 : 1;
-    for (int s = 0; s < p.nslab; ++s) {
-      const float *src = p.x + (size_t)s * p.slab + i;
-      if (vec) {
-        const float4 t = *reinterpret_cast<const float4 *>(src);
-        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-      } else {
-        v[0] += src[0];
+    if (vec) {  // 4 slabs in flight per lane, summed in slab order
+      int s = 0;
+      for (; s + 4 <= p.nslab; s += 4) {
+        float4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)(s + u) * p.slab + i);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
       }
+      for (; s < p.nslab; ++s) {
+        const float4 t = *reinterpret_cast<const float4 *>(p.x + (size_t)s * p.slab + i);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      }
+    } else {
+      for (int s = 0; s < p.nslab; ++s) v[0] += p.x[(size_t)s * p.slab + i];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
