@@ -19,6 +19,8 @@ from __future__ import annotations
 import math
 from typing import Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -130,27 +132,71 @@ class TrainingStep:
             return out
         if key not in self._graphs:
             torch.cuda.synchronize()
-            if self.distributed:
+            if self.distributed and os.environ.get("TBG_GRAPH_SPLIT", "1") != "0":
+                self._graphs[key] = self._capture_split(st, do_r1, do_pl)
+            elif self.distributed:  # conservative fallback: one gradient graph, three blocking all-reduces, one update graph
                 ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga):
                     outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl,
                                                st["w"], {})
                 with torch.cuda.graph(gb, pool=ga.pool()):
                     self._apply_updates()
-                self._graphs[key] = (ga, gb, outs)
+                self._graphs[key] = ([ga, gb], outs)
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl,
                                                st["w"], {})
                     self._apply_updates()
-                self._graphs[key] = (g, None, outs)
-        ga, gb, outs = self._graphs[key]
-        ga.replay()
-        if gb is not None:
+                self._graphs[key] = ([g], outs)
+        graphs, outs = self._graphs[key]
+        if len(graphs) == 1:
+            graphs[0].replay()
+            return outs
+        if len(graphs) == 2:
+            graphs[0].replay()
             self.exchange.reduce_now((self.g_grad, self.o_grad, self.d_grad))
-            gb.replay()
+            graphs[1].replay()
+            return outs
+        # data-parallel: [fwd + g-pass] -> all-reduce(g) || [ocr-pass] -> all-reduce(ocr) || [d-pass] -> all-reduce(d) -> [Adam x3]
+        handles = []
+        for g, buf in zip(graphs[:3], (self.g_grad, self.o_grad, self.d_grad)):
+            g.replay()
+            handles.append(self.exchange.start(buf))  # ordered after the graph on this stream, runs on the RCCL stream
+        for h in handles:
+            GradExchange.finish(h)
+        graphs[3].replay()
         return outs
+
+    def _capture_split(self, st, do_r1, do_pl):
+        """Capture the step as FOUR HIP graphs sharing one memory pool (the autograd state of the forward lives across
+        them, as in torch's make_graphed_callables): the three gradient all-reduces (training_step.py:233-235) are issued
+        between the graphs and overlap the next backward pass instead of sitting in front of the Adam updates."""
+        import gc
+        graphs = [torch.cuda.CUDAGraph() for _ in range(4)]
+        pool = torch.cuda.graph_pool_handle()
+        cap = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        gc.collect()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            idx = [0]
+            graphs[0].capture_begin(pool=pool)
+
+            def boundary():
+                graphs[idx[0]].capture_end()
+                idx[0] += 1
+                graphs[idx[0]].capture_begin(pool=pool)
+
+            outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl, st["w"], {},
+                                       None, boundary)
+            graphs[2].capture_end()
+            graphs[3].capture_begin(pool=pool)
+            self._apply_updates()
+            graphs[3].capture_end()
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        return (graphs, outs)
 
     def prepare_graphs(self, real_images, ocr_images, input_words, ocr_labels, ocr_loss_weight: float = 1e-4):
         """Warm up and capture the three step variants (plain, +PL, +PL+R1) ahead of time.  Every call
@@ -183,7 +229,10 @@ class TrainingStep:
             return self._compute_grads_impl(*args, **kw)
 
     def _compute_grads_impl(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg, do_pl_reg,
-                            ocr_loss_weight, rand, handles=None):
+                            ocr_loss_weight, rand, handles=None, boundary=None):
+        """``handles``: eager mode -- the async all-reduce of each gradient set is appended right after its pass.
+        ``boundary``: split-capture mode -- called after the g-pass and after the ocr-pass (the capture of one HIP graph
+        ends and the next begins there, so that the replay can overlap each all-reduce with the following graph)."""
         cfg, G, D = self.cfg, self.generator, self.discriminator
         dev = real_images.device
         zero = torch.zeros((), device=dev)
@@ -234,9 +283,16 @@ class TrainingStep:
         write_grads(self.g_views, grads)
         if handles is not None:
             handles.append(self._all_reduce_async(self.g_grad))
+        ocr_joined = False
+        if boundary is not None:
+            if self.overlap_ocr:  # a forked stream must rejoin the capturing stream before its graph ends
+                main_stream.wait_stream(self._ocr_stream)
+                ocr_joined = True
+            boundary()
 
         if self.overlap_ocr:
-            main_stream.wait_stream(self._ocr_stream)
+            if not ocr_joined:
+                main_stream.wait_stream(self._ocr_stream)
             dfake_ocr.record_stream(main_stream)
             grads = torch.autograd.grad(fake_images, self.o_params, grad_outputs=dfake_ocr, retain_graph=True,
                                         allow_unused=True)
@@ -245,6 +301,8 @@ class TrainingStep:
         write_grads(self.o_views, grads)
         if handles is not None:
             handles.append(self._all_reduce_async(self.o_grad))
+        if boundary is not None:
+            boundary()
 
         ops.FLAGS.skip_image_grad = True
         try:
@@ -255,7 +313,7 @@ class TrainingStep:
         if handles is not None:
             handles.append(self._all_reduce_async(self.d_grad))
 
-        if self.overlap_ocr:
+        if self.overlap_ocr and not ocr_joined:
             main_stream.wait_stream(self._ocr_stream)  # join
         return ((reg_g_loss.detach(), g_loss.detach(), pl_penalty.detach()),
                 (reg_d_loss.detach(), d_loss.detach(), r1_penalty.detach()),
