@@ -178,7 +178,7 @@ int tbg_lstm_step_bwd_f32(const float *dseq, const float *dh_rec, float *dc, con
 
 /* Bahdanau attention context of the OCR decoder (frozen weights), one launch per decoder step:
  *   e[t] = sum_k v[k] tanh(enc_proj[b,t,k] + q[b,k]);  a = softmax_t(e) -> a [B][T];  ctx[b,:] = sum_t a[t] enc[b,t,:]
- * bwd: dq [B][H] written; denc_proj [B][T][H] and denc [B][T][E] ACCUMULATED (+=).  T <= 64. */
+ * bwd: dq [B][H] written; denc_proj [B][T][H] and (if not NULL) denc [B][T][E] ACCUMULATED (+=).  T <= 64. */
 int tbg_attn_ctx_fwd_f32(const float *q, const float *enc_proj, const float *enc, const float *v, float *ctx,
                          float *a, int B, int T, int H, int E, void *stream);
 int tbg_attn_ctx_bwd_f32(const float *dctx, const float *a, const float *q, const float *enc_proj,

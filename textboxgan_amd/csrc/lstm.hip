@@ -171,19 +171,33 @@ __global__ __launch_bounds__(256) void attn_ctx_bwd_kernel(const float *__restri
     if (lane < T) de_s[lane] = a * (da - dot);
   }
   __syncthreads();
-  for (int j = tid; j < E; j += 256) {  // denc[t, j] += a[t] * dctx[j]
-    const float d = dcb[j];
-    for (int t = 0; t < T; ++t) denc[((size_t)b * T + t) * E + j] += a_s[t] * d;
+  if (denc) {  // denc[t, j] += a[t] * dctx[j]  (callers may instead form sum_s a_s (x) dctx_s with one batched GEMM)
+    for (int j = tid; j < E; j += 256) {
+      const float d = dcb[j];
+      for (int t = 0; t < T; ++t) denc[((size_t)b * T + t) * E + j] += a_s[t] * d;
+    }
   }
   const float *epb = ep + (size_t)b * T * H;
   for (int k = tid; k < H; k += 256) {
     const float qk = q[(size_t)b * H + k], vk = v[k];
     float acc = 0.f;
-    for (int t = 0; t < T; ++t) {
-      const float th = tanhf(epb[(size_t)t * H + k] + qk);
-      const float dp = de_s[t] * vk * (1.f - th * th);
-      dep[((size_t)b * T + t) * H + k] += dp;
-      acc += dp;
+    for (int t0 = 0; t0 < T; t0 += 8) {  // 8 read-modify-writes in flight (one at a time was a serial round-trip chain)
+      float e8[8], o8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = min(t0 + u, T - 1);
+        e8[u] = epb[(size_t)t * H + k];
+        o8[u] = dep[((size_t)b * T + t) * H + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (t0 + u < T) {
+          const float th = tanhf(e8[u] + qk);
+          const float dp = de_s[t0 + u] * vk * (1.f - th * th);
+          dep[((size_t)b * T + t0 + u) * H + k] = o8[u] + dp;
+          acc += dp;
+        }
+      }
     }
     dq[(size_t)b * H + k] = acc;
   }
@@ -201,7 +215,7 @@ extern "C" int tbg_attn_ctx_fwd_f32(const float *q, const float *enc_proj, const
 extern "C" int tbg_attn_ctx_bwd_f32(const float *dctx, const float *a, const float *q, const float *enc_proj, const float *enc,
                                     const float *v, float *dq, float *denc_proj, float *denc, int B, int T, int H, int E,
                                     void *stream) {
-  if (!dctx || !a || !q || !enc_proj || !enc || !v || !dq || !denc_proj || !denc || B < 1 || T < 1 || H < 1 || E < 1)
+  if (!dctx || !a || !q || !enc_proj || !enc || !v || !dq || !denc_proj || B < 1 || T < 1 || H < 1 || E < 1)
     return TBG_EINVAL;
   if (T > ATT_MAXT) return TBG_EUNSUPPORTED;
   hipLaunchKernelGGL(attn_ctx_bwd_kernel, dim3(B), dim3(256), 0, tbg_stream(stream), dctx, a, q, enc_proj, enc, v, dq, denc_proj,

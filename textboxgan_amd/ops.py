@@ -888,12 +888,11 @@ class _FrozenAttnDecoder(torch.autograd.Function):
         dev = enc.device
         f32 = dict(device=dev, dtype=torch.float32)
         dl = dlogits.transpose(0, 1).contiguous()  # [S,B,C]
-        denc = torch.zeros((B, T, E), **f32)
         dep = torch.zeros((B, T, H), **f32)
+        dctxs = torch.empty((steps, B, E), **f32)
         dgates = torch.empty((1, B, 4 * H), **f32)
         dc = torch.empty((1, B, H), **f32)
         dq = torch.empty((B, H), **f32)
-        dctx = torch.empty((B, E), **f32)
         dh = torch.empty((1, B, H), **f32)
         dh_next = None
         for s in range(steps - 1, -1, -1):
@@ -903,12 +902,14 @@ class _FrozenAttnDecoder(torch.autograd.Function):
                 torch.addmm(dh_next, dl[s], W.w_o, out=dh[0])
             N.check(N.lib().tbg_lstm_step_bwd_f32(None, N.ptr(dh), N.ptr(dc), N.ptr(act), N.ptr(cs), None, N.ptr(dgates), 1,
                                                   steps, B, H, s, int(s == steps - 1), N.stream()), "tbg_lstm_step_bwd")
-            torch.mm(dgates[0], W.w_ctx, out=dctx)
-            N.check(N.lib().tbg_attn_ctx_bwd_f32(N.ptr(dctx), N.ptr(a_all[s]), N.ptr(qs[s]), N.ptr(ep), N.ptr(enc), N.ptr(W.v),
-                                                 N.ptr(dq), N.ptr(dep), N.ptr(denc), B, T, H, E, N.stream()),
+            torch.mm(dgates[0], W.w_ctx, out=dctxs[s])
+            N.check(N.lib().tbg_attn_ctx_bwd_f32(N.ptr(dctxs[s]), N.ptr(a_all[s]), N.ptr(qs[s]), N.ptr(ep), N.ptr(enc), N.ptr(W.v),
+                                                 N.ptr(dq), N.ptr(dep), None, B, T, H, E, N.stream()),
                     "tbg_attn_ctx_bwd")
             if s > 0:  # h_{s-1} feeds the cell (W_hh) and the attention query (att_dec)
                 dh_next = torch.addmm(torch.mm(dgates[0], W.w_hh), dq, W.w_d)
+        # d(enc) through the context sums: sum_s a_s (x) dctx_s as ONE batched GEMM over the images, + through enc_proj
+        denc = torch.bmm(a_all.permute(1, 2, 0), dctxs.permute(1, 0, 2))  # [B,T,S] @ [B,S,E]
         denc.view(B * T, E).addmm_(dep.view(B * T, H), W.w_enc)
         return denc, None, None, None
 
