@@ -220,6 +220,38 @@ def test_conv2d_wgrad(dev, case):
     assert rel_err(dw, dw_ref) < 3e-5
 
 
+def test_conv_random_shapes_all_three_passes(dev):
+    """seeded sweep over awkward shapes (channels not multiples of 4 / 32, odd maps, 1- and 2-pixel maps, every stride
+    the kernels accept): forward, data gradient and filter gradient against float64 autograd."""
+    from textboxgan_amd import ops
+    rng = np.random.RandomState(1234)
+    n_split = 0
+    for case in range(28):
+        k = int(rng.choice([1, 3]))
+        stride = (1, 1) if rng.rand() < 0.6 else tuple(int(v) for v in rng.choice([1, 2], size=2))
+        pad = (k // 2, k // 2) if stride == (1, 1) else (0, 0)
+        B = int(rng.randint(1, 6))
+        C = int(rng.choice([1, 3, 5, 8, 17, 33, 64, 100, 130]))
+        M = int(rng.choice([1, 3, 7, 16, 31, 40, 64, 96, 129]))
+        H = int(rng.randint(max(1, k if pad == (0, 0) else 1), 20))
+        W = int(rng.randint(max(1, k if pad == (0, 0) else 1), 40))
+        x = rnd(B, C, H, W, seed=100 + case).requires_grad_(True)
+        w = rnd(k, k, C, M, seed=200 + case).requires_grad_(True)
+        y = ref_conv(x, w, stride, pad)
+        dy = rnd(*y.shape, seed=300 + case)
+        gx, gw = torch.autograd.grad(y, (x, w), dy)
+        g = ops._Geom(stride, pad, k, k, (H, W), (y.shape[2], y.shape[3]))
+        xd, wd, dyd = x.detach().float().to(dev), w.detach().float().to(dev), dy.float().to(dev)
+        tag = (case, B, C, M, H, W, k, stride)
+        assert rel_err(ops._fwd_launch(xd, wd, g), y) < 3e-5, ("fwd", tag)
+        if k == 3 or stride == (1, 1) or True:
+            assert rel_err(ops._bwd_data_launch(dyd, wd, g), gx) < 3e-5, ("dgrad", tag)
+        if (k == 3) or (k == 1):
+            assert rel_err(ops._bwd_weight_launch(xd, dyd, g, C, M), gw) < 5e-5, ("wgrad", tag)
+        n_split += 1
+    assert n_split == 28
+
+
 def test_conv_primitives_double_backward(dev):
     """conv2d / bwd_data / bwd_weight close under differentiation (R1 and path-length need it)."""
     from textboxgan_amd import ops

@@ -558,24 +558,31 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
     }
   }
   static const int twmax = getenv("TBG_TW_MAX") ? atoi(getenv("TBG_TW_MAX")) : 32;
-  const int TW = pow2ceil(maxVg) < twmax ? pow2ceil(maxVg) : (twmax < BN ? twmax : BN);
-  const int TR = BN / TW;
-  const int THs = pow2ceil(maxUg) < TR ? pow2ceil(maxUg) : TR;
-  p.logTW = ilog2(TW); p.logTHs = ilog2(THs); p.NSEG = TR / THs;
-  p.IHs = (THs - 1) * p.sy + maxKH;
-  p.IWs = (TW - 1) * p.sx + maxKW;
-  p.HALFW = (p.IWs + 1) / 2;
-  int iwp = (p.sx == 2) ? 2 * p.HALFW : p.IWs;
-  if (TW < 32 && TW >= 8) {  // rows of a 32-lane B read land on disjoint banks (cheap for TW >= 8 only)
-    int cand = iwp;
-    for (int it = 0; it < 32 && ((p.sy * cand) & 31) != (TW & 31); ++it) ++cand;
-    if (((p.sy * cand) & 31) == (TW & 31) && cand <= iwp + iwp / 2 + 8) iwp = cand;
+  int TW = 1, THs = 1;
+  for (int attempt = 0;; ++attempt) {
+    TW = pow2ceil(maxVg) < twmax ? pow2ceil(maxVg) : (twmax < BN ? twmax : BN);
+    const int TR = BN / TW;
+    THs = pow2ceil(maxUg) < TR ? pow2ceil(maxUg) : TR;
+    p.logTW = ilog2(TW); p.logTHs = ilog2(THs); p.NSEG = TR / THs;
+    p.IHs = (THs - 1) * p.sy + maxKH;
+    p.IWs = (TW - 1) * p.sx + maxKW;
+    p.HALFW = (p.IWs + 1) / 2;
+    int iwp = (p.sx == 2) ? 2 * p.HALFW : p.IWs;
+    if (TW < 32 && TW >= 8) {  // rows of a 32-lane B read land on disjoint banks (cheap for TW >= 8 only)
+      int cand = iwp;
+      for (int it = 0; it < 32 && ((p.sy * cand) & 31) != (TW & 31); ++it) ++cand;
+      if (((p.sy * cand) & 31) == (TW & 31) && cand <= iwp + iwp / 2 + 8) iwp = cand;
+    }
+    p.IWp = iwp;
+    p.planeStride = p.NSEG * p.IHs * p.IWp;
+    p.ppc = p.NSEG * p.IHs * p.IWs;
+    p.NJ = ceil_div(p.ppc, 256);
+    if (p.NJ <= MAXNJ) break;
+    // very narrow maps pack many images into a 256-pixel tile and the halo of all of them exceeds what a thread can
+    // describe: fall back to the 64x64 tile once
+    if (attempt == 0 && BN > 64) { BM = 64; BN = 64; continue; }
+    return TBG_EUNSUPPORTED;
   }
-  p.IWp = iwp;
-  p.planeStride = p.NSEG * p.IHs * p.IWp;
-  p.ppc = p.NSEG * p.IHs * p.IWs;
-  p.NJ = ceil_div(p.ppc, 256);
-  if (p.NJ > MAXNJ) return TBG_EUNSUPPORTED;
   p.nBG = ceil_div(p.B, p.NSEG);
   int maxTilesN = 0;
   for (int k = 0; k < p.nclass; ++k) {
@@ -970,18 +977,25 @@ static int wgrad_geometry(const tbg_wgrad_desc *d, WgradP &p, int &PIX) {
   p.st_t = d->st_t; p.st_l = d->st_l; p.st_s = d->st_s; p.alpha = d->alpha;
   const bool strided = d->sy == 2 || d->sx == 2;
   PIX = strided ? 32 : 64;
-  const int TW = pow2ceil(d->Ws) < 32 ? pow2ceil(d->Ws) : 32;
-  const int TR = PIX / TW;
-  const int THs = pow2ceil(d->Hs) < TR ? pow2ceil(d->Hs) : TR;
-  p.logTW = ilog2(TW); p.logTHs = ilog2(THs); p.NSEG = TR / THs;
-  p.IHs = (THs - 1) * d->sy + d->KH;
-  p.IWs = (TW - 1) * d->sx + d->KW;
-  p.HALFW = (p.IWs + 1) / 2;
-  p.IWp = (d->sx == 2) ? 2 * p.HALFW : p.IWs;
-  p.lplane = (p.NSEG * p.IHs * p.IWp) | 1;  // odd plane pitch: lanes walk channels conflict-free
-  p.ppc = p.NSEG * p.IHs * p.IWs;
-  p.NJ = ceil_div(p.ppc, 64);
-  if (p.NJ > WG_MAXNJ) return TBG_EUNSUPPORTED;
+  int TW = 1, THs = 1;
+  for (;;) {
+    TW = pow2ceil(d->Ws) < 32 ? pow2ceil(d->Ws) : 32;
+    if (TW > PIX) TW = PIX;
+    const int TR = PIX / TW;
+    THs = pow2ceil(d->Hs) < TR ? pow2ceil(d->Hs) : TR;
+    p.logTW = ilog2(TW); p.logTHs = ilog2(THs); p.NSEG = TR / THs;
+    p.IHs = (THs - 1) * d->sy + d->KH;
+    p.IWs = (TW - 1) * d->sx + d->KW;
+    p.HALFW = (p.IWs + 1) / 2;
+    p.IWp = (d->sx == 2) ? 2 * p.HALFW : p.IWs;
+    p.lplane = (p.NSEG * p.IHs * p.IWp) | 1;  // odd plane pitch: lanes walk channels conflict-free
+    p.ppc = p.NSEG * p.IHs * p.IWs;
+    p.NJ = ceil_div(p.ppc, 64);
+    const int cap = (d->KH * d->KW == 1 && PIX == 64) ? 1 : WG_MAXNJ;
+    if (p.NJ <= cap) break;
+    if (PIX == 64) { PIX = 32; continue; }  // very narrow maps: the 32-pixel chunk packs fewer images per tile
+    return TBG_EUNSUPPORTED;
+  }
   p.nBG = ceil_div(d->B, p.NSEG);
   p.tilesU = ceil_div(d->Hs, THs);
   p.tilesV = ceil_div(d->Ws, TW);
