@@ -133,13 +133,21 @@ class TrainingStep:
         if key not in self._graphs:
             torch.cuda.synchronize()
             if self.distributed and os.environ.get("TBG_GRAPH_SPLIT", "1") != "0":
-                self._graphs[key] = self._capture_split(st, do_r1, do_pl)
+                try:
+                    self._graphs[key] = self._capture_split(st, do_r1, do_pl)
+                except Exception as e:  # a failed capture must not take a multi-GPU job down: finish it eagerly
+                    import sys
+                    print(f"[tbg] HIP-graph capture failed ({type(e).__name__}: {e}); continuing WITHOUT graphs",
+                          file=sys.stderr, flush=True)
+                    torch.cuda.synchronize()
+                    self.use_graphs = False
+                    return self._train_step(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl, st["w"], None)
             elif self.distributed:  # conservative fallback: one gradient graph, three blocking all-reduces, one update graph
                 ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl,
                                                st["w"], {})
-                with torch.cuda.graph(gb, pool=ga.pool()):
+                with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
                     self._apply_updates()
                 self._graphs[key] = ([ga, gb], outs)
             else:
@@ -181,19 +189,31 @@ class TrainingStep:
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
             idx = [0]
-            graphs[0].capture_begin(pool=pool)
+            # thread_local: the RCCL watchdog thread polls events while we capture; its calls must not abort the capture
+            graphs[0].capture_begin(pool=pool, capture_error_mode="thread_local")
+            if os.environ.get("TBG_TEST_CAPTURE_FAIL"):
+                graphs[0].capture_end()
+                raise RuntimeError("injected capture failure (TBG_TEST_CAPTURE_FAIL)")
 
             def boundary():
                 graphs[idx[0]].capture_end()
                 idx[0] += 1
-                graphs[idx[0]].capture_begin(pool=pool)
+                graphs[idx[0]].capture_begin(pool=pool, capture_error_mode="thread_local")
 
-            outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl, st["w"], {},
-                                       None, boundary)
-            graphs[2].capture_end()
-            graphs[3].capture_begin(pool=pool)
-            self._apply_updates()
-            graphs[3].capture_end()
+            try:
+                outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl, st["w"], {},
+                                           None, boundary)
+                graphs[2].capture_end()
+                idx[0] = 3
+                graphs[3].capture_begin(pool=pool, capture_error_mode="thread_local")
+                self._apply_updates()
+                graphs[3].capture_end()
+            except Exception:
+                try:
+                    graphs[idx[0]].capture_end()  # leave capture mode before propagating
+                except Exception:
+                    pass
+                raise
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         return (graphs, outs)
