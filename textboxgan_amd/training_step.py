@@ -152,10 +152,18 @@ class TrainingStep:
                 self._graphs[key] = ([ga, gb], outs)
             else:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl,
-                                               st["w"], {})
-                    self._apply_updates()
+                try:
+                    with torch.cuda.graph(g):
+                        outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl,
+                                                   st["w"], {})
+                        self._apply_updates()
+                except Exception as e:
+                    import sys
+                    print(f"[tbg] HIP-graph capture failed ({type(e).__name__}: {e}); continuing WITHOUT graphs",
+                          file=sys.stderr, flush=True)
+                    torch.cuda.synchronize()
+                    self.use_graphs = False
+                    return self._train_step(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl, st["w"], None)
                 self._graphs[key] = ([g], outs)
         graphs, outs = self._graphs[key]
         if len(graphs) == 1:
