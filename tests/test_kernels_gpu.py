@@ -77,6 +77,50 @@ def test_upfirdn2d_error_codes(dev):
     assert b"invalid" in L.tbg_strerror(-1)
 
 
+def test_conv_and_friends_error_codes(dev):
+    """argument validation of the other entries: a bad call returns a negative code (never launches, never throws) --
+    the C-ABI counterpart of the reference op's OP_REQUIRES checks (upfirdn_2d.cu:232-307)."""
+    import ctypes as C
+    from textboxgan_amd import native as N, ops
+    L = N.lib()
+    EINVAL, EUNSUP = -1, -4
+    x = torch.zeros(1, 8, 4, 4, device=dev)
+    wp = ops.pack_filter(torch.zeros(9, 8, 8, device=dev), False, False)
+    y = torch.zeros(1, 8, 4, 4, device=dev)
+    e = N.epilogue()
+    ok = N.ConvDesc(1, 8, 8, 4, 4, 4, 4, 3, 3, 1, 1, 1, 1, 0, 0, 8, 1)
+    call = lambda d, xx=x, ww=wp.data, yy=y, ep=e: L.tbg_conv2d_f32(C.byref(d), N.ptr(xx), N.ptr(ww), N.ptr(yy), None,
+                                                                   C.byref(ep), N.stream())
+    assert call(ok) == 0
+    assert call(ok, xx=None) == EINVAL and call(ok, yy=None) == EINVAL
+    assert call(N.ConvDesc(0, 8, 8, 4, 4, 4, 4, 3, 3, 1, 1, 1, 1, 0, 0, 8, 1)) == EINVAL            # B = 0
+    assert call(N.ConvDesc(1, 8, 8, 4, 4, 4, 4, 5, 5, 1, 1, 2, 2, 0, 0, 8, 1)) == EUNSUP            # 25 taps
+    assert call(N.ConvDesc(1, 8, 8, 4, 4, 4, 4, 3, 3, 3, 1, 1, 1, 0, 0, 8, 1)) == EUNSUP            # stride 3
+    assert call(N.ConvDesc(1, 8, 8, 4, 4, 4, 4, 3, 3, 1, 1, 1, 1, 0, 0, 4, 1)) == EINVAL            # ldw < M
+    assert call(N.ConvDesc(1, 8, 8, 4, 4, 4, 4, 3, 3, 1, 1, 1, 1, 0, 0, 8, 0)) == EINVAL            # ksplit 0
+    assert call(N.ConvDesc(1, 8, 8, 4, 4, 4, 4, 3, 3, 1, 1, 1, 1, 0, 0, 8, 2),
+                ep=N.epilogue(bias=torch.zeros(8, device=dev))) == EINVAL                            # split-K + epilogue
+    assert call(N.ConvDesc(1, 8, 8, 4, 4, 4, 4, 3, 3, 2, 2, 1, 1, 1, 0, 8, 1)) == EINVAL            # transposed with padding
+    wd = N.WgradDesc(1, 8, 8, 4, 4, 4, 4, 3, 3, 1, 1, 1, 1, 72, 8, 1, 1.0)
+    nbytes = L.tbg_conv2d_wgrad_workspace_bytes(C.byref(wd))
+    assert nbytes > 0
+    ws = torch.empty(nbytes // 4, device=dev)
+    dw = torch.zeros(9, 8, 8, device=dev)
+    wg = lambda d, w_=ws, nb=nbytes: L.tbg_conv2d_wgrad_f32(C.byref(d), N.ptr(x), N.ptr(x), N.ptr(dw), None, None, N.ptr(w_), nb,
+                                                         N.stream())
+    assert wg(wd) == 0
+    assert wg(wd, nb=16) == EINVAL                                                                   # workspace too small
+    assert wg(N.WgradDesc(1, 8, 8, 4, 4, 4, 4, 2, 2, 1, 1, 0, 0, 32, 8, 1, 1.0)) == EUNSUP           # 2x2 filter
+    assert L.tbg_conv2d_wgrad_workspace_bytes(C.byref(N.WgradDesc(1, 8, 8, 4, 4, 4, 4, 2, 2, 1, 1, 0, 0, 32, 8, 1, 1.0))) < 0
+    assert L.tbg_weight_pack_f32(N.ptr(x), None, 9, 8, 8, 0, 0, N.stream()) == EINVAL
+    assert L.tbg_slab_epilogue_f32(N.ptr(x), N.ptr(y), 1, 8, 16, 0, C.byref(e), N.stream()) == EINVAL   # nslab 0
+    h = torch.zeros(1, 2, 4, device=dev)
+    assert L.tbg_lstm_step_fwd_f32(None, None, N.ptr(h), N.ptr(h), N.ptr(h), None, 1, 3, 2, 4, 0, N.stream()) == EINVAL
+    assert L.tbg_lstm_step_fwd_f32(N.ptr(h), None, N.ptr(h), N.ptr(h), N.ptr(h), None, 1, 3, 2, 4, 3, N.stream()) == EINVAL  # s >= T
+    assert L.tbg_attn_ctx_fwd_f32(N.ptr(h), N.ptr(h), N.ptr(h), N.ptr(h), N.ptr(h), N.ptr(h), 1, 65, 4, 4, N.stream()) == EUNSUP
+    torch.cuda.synchronize()
+
+
 def test_upfirdn2d_grad_and_gradgrad(dev):
     """first and second order gradients through the recursive Function == autograd through the oracle."""
     from textboxgan_amd import ops
