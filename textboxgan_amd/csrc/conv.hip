@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
       }
     return;
   }
-  constexpr int RG = 2;  // rows per load batch (register budget: the epilogue must not raise the kernel's allocation)
+  constexpr int RG = OCC == 4 ? 2 : 4;  // rows per load batch (register budget: the epilogue must not raise the kernel's allocation)
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
 #pragma unroll

@@ -16,6 +16,20 @@ elif kind == "fwdmod":
     nz = torch.randn(B, 1, H, W, device=dev); st = torch.tensor(0.1, device=dev); b = torch.randn(M, device=dev)
     epi = N.epilogue(out_scale=d, bias=b, noise=nz, strength=st, act=N.ACT_LRELU, alpha=0.03)
     fn = lambda: ops.conv2d_raw(x, wp, M, 3, 3, (H, W), (1, 1), (1, 1), in_scale=s, epi=epi)
+elif kind == "dgradmod":   # data gradient of a modulated conv: in_scale = d, out_scale = s, fused style-gradient dot
+    s = torch.rand(B, C, device=dev) + 0.5; d = torch.rand(B, M, device=dev) + 0.5
+    dy = torch.randn(B, M, H, W, device=dev); ds = torch.zeros(B, C, device=dev)
+    wt = ops.pack_filter(w, True, True)
+    epi = N.epilogue(alpha=0.03, out_scale=s)
+    fn = lambda: ops.conv2d_raw(dy, wt, C, 3, 3, (H, W), (1, 1), (1, 1), in_scale=d, epi=epi, dot=(x, ds))
+elif kind == "dgradscale":
+    s = torch.rand(B, C, device=dev) + 0.5; d = torch.rand(B, M, device=dev) + 0.5
+    dy = torch.randn(B, M, H, W, device=dev); wt = ops.pack_filter(w, True, True)
+    epi = N.epilogue(alpha=0.03, out_scale=s)
+    fn = lambda: ops.conv2d_raw(dy, wt, C, 3, 3, (H, W), (1, 1), (1, 1), in_scale=d, epi=epi)
+elif kind == "dgrad":
+    dy = torch.randn(B, M, H, W, device=dev); wt = ops.pack_filter(w, True, True)
+    fn = lambda: ops.conv2d_raw(dy, wt, C, 3, 3, (H, W), (1, 1), (1, 1))
 elif kind == "wgrad":
     dy = torch.randn(B, M, H, W, device=dev)
     fn = lambda: ops._bwd_weight_launch(x, dy, g, C, M)
