@@ -325,6 +325,11 @@ class AsterLikeOCRHip(AsterLikeOCR):
         self._cache = {}
         return super()._apply(fn, *a, **kw)
 
+    def load_state_dict(self, *a, **kw):
+        r = super().load_state_dict(*a, **kw)
+        self._cache = {}  # folded filters, packed filters, stacked LSTM / decoder constants derive from the weights
+        return r
+
     def _encode_rnn(self, seq):
         """The frozen BiLSTM stack on batched GEMMs + one pointwise launch per step (ops.frozen_bilstm_layer) instead of
         MIOpen's per-direction per-step GEMM + pointwise pairs."""
