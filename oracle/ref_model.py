@@ -287,14 +287,23 @@ def mean_squared_loss(y_a, y_b, batch_size):
     return (y_a - y_b).square().mean(dim=-1).sum() / batch_size
 
 
+def ocr_call(inputs_nhwc: torch.Tensor, serve_fn: Callable, max_char_number=8):
+    """AsterInferer.call, aster_inferer.py:28-37: the SavedModel is called ONE SAMPLE AT A TIME; each sample's
+    ``forward_logits`` [1, T_i, C] (T_i = that sample's own dynamic-decode length) is post-processed and the rows are
+    concatenated.  ``serve_fn``: NHWC [1,64,256,3] -> {"forward_logits": [1,T,C]} (the serving signature)."""
+    rows = []
+    for i in range(inputs_nhwc.shape[0]):
+        prediction = serve_fn(inputs_nhwc[i:i + 1])
+        rows.append(ocr_postprocess_simple(prediction["forward_logits"], max_char_number))
+    return torch.cat(rows, dim=0)
+
+
 def get_ocr_loss(fake, labels, ocr_images, cfg, ocr_fn: Callable):
-    """training_step.py:375-402.  The reference runs the OCR sample by sample
-    (aster_inferer.py:28-37); a frozen eval-mode network is batch independent, so one batched
-    call is the same function."""
+    """training_step.py:375-402.  ``ocr_fn`` is the serving signature (see ocr_call)."""
     inp = ocr_convert_inputs(fake, labels, cfg)
-    logits = ocr_postprocess_simple(ocr_fn(inp), cfg.max_char_number)
+    logits = ocr_call(inp, ocr_fn, cfg.max_char_number)
     if cfg.ocr_loss_type == "mse":
-        real_logits = ocr_postprocess_simple(ocr_fn(ocr_images), cfg.max_char_number)
+        real_logits = ocr_call(ocr_images, ocr_fn, cfg.max_char_number)
         return mean_squared_loss(real_logits, logits, cfg.batch_size)
     return softmax_cross_entropy_loss(logits, labels, cfg.batch_size)
 

@@ -109,10 +109,21 @@ def test_aster_wrapper_matches_oracle_wrapper_on_cpu():
     np.testing.assert_allclose(o.convert_inputs(fake, labels).numpy(), M.ocr_convert_inputs(fake, labels, cfg).numpy(), atol=1e-5)
     logits = torch.randn(2, 8, 97, generator=torch.Generator().manual_seed(0)) * 0.01
     logits[:, :, 1] = -5.0  # nobody predicts EOS ...
-    logits[0, 2, 1] = 5.0   # ... except sample 0 at step 2 -> its steps 3.. are the reference's padding
-    out = o._postprocess_simple(logits)
+    logits[0, 2, 1] = 5.0   # ... except sample 0 at step 2: the network's dynamic decode emits 3 steps for it
+    lengths = o.model.decode_lengths(logits)
+    assert lengths.tolist() == [3, 8]
+    # the wrapper is the literal :116-151 rule; the oracle applies it sample by sample to each sample's own [1,T_i,C]
+    out = o._postprocess_simple(logits, lengths)
+    exp = torch.cat([M.ocr_postprocess_simple(logits[i:i + 1, : int(lengths[i])], 8) for i in range(2)])
+    assert torch.equal(out, exp)
     assert torch.equal(out[0, :3], logits[0, :3]) and float(out[0, 3, 1]) == 1000.0 and float(out[0, 7].sum()) == 1000.0
-    assert torch.equal(out[1], logits[1])
+    assert torch.equal(o._postprocess_simple(logits), logits)  # without lengths: plain truncate/pad only
+    short = o._postprocess_simple(logits[:, :5])
+    assert torch.equal(short, M.ocr_postprocess_simple(logits[:, :5], 8))
+    # whole wrapper (batched) == the reference's per-sample loop over the serving signature (aster_inferer.py:28-37)
+    x = o.convert_inputs(fake[:2], labels[:2])
+    with torch.no_grad():
+        np.testing.assert_allclose(o(x).numpy(), M.ocr_call(x, o.model.serve, 8).numpy(), atol=2e-5)
     assert not any(p.requires_grad for p in o.parameters())
 
 

@@ -225,15 +225,15 @@ def test_golden_upfirdn_and_modconv_and_networks():
 
 
 def test_training_step_oracle_runs_and_is_deterministic():
-    from textboxgan_amd.aster import AsterInferer
+    from textboxgan_amd.aster import AsterLikeOCR
     cfg = small_config(2)
-    ocr = AsterInferer()
+    ocr = AsterLikeOCR(max_steps=cfg.max_char_number)  # the stand-in network behind its serving signature
     outs = []
     for _ in range(2):
         st = M.make_state(cfg, 0, bench_init=True)
         batch, rand = M.make_batch(cfg), M.make_rand(cfg, seed=99)
         losses = M.training_step(st, cfg, batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"],
-                                 True, True, 1e-4, rand, lambda x: ocr(x), update_clone=True)
+                                 True, True, 1e-4, rand, ocr.serve, update_clone=True)
         outs.append([float(v) for v in losses[0]] + [float(v) for v in losses[1]] + [float(losses[2])])
         assert st["g_opt"].iterations == 1 and float(st["pl_mean"]) > 0
     assert outs[0] == outs[1] and all(math.isfinite(v) for v in outs[0])

@@ -31,11 +31,11 @@ def _todev(rand, dev):
 
 @pytest.mark.parametrize("reg", [(False, False), (True, True)], ids=["plain", "r1+pl"])
 def test_training_step_matches_oracle(dev, reg):
-    from textboxgan_amd.aster import AsterInferer
+    from textboxgan_amd.aster import AsterLikeOCR
     from textboxgan_amd.training_step import build_trainer_state
     do_r1, do_pl = reg
     cfg = small_config(4)
-    ocr_cpu = AsterInferer()
+    ocr_cpu = AsterLikeOCR(max_steps=cfg.max_char_number)  # same synthetic frozen weights as the product's HIP network
     st = M.make_state(cfg, seed=0, bench_init=True)
     batch, rand = M.make_batch(cfg), M.make_rand(cfg, seed=99)
 
@@ -47,7 +47,7 @@ def test_training_step_matches_oracle(dev, reg):
 
     w = 1e-4
     ref_losses, ref_grads = M.training_step(st, cfg, batch["real_images"], batch["ocr_images"], batch["input_words"],
-                                            batch["ocr_labels"], do_r1, do_pl, w, rand, lambda x: ocr_cpu(x),
+                                            batch["ocr_labels"], do_r1, do_pl, w, rand, ocr_cpu.serve,
                                             update_clone=True, return_grads=True)
     b = {k: v.to(dev) for k, v in batch.items()}
     losses = ts.dist_train_step(b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], do_r1, do_pl, w,
@@ -104,7 +104,7 @@ def test_two_steps_run_and_stay_finite(dev):
 
 def test_validation_step_and_chosen_words(dev):
     """validation_step.py:57-90 and infer.py:37-104 on the HIP path vs the oracle forward."""
-    from textboxgan_amd.aster import AsterInferer
+    from textboxgan_amd.aster import AsterLikeOCR
     from textboxgan_amd.training_step import build_trainer_state
     from textboxgan_amd.validation_step import ValidationStep, generate_chosen_words
     from oracle import ref_ops as R
@@ -117,8 +117,8 @@ def test_validation_step_and_chosen_words(dev):
                                    rand=dict(noises=[n.to(dev) for n in rand["noises"]]))
     img = M.generator(P, cfg, batch["input_words"], rand["z"], rand, training=False)
     img = R.t_mask_text_box(img, batch["input_words"], cfg.char_width)
-    ocr_cpu = AsterInferer()
-    ref = M.softmax_cross_entropy_loss(M.ocr_postprocess_simple(ocr_cpu(M.ocr_convert_inputs(img, batch["ocr_labels"], cfg))),
+    ocr_cpu = AsterLikeOCR(max_steps=cfg.max_char_number)
+    ref = M.softmax_cross_entropy_loss(M.ocr_call(M.ocr_convert_inputs(img, batch["ocr_labels"], cfg), ocr_cpu.serve),
                                        batch["ocr_labels"], cfg.batch_size)
     assert abs(float(loss) - float(ref)) <= 2e-4 * max(1.0, abs(float(ref)))
     outs = generate_chosen_words(prod["g_clone"], ["Hello", "GAN", "abcdefghij"], cfg)

@@ -6,10 +6,12 @@ Wrapper semantics (exact restatement, reference ``aster_ocr_utils/aster_inferer.
   label == blank(1) times char_width), bilinear-resize (TF2 half-pixel centres, no antialias)
   to 64x256.  Here the per-sample crop+resize is ONE batched matmul with a per-word-length
   interpolation matrix (the resize is linear in the pixels and the height scale is 1).
-* ``call`` (:28-37) + ``_postprocess_simple`` (:116-151): forward logits, first 8 steps; a
-  sample whose decode stopped before 8 steps is padded with ``1000 * onehot(class 1)``.
-  The reference calls the SavedModel once per sample; the network is frozen/eval so one
-  batched call computes the same function.
+* ``call`` (:28-37) + ``_postprocess_simple`` (:116-151): per sample, the forward logits
+  ``[1, T_i, C]`` of the SavedModel are cut to the first 8 steps and, when ``T_i < 8``, padded
+  with ``1000 * onehot(class 1)``.  The reference calls the SavedModel once per sample; the
+  network is frozen/eval, so one batched call computes the same rows -- the per-sample length
+  ``T_i`` (a property of the NETWORK's dynamic decode, not of the wrapper) travels beside the
+  batched logits as ``lengths`` and ``_postprocess_simple`` applies the literal rule row-wise.
 
 The network: the ASTER SavedModel is an external download that is NOT in the reference
 (``aster_weights/.keep`` only) -- architecture, class count and weights cannot be derived
@@ -90,21 +92,23 @@ class AsterInferer(nn.Module):
         return out.permute(0, 2, 3, 1)
 
     def forward(self, inputs_nhwc: torch.Tensor) -> torch.Tensor:
-        logits = self.model(inputs_nhwc.permute(0, 3, 1, 2))  # [B, T, C]
-        return self._postprocess_simple(logits)
+        """aster_inferer.py:28-37 (``call``), batched: ``forward_logits`` of every sample, post-processed."""
+        logits, lengths = self.model.forward_logits(inputs_nhwc.permute(0, 3, 1, 2))  # [B, S, C], [B] (T_i of sample i)
+        return self._postprocess_simple(logits, lengths)
 
-    def _postprocess_simple(self, logits: torch.Tensor) -> torch.Tensor:
-        """Keep 8 steps; steps after the first predicted EOS are what a batch-1 dynamic decode
-        never produced, i.e. the reference's ``1000 * onehot(1)`` padding."""
+    def _postprocess_simple(self, logits: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """aster_inferer.py:116-151 for a batch of samples whose own logits have ``lengths[i]`` time steps (``None``:
+        all ``logits.shape[1]``): keep the first ``max_char_number`` steps, pad the missing ones with
+        ``1000 * onehot(class 1)``.  Row-wise ``where`` instead of per-sample concat: no host sync (HIP-graph capturable)."""
         logits = logits[:, : self.max_char_number]
         B, T, C = logits.shape
-        if T < self.max_char_number:
-            row = (torch.arange(C, device=logits.device) == EOS).to(logits.dtype) * 1000.0
-            logits = torch.cat([logits, row.expand(B, self.max_char_number - T, C)], dim=1)
-        is_eos = logits.argmax(dim=2) == EOS
-        after = (torch.cumsum(is_eos.to(torch.int32), dim=1) - is_eos.to(torch.int32)) > 0  # strictly after first EOS
-        pad_row = (torch.arange(C, device=logits.device) == EOS).to(logits.dtype) * 1000.0  # capture-safe
-        return torch.where(after[:, :, None], pad_row, logits)
+        pad_row = (torch.arange(C, device=logits.device) == EOS).to(logits.dtype) * 1000.0
+        if T < self.max_char_number:  # padding_len > 0 for every sample (:134-149)
+            logits = torch.cat([logits, pad_row.expand(B, self.max_char_number - T, C)], dim=1)
+        if lengths is not None:  # sample i only HAS rows t < lengths[i]; the rest is its padding
+            missing = torch.arange(self.max_char_number, device=logits.device)[None, :] >= lengths[:, None]
+            logits = torch.where(missing[:, :, None], pad_row, logits)
+        return logits
 
 
 # ----------------------------------------------------------------------------------------
@@ -284,11 +288,35 @@ class AsterLikeOCR(nn.Module):
         return x
 
     def forward(self, img_nchw: torch.Tensor) -> torch.Tensor:
-        """[B,3,64,256] in [-1,1] -> forward logits [B, max_steps, num_classes]."""
+        """[B,3,64,256] in [-1,1] -> forward logits [B, max_steps, num_classes] (all decoder steps)."""
         x = self.encode(self.rectify(img_nchw))  # [B,512,1,25]
         seq = x.squeeze(2).permute(0, 2, 1)
         enc = self._encode_rnn(seq)  # [B,25,512]
         return self._decode(enc)
+
+    @staticmethod
+    def decode_lengths(logits: torch.Tensor) -> torch.Tensor:
+        """Number of time steps T_i the SavedModel's dynamic decode emits for sample i: it stops once the greedy symbol
+        is EOS (the EOS step itself is emitted), else runs to the step limit.  This models the NETWORK (tf.contrib
+        seq2seq dynamic_decode inside the ASTER graph); it is a guess like the rest of the stand-in (parity unpinned)."""
+        S = logits.shape[1]
+        is_eos = logits.argmax(dim=2) == EOS
+        first = torch.where(is_eos.any(dim=1), is_eos.to(torch.int32).argmax(dim=1) + 1,
+                            torch.full((logits.shape[0],), S, device=logits.device, dtype=torch.int64))
+        return first
+
+    def forward_logits(self, img_nchw: torch.Tensor):
+        """batched form of the serving signature: (logits [B,S,C], lengths [B]); rows t >= lengths[i] do not exist in
+        sample i's own ``forward_logits``."""
+        logits = self.forward(img_nchw)
+        return logits, self.decode_lengths(logits.detach())
+
+    def serve(self, inputs_nhwc: torch.Tensor) -> dict:
+        """The SavedModel's serving signature as the reference calls it (aster_inferer.py:31, batch 1):
+        NHWC [1,64,256,3] -> {"forward_logits": [1, T, C]} with the decode's own length T."""
+        assert inputs_nhwc.shape[0] == 1, "the reference calls the SavedModel one sample at a time"
+        logits, lengths = self.forward_logits(inputs_nhwc.permute(0, 3, 1, 2))
+        return {"forward_logits": logits[:, : int(lengths[0])]}
 
     def _decode(self, enc):
         """Bahdanau-attention LSTM decoder, greedy feedback (overridden by the HIP subclass)."""

@@ -317,7 +317,7 @@ class FromRGB(nn.Module):
 
     def forward(self, x, mode="fused"):
         if mode == "fused":
-            return ops.conv_bias_act_fused(x, self.conv.w, self.apply_bias_act.b)
+            return ops.conv_bias_act_fused(x, self.conv.w, self.apply_bias_act.b, role="d_image")
         return self.apply_bias_act(ops.conv2d(x, self.conv.w * _coef(self.conv.w.shape)))
 
 
@@ -340,10 +340,10 @@ class DiscriminatorBlock(nn.Module):
         # skip: blur + strided 1x1 conv == (blur evaluated only at the strided sites) + 1x1 conv
         xd = ops.upfirdn2d(x, k, down=(2, sh), pad=(1, 2, 1, 2))
         if mode == "fused":
-            t = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1))
+            t = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1), role="d")
             tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3))  # conv_downsample_2d, upfirdn_2d_v2.py:106-113
-            u = ops.conv_bias_act_fused(tb, self.conv_1.w, self.apply_bias_act_1.b, stride=(sh, 2))
-            return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=rs)
+            u = ops.conv_bias_act_fused(tb, self.conv_1.w, self.apply_bias_act_1.b, stride=(sh, 2), role="d")
+            return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=rs, role="d")
         t = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w * _coef(self.conv_0.w.shape), (1, 1), (1, 1)))
         tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3))
         u = self.apply_bias_act_1(ops.conv2d(tb, self.conv_1.w * _coef(self.conv_1.w.shape), (sh, 2)))
@@ -375,7 +375,7 @@ class DiscriminatorLastBlock(nn.Module):
     def forward(self, x, mode="fused"):
         x = minibatch_std(x, 4).contiguous()
         if mode == "fused":
-            x = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1))
+            x = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1), role="d")
         else:
             x = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w * _coef(self.conv_0.w.shape), (1, 1), (1, 1)))
         return self.apply_bias_act_1(self.dense_1(x))

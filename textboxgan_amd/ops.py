@@ -29,9 +29,11 @@ from .native import ACT_LINEAR, ACT_LRELU, SQRT2
 
 class _Flags:
     """Set by the training step around each of its three backward passes so layers skip
-    gradients nobody consumes (torch gives custom Functions no per-call pruning info)."""
-    skip_d_wgrad = False     # G-loss pass only needs dL/d(image) through the discriminator
-    skip_image_grad = False  # D-loss pass does not need dL/d(image)
+    gradients nobody consumes (torch gives custom Functions no per-call pruning info).  The flags act only on nodes that
+    carry the matching ROLE tag (set by the discriminator's layers when they call conv_bias_act_fused): a node without a
+    tag is never pruned, whatever its shape or owner."""
+    skip_d_wgrad = False     # G-loss pass only needs dL/d(image) through the discriminator  (role "d" / "d_image")
+    skip_image_grad = False  # D-loss pass does not need dL/d(image)                          (role "d_image")
 
 
 FLAGS = _Flags()
@@ -207,17 +209,12 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     return y
 
 
-_WS = {}
-
-
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    """Grow-only scratch buffer per (device, stream): consumed by the very next launch on that stream."""
-    key = (str(device), N.stream())
-    buf = _WS.get(key)
-    if buf is None or buf.numel() * 4 < nbytes:
-        buf = torch.empty((max(nbytes, 1 << 20) + 3) // 4, device=device, dtype=torch.float32)
-        _WS[key] = buf
-    return buf
+    """Stream-ordered temporary from the caching allocator (the role of TF's allocate_temp): consumed by the two launches
+    of one filter-gradient call.  Deliberately NOT cached across calls -- a module-level grow-only buffer first allocated
+    during a HIP-graph capture would live in that graph's private pool and then be shared with other captures and with
+    eager launches."""
+    return torch.empty((max(nbytes, 16) + 3) // 4, device=device, dtype=torch.float32)
 
 
 def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, out: torch.Tensor, st_t: int, st_l: int,
@@ -626,7 +623,7 @@ class _ConvBiasActFused(torch.autograd.Function):
     conv.py:51-73 + bias_act.py:25-34; discriminator.py:68-84 for the residual form."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, stride, pad, act, res_scale):
+    def forward(ctx, x, w, b, residual, stride, pad, act, res_scale, role):
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
         x = x.contiguous()
@@ -636,6 +633,7 @@ class _ConvBiasActFused(torch.autograd.Function):
         out = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, yhw, stride, pad, epi=epi)
         ctx.save_for_backward(x, w, b, out if act == ACT_LRELU else None)
         ctx.cfgv = (stride, pad, act, res_scale, coef, residual is not None, yhw)
+        ctx.role = role
         return out
 
     @staticmethod
@@ -657,13 +655,14 @@ class _ConvBiasActFused(torch.autograd.Function):
         g = _Geom(stride, pad, KH, KW, (x.shape[2], x.shape[3]), yhw)
         dx = None
         thin = KH == 1 and KW == 1 and I <= 4 and stride == (1, 1)  # fromRGB: streaming kernels, not MFMA tiles
-        if ctx.needs_input_grad[0] and not (FLAGS.skip_image_grad and I == 3):
+        prune_w = FLAGS.skip_d_wgrad and ctx.role in ("d", "d_image")
+        if ctx.needs_input_grad[0] and not (FLAGS.skip_image_grad and ctx.role == "d_image"):
             if thin:  # d(image)[b,c,p] = coef * sum_o w[c,o] dpre[b,o,p]
                 dx = rgb_project_raw(dpre, w.reshape(I, O).t().contiguous(), I, None, None, None, coef)
             else:
                 dx = _bwd_data_launch(dpre, w, g, alpha=coef)
         dw = None
-        if not FLAGS.skip_d_wgrad:
+        if not prune_w:
             if thin:  # G[b,o,c] = sum_p dpre[b,o,p] x[b,c,p]
                 _, G = rgb_backproject_raw(dpre, x, None, None, 1.0, want_dx=False, want_G=True)
                 dw = (coef * G.sum(dim=0).t()).reshape(w.shape).contiguous()
@@ -671,7 +670,7 @@ class _ConvBiasActFused(torch.autograd.Function):
                 dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef)
         else:
             db = None
-        return dx, dw, db, dres, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None
 
 
 def modconv_fused(x, w, s, noise, strength, b):
@@ -687,8 +686,11 @@ def torgb_fused(x, w, s, b, skip=None):
     return _ToRGBFused.apply(x, w, s, b, skip)
 
 
-def conv_bias_act_fused(x, w, b, stride=(1, 1), pad=(0, 0), act=ACT_LRELU, residual=None, res_scale=1.0):
-    return _ConvBiasActFused.apply(x, w, b, residual, tuple(stride), tuple(pad), act, res_scale)
+def conv_bias_act_fused(x, w, b, stride=(1, 1), pad=(0, 0), act=ACT_LRELU, residual=None, res_scale=1.0, role=None):
+    """role: None (never pruned), "d" (a discriminator layer: its filter/bias gradients are skipped while
+    FLAGS.skip_d_wgrad), "d_image" (the discriminator's fromRGB: additionally its input gradient is skipped while
+    FLAGS.skip_image_grad)."""
+    return _ConvBiasActFused.apply(x, w, b, residual, tuple(stride), tuple(pad), act, res_scale, role)
 
 
 class _DemodCoefs(torch.autograd.Function):

@@ -118,6 +118,11 @@ class TrainingStep:
             self._static = dict(real=real_images.clone(), ocr_img=ocr_images.clone(), words=input_words.clone(),
                                 labels=ocr_labels.clone(), w=torch.zeros((), device=real_images.device))
         st = self._static
+        for name, t in (("real", real_images), ("ocr_img", ocr_images), ("words", input_words), ("labels", ocr_labels)):
+            if tuple(t.shape) != tuple(st[name].shape):
+                # a captured graph is bound to its batch geometry: a ragged final batch must not broadcast silently
+                # into the static buffers -- run it eagerly instead
+                return self._train_step(real_images, ocr_images, input_words, ocr_labels, do_r1, do_pl, ocr_w, None)
         st["real"].copy_(real_images); st["ocr_img"].copy_(ocr_images); st["words"].copy_(input_words)
         st["labels"].copy_(ocr_labels); st["w"].fill_(ocr_w)
         key = (do_r1, do_pl)
@@ -166,14 +171,16 @@ class TrainingStep:
                     return self._train_step(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl, st["w"], None)
                 self._graphs[key] = ([g], outs)
         graphs, outs = self._graphs[key]
+        # the graph's output tensors are static (overwritten by the next replay): hand CLONES to the caller (7 scalars)
+        fresh = lambda o: (tuple(t.clone() for t in o[0]), tuple(t.clone() for t in o[1]), o[2].clone())
         if len(graphs) == 1:
             graphs[0].replay()
-            return outs
+            return fresh(outs)
         if len(graphs) == 2:
             graphs[0].replay()
             self.exchange.reduce_now((self.g_grad, self.o_grad, self.d_grad))
             graphs[1].replay()
-            return outs
+            return fresh(outs)
         # data-parallel: [fwd + g-pass] -> all-reduce(g) || [ocr-pass] -> all-reduce(ocr) || [d-pass] -> all-reduce(d) -> [Adam x3]
         handles = []
         for g, buf in zip(graphs[:3], (self.g_grad, self.o_grad, self.d_grad)):
@@ -182,7 +189,7 @@ class TrainingStep:
         for h in handles:
             GradExchange.finish(h)
         graphs[3].replay()
-        return outs
+        return fresh(outs)
 
     def _capture_split(self, st, do_r1, do_pl):
         """Capture the step as FOUR HIP graphs sharing one memory pool (the autograd state of the forward lives across
@@ -199,9 +206,6 @@ class TrainingStep:
             idx = [0]
             # thread_local: the RCCL watchdog thread polls events while we capture; its calls must not abort the capture
             graphs[0].capture_begin(pool=pool, capture_error_mode="thread_local")
-            if os.environ.get("TBG_TEST_CAPTURE_FAIL"):
-                graphs[0].capture_end()
-                raise RuntimeError("injected capture failure (TBG_TEST_CAPTURE_FAIL)")
 
             def boundary():
                 graphs[idx[0]].capture_end()
@@ -414,6 +418,12 @@ def build_trainer_state(cfg: Config, device, aster_ocr=None, seed: int = 0, proc
     aster_ocr = aster_ocr.to(device)
     step = TrainingStep(G, D, aster_ocr, g_optimizer, ocr_optimizer, d_optimizer, cfg.g_opt.reg_interval,
                         cfg.d_opt.reg_interval, pl_mean, cfg, process_group, use_graphs)
+    # Replicas must start from IDENTICAL weights (same seed above) but draw INDEPENDENT z / z2 / mixing cut-off / noise /
+    # dropout / pl_z / pl_noise afterwards, as MirroredStrategy's replicas do (training_step.py:147, latent_encoder.py:47-60,
+    # noise.py:16-19): reseed every device generator per rank once the models exist.  The captured HIP graphs read the
+    # same default generator (philox seed + offset registered at capture), so the streams stay distinct in replay too.
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        torch.manual_seed(seed + 1 + dist.get_rank(process_group))
     return dict(generator=G, discriminator=D, g_clone=g_clone, g_optimizer=g_optimizer,
                 ocr_optimizer=ocr_optimizer, d_optimizer=d_optimizer, pl_mean=pl_mean, aster_ocr=aster_ocr,
                 training_step=step)
