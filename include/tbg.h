@@ -11,7 +11,7 @@
  *   - all pointers are DEVICE pointers to contiguous fp32 unless noted; kernels are enqueued
  *     asynchronously on `stream` (a hipStream_t passed as void*; NULL = default stream), the
  *     analogue of launching on TF's stream (.cu:234-235,305-306).
- *   - re-entrant; no mutable global state.
+ *   - re-entrant; no mutable global state, no environment variables: what runs is a pure function of the arguments.
  *   - shape/argument errors -> TBG_EINVAL (OP_REQUIRES InvalidArgument, .cu:228-256),
  *     more than INT32_MAX elements -> TBG_ERANGE (.cu:243-244,266), launch failure -> TBG_EHIP
  *     (.cu:20,306).
@@ -77,6 +77,11 @@ typedef struct tbg_epilogue {
  * op with transformed parameters (upfirdn_2d_v2.py:204-244), so no separate backward entry.
  * _ex adds an optional per-`major` input scale and the fused epilogue (minor must be 1;
  * channel m = major % M, sample b = major / M).
+ * _sep is _ex for a SEPARABLE filter k = ky (x) kx given by its 1-D factors kx[kW], ky[kH] -- the
+ * form the model uses (_setup_kernel, upfirdn_2d_v2.py:18-25, builds k as an outer product): a
+ * horizontal then a vertical pass, 4+4 instead of 16 MACs per output for the [1,3,3,1] blur.
+ * Any filter size / factors / minor are accepted (filters <= 4x4 with factors <= 2 and minor == 1 take
+ * the register-tiled kernel, everything else a one-lane-per-output kernel).
  * ---------------------------------------------------------------------------------------- */
 int tbg_upfirdn2d_f32(const float *x, const float *k, float *y, int major, int inH, int inW,
                       int minor, int kH, int kW, int upx, int upy, int downx, int downy,
@@ -86,6 +91,11 @@ int tbg_upfirdn2d_ex_f32(const float *x, const float *k, float *y, int major, in
                          int kH, int kW, int upx, int upy, int downx, int downy, int padx0,
                          int padx1, int pady0, int pady1, const float *in_scale, int M,
                          const tbg_epilogue *epi, void *stream);
+
+int tbg_upfirdn2d_sep_f32(const float *x, const float *kx, const float *ky, float *y, int major,
+                          int inH, int inW, int kH, int kW, int upx, int upy, int downx, int downy,
+                          int padx0, int padx1, int pady0, int pady1, const float *in_scale, int M,
+                          const tbg_epilogue *epi, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution as fp32-MFMA implicit GEMM (v_mfma_f32_32x32x2_f32).  One descriptor serves:
@@ -118,9 +128,11 @@ typedef struct tbg_conv_desc {
 int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                    const float *in_scale, const tbg_epilogue *epi, void *stream);
 
-/* Kernel instantiation (rocprofv3 spelling) launched by the calling thread's last tbg_conv2d_f32 /
- * tbg_conv2d_wgrad_f32 call; profiling aid (bench.py attributes HIP-event timings with it). */
-const char *tbg_last_conv_kernel(void);
+/* Kernel instantiation (rocprofv3 spelling) that tbg_conv2d_f32 selects for a descriptor (has_in_scale: whether an
+ * in_scale pointer will be passed -- it enters the LDS budget).  A pure function of its arguments: the dispatch has no
+ * environment knobs and the library keeps no mutable state.  Profiling aid (bench.py attributes HIP-event timings to
+ * rocprofv3 kernel names with it; tests use it to prove every instantiation is compared with the oracle). */
+int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
 
 /* Weight gradient:  dW[t*st_t + cl*st_l + cs*st_s] = alpha * sum_{b,u,v}
  *     S[b,cs,u,v]*s_scale[b,cs] * L[b,cl,u*sy-py+kh,v*sx-px+kw]*l_scale[b,cl]
@@ -139,6 +151,7 @@ typedef struct tbg_wgrad_desc {
 } tbg_wgrad_desc;
 
 long long tbg_conv2d_wgrad_workspace_bytes(const tbg_wgrad_desc *d);
+int tbg_conv2d_wgrad_kernel_name(const tbg_wgrad_desc *d, char *buf, int n);
 int tbg_conv2d_wgrad_f32(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
                          const float *s_scale, const float *l_scale, float *workspace,
                          long long workspace_bytes, void *stream);

@@ -102,8 +102,11 @@ def test_upfirdn_gradient_is_adjoint_full_size(dev):
 
 
 def test_graph_replay_equals_eager_step_full_size(dev):
-    """same seeded state + same injected randomness: the captured step and the eager step agree on all seven losses and
-    on the updated weights (fp32 atomics in the style-gradient dot reduce are the only order-dependent sums)."""
+    """same seeded state + the same device RNG streams (the captured graph reads seed/offset of the default generator at
+    replay time): the captured step and the eager step run the same kernels on the same numbers -- only the fp32
+    atomics of the style-gradient dot reduce are order dependent.  All seven losses and the flat weight buffers of G and
+    D after three optimisation steps must therefore agree to ~1e-5 RELATIVE (the first round's 5e-3 absolute bound was
+    the size of the Adam updates themselves and could not have detected a wrong gradient)."""
     from textboxgan_amd.config import Config
     from textboxgan_amd.training_step import build_trainer_state
     from bench import synthetic_batch, bench_init_
@@ -115,15 +118,19 @@ def test_graph_replay_equals_eager_step_full_size(dev):
         st = build_trainer_state(cfg, dev, seed=0, use_graphs=use_graphs)
         bench_init_(st)
         ts = st["training_step"]
+        w_start = st["generator"]._flat.flat.clone()
         losses = None
-        for _ in range(3 if use_graphs else 3):  # graph mode: step 1 eager warm-up, step 2 capture+replay, step 3 replay
+        for _ in range(3):  # graph mode: step 1 eager warm-up, step 2 capture + replay, step 3 replay
             torch.manual_seed(100 + ts.g_optimizer.iterations)  # device RNG drives z, z2, noise, dropout identically
             losses = ts.dist_train_step(batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"],
                                         False, False, 1e-4)
         flat = [float(v) for grp in losses[:2] for v in grp] + [float(losses[2])]
-        results.append((flat, st["generator"].flat.flat.clone() if hasattr(st["generator"], "flat") else
-                        torch.cat([p.detach().reshape(-1) for p in st["generator"].parameters()])))
-    (l0, w0), (l1, w1) = results
+        results.append((flat, st["generator"]._flat.flat.clone(), st["discriminator"]._flat.flat.clone(), w_start))
+    (l0, g0, d0, s0), (l1, g1, d1, _) = results
     for a, b in zip(l0, l1):
-        assert math.isfinite(a) and _close(a, b, 5e-3), (l0, l1)
-    assert float((w0 - w1).abs().max()) <= 5e-3
+        assert math.isfinite(a) and _close(a, b, 2e-5), (l0, l1)
+    moved = float((g0 - s0).abs().max())
+    assert moved > 1e-3, "three Adam steps must have moved the weights (otherwise the comparison is vacuous)"
+    for name, a, b in (("G", g0, g1), ("D", d0, d1)):
+        err = float((a - b).abs().max())
+        assert err <= 2e-5 * float(a.abs().max()), (name, err, float(a.abs().max()), moved)

@@ -36,6 +36,12 @@ UF_CASES = [
     (4, 8, 16, (2, 1), (1, 1), (2, 1, 2, 1), 1.0, "grad of keep-height decimation"),
     (2, 64, 256, (1, 1), (1, 1), (2, 3, 2, 3), 1.0, "full-size plane"),
     (3, 5, 7, (1, 1), (1, 1), (-1, 2, 3, -1), 1.0, "negative pads (crop)"),
+    (3, 9, 13, (2, 2), (1, 1), (1, 2, 1, 2), 4.0, "up 2x2, odd pads (phase 1,1)"),
+    (3, 9, 13, (2, 2), (1, 1), (3, 0, 2, 1), 4.0, "up 2x2, phase (1,0)"),
+    (3, 9, 13, (2, 2), (1, 1), (2, 1, 3, 0), 4.0, "up 2x2, phase (0,1)"),
+    (4, 8, 16, (2, 1), (1, 1), (1, 2, 2, 1), 1.0, "up 2x1, phase 1"),
+    (2, 64, 256, (1, 1), (1, 1), (2, 2, 2, 2), 4.0, "grad of the up-conv blur: 65x257 out"),
+    (3, 7, 9, (3, 1), (1, 2), (2, 3, 1, 2), 1.0, "factor 3 (direct kernel)"),
 ]
 
 
@@ -50,6 +56,72 @@ def test_upfirdn2d_matches_oracle(dev, case):
                         padx0=pad[0], padx1=pad[1], pady0=pad[2], pady1=pad[3])[..., 0][None]
     y = ops.upfirdn2d_raw(x.float().to(dev), k.float().to(dev), up, down, pad)
     assert rel_err(y, ref) < 1e-5
+
+
+@pytest.mark.parametrize("case", UF_CASES, ids=[c[-1] for c in UF_CASES])
+@pytest.mark.parametrize("taps", [4, 3, 2], ids=["4tap", "3tap", "2tap"])
+def test_upfirdn2d_separable_matches_oracle(dev, case, taps):
+    """tbg_upfirdn2d_sep_f32 (1-D factors; the path the model's [1,3,3,1] filters take) == the oracle applied to
+    outer(ky, kx), with the fused per-plane input scale and epilogue (demod scale, noise, bias, lrelu*sqrt2)."""
+    import ctypes as C
+    from textboxgan_amd import native as N
+    major, H, W, up, down, pad, gain, _ = case
+    kx = torch.tensor([1.0, 3.0, 3.5, 1.25][:taps], dtype=torch.float64) / 8.0   # asymmetric factors
+    ky = torch.tensor([0.75, 2.5, 3.0, 1.0][:taps], dtype=torch.float64) / 8.0 * gain
+    outW = (W * up[0] + pad[0] + pad[1] - taps + down[0]) // down[0]
+    outH = (H * up[1] + pad[2] + pad[3] - taps + down[1]) // down[1]
+    if outW < 1 or outH < 1:
+        pytest.skip("empty output for this filter size")
+    Bn, Mc = (2, major // 2) if major % 2 == 0 else (1, major)
+    x = rnd(1, major, H, W, seed=1)
+    isc = rnd(major, seed=2).abs() + 0.5
+    osc = rnd(major, seed=3).abs() + 0.5
+    bias = rnd(Mc, seed=4)
+    noise = rnd(Bn, outH * outW, seed=5)
+    strength = torch.tensor(0.3, dtype=torch.float64)
+    k2 = torch.outer(ky, kx)
+    ref = R.t_upfirdn2d((x[0] * isc[:, None, None])[..., None], k2.numpy(), upx=up[0], upy=up[1], downx=down[0],
+                        downy=down[1], padx0=pad[0], padx1=pad[1], pady0=pad[2], pady1=pad[3])[..., 0]
+    pre = ref * 0.7 * osc[:, None, None] + (noise.reshape(Bn, 1, outH, outW) * strength).expand(Bn, Mc, outH, outW).reshape(
+        major, outH, outW) + bias.repeat(Bn)[:, None, None]
+    exp = F.leaky_relu(pre, 0.2) * math.sqrt(2.0)
+    f = lambda t: t.float().to(dev).contiguous()
+    xd, kxd, kyd, iscd, oscd, bd, nd, sd = map(f, (x, kx, ky, isc, osc, bias, noise, strength))
+    y = torch.empty((major, outH, outW), device=dev)
+    epi = N.epilogue(out_scale=oscd, bias=bd, noise=nd, strength=sd, alpha=0.7, act=N.ACT_LRELU, slope=0.2)
+    rc = N.lib().tbg_upfirdn2d_sep_f32(N.ptr(xd), N.ptr(kxd), N.ptr(kyd), N.ptr(y), major, H, W, taps, taps, up[0], up[1],
+                                       down[0], down[1], pad[0], pad[1], pad[2], pad[3], N.ptr(iscd), Mc, C.byref(epi),
+                                       N.stream())
+    assert rc == 0
+    assert rel_err(y, exp) < 2e-5
+    # plain form (no scale / epilogue) as well
+    y2 = torch.empty((major, outH, outW), device=dev)
+    rc = N.lib().tbg_upfirdn2d_sep_f32(N.ptr(xd), N.ptr(kxd), N.ptr(kyd), N.ptr(y2), major, H, W, taps, taps, up[0], up[1],
+                                       down[0], down[1], pad[0], pad[1], pad[2], pad[3], None, 1, None, N.stream())
+    assert rc == 0
+    ref0 = R.t_upfirdn2d(x[0][..., None], k2.numpy(), upx=up[0], upy=up[1], downx=down[0], downy=down[1], padx0=pad[0],
+                         padx1=pad[1], pady0=pad[2], pady1=pad[3])[..., 0]
+    assert rel_err(y2, ref0) < 1e-5
+
+
+def test_upfirdn2d_hand_computed_vector(dev):
+    """an answer worked out by hand (independent of the oracle): x = [[1,2],[3,4]], k = [[1,2],[3,4]] (applied flipped),
+    up 2, pads (1,0): u = zero-insert -> [[1,0,2,0],[0,0,0,0],[3,0,4,0],[0,0,0,0]], left/top pad 1, true convolution with k:
+    y[Y][X] = sum_{i,j} upad[Y+i][X+j] * k[1-i][1-j]."""
+    from textboxgan_amd import native as N
+    x = torch.tensor([[1.0, 2.0], [3.0, 4.0]])
+    k = torch.tensor([[1.0, 2.0], [3.0, 4.0]])
+    upad = torch.zeros(5, 5)
+    upad[1::2, 1::2][:2, :2] = x
+    exp = torch.zeros(4, 4)
+    for Y in range(4):
+        for X in range(4):
+            exp[Y, X] = sum(upad[Y + i, X + j] * k[1 - i, 1 - j] for i in range(2) for j in range(2))
+    assert exp[0].tolist() == [1.0, 2.0, 2.0, 4.0] and exp[1].tolist() == [3.0, 4.0, 6.0, 8.0]  # the hand values
+    y = torch.empty(1, 4, 4, 1, device=dev)
+    rc = N.lib().tbg_upfirdn2d_f32(N.ptr(x.to(dev)), N.ptr(k.to(dev)), N.ptr(y), 1, 2, 2, 1, 2, 2, 2, 2, 1, 1, 1, 0, 1, 0,
+                                   N.stream())
+    assert rc == 0 and torch.equal(y.cpu().reshape(4, 4), exp)
 
 
 def test_upfirdn2d_generic_minor_and_big_filter(dev):

@@ -237,3 +237,38 @@ def test_training_step_oracle_runs_and_is_deterministic():
         outs.append([float(v) for v in losses[0]] + [float(v) for v in losses[1]] + [float(losses[2])])
         assert st["g_opt"].iterations == 1 and float(st["pl_mean"]) > 0
     assert outs[0] == outs[1] and all(math.isfinite(v) for v in outs[0])
+
+
+def test_hand_evaluated_literal_vectors_pin_the_oracle():
+    """Literal answers worked out by hand from the reference's definitions (no oracle code involved in producing them):
+    ADVICE round 1 asked for vectors that do not come from the oracle itself.
+
+    1. upfirdn (upfirdn_2d.cu:64-117 semantics): x = [[1,2],[3,4]], k = [[1,2],[3,4]], up 2, pads (1,0):
+       zero-insert -> rows [1,0,2,0],[0,0,0,0],[3,0,4,0],[0,0,0,0]; pad 1 top/left; y[Y][X] = sum upad[Y+i][X+j] k[1-i][1-j].
+       Row 0: X=0 -> upad[1][1]*k[0][0] = 1;  X=1 -> upad[1][1]*k[0][1] = 2;  X=2 -> upad[1][3]*k[0][0] = 2;  X=3 -> 2*2 = 4.
+       Row 1: only i = 0 meets row 1 of upad (taps k[1][.]): 1*3, 1*4, 2*3, 2*4.
+    2. modulated 1x1 conv (modulated_conv2d.py:66-122): one input channel x = [[1,2],[3,4]], w = [2,-1] (O = 2), style
+       scale s = 3: w*s = [6,-3]; demodulation 1/sqrt(36 + 1e-8), 1/sqrt(9 + 1e-8) -> [1,-1] -> out = [x, -x].
+    3. minibatch-std (mini_batch_std.py:10-35), B = 4, group 4, one channel, 1x1: values 1,2,3,6 -> mean 3,
+       var = (4+1+0+9)/4 = 3.5, std = sqrt(3.5 + 1e-8), appended as channel 2 for every sample.
+    4. softplus losses (gan_losses.py:8-16): fake score 0, real score 0, batch 1 -> Lg = ln 2, Ld = 2 ln 2.
+    5. Keras Adam first step (train.py:58-75), beta1 = 0, beta2 = 0.99, lr = 0.002, eps = 1e-8, g = 0.5:
+       m = 0.5, v = 0.0025, lr_t = 0.002*sqrt(0.01) = 0.0002, theta -= 0.0002 * 0.5 / (0.05 + 1e-8)."""
+    x = torch.tensor([[1.0, 2.0], [3.0, 4.0]], dtype=torch.float64)
+    y = R.t_upfirdn2d(x[None, ..., None], np.array([[1.0, 2.0], [3.0, 4.0]]), upx=2, upy=2, padx0=1, padx1=0, pady0=1,
+                      pady1=0)[0, ..., 0]
+    assert y.tolist() == [[1, 2, 2, 4], [3, 4, 6, 8], [3, 6, 4, 8], [9, 12, 12, 16]]
+    out = R.np_modulated_conv2d_def(x.numpy()[None, None], np.array([[3.0]]), np.array([2.0, -1.0]).reshape(1, 1, 1, 2))
+    np.testing.assert_allclose(out[0, 0], x.numpy(), rtol=1e-8)
+    np.testing.assert_allclose(out[0, 1], -x.numpy(), rtol=1e-8)
+    mb = R.np_minibatch_std(np.array([1.0, 2.0, 3.0, 6.0]).reshape(4, 1, 1, 1))
+    np.testing.assert_allclose(mb[:, 1, 0, 0], [math.sqrt(3.5 + 1e-8)] * 4, rtol=1e-12)
+    np.testing.assert_allclose(mb[:, 0, 0, 0], [1, 2, 3, 6])
+    z = torch.zeros(1, 1, dtype=torch.float64)
+    assert abs(float(M.generator_loss(z, 1)) - math.log(2)) < 1e-12
+    assert abs(float(M.discriminator_loss(z, z, 1)) - 2 * math.log(2)) < 1e-12
+    from textboxgan_amd.config import OptParams
+    opt = M.AdamTF(OptParams(learning_rate=0.002, beta1=0.0, beta2=0.99, epsilon=1e-8, reg_interval=1))
+    th = {"p": torch.tensor([1.0], dtype=torch.float64)}
+    opt.apply(th, ["p"], [torch.tensor([0.5], dtype=torch.float64)])
+    assert abs(float(th["p"]) - (1.0 - 0.0002 * 0.5 / (0.05 + 1e-8))) < 1e-12

@@ -6,22 +6,24 @@
 //   * One 256-thread block (4 wave64) owns a BM x BN tile; every wave owns WTM x WTN MFMA tiles
 //     of 32x32 whose accumulators stay in registers for the whole K loop.
 //   * K is walked in chunks of CK input channels.  Per chunk the block stages into LDS
-//       As[tap][c][BM]  the filter slice (16-byte loads; the HWIO parameter layout is already
-//                       "output channel contiguous", i.e. the MFMA A-operand order) and
-//       Xs[c][halo tile] ONE halo tile of the input -- the 9 taps re-read it at shifted LDS
-//                       offsets (implicit im2col, no 9x expansion); the style modulation
-//                       s[b,c] is multiplied in while staging.
-//     MFMA operands are single ds_read_b32 per lane: A lanes walk 32 consecutive channels,
-//     B lanes walk 32 consecutive pixels -> bank-conflict free; the two half-waves read the
-//     two k-slices.  Stride-2 inputs are de-interleaved (even | odd columns) on the way in so
-//     the strided taps stay unit-stride in LDS.
+//       As4[tap][quad][BM]  the PACKED filter slice (tbg_weight_pack_f32: 16-byte units of 4 consecutive reduction
+//                           channels of one output channel) by direct global->LDS DMA (global_load_lds), and
+//       Xs4[quad][position] ONE halo tile of the input (4 channels of a position = one ds_write_b128) -- the 9 taps
+//                           re-read it at shifted LDS offsets (implicit im2col, no 9x expansion); the style
+//                           modulation s[b,c] is multiplied in while staging; halo loads are branch-free.
+//     MFMA operands: half-wave h reads channel quad 2o+h, so ONE ds_read_b128 per operand sub-tile feeds 4 k-steps.
+//     Stride-2 inputs are de-interleaved (even | odd columns) on the way in so the strided taps stay unit-stride.
 //   * Stride-2 TRANSPOSED convolution is decomposed into its sy*sx output-parity classes; each
 //     class is a dense small-tap correlation on the class grid, so the same kernel runs it with
 //     a per-class tap table and a strided output mapping (no zero-insertion, no atomics).
-//   * Epilogue fused: runtime coef, demodulation d[b,m], noise, bias, LeakyReLU*sqrt2, residual.
-//   * Small-spatial / wide-channel layers get split-K over channel chunks (atomic add).
-// Weight gradient: M = 32 S-channels, N = 32 L-channels per wave, 9 taps = 9 accumulators that
-// share ONE staged halo tile of L; K = pixels; blocks split K and atomically add.
+//   * Epilogue fused: runtime coef, demodulation d[b,m], noise, bias, LeakyReLU*sqrt2, residual, per-(b,m) dot.
+//   * Small-spatial / wide-channel layers split K over channel chunks into SLABS (plain stores, no atomics, no
+//     zero-fill); tbg_slab_epilogue_f32 sums the slabs and applies the real epilogue.
+// Weight gradient: M = 32 S-channels, N = 32 L-channels per wave, 9 taps = 9 accumulators that share ONE staged halo
+// tile of L; K = pixels; blocks split K and write partial tiles to a caller workspace that a second kernel sums
+// (deterministic, no atomics).
+// The dispatch is a pure function of the descriptor (no environment knobs, no mutable state): tbg_conv2d_kernel_name /
+// tbg_conv2d_wgrad_kernel_name report the instantiation a descriptor selects.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -430,14 +432,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   }
 }
 
-static thread_local char g_last_kernel[96] = "";
-
-// name of the kernel instantiation the calling thread's last tbg_conv2d_f32 / tbg_conv2d_wgrad_f32 launched (as rocprofv3
-// prints it) -- lets a profiler attribute event timings to the exact instantiation
-extern "C" const char *tbg_last_conv_kernel(void) { return g_last_kernel; }
+// name-only mode (name != NULL): write the instantiation the descriptor selects (rocprofv3 spelling) and launch nothing
+struct NameOut { char *buf; int n; };
 
 template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3>
-static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
+static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, const NameOut *name) {
   constexpr int BM = WGM * WTM * 32;
   constexpr int G4 = (CK + 3) / 4;
   if (PF > 0 && p.NJ > PF) return TBG_EUNSUPPORTED;
@@ -449,44 +448,30 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN) {
                       (p.in_scale ? (size_t)p.NSEG * p.C : 0)) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   if (maxtaps > MT) return TBG_EUNSUPPORTED;
-  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF, OCC>;
-  if (getenv("TBG_DEBUG_OCC")) {
-    int nb = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, lds);
-    fprintf(stderr, "[tbg] fprop<%d,%d,%d,%d,%d> lds=%zu occupancy(blocks/CU)=%d grid=%d x %d x %d\n", WGM, WGN, WTM, WTN, CK,
-            lds, nb, maxTilesN, ceil_div(p.M, BM), p.nclass * p.ksplit);
-    hipFuncAttributes fa;
-    hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
-    fprintf(stderr, "[tbg]   numRegs=%d sharedSizeBytes=%zu localSizeBytes=%zu maxThreadsPerBlock=%d maxDynShared=%d\n", fa.numRegs,
-            fa.sharedSizeBytes, fa.localSizeBytes, fa.maxThreadsPerBlock, fa.maxDynamicSharedSizeBytes);
-    for (size_t l : {(size_t)0, (size_t)8192, (size_t)16384, (size_t)24576, (size_t)32768, (size_t)49152, (size_t)65536}) {
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, l);
-      fprintf(stderr, "[tbg]   dyn lds %zu -> %d blocks/CU\n", l, nb);
-    }
-    hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
-    fprintf(stderr, "[tbg]   device: sharedMemPerMultiprocessor=%zu sharedMemPerBlock=%zu regsPerMultiprocessor=%d regsPerBlock=%d maxThreadsPerMP=%d\n",
-            pr.sharedMemPerMultiprocessor, pr.sharedMemPerBlock, pr.regsPerMultiprocessor, pr.regsPerBlock, pr.maxThreadsPerMultiProcessor);
+  if (name) {
+    snprintf(name->buf, name->n, "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC);
+    return TBG_OK;
   }
+  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF, OCC>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TBG_EHIP;
   }
   dim3 grid(maxTilesN, ceil_div(p.M, BM), p.nclass * p.ksplit);
-  snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
 
 
-extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float *y,
-                              const float *in_scale, const tbg_epilogue *epi, void *stream) {
-  if (!d || !x || !w || !y || !epi_valid(epi)) return TBG_EINVAL;
+static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, float *y, const float *in_scale,
+                       const tbg_epilogue *epi, void *stream, const NameOut *name) {
+  if (!d || !epi_valid(epi)) return TBG_EINVAL;
+  if (!name && (!x || !w || !y)) return TBG_EINVAL;
   if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1 || d->Hout < 1 || d->Wout < 1) return TBG_EINVAL;
   if (d->KH < 1 || d->KW < 1 || d->KH * d->KW > MAXTAPS) return TBG_EUNSUPPORTED;
   if (d->sy < 1 || d->sy > 2 || d->sx < 1 || d->sx > 2) return TBG_EUNSUPPORTED;
   if (d->ldw < d->M || (reinterpret_cast<uintptr_t>(w) & 15) != 0) return TBG_EINVAL;
-  if ((((uintptr_t)w) & 15) != 0) return TBG_EINVAL;
   if (d->ksplit < 1) return TBG_EINVAL;
   if (d->ksplit > 1 && epi && (epi->out_scale || epi->bias || epi->noise || epi->residual || epi->dot_aux || epi->act != TBG_ACT_LINEAR))
     return TBG_EINVAL;
@@ -551,13 +536,11 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
     else if (d->M <= 64) { BM = 64; BN = (npix + 255) / 256 < 96 ? 64 : 256; }
     else {
       const long long tiles128 = (long long)ceil_div(d->M, 128) * ((npix + 127) / 128);
-      static const int big = getenv("TBG_CONV_BN256") ? atoi(getenv("TBG_CONV_BN256")) : 0;  // experiment knob
       if (tiles128 <= 16) { BM = 64; BN = 64; }  // tiny-spatial / wide-channel: more, smaller blocks
-      else if (big > 0 && tiles128 >= big && maxtaps == 9) { BM = 128; BN = 256; }
       else { BM = 128; BN = 128; }
     }
   }
-  static const int twmax = getenv("TBG_TW_MAX") ? atoi(getenv("TBG_TW_MAX")) : 32;
+  constexpr int twmax = 32;  // tile rows of at most 32 pixels (wider rows were measured slower: fewer rows per halo)
   int TW = 1, THs = 1;
   for (int attempt = 0;; ++attempt) {
     TW = pow2ceil(maxVg) < twmax ? pow2ceil(maxVg) : (twmax < BN ? twmax : BN);
@@ -595,46 +578,39 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
   p.ksplit = d->ksplit;
   p.slab = (long long)d->B * d->M * d->Hout * d->Wout;
   hipStream_t st = tbg_stream(stream);
-  static const bool ck32 = getenv("TBG_CONV_1X1_CK32") != nullptr;  // experiment knob: measured no gain (1x1 is HBM/latency bound)
-  if (maxtaps == 1 && ck32) {
-    if (BM == 32) return launch_fprop<1, 4, 1, 2, 32, 1>(p, st, maxtaps, maxTilesN);
-    if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 32, 1>(p, st, maxtaps, maxTilesN);
-    if (BM == 64) return launch_fprop<1, 4, 2, 2, 32, 1>(p, st, maxtaps, maxTilesN);
-    return launch_fprop<2, 2, 2, 2, 32, 1>(p, st, maxtaps, maxTilesN);
-  }
   // few-tap launches (the parity classes of a stride-2 transposed 3x3: 1/2/2/4 taps): a deeper channel chunk keeps
   // the MFMA count per barrier pair up (4 taps x 16 channels instead of 4 x 8)
-  static const int tck = getenv("TBG_CONV_T_CK") ? atoi(getenv("TBG_CONV_T_CK")) : 16;
-  if (maxtaps > 1 && maxtaps <= 4 && tck == 16) {
-    if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, 4>(p, st, maxtaps, maxTilesN);
-    if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 16, 4>(p, st, maxtaps, maxTilesN);
-    if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN);
-    if (BN == 128) return launch_fprop<2, 2, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN);
+  if (maxtaps > 1 && maxtaps <= 4) {
+    if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
+    if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 16, 4>(p, st, maxtaps, maxTilesN, name);
+    if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
+    return launch_fprop<2, 2, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
   }
-  // Software-pipelined variants (double-buffered LDS, one barrier per chunk).  Measured (tools/bench_conv.py): +12% on
-  // the 64x256 tile (76 -> 86 TFLOP/s), neutral on 128x128 (99-108 both ways), -5..10% on the small-spatial 64x64 tile
-  // -> default: 64x256 only.  TBG_CONV_PF=0 disables, =2 enables everywhere.
-  static const int pf = getenv("TBG_CONV_PF") ? atoi(getenv("TBG_CONV_PF")) : 1;
-  if (pf && p.NJ <= 3) {
-    if (BM == 64 && BN == 256) return launch_fprop<1, 4, 2, 2, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN);
-    if (pf >= 2) {
-      if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS, 3>(p, st, maxtaps, maxTilesN);
-      if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN);
-      if (BN == 128) return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN);
-    }
-  }
-  if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
-  if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
-  if (BM == 64) return launch_fprop<1, 4, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
+  // Software-pipelined variant (double-buffered LDS, one barrier per chunk).  Measured (tools/bench_conv.py): +12% on
+  // the 64x256 tile (76 -> 86 TFLOP/s), neutral on 128x128, -5..10% on the small-spatial 64x64 tile -> 64x256 only.
+  if (p.NJ <= 3 && BM == 64 && BN == 256) return launch_fprop<1, 4, 2, 2, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
+  if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
+  if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
+  if (BM == 64) return launch_fprop<1, 4, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
   // Largest launches (>= 1.5 waves of the 1024 block slots that 4 blocks/CU give): CK=4 chunks need 22 KB of LDS and
   // 109 registers -> 4 waves/SIMD and a grid that fills whole rounds: 98 -> 104 TFLOP/s on 64x256 128->128
   // (tools/bench_conv.py).  Smaller launches lose (more barriers per FLOP), so they keep CK=8 at 3 waves/SIMD.
-  static const int occ4 = getenv("TBG_CONV_OCC4") ? atoi(getenv("TBG_CONV_OCC4")) : 1;
-  if (occ4 && BM == 128 && BN == 128 && maxtaps == 9 && p.NJ <= 3 &&
-      (long long)maxTilesN * ceil_div(p.M, BM) * p.nclass >= 1536 && p.ksplit == 1)
-    return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 0, 4>(p, st, maxtaps, maxTilesN);
-  if (BN == 256) return launch_fprop<2, 2, 2, 4, 8, MAXTAPS, 0, 1>(p, st, maxtaps, maxTilesN);
-  return launch_fprop<2, 2, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN);
+  if (maxtaps == 9 && p.NJ <= 3 && (long long)maxTilesN * ceil_div(p.M, BM) * p.nclass >= 1536 && p.ksplit == 1)
+    return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 0, 4>(p, st, maxtaps, maxTilesN, name);
+  return launch_fprop<2, 2, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
+}
+
+extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float *y,
+                              const float *in_scale, const tbg_epilogue *epi, void *stream) {
+  return conv2d_impl(d, x, w, y, in_scale, epi, stream, nullptr);
+}
+
+extern "C" int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n) {
+  if (!buf || n < 1) return TBG_EINVAL;
+  buf[0] = 0;
+  NameOut no{buf, n};
+  static const float dummy = 0.f;  // name-only mode never dereferences; in_scale only sizes the LDS request
+  return conv2d_impl(d, nullptr, nullptr, nullptr, has_in_scale ? &dummy : nullptr, nullptr, nullptr, &no);
 }
 
 // ============================================================================================
@@ -934,8 +910,12 @@ static int wgrad_ksplit(int tiles, int nchunks) {
 }
 
 template <int WGS, int WGL, int NT, int PIX, bool GRP>
-static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes) {
+static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
   constexpr int BS = WGS * 32, BL = WGL * 32;
+  if (name) {
+    snprintf(name->buf, name->n, "conv_wgrad_kernel<%d, %d, %d, %d, %s>", WGS, WGL, NT, PIX, GRP ? "true" : "false");
+    return TBG_OK;
+  }
   const size_t lds = ((size_t)BS * (PIX + 4) + (size_t)BL * p.lplane) * sizeof(float);
   if (p.NJ > ((NT == 1 && PIX == 64) ? 1 : WG_MAXNJ)) return TBG_EUNSUPPORTED;
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
@@ -947,7 +927,6 @@ static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes) {
   const int tx = ceil_div(p.CS, BS), ty = ceil_div(p.CL, BL);
   p.ksplit = wgrad_ksplit(tx * ty, p.nchunks);
   if ((size_t)p.ksplit * tx * ty * NT * 16 * 256 * sizeof(float) > ws_bytes) return TBG_EINVAL;
-  snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_wgrad_kernel<%d, %d, %d, %d, %s>", WGS, WGL, NT, PIX, GRP ? "true" : "false");
   hipLaunchKernelGGL(kern, dim3(tx, ty, p.ksplit), dim3(256), lds, st, p);
   TBG_LAUNCH_CHECK();
   if (tx * ty * NT >= 256)
@@ -959,9 +938,9 @@ static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes) {
 }
 
 template <int WGS, int WGL, int NT, int PIX>
-static int launch_wgrad(WgradP &p, hipStream_t st, size_t ws_bytes) {
-  if (p.logTW >= 2) return launch_wgrad_impl<WGS, WGL, NT, PIX, true>(p, st, ws_bytes);
-  return launch_wgrad_impl<WGS, WGL, NT, PIX, false>(p, st, ws_bytes);
+static int launch_wgrad(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
+  if (p.logTW >= 2) return launch_wgrad_impl<WGS, WGL, NT, PIX, true>(p, st, ws_bytes, name);
+  return launch_wgrad_impl<WGS, WGL, NT, PIX, false>(p, st, ws_bytes, name);
 }
 
 // geometry shared by the launcher and the workspace query
@@ -1018,6 +997,15 @@ extern "C" int tbg_conv2d_wgrad_f32(const tbg_wgrad_desc *d, const float *S, con
   return tbg_conv2d_wgrad_ex_f32(d, S, L, dW, s_scale, l_scale, nullptr, nullptr, 0.f, workspace, workspace_bytes, stream);
 }
 
+static int wgrad_select(WgradP &p, int NT, int PIX, hipStream_t st, size_t wsb, const NameOut *name) {
+  if (NT == 9) {
+    if (PIX == 32) return launch_wgrad<2, 2, 9, 32>(p, st, wsb, name);
+    return launch_wgrad<2, 2, 9, 64>(p, st, wsb, name);
+  }
+  if (PIX == 32) return launch_wgrad<2, 2, 1, 32>(p, st, wsb, name);
+  return launch_wgrad<2, 2, 1, 64>(p, st, wsb, name);
+}
+
 extern "C" int tbg_conv2d_wgrad_ex_f32(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
                                        const float *s_scale, const float *l_scale, const float *addw, const float *addq,
                                        float gamma, float *workspace, long long workspace_bytes, void *stream) {
@@ -1028,13 +1016,17 @@ extern "C" int tbg_conv2d_wgrad_ex_f32(const tbg_wgrad_desc *d, const float *S, 
   if (rc != TBG_OK) return rc;
   p.S = S; p.L = L; p.s_scale = s_scale; p.l_scale = l_scale; p.dW = dW; p.ws = workspace;
   p.addw = addw; p.addq = addq; p.gamma = gamma;
-  const int NT = d->KH * d->KW;
-  hipStream_t st = tbg_stream(stream);
   const size_t wsb = workspace_bytes < 0 ? 0 : (size_t)workspace_bytes;
-  if (NT == 9) {
-    if (PIX == 32) return launch_wgrad<2, 2, 9, 32>(p, st, wsb);
-    return launch_wgrad<2, 2, 9, 64>(p, st, wsb);
-  }
-  if (PIX == 32) return launch_wgrad<2, 2, 1, 32>(p, st, wsb);
-  return launch_wgrad<2, 2, 1, 64>(p, st, wsb);
+  return wgrad_select(p, d->KH * d->KW, PIX, tbg_stream(stream), wsb, nullptr);
+}
+
+extern "C" int tbg_conv2d_wgrad_kernel_name(const tbg_wgrad_desc *d, char *buf, int n) {
+  if (!buf || n < 1) return TBG_EINVAL;
+  buf[0] = 0;
+  WgradP p;
+  int PIX;
+  const int rc = wgrad_geometry(d, p, PIX);
+  if (rc != TBG_OK) return rc;
+  NameOut no{buf, n};
+  return wgrad_select(p, d->KH * d->KW, PIX, nullptr, 0, &no);
 }

@@ -1,279 +1,6 @@
-// HBM-bound kernels of libtbg_hip.so (gfx950): upfirdn2d, bias_act fwd/bwd, weight transpose,
-// Keras-semantics Adam, EMA lerp, demodulation coefficients.
-//
-// upfirdn2d follows the MATHS of the reference op (upfirdn_2d.cu:64-207: pad -> zero-insert ->
-// FIR with flipped k -> decimate) but is laid out for CDNA4: 256-thread blocks = 4 wave64,
-// one LDS-staged input tile per block, 4 consecutive outputs per lane so the store is one
-// 16-byte global_store per lane (1 KiB per wave), taps held in registers for the up=1 forms.
+// HBM-bound kernels of libtbg_hip.so (gfx950): bias_act fwd/bwd, split-K slab epilogue, filter packing,
+// Keras-semantics Adam, EMA lerp, demodulation coefficients.  (upfirdn2d lives in upfirdn.hip.)
 #include "common.h"
-
-// ============================================================================================
-// upfirdn2d
-// ============================================================================================
-struct UpfirdnP {
-  const float *x, *k, *in_scale;
-  float *y;
-  int major, inH, inW, minor, kH, kW;
-  int upx, upy, downx, downy, padx0, pady0;
-  int outH, outW;
-  int M, has_epi;
-  EpiK e;
-};
-
-__device__ __forceinline__ int floor_div(int a, int b) {
-  int c = a / b;
-  if (c * b > a) c--;
-  return c;
-}
-
-__device__ __forceinline__ float upfirdn_epilogue(const UpfirdnP &p, float v, int major, int oy, int ox) {
-  if (!p.has_epi) return v;
-  const int b = major / p.M, m = major - b * p.M;
-  float pre = v * p.e.alpha;
-  if (p.e.out_scale) pre *= p.e.out_scale[major];
-  if (p.e.noise) pre += p.e.noise[(size_t)b * p.outH * p.outW + (size_t)oy * p.outW + ox] * p.e.strength[0];
-  if (p.e.bias) pre += p.e.bias[m] * p.e.bias_mul;
-  return epi_act(p.e, pre);
-}
-
-template <int UPX, int UPY, int DNX, int DNY, int KW, int KH, int TOW, int TOH>
-__global__ __launch_bounds__(256) void upfirdn2d_small_kernel(const UpfirdnP p) {
-  constexpr int TIW = ((TOW - 1) * DNX + KW - 1) / UPX + 1;
-  constexpr int TIH = ((TOH - 1) * DNY + KH - 1) / UPY + 1;
-  constexpr int TIWP = TIW | 1;  // odd row pitch
-  static_assert(TOW % 4 == 0 && (TOW / 4) * TOH == 256, "one float4 of outputs per lane");
-  __shared__ float sk[KH][KW];
-  __shared__ float sx[TIH][TIWP];
-
-  const int tid = threadIdx.x;
-  const int tileOutX = blockIdx.x * TOW;
-  const int tileOutY = blockIdx.y * TOH;
-
-  for (int tap = tid; tap < KH * KW; tap += 256) {
-    const int ky = tap / KW, kx = tap - ky * KW;
-    float v = 0.f;
-    if (kx < p.kW && ky < p.kH) v = p.k[(p.kH - 1 - ky) * p.kW + (p.kW - 1 - kx)];  // flipped
-    sk[ky][kx] = v;
-  }
-
-  const int tileMidX = tileOutX * DNX + UPX - 1 - p.padx0;
-  const int tileMidY = tileOutY * DNY + UPY - 1 - p.pady0;
-  const int tileInX = floor_div(tileMidX, UPX);
-  const int tileInY = floor_div(tileMidY, UPY);
-  const int remX = tileMidX - tileInX * UPX;  // >= 0
-  const int remY = tileMidY - tileInY * UPY;
-
-  const int relOutY = tid / (TOW / 4);
-  const int relOutX0 = (tid - relOutY * (TOW / 4)) * 4;
-
-  // input-tile descriptors are plane-independent: decode once; when the tile is small enough (<= 8 elements per
-  // lane: the up=1/down=1 blur and the up-sampling forms) the tile of plane k+1 is prefetched into registers while
-  // plane k is filtered -- one exposed HBM round trip per block instead of one per plane (blur 3.0 -> 3.7 TB/s).
-  // The down-sampling forms (18 elements per lane) keep the plain loop: the extra registers cost more than they hide.
-  constexpr int NLD = (TIH * TIW + 255) / 256;
-  constexpr bool PREFETCH = NLD <= 8;
-  constexpr int NLR = PREFETCH ? NLD : 1;
-  int l_goff[NLR], l_soff[NLR];
-  bool l_any[NLR];  // wave-uniform
-  float pre[NLR];
-  const size_t plane = (size_t)p.inH * p.inW;
-  if constexpr (PREFETCH) {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int idx = tid + 256 * i;
-      const int ry = idx / TIW, rx = idx - ry * TIW;
-      const int ix = rx + tileInX, iy = ry + tileInY;
-      l_soff[i] = idx < TIH * TIW ? ry * TIWP + rx : -1;
-      l_goff[i] = (idx < TIH * TIW && ix >= 0 && iy >= 0 && ix < p.inW && iy < p.inH) ? iy * p.inW + ix : -1;
-      l_any[i] = __builtin_amdgcn_ballot_w64(l_goff[i] >= 0) != 0;
-      pre[i] = 0.f;
-    }
-    if ((int)blockIdx.z < p.major) {
-      const float *xin = p.x + (size_t)blockIdx.z * plane;
-#pragma unroll
-      for (int i = 0; i < NLD; ++i)  // clamp + select below; a wave skips pieces that are entirely outside the plane
-        if (l_any[i]) pre[i] = xin[l_goff[i] >= 0 ? l_goff[i] : 0];
-    }
-  }
-  for (int major = blockIdx.z; major < p.major; major += gridDim.z) {
-    const float isc = p.in_scale ? p.in_scale[major] : 1.f;
-    __syncthreads();
-    if constexpr (PREFETCH) {
-#pragma unroll
-      for (int i = 0; i < NLD; ++i)
-        if (l_soff[i] >= 0) (&sx[0][0])[l_soff[i]] = l_goff[i] >= 0 ? pre[i] * isc : 0.f;
-      __syncthreads();
-      if (major + (int)gridDim.z < p.major) {
-        const float *xin = p.x + (size_t)(major + gridDim.z) * plane;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-          if (l_any[i]) pre[i] = xin[l_goff[i] >= 0 ? l_goff[i] : 0];
-      }
-    } else {
-      const float *xin = p.x + (size_t)major * plane;
-      for (int idx = tid; idx < TIH * TIW; idx += 256) {
-        const int ry = idx / TIW, rx = idx - ry * TIW;
-        const int ix = rx + tileInX, iy = ry + tileInY;
-        float v = 0.f;
-        if (ix >= 0 && iy >= 0 && ix < p.inW && iy < p.inH) v = xin[(size_t)iy * p.inW + ix] * isc;
-        sx[ry][rx] = v;
-      }
-      __syncthreads();
-    }
-
-    const int outY = tileOutY + relOutY;
-    const int relY = remY + relOutY * DNY;
-    const int relInY = relY / UPY;
-    const int kernelY = (relInY + 1) * UPY - relY - 1;
-    float res[4];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int relX = remX + (relOutX0 + o) * DNX;
-      const int relInX = relX / UPX;
-      const int kernelX = (relInX + 1) * UPX - relX - 1;
-      float v = 0.f;
-#pragma unroll
-      for (int yy = 0; yy < KH / UPY; ++yy)
-#pragma unroll
-        for (int xx = 0; xx < KW / UPX; ++xx)
-          v += sx[relInY + yy][relInX + xx] * sk[kernelY + yy * UPY][kernelX + xx * UPX];
-      res[o] = v;
-    }
-    if (outY < p.outH) {
-      const int outX0 = tileOutX + relOutX0;
-      float *yo = p.y + ((size_t)major * p.outH + outY) * p.outW + outX0;
-      const bool vec = (p.outW & 3) == 0 && outX0 + 3 < p.outW;
-      if (p.has_epi) {
-        // per-plane epilogue terms once per thread, the four noise values as one 16-byte load (the per-element
-        // upfirdn_epilogue() re-read the descriptor and every operand for each output: +70% on the blur)
-        const int b = major / p.M, m = major - b * p.M;
-        const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[major] : 1.f);
-        const float bias = p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f;
-        const float str = p.e.noise ? p.e.strength[0] : 0.f;
-        const bool lrelu = p.e.act == TBG_ACT_LRELU;
-        const float slope = p.e.slope, gain = p.e.gain;
-        float nz[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.e.noise) {
-          const float *np = p.e.noise + (size_t)b * p.outH * p.outW + (size_t)outY * p.outW + outX0;
-          if (vec) {
-            const float4 t = *reinterpret_cast<const float4 *>(np);
-            nz[0] = t.x; nz[1] = t.y; nz[2] = t.z; nz[3] = t.w;
-          } else {
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-              if (outX0 + o < p.outW) nz[o] = np[o];
-          }
-        }
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-          const float pre = res[o] * sc + nz[o] * str + bias;
-          res[o] = (lrelu ? (pre > 0.f ? pre : pre * slope) : pre) * gain;
-        }
-      }
-      if (vec) {
-        *reinterpret_cast<float4 *>(yo) = make_float4(res[0], res[1], res[2], res[3]);
-      } else {
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-          if (outX0 + o < p.outW) yo[o] = res[o];
-      }
-    }
-  }
-}
-
-// Generic form (any filter size / factors / minor): one lane per output element, explicit
-// receptive-field clamp.  Same arithmetic as upfirdn_2d.cu:64-117.
-__global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(const UpfirdnP p) {
-  const size_t total = (size_t)p.major * p.outH * p.outW * p.minor;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    size_t r = idx;
-    const int mi = (int)(r % p.minor); r /= p.minor;
-    const int ox = (int)(r % p.outW); r /= p.outW;
-    const int oy = (int)(r % p.outH);
-    const int major = (int)(r / p.outH);
-    const int midY = oy * p.downy + p.upy - 1 - p.pady0;
-    const int inY = min(max(floor_div(midY, p.upy), 0), p.inH);
-    const int h = min(max(floor_div(midY + p.kH, p.upy), 0), p.inH) - inY;
-    const int kernelY = midY + p.kH - (inY + 1) * p.upy;
-    const int midX = ox * p.downx + p.upx - 1 - p.padx0;
-    const int inX = min(max(floor_div(midX, p.upx), 0), p.inW);
-    const int w = min(max(floor_div(midX + p.kW, p.upx), 0), p.inW) - inX;
-    const int kernelX = midX + p.kW - (inX + 1) * p.upx;
-    float v = 0.f;
-    for (int yy = 0; yy < h; ++yy)
-      for (int xx = 0; xx < w; ++xx)
-        v += p.x[(((size_t)major * p.inH + inY + yy) * p.inW + inX + xx) * p.minor + mi] *
-             p.k[(kernelY - yy * p.upy) * p.kW + (kernelX - xx * p.upx)];
-    if (p.in_scale) v *= p.in_scale[major];
-    p.y[idx] = upfirdn_epilogue(p, v, major, oy, ox);
-  }
-}
-
-template <int UPX, int UPY, int DNX, int DNY, int KW, int KH>
-static int launch_upfirdn_small(const UpfirdnP &p, hipStream_t st) {
-  constexpr int TOW = 64, TOH = 16;
-  dim3 grid((p.outW + TOW - 1) / TOW, (p.outH + TOH - 1) / TOH, p.major > 65535 ? 65535 : p.major);
-  hipLaunchKernelGGL((upfirdn2d_small_kernel<UPX, UPY, DNX, DNY, KW, KH, TOW, TOH>), grid, dim3(256), 0, st, p);
-  TBG_LAUNCH_CHECK();
-  return TBG_OK;
-}
-
-static int upfirdn_dispatch(UpfirdnP &p, hipStream_t st) {
-  if (p.minor == 1 && p.kW <= 4 && p.kH <= 4) {
-#define TBG_UF(ux, uy, dx, dy) \
-  if (p.upx == ux && p.upy == uy && p.downx == dx && p.downy == dy) return launch_upfirdn_small<ux, uy, dx, dy, 4, 4>(p, st);
-    TBG_UF(1, 1, 1, 1) TBG_UF(2, 2, 1, 1) TBG_UF(1, 1, 2, 2) TBG_UF(1, 1, 2, 1) TBG_UF(2, 1, 1, 1)
-#undef TBG_UF
-  }
-  const size_t total = (size_t)p.major * p.outH * p.outW * p.minor;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(upfirdn2d_generic_kernel, dim3(blocks), dim3(256), 0, st, p);
-  TBG_LAUNCH_CHECK();
-  return TBG_OK;
-}
-
-static int upfirdn_fill(UpfirdnP &p, const float *x, const float *k, float *y, int major, int inH, int inW,
-                        int minor, int kH, int kW, int upx, int upy, int downx, int downy, int padx0,
-                        int padx1, int pady0, int pady1) {
-  if (!x || !k || !y) return TBG_EINVAL;
-  if (major < 1 || inH < 1 || inW < 1 || minor < 1) return TBG_EINVAL;
-  if (upx < 1 || upy < 1 || downx < 1 || downy < 1) return TBG_EINVAL;  // .cu:228-229
-  if (kW < 1 || kH < 1) return TBG_EINVAL;                            // .cu:252
-  const int outW = (inW * upx + padx0 + padx1 - kW + downx) / downx;  // .cu:254-255
-  const int outH = (inH * upy + pady0 + pady1 - kH + downy) / downy;
-  if (outW < 1 || outH < 1) return TBG_EINVAL;  // .cu:256
-  if ((double)major * inH * inW * minor > 2147483647.0 || (double)major * outH * outW * minor > 2147483647.0)
-    return TBG_ERANGE;  // .cu:243,266
-  p.x = x; p.k = k; p.y = y; p.in_scale = nullptr;
-  p.major = major; p.inH = inH; p.inW = inW; p.minor = minor; p.kH = kH; p.kW = kW;
-  p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
-  p.outH = outH; p.outW = outW; p.M = 1; p.has_epi = 0; p.e = make_epi(nullptr);
-  return TBG_OK;
-}
-
-extern "C" int tbg_upfirdn2d_f32(const float *x, const float *k, float *y, int major, int inH, int inW,
-                                 int minor, int kH, int kW, int upx, int upy, int downx, int downy,
-                                 int padx0, int padx1, int pady0, int pady1, void *stream) {
-  UpfirdnP p;
-  int rc = upfirdn_fill(p, x, k, y, major, inH, inW, minor, kH, kW, upx, upy, downx, downy, padx0, padx1, pady0, pady1);
-  if (rc != TBG_OK) return rc;
-  return upfirdn_dispatch(p, tbg_stream(stream));
-}
-
-extern "C" int tbg_upfirdn2d_ex_f32(const float *x, const float *k, float *y, int major, int inH, int inW,
-                                    int kH, int kW, int upx, int upy, int downx, int downy, int padx0,
-                                    int padx1, int pady0, int pady1, const float *in_scale, int M,
-                                    const tbg_epilogue *epi, void *stream) {
-  UpfirdnP p;
-  int rc = upfirdn_fill(p, x, k, y, major, inH, inW, 1, kH, kW, upx, upy, downx, downy, padx0, padx1, pady0, pady1);
-  if (rc != TBG_OK) return rc;
-  if (!epi_valid(epi) || (epi && epi->residual)) return TBG_EINVAL;
-  if (epi && (M < 1 || major % M != 0)) return TBG_EINVAL;
-  p.in_scale = in_scale;
-  if (epi) { p.has_epi = 1; p.M = M; p.e = make_epi(epi); }
-  return upfirdn_dispatch(p, tbg_stream(stream));
-}
 
 // ============================================================================================
 // bias_act forward / backward

@@ -20,8 +20,8 @@ ACT_LINEAR, ACT_LRELU = 0, 1
 SQRT2 = 1.4142135623730951
 
 EXPORTS = [
-    "tbg_version", "tbg_strerror", "tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_conv2d_f32",
-    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_last_conv_kernel", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_attn_ctx_fwd_f32", "tbg_attn_ctx_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
+    "tbg_version", "tbg_strerror", "tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_upfirdn2d_sep_f32", "tbg_conv2d_f32",
+    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_conv2d_kernel_name", "tbg_conv2d_wgrad_kernel_name", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_attn_ctx_fwd_f32", "tbg_attn_ctx_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
     "tbg_bias_act_bwd_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -64,6 +64,7 @@ def lib():
         vp, ci, cf, ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
         l.tbg_upfirdn2d_f32.argtypes = [vp, vp, vp] + [ci] * 14 + [vp]
         l.tbg_upfirdn2d_ex_f32.argtypes = [vp, vp, vp] + [ci] * 13 + [vp, ci, C.POINTER(Epilogue), vp]
+        l.tbg_upfirdn2d_sep_f32.argtypes = [vp, vp, vp, vp] + [ci] * 13 + [vp, ci, C.POINTER(Epilogue), vp]
         l.tbg_conv2d_f32.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(Epilogue), vp]
         l.tbg_conv2d_wgrad_f32.argtypes = [C.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, ll, vp]
         l.tbg_conv2d_wgrad_ex_f32.argtypes = [C.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, vp, cf, vp, ll, vp]
@@ -76,8 +77,8 @@ def lib():
         l.tbg_lstm_step_bwd_f32.argtypes = [vp] * 7 + [ci] * 6 + [vp]
         l.tbg_attn_ctx_fwd_f32.argtypes = [vp] * 6 + [ci] * 4 + [vp]
         l.tbg_attn_ctx_bwd_f32.argtypes = [vp] * 9 + [ci] * 4 + [vp]
-        l.tbg_last_conv_kernel.restype = C.c_char_p
-        l.tbg_last_conv_kernel.argtypes = []
+        l.tbg_conv2d_kernel_name.argtypes = [C.POINTER(ConvDesc), ci, C.c_char_p, ci]
+        l.tbg_conv2d_wgrad_kernel_name.argtypes = [C.POINTER(WgradDesc), C.c_char_p, ci]
         l.tbg_bias_act_fwd_f32.argtypes = [vp, vp, ci, ci, ci, C.POINTER(Epilogue), vp]
         l.tbg_slab_epilogue_f32.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(Epilogue), vp]
         l.tbg_bias_act_bwd_f32.argtypes = [vp] * 7 + [ci, ci, ci, C.POINTER(Epilogue), vp]
@@ -117,3 +118,15 @@ def epilogue(out_scale=None, bias=None, noise=None, strength=None, residual=None
         gain = SQRT2 if act == ACT_LRELU else 1.0
     return Epilogue(ptr(out_scale), ptr(bias), ptr(noise), ptr(strength), ptr(residual), ptr(dot_aux), ptr(dot_out), alpha, bias_mul, slope, gain,
                     res_scale, act, res_first)
+
+
+def conv_kernel_name(desc: ConvDesc, has_in_scale: bool) -> str:
+    buf = C.create_string_buffer(128)
+    check(lib().tbg_conv2d_kernel_name(C.byref(desc), int(has_in_scale), buf, 128), "tbg_conv2d_kernel_name")
+    return buf.value.decode()
+
+
+def wgrad_kernel_name(desc: WgradDesc) -> str:
+    buf = C.create_string_buffer(128)
+    check(lib().tbg_conv2d_wgrad_kernel_name(C.byref(desc), buf, 128), "tbg_conv2d_wgrad_kernel_name")
+    return buf.value.decode()

@@ -40,9 +40,10 @@ FLAGS = _Flags()
 
 
 class _Profile:
-    """bench.py's roofline pass: bracket every convolution launch with HIP events on the stream the
-    kernel is enqueued on and attribute its ALGORITHMIC FLOPs (2 x MACs of the dense contraction) to
-    the kernel instantiation that ran it.  Off by default (zero overhead)."""
+    """bench.py's roofline pass: bracket kernel launches with HIP events on the stream the kernel is enqueued on and
+    attribute their ALGORITHMIC work to the kernel that ran: FLOPs (2 x MACs of the dense contraction) for the MFMA
+    convolutions, bytes (every operand read once + every result written once) for the HBM-bound kernels.  For the
+    convolutions the name is the instantiation the descriptor selects (rocprofv3 spelling).  Off by default."""
 
     def __init__(self):
         self.on = False
@@ -55,30 +56,29 @@ class _Profile:
     def disable(self):
         self.on = False
 
-    def launch(self, name, flops, fn, shape=None):
+    def launch(self, name, flops, fn, shape=None, nbytes=0.0):
         if not self.on:
             return fn()
-        if name is not None and self.by_shape and shape is not None:
-            name = name + " " + shape
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn()
         e1.record()
-        if name is None:  # the instantiation the library actually launched (rocprofv3 spelling)
-            name = N.lib().tbg_last_conv_kernel().decode()
-            if self.by_shape and shape is not None:
-                name = name + " " + shape
-        self.recs.append((name, flops, e0, e1))
+        if callable(name):  # resolved lazily: the instantiation the descriptor selects
+            name = name()
+        if self.by_shape and shape is not None:
+            name = name + " " + shape
+        self.recs.append((name, flops, nbytes, e0, e1))
         return rc
 
     def collect(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, e0, e1 in self.recs:
-            r = out.setdefault(name, dict(n=0, ms=0.0, flops=0.0))
+        for name, flops, nbytes, e0, e1 in self.recs:
+            r = out.setdefault(name, dict(n=0, ms=0.0, flops=0.0, bytes=0.0))
             r["n"] += 1
             r["ms"] += e0.elapsed_time(e1)
             r["flops"] += flops
+            r["bytes"] += nbytes
         self.recs = []
         return out
 
@@ -101,16 +101,31 @@ def _fprop_tile(M, npix):
 # FIR filters (upfirdn_2d_v2.py:18-25) cached per device
 # ----------------------------------------------------------------------------------------
 _FIR_CACHE = {}
+_FIR_SEP = {}  # data_ptr of a cached 2-D filter -> (k2d, kx, ky): its 1-D factors, k2d == outer(ky, kx)
 
 
 def fir_kernel(device, gain: float = 1.0, taps=(1, 3, 3, 1)) -> torch.Tensor:
+    """_setup_kernel (upfirdn_2d_v2.py:18-25): k = outer(taps, taps) / sum * gain.  The 2-D tensor is the handle the
+    model passes around; its separable factors (kx = taps/sum, ky = gain*taps/sum) are kept beside it so the launches
+    can take the separable kernel (tbg_upfirdn2d_sep_f32)."""
     key = (str(device), float(gain), tuple(taps))
     if key not in _FIR_CACHE:
-        k = np.asarray(taps, dtype=np.float32)
-        k = np.outer(k, k)
+        t = np.asarray(taps, dtype=np.float32)
+        k = np.outer(t, t)
         k = k / k.sum() * gain
-        _FIR_CACHE[key] = torch.from_numpy(k).to(device)
+        k2 = torch.from_numpy(k).to(device)
+        _FIR_CACHE[key] = k2
+        if k2.is_cuda:
+            t64 = np.asarray(taps, dtype=np.float64)
+            kx = torch.from_numpy((t64 / t64.sum()).astype(np.float32)).to(device)
+            ky = torch.from_numpy((t64 / t64.sum() * gain).astype(np.float32)).to(device)
+            _FIR_SEP[k2.data_ptr()] = (k2, kx, ky)
     return _FIR_CACHE[key]
+
+
+def _sep_factors(k: torch.Tensor):
+    hit = _FIR_SEP.get(k.data_ptr())  # the registry keeps hit[0] alive, so its address cannot be recycled
+    return (hit[1], hit[2]) if hit is not None and hit[0].shape == k.shape and k.is_contiguous() else None
 
 
 # ----------------------------------------------------------------------------------------
@@ -125,7 +140,13 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
     outW = (W * up[0] + pad[0] + pad[1] - kW + down[0]) // down[0]
     outH = (H * up[1] + pad[2] + pad[3] - kH + down[1]) // down[1]
     y = torch.empty((B, Cc, outH, outW), device=x.device, dtype=torch.float32)
-    if in_scale is None and epi is None:
+    sep = _sep_factors(k)
+    if sep is not None:  # the model's filters: separable passes
+        _nb = 4.0 * (x.numel() + y.numel() + (B * outH * outW if epi is not None and epi.noise else 0))
+        rc = PROFILE.launch(f"upfirdn2d_tile_kernel up{up} down{down}", 0.0, lambda: N.lib().tbg_upfirdn2d_sep_f32(
+            N.ptr(x), N.ptr(sep[0]), N.ptr(sep[1]), N.ptr(y), B * Cc, H, W, kH, kW, up[0], up[1], down[0], down[1], pad[0],
+            pad[1], pad[2], pad[3], N.ptr(in_scale), Cc, C.byref(epi) if epi is not None else None, N.stream()), nbytes=_nb)
+    elif in_scale is None and epi is None:
         rc = N.lib().tbg_upfirdn2d_f32(N.ptr(x), N.ptr(k), N.ptr(y), B * Cc, H, W, 1, kH, kW, up[0], up[1], down[0],
                                        down[1], pad[0], pad[1], pad[2], pad[3], N.stream())
     else:
@@ -177,14 +198,15 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     _what = (f"tbg_conv2d[B={B} C={Cc} M={M} in={Hin}x{Win} out={Hout}x{Wout} k={KH}x{KW} s={tuple(stride)} "
              f"p={tuple(pad)} T={int(transposed)} ldw={ldw} ksplit={ksplit}]")
     _flops = 2.0 * B * M * Cc * KH * KW * (Hin * Win if transposed else Hout * Wout)
-    _kname = None  # resolved from tbg_last_conv_kernel()
+    _bytes = 4.0 * (B * Cc * Hin * Win + B * M * Hout * Wout * ksplit + KH * KW * Cc * M)  # x + y (slabs) + filter, once each
+    _kname = lambda: N.conv_kernel_name(d, in_scale is not None)
     if ksplit > 1:
         # split-K: every split stores alpha*acc into its own slab (no zero-fill, no atomics); one flat pass sums the
         # slabs and applies the real epilogue
         slabs = torch.empty((ksplit, B, M, Hout, Wout), device=x.device, dtype=torch.float32)
         e0 = N.epilogue(alpha=epi.alpha)
         N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
-            C.byref(d), N.ptr(x), N.ptr(w), N.ptr(slabs), N.ptr(in_scale), C.byref(e0), N.stream()), _what), _what)
+            C.byref(d), N.ptr(x), N.ptr(w), N.ptr(slabs), N.ptr(in_scale), C.byref(e0), N.stream()), _what, _bytes), _what)
         e1 = N.Epilogue.from_buffer_copy(epi)
         e1.alpha = 1.0
         if dot is not None:  # the fused dot needs the complete sum: reduce first (rare: the smallest G layers' backward)
@@ -205,7 +227,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(dot[1])
     y = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
     N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
-        C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream()), _what), _what)
+        C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream()), _what, _bytes), _what)
     return y
 
 
@@ -229,13 +251,13 @@ def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, o
         raise N.TbgError("tbg_conv2d_wgrad: unsupported geometry")
     ws = _workspace(S.device, nbytes)
     _flops = 2.0 * B * CS * CL * Hs * Ws * KH * KW
-    _kname = None
+    _kname = lambda: N.wgrad_kernel_name(d)
     addw, addq, gamma = add if add is not None else (None, None, 0.0)
     N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_wgrad_ex_f32(
         C.byref(d), N.ptr(S), N.ptr(L), N.ptr(out) + 4 * out_offset, N.ptr(s_scale), N.ptr(l_scale),
         (N.ptr(addw) + 4 * out_offset) if addw is not None else None, N.ptr(addq), gamma, N.ptr(ws),
-        ws.numel() * 4, N.stream()), f"wgrad[B={B} CS={CS} CL={CL} S={Hs}x{Ws} L={Hl}x{Wl} k={KH} s={tuple(stride)}]"),
-        "tbg_conv2d_wgrad")
+        ws.numel() * 4, N.stream()), f"wgrad[B={B} CS={CS} CL={CL} S={Hs}x{Ws} L={Hl}x{Wl} k={KH} s={tuple(stride)}]",
+        4.0 * (S.numel() + L.numel() + KH * KW * CS * CL)), "tbg_conv2d_wgrad")
     return out
 
 
@@ -301,8 +323,11 @@ def bias_act_bwd_raw(dout, out_act, epi: N.Epilogue, want_dx=False, want_dpre=Tr
     pdb = mk() if want_db else None
     pdn = mk() if want_dn else None
     pdy = mk() if want_dyy else None
-    N.check(N.lib().tbg_bias_act_bwd_f32(N.ptr(dout), N.ptr(out_act), N.ptr(dx), N.ptr(dpre), N.ptr(pdb), N.ptr(pdn),
-                                         N.ptr(pdy), B, M, HW, C.byref(epi), N.stream()), "tbg_bias_act_bwd")
+    _nb = 4.0 * dout.numel() * (2 + int(want_dx) + int(want_dpre)) + (4.0 * B * HW if epi.noise else 0.0)
+    N.check(PROFILE.launch("bias_act_bwd_kernel" if HW > 1024 else "bias_act_bwd_small_kernel", 0.0,
+                           lambda: N.lib().tbg_bias_act_bwd_f32(N.ptr(dout), N.ptr(out_act), N.ptr(dx), N.ptr(dpre), N.ptr(pdb),
+                                                                N.ptr(pdn), N.ptr(pdy), B, M, HW, C.byref(epi), N.stream()),
+                           nbytes=_nb), "tbg_bias_act_bwd")
     return dx, dpre, pdb, pdn, pdy
 
 
@@ -360,6 +385,9 @@ def _flipped_fir(k: torch.Tensor) -> torch.Tensor:
             kf = torch.flip(k, (0, 1)).contiguous()
             _FLIP_CACHE[key] = (k, kf)
             _FLIP_CACHE[kf.data_ptr()] = (kf, k)  # flip(flip(k)) = k: gradients of gradients bounce between the two
+            sep = _sep_factors(k)
+            if sep is not None:
+                _FIR_SEP[kf.data_ptr()] = (kf, torch.flip(sep[0], (0,)).contiguous(), torch.flip(sep[1], (0,)).contiguous())
             return kf
         return hit[1]
     return torch.flip(k, (0, 1)).contiguous()
@@ -924,8 +952,9 @@ def frozen_attn_decoder(enc, W: FrozenDecoderWeights, steps: int, go: int):
 # optimiser / EMA over flat buffers
 # ----------------------------------------------------------------------------------------
 def adam_tf_(theta, m, v, g, step, lr, beta1, beta2, eps):
-    N.check(N.lib().tbg_adam_tf_f32(N.ptr(theta), N.ptr(m), N.ptr(v), N.ptr(g), theta.numel(), lr, beta1, beta2, eps,
-                                    N.ptr(step), N.stream()), "tbg_adam_tf")
+    N.check(PROFILE.launch("adam_tf_kernel", 0.0, lambda: N.lib().tbg_adam_tf_f32(
+        N.ptr(theta), N.ptr(m), N.ptr(v), N.ptr(g), theta.numel(), lr, beta1, beta2, eps, N.ptr(step), N.stream()),
+        nbytes=28.0 * theta.numel()), "tbg_adam_tf")
 
 
 def ema_lerp_(dst, src, beta):
