@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense (~2.5 PF; never the 2:1-sparsity figure)
 CONV_GFLOP_PER_IMAGE = 85.2   # dense-conv work of one non-regularised step
 
 
@@ -146,11 +147,23 @@ class _TinyOCR(torch.nn.Module):
 HBM_PEAK_TBS = 8.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 achievable)
 
 
-def roofline_record(recs):
+def roofline_record(recs, dtype="f32"):
     """dominant conv instantiation (largest summed time): algorithmic FLOPs / HIP-event time of its launches."""
     convs = {k: v for k, v in recs.items() if k.startswith("conv_")}
     name, r = max(((k, v) for k, v in convs.items() if "fprop" in k), key=lambda kv: kv[1]["ms"])
     achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+    if dtype == "bf16":
+        # bf16-in MFMA with fp32 tensors in HBM: the dominant 3x3 convolutions sit below the bf16 ridge (SURVEY 8(d):
+        # ~288 FLOP/B of fp32 traffic vs a ridge of 2500/8 = 312), so the bounding roof is HBM; both fractions are reported.
+        tbs = r["bytes"] / (r["ms"] * 1e-3) / 1e12
+        return {"bound": "hbm", "kernel": name, "achieved": round(tbs * 1e3, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
+                "frac": round(tbs / HBM_PEAK_TBS, 4), "traffic": None, "algorithmic_bytes": round(r["bytes"] / r["n"]),
+                "launches": r["n"], "avg_launch_us": round(1e3 * r["ms"] / r["n"], 2),
+                "gflop_per_launch": round(r["flops"] / r["n"] / 1e9, 3), "achieved_tflops": round(achieved, 2),
+                "mfma_peak_tflops": BF16_MFMA_PEAK_TFLOPS, "frac_of_mfma_peak": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                "all_kernels": {k: {"n": v["n"], "ms": round(v["ms"], 3),
+                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                    "tb_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e12, 3)} for k, v in convs.items()}}
     # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 --pmc passes over
     # `bench.py --roofline-only` (tools/pmc_traffic.sh), matched by kernel instantiation; null if none is committed
     traffic, traffic_src, mfma_busy = None, None, None
@@ -184,7 +197,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (BASELINE configs[1]: 16; configs[2]: 32)")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="arithmetic of the MFMA contractions: f32 = BASELINE configs[1] (the headline); bf16 = configs[2] "
+                         "(bf16 operands, fp32 accumulate, fp32 master weights / Adam; default batch 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="SURVEY 8(d) protocol instead of the bounded sample: batch 16, 3 warm-up + 10 timed steps at all "
@@ -198,6 +214,8 @@ def main():
                          "profiles/*_roofline_kernel_stats.txt rocprofv3 summaries are taken with, so that rocprof's "
                          "per-kernel average covers the same launches as roofline.avg_launch_us")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 32 if args.dtype == "bf16" else 16
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -221,7 +239,8 @@ def main():
     from textboxgan_amd.training_step import build_trainer_state
 
     cfg = Config(batch_size_per_gpu=args.batch, num_replicas=world)
-    state = build_trainer_state(cfg, device, seed=0, use_graphs=not args.no_graphs)  # identical replicas on every rank
+    state = build_trainer_state(cfg, device, seed=0, use_graphs=not args.no_graphs,  # identical replicas on every rank
+                                compute_dtype=args.dtype)
     bench_init_(state)
     batch = synthetic_batch(cfg, device, 1234 + rank)
 
@@ -235,7 +254,7 @@ def main():
         ops.PROFILE.enable()
         for _ in range(args.steps):
             ts.dist_train_step(*a)
-        print(json.dumps({"roofline": roofline_record(ops.PROFILE.collect()), "steps": args.steps,
+        print(json.dumps({"roofline": roofline_record(ops.PROFILE.collect(), args.dtype), "steps": args.steps,
                           "warmup": args.warmup}), flush=True)
         return
     if not args.no_graphs:  # untimed: warm up + capture the three step variants (6 real steps)
@@ -264,10 +283,12 @@ def main():
         out = {
             "metric": "text-boxes/sec (G+D+OCR training_step)", "value": round(value, 2), "unit": "text-boxes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "training_step G+D+OCR, bs=16/GPU, 64x256 boxes, max_char_number=8, fp32 "
-                                   "(BASELINE configs[1]); PL every 8th / R1 every 16th step (config.py:81-94); "
-                                   "g_clone EMA included; OCR = ASTER-shaped frozen net (synthetic weights)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": (f"training_step G+D+OCR, bs={args.batch}/GPU, 64x256 boxes, max_char_number=8, " +
+                                    ("fp32 (BASELINE configs[1])" if args.dtype == "f32" else
+                                     "bf16 MFMA operands / fp32 accumulate / fp32 master weights + Adam (BASELINE configs[2])") +
+                                    "; PL every 8th / R1 every 16th step (config.py:81-94); "
+                                    "g_clone EMA included; OCR = ASTER-shaped frozen net (synthetic weights)"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "conv_gflop_per_image_nonreg_step": CONV_GFLOP_PER_IMAGE},
             "conv_tflops_vs_step_time": round(value * CONV_GFLOP_PER_IMAGE / 1e3 / world, 2),
@@ -285,7 +306,7 @@ def main():
         recs = ops.PROFILE.collect()
         ops.PROFILE.disable()
         if recs:
-            out["roofline"] = roofline_record(recs)
+            out["roofline"] = roofline_record(recs, args.dtype)
     if world > 1:
         dist.barrier()
     # ---- same loop with the OCR NETWORK excluded (the ASTER-shaped stand-in is a guess)
@@ -294,7 +315,7 @@ def main():
         del state
         torch.cuda.empty_cache()
         st2 = build_trainer_state(cfg, device, aster_ocr=AsterInferer(model=_TinyOCR(cfg.max_char_number)), seed=0,
-                                  use_graphs=not args.no_graphs)
+                                  use_graphs=not args.no_graphs, compute_dtype=args.dtype)
         bench_init_(st2)
         if not args.no_graphs:
             st2["training_step"].prepare_graphs(batch["real_images"], batch["ocr_images"], batch["input_words"],

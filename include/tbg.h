@@ -174,6 +174,29 @@ int tbg_weight_pack_f32(const float *src, float *dst, int T, int I, int O, int t
                         void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * bf16-in / fp32-accumulate forms (BASELINE configs[2]; the reference op itself registers a 16-bit type beside
+ * float, upfirdn_2d.cu:323-324).  Activations, gradients, epilogue operands and outputs stay fp32 in HBM; the kernels
+ * round the staged operands to bf16 (round-to-nearest-even) on their way into LDS and contract them on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Master weights stay fp32: tbg_weight_pack_bf16 writes the bf16
+ * filter Wp[T][ceil(C/8)][M][8] (tbg_weight_pack_bf16_bytes bytes, 16-byte aligned) that tbg_conv2d_bf16 consumes.
+ * Descriptors, epilogues, split-K slabs, workspaces and error codes are those of the fp32 entries.  A result equals the
+ * fp32 entry's result on operands pre-rounded to bf16, up to fp32 summation order.
+ * ---------------------------------------------------------------------------------------- */
+long long tbg_weight_pack_bf16_bytes(int T, int I, int O, int transpose);
+int tbg_weight_pack_bf16(const float *src, void *dst, int T, int I, int O, int transpose, int flip,
+                         void *stream);
+int tbg_conv2d_bf16(const tbg_conv_desc *d, const float *x, const void *w, float *y,
+                    const float *in_scale, const tbg_epilogue *epi, void *stream);
+int tbg_conv2d_bf16_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
+/* filter gradient; tile rows narrower than 8 pixels (Ws <= 4) fall back to the exact fp32 kernel.  Workspace size =
+ * tbg_conv2d_wgrad_workspace_bytes(d). */
+int tbg_conv2d_wgrad_bf16(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
+                          const float *s_scale, const float *l_scale, const float *addw,
+                          const float *addq, float gamma, float *workspace,
+                          long long workspace_bytes, void *stream);
+int tbg_conv2d_wgrad_bf16_kernel_name(const tbg_wgrad_desc *d, char *buf, int n);
+
+/* ------------------------------------------------------------------------------------------
  * One time step of a frozen (bi)directional LSTM layer, pointwise part for all directions in one launch -- the
  * recurrent encoder of the OCR branch (aster_inferer.py:28-190 runs the ASTER SavedModel: 2x BiLSTM).  The step's
  * GEMMs (h @ Whh^T forward, dgates @ Whh backward) stay library GEMMs batched over the directions.

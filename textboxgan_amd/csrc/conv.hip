@@ -30,6 +30,15 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 8 floats -> 8 bf16 (round to nearest even: v_cvt_pk_bf16_f32), one 16-byte LDS unit
+__device__ __forceinline__ bf16x8 pack_bf16x8(const float (&v)[8]) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
+  return r;
+}
 
 #define MAXCLS 4
 #define MAXTAPS 9
@@ -62,14 +71,20 @@ static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF, int OCC = 3>
+// BF = true: the bf16-in / fp32-accumulate form (BASELINE configs[2]).  Activations stay fp32 in HBM; they are rounded to
+// bf16 (RNE) on their way into LDS, the filter arrives pre-packed in bf16 (tbg_weight_pack_bf16) and the contraction runs on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate).  A 16-byte LDS unit then holds 8 channels instead of 4, so the
+// same tile geometry / DMA / operand-read code serves both: only the unit width KP and the MFMA differ.
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF, int OCC = 3, bool BF = false>
 __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   constexpr int BM = WGM * WTM * 32;
-  constexpr int G4 = (CK + 3) / 4;          // channel quads per chunk
+  constexpr int KP = BF ? 8 : 4;            // channels per 16-byte unit
+  constexpr int G4 = (CK + KP - 1) / KP;    // units (fp32: channel quads, bf16: octets) per chunk
   constexpr int CB = CK < 8 ? CK : 8;       // channels per halo load batch
   constexpr int NB = PF ? 2 : 1;            // LDS buffers (PF > 0: software-pipelined K loop)
   constexpr int NJC = PF ? PF : MAXNJ;      // halo positions per thread this instance can hold
-  static_assert(CK == 4 || CK % 8 == 0, "chunk = one quad (half-waves split it) or whole quad pairs");
+  static_assert(BF ? (CK % 16 == 0 && PF == 0) : (CK == 4 || CK % 8 == 0),
+                "chunk = one quad (half-waves split it) or whole unit pairs (half-wave h reads unit 2o+h)");
   static_assert(!PF || CK <= 8, "the pipelined variant prefetches one load batch");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   constexpr int PPT = UPT >= 256 ? UPT / 256 : 1, TPP = UPT >= 256 ? 1 : 256 / UPT;
   constexpr int A_IT_ = UPT >= 256 ? MT * PPT : (MT + TPP - 1) / TPP;
   static_assert(UPT >= 64 && (UPT >= 256 ? UPT % 256 == 0 : 256 % UPT == 0), "tile/chunk combination");
-  const int C4 = (p.C + 3) >> 2;
+  const int C4 = (p.C + KP - 1) / KP;  // 16-byte units along the reduction
   const int t_local = UPT >= 256 ? 0 : __builtin_amdgcn_readfirstlane(tid / UPT);
   int tapbase[A_IT_];
 #pragma unroll
@@ -211,9 +226,13 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
       }
 #pragma unroll
       for (int cc = 0; cc < CB; ++cc) xv[cc] = (lane_ok && (c0 + cc) < p.C) ? xv[cc] : 0.f;
-      f32x4 *X4 = reinterpret_cast<f32x4 *>(Xbuf);
-      X4[qb * p.planeStride + loff[j]] = f32x4{xv[0], xv[1], xv[2], xv[3]};
-      if constexpr (CB == 8) X4[(qb + 1) * p.planeStride + loff[j]] = f32x4{xv[4], xv[5], xv[6], xv[7]};
+      if constexpr (BF) {  // 8 channels of a position = one 16-byte unit of bf16
+        reinterpret_cast<bf16x8 *>(Xbuf)[qb * p.planeStride + loff[j]] = pack_bf16x8(xv);
+      } else {
+        f32x4 *X4 = reinterpret_cast<f32x4 *>(Xbuf);
+        X4[qb * p.planeStride + loff[j]] = f32x4{xv[0], xv[1], xv[2], xv[3]};
+        if constexpr (CB == 8) X4[(qb + 1) * p.planeStride + loff[j]] = f32x4{xv[4], xv[5], xv[6], xv[7]};
+      }
     }
   };
   auto mfma_taps = [&](const float *Abuf, const float *Xbuf) {
@@ -221,7 +240,23 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     const char *Xb = reinterpret_cast<const char *>(Xbuf);
     for (int t = 0; t < ntaps; ++t) {
       const int toffb = __builtin_amdgcn_readlane(tofft, t);  // tap shift in bytes (lane t of the table)
-      if constexpr (CK == 4) {
+      if constexpr (BF) {
+#pragma unroll
+        for (int o = 0; o < CK / 16; ++o) {  // half-wave h holds k = 8h .. 8h+7 = the 8 channels of unit 2o+h
+          bf16x8 a[WTM], b[WTN];
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+            a[i] = *reinterpret_cast<const bf16x8 *>(Ab + ((t * G4 + o * 2) * BM + i * 32) * 16);
+#pragma unroll
+          for (int j = 0; j < WTN; ++j)
+            b[j] = *reinterpret_cast<const bf16x8 *>(Xb + (bbytes[j] + toffb + o * 2 * p.planeStride * 16));
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+      } else if constexpr (CK == 4) {
         f32x2 a[WTM], b[WTN];
 #pragma unroll
         for (int i = 0; i < WTM; ++i) a[i] = *reinterpret_cast<const f32x2 *>(Ab + (t * BM + i * 32) * 16);
@@ -313,7 +348,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
             } else {
               load_halo(c0 + cb, j, xv);
             }
-            store_halo(c0 + cb, cb >> 2, j, xv, Xs);
+            store_halo(c0 + cb, cb / KP, j, xv, Xs);
           }
         }
       }
@@ -435,10 +470,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
 // name-only mode (name != NULL): write the instantiation the descriptor selects (rocprofv3 spelling) and launch nothing
 struct NameOut { char *buf; int n; };
 
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, const NameOut *name) {
   constexpr int BM = WGM * WTM * 32;
-  constexpr int G4 = (CK + 3) / 4;
+  constexpr int G4 = (CK + (BF ? 7 : 3)) / (BF ? 8 : 4);
   if (PF > 0 && p.NJ > PF) return TBG_EUNSUPPORTED;
   p.a_floats = maxtaps * G4 * 4 * BM;
   p.ck_rt = CK;
@@ -449,10 +484,11 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   if (maxtaps > MT) return TBG_EUNSUPPORTED;
   if (name) {
-    snprintf(name->buf, name->n, "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC);
+    snprintf(name->buf, name->n, "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC,
+             BF ? "true" : "false");
     return TBG_OK;
   }
-  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF, OCC>;
+  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF, OCC, BF>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TBG_EHIP;
@@ -465,7 +501,7 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
 
 
 static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, float *y, const float *in_scale,
-                       const tbg_epilogue *epi, void *stream, const NameOut *name) {
+                       const tbg_epilogue *epi, void *stream, const NameOut *name, bool bf = false) {
   if (!d || !epi_valid(epi)) return TBG_EINVAL;
   if (!name && (!x || !w || !y)) return TBG_EINVAL;
   if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1 || d->Hout < 1 || d->Wout < 1) return TBG_EINVAL;
@@ -578,6 +614,18 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   p.ksplit = d->ksplit;
   p.slab = (long long)d->B * d->M * d->Hout * d->Wout;
   hipStream_t st = tbg_stream(stream);
+  if (bf) {  // bf16-in MFMA: chunks of 16 channels (32 for the few-tap classes), the same four tile shapes
+    if (maxtaps > 1 && maxtaps <= 4) {
+      if (BM == 32) return launch_fprop<1, 4, 1, 2, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
+      if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
+      if (BM == 64) return launch_fprop<1, 4, 2, 2, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
+      return launch_fprop<2, 2, 2, 2, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
+    }
+    if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, MAXTAPS, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
+    if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 16, MAXTAPS, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
+    if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, MAXTAPS, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
+    return launch_fprop<2, 2, 2, 2, 16, MAXTAPS, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
+  }
   // few-tap launches (the parity classes of a stride-2 transposed 3x3: 1/2/2/4 taps): a deeper channel chunk keeps
   // the MFMA count per barrier pair up (4 taps x 16 channels instead of 4 x 8)
   if (maxtaps > 1 && maxtaps <= 4) {
@@ -605,12 +653,25 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
   return conv2d_impl(d, x, w, y, in_scale, epi, stream, nullptr);
 }
 
-extern "C" int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n) {
+extern "C" int tbg_conv2d_bf16(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,
+                               const tbg_epilogue *epi, void *stream) {
+  return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, true);
+}
+
+static int conv_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n, bool bf) {
   if (!buf || n < 1) return TBG_EINVAL;
   buf[0] = 0;
   NameOut no{buf, n};
   static const float dummy = 0.f;  // name-only mode never dereferences; in_scale only sizes the LDS request
-  return conv2d_impl(d, nullptr, nullptr, nullptr, has_in_scale ? &dummy : nullptr, nullptr, nullptr, &no);
+  return conv2d_impl(d, nullptr, nullptr, nullptr, has_in_scale ? &dummy : nullptr, nullptr, nullptr, &no, bf);
+}
+
+extern "C" int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n) {
+  return conv_name(d, has_in_scale, buf, n, false);
+}
+
+extern "C" int tbg_conv2d_bf16_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n) {
+  return conv_name(d, has_in_scale, buf, n, true);
 }
 
 // ============================================================================================
@@ -813,6 +874,180 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     for (int r16 = 0; r16 < 16; ++r16) wsp[(t * 16 + r16) * 256 + tid] = acc[t][r16];
 }
 
+// ---- bf16-in / fp32-accumulate filter gradient (v_mfma_f32_32x32x16_bf16).  Same block / wave / accumulator structure as
+// conv_wgrad_kernel (GRP form); S and L are rounded to bf16 (RNE) while they are staged, K (= pixels) is walked in groups of
+// 16: half-wave h takes pixels 16g+8h .. +7 of one tile row, so the A operand is ONE aligned ds_read_b128.  The B
+// operand of tap (kh, kw) starts kw pixels further along the row -- a 2-byte shift that a 16-byte LDS read cannot make --
+// so per kh ONE 10-pixel window (ds_read_b128 + ds_read_b32) is read and the three kw operands are cut from it in
+// registers (kw = 1: four v_alignbit_b32; kw = 2: the dwords one place on).  With x-stride 2 the halo tile is stored
+// de-interleaved (even | odd columns): kw = 0 / 2 come from the even window, kw = 1 is an aligned read of the odd one.
+// Row pitches are multiples of 8 pixels; channel pitches are ODD multiples of 16 bytes (conflict-free b128 across lanes).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int WGS, int WGL, int NT, int PIX, int SX>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p) {
+  constexpr int BS = WGS * 32, BL = WGL * 32, SPB = PIX + 8;  // S row pitch (bf16 elements): 2*SPB bytes = odd * 16
+  constexpr int KHn = (NT == 9) ? 3 : 1;
+  constexpr int NJC = (NT == 1 && PIX == 64) ? 1 : WG_MAXNJ;
+  static_assert(((SPB / 8) & 1) == 1, "S channel pitch must be an odd multiple of 16 bytes");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16 *Ss = reinterpret_cast<__bf16 *>(smem);  // [BS][SPB]
+  __bf16 *Ls = Ss + BS * SPB;                      // [BL][lplane]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ws = wave / WGL, wl = wave - ws * WGL;
+  const int cs0 = blockIdx.x * BS, cl0 = blockIdx.y * BL;
+  const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTHs) - 1;
+
+  int d_pos[NJC], d_loff[NJC];
+#pragma unroll
+  for (int j = 0; j < NJC; ++j) {
+    d_pos[j] = -1; d_loff[j] = 0;
+    const int e = lane + 64 * j;
+    if (j < p.NJ && e < p.ppc) {
+      const int per = p.IHs * p.IWs;
+      const int seg = e / per;
+      const int rem = e - seg * per;
+      const int iyl = rem / p.IWs;
+      const int ixl = rem - iyl * p.IWs;
+      d_pos[j] = (seg << 16) | (iyl << 8) | ixl;
+      const int col = (SX == 2) ? (ixl & 1) * p.HALFW + (ixl >> 1) : ixl;
+      d_loff[j] = (seg * p.IHs + iyl) * p.IWp + col;
+    }
+  }
+  const int spix = tid & (PIX - 1);
+  const int sch0 = tid / PIX;
+  const int sq = spix & TWm, srr = spix >> p.logTW;
+  const int sseg = srr >> p.logTHs, sr = srr & THm;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int HWs = p.Hs * p.Ws, HWl = p.Hl * p.Wl;
+  const int half = lane >> 5;
+
+  for (int chunk = blockIdx.z; chunk < p.nchunks; chunk += p.ksplit) {
+    const int tv = chunk % p.tilesV;
+    const int t2 = chunk / p.tilesV;
+    const int tu = t2 % p.tilesU;
+    const int bg = t2 / p.tilesU;
+    const int u0 = tu << p.logTHs, v0 = tv << p.logTW;
+    __syncthreads();
+    {  // S tile (branch-free, as in the fp32 kernel)
+      const int b = bg * p.NSEG + sseg, u = u0 + sr, v = v0 + sq;
+      const bool ok = b < p.B && u < p.Hs && v < p.Ws;
+      const int base = ok ? (b * p.CS) * HWs + u * p.Ws + v : 0;
+      const int sb = ok ? b * p.CS : 0;
+      constexpr int S_IT = BS / (256 / PIX), S_B = 8;
+#pragma unroll
+      for (int it0 = 0; it0 < S_IT; it0 += S_B) {
+        float sv[S_B], sc[S_B];
+#pragma unroll
+        for (int u = 0; u < S_B; ++u) {
+          const int chc = min(cs0 + sch0 + (it0 + u) * (256 / PIX), p.CS - 1);
+          sv[u] = p.S[base + chc * HWs];
+          sc[u] = p.s_scale ? p.s_scale[sb + chc] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < S_B; ++u) {
+          const int ch = sch0 + (it0 + u) * (256 / PIX);
+          Ss[ch * SPB + spix] = (__bf16)((ok && cs0 + ch < p.CS) ? sv[u] * sc[u] : 0.f);
+        }
+      }
+    }
+    {  // L halo tile: wave w stages channels w, w+4, ...
+      int g[NJC], bb[NJC];
+#pragma unroll
+      for (int j = 0; j < NJC; ++j) {
+        const int seg = d_pos[j] >> 16, iyl = (d_pos[j] >> 8) & 255, ixl = d_pos[j] & 255;
+        const int b = bg * p.NSEG + seg;
+        const int iy = u0 * p.sy - p.py + iyl;
+        const int ix = v0 * p.sx - p.px + ixl;
+        const bool ok = d_pos[j] >= 0 && b < p.B && iy >= 0 && iy < p.Hl && ix >= 0 && ix < p.Wl;
+        g[j] = ok ? (b * p.CL) * HWl + iy * p.Wl + ix : -1;
+        bb[j] = ok ? b * p.CL : 0;
+      }
+      constexpr int LB = 4;
+      for (int ch0 = wave; ch0 < BL; ch0 += 4 * LB) {
+        float lv[LB][NJC];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+          const int chc = min(cl0 + ch0 + 4 * u, p.CL - 1);
+#pragma unroll
+          for (int j = 0; j < NJC; ++j) lv[u][j] = p.L[(g[j] >= 0 ? g[j] : 0) + chc * HWl];
+        }
+        if (p.l_scale) {  // uniform
+          float lsc[LB][NJC];
+#pragma unroll
+          for (int u = 0; u < LB; ++u) {
+            const int chc = min(cl0 + ch0 + 4 * u, p.CL - 1);
+#pragma unroll
+            for (int j = 0; j < NJC; ++j) lsc[u][j] = p.l_scale[bb[j] + chc];
+          }
+#pragma unroll
+          for (int u = 0; u < LB; ++u)
+#pragma unroll
+            for (int j = 0; j < NJC; ++j) lv[u][j] *= lsc[u][j];
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+          const int ch = ch0 + 4 * u;
+#pragma unroll
+          for (int j = 0; j < NJC; ++j)
+            if (d_pos[j] >= 0 && ch < BL)
+              Ls[ch * p.lplane + d_loff[j]] = (__bf16)((g[j] >= 0 && cl0 + ch < p.CL) ? lv[u][j] : 0.f);
+        }
+      }
+    }
+    __syncthreads();
+    const __bf16 *Sp = Ss + (ws * 32 + (lane & 31)) * SPB + 8 * half;
+    const __bf16 *Lp = Ls + (wl * 32 + (lane & 31)) * p.lplane;
+#pragma unroll 2
+    for (int gp = 0; gp < PIX / 16; ++gp) {
+      const int pp = 16 * gp + 8 * half;  // first of this half-wave's 8 pixels (one tile row: TW >= 8)
+      const int q = pp & TWm, rr = pp >> p.logTW;
+      const int seg = rr >> p.logTHs, r = rr & THm;
+      const __bf16 *Lg = Lp + (seg * p.IHs + r * p.sy) * p.IWp + q;  // multiple of 8 elements: 16-byte aligned
+      const bf16x8 a8 = *reinterpret_cast<const bf16x8 *>(Sp + 16 * gp);
+#pragma unroll
+      for (int kh = 0; kh < KHn; ++kh) {
+        const __bf16 *row = Lg + kh * p.IWp;
+        const i32x4 e = *reinterpret_cast<const i32x4 *>(row);  // pixels 0..7 (even columns when SX == 2)
+        if constexpr (NT == 1) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8, e), acc[0], 0, 0, 0);
+        } else {
+          const int e4 = *reinterpret_cast<const int *>(row + 8);  // pixels 8, 9
+          i32x4 s1, s2;
+          s1[0] = __builtin_amdgcn_alignbit(e[1], e[0], 16); s1[1] = __builtin_amdgcn_alignbit(e[2], e[1], 16);
+          s1[2] = __builtin_amdgcn_alignbit(e[3], e[2], 16); s1[3] = __builtin_amdgcn_alignbit(e4, e[3], 16);
+          s2[0] = e[1]; s2[1] = e[2]; s2[2] = e[3]; s2[3] = e4;
+          i32x4 b0 = e, b1, b2;
+          if constexpr (SX == 2) {  // kw = 0: even[0..7], kw = 1: odd[0..7], kw = 2: even[1..8]
+            b1 = *reinterpret_cast<const i32x4 *>(row + p.HALFW);
+            b2 = s1;
+          } else {                  // kw = 0, 1, 2: window[0..7], [1..8], [2..9]
+            b1 = s1;
+            b2 = s2;
+          }
+          acc[3 * kh + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8, b0), acc[3 * kh + 0], 0, 0, 0);
+          acc[3 * kh + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8, b1), acc[3 * kh + 1], 0, 0, 0);
+          acc[3 * kh + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8, b2), acc[3 * kh + 2], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float *wsp = p.ws + blk * (size_t)(NT * 16 * 256);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r16 = 0; r16 < 16; ++r16) wsp[(t * 16 + r16) * 256 + tid] = acc[t][r16];
+}
+
 // few output tiles, many partials: one block per (tile, tap, accumulator register) -- 16x more blocks than the
 // transposing kernel below, scattered 4-byte stores
 template <int WGS, int WGL, int NT>
@@ -937,6 +1172,34 @@ static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes, const N
   return TBG_OK;
 }
 
+template <int WGS, int WGL, int NT, int PIX, int SX>
+static int launch_wgrad_bf16(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
+  constexpr int BS = WGS * 32, BL = WGL * 32;
+  if (name) {
+    snprintf(name->buf, name->n, "conv_wgrad_bf16_kernel<%d, %d, %d, %d, %d>", WGS, WGL, NT, PIX, SX);
+    return TBG_OK;
+  }
+  const size_t lds = ((size_t)BS * (PIX + 8) + (size_t)BL * p.lplane) * 2;
+  if (p.NJ > ((NT == 1 && PIX == 64) ? 1 : WG_MAXNJ)) return TBG_EUNSUPPORTED;
+  if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
+  auto kern = conv_wgrad_bf16_kernel<WGS, WGL, NT, PIX, SX>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return TBG_EHIP;
+  }
+  const int tx = ceil_div(p.CS, BS), ty = ceil_div(p.CL, BL);
+  p.ksplit = wgrad_ksplit(tx * ty, p.nchunks);
+  if ((size_t)p.ksplit * tx * ty * NT * 16 * 256 * sizeof(float) > ws_bytes) return TBG_EINVAL;
+  hipLaunchKernelGGL(kern, dim3(tx, ty, p.ksplit), dim3(256), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  if (tx * ty * NT >= 256)
+    hipLaunchKernelGGL((conv_wgrad_reduce_kernel<WGS, WGL, NT>), dim3(tx, ty, NT), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_reduce_wide_kernel<WGS, WGL, NT>), dim3(tx, ty, NT * 16), dim3(256), 0, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
 template <int WGS, int WGL, int NT, int PIX>
 static int launch_wgrad(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
   if (p.logTW >= 2) return launch_wgrad_impl<WGS, WGL, NT, PIX, true>(p, st, ws_bytes, name);
@@ -944,7 +1207,7 @@ static int launch_wgrad(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOu
 }
 
 // geometry shared by the launcher and the workspace query
-static int wgrad_geometry(const tbg_wgrad_desc *d, WgradP &p, int &PIX) {
+static int wgrad_geometry(const tbg_wgrad_desc *d, WgradP &p, int &PIX, bool bf = false) {
   if (!d) return TBG_EINVAL;
   if (d->B < 1 || d->CS < 1 || d->CL < 1 || d->Hs < 1 || d->Ws < 1 || d->Hl < 1 || d->Wl < 1) return TBG_EINVAL;
   if (!((d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 1))) return TBG_EUNSUPPORTED;
@@ -968,6 +1231,12 @@ static int wgrad_geometry(const tbg_wgrad_desc *d, WgradP &p, int &PIX) {
     p.HALFW = (p.IWs + 1) / 2;
     p.IWp = (d->sx == 2) ? 2 * p.HALFW : p.IWs;
     p.lplane = (p.NSEG * p.IHs * p.IWp) | 1;  // odd plane pitch: lanes walk channels conflict-free
+    if (bf && TW >= 8) {  // bf16 tiles: row pitches in whole 16-byte units, channel pitch an ODD number of units
+      p.HALFW = (p.HALFW + 7) & ~7;
+      p.IWp = (d->sx == 2) ? 2 * p.HALFW : ((p.IWs + 7) & ~7);
+      p.lplane = p.NSEG * p.IHs * p.IWp;
+      if (((p.lplane / 8) & 1) == 0) p.lplane += 8;
+    }
     p.ppc = p.NSEG * p.IHs * p.IWs;
     p.NJ = ceil_div(p.ppc, 64);
     const int cap = (d->KH * d->KW == 1 && PIX == 64) ? 1 : WG_MAXNJ;
@@ -1018,6 +1287,44 @@ extern "C" int tbg_conv2d_wgrad_ex_f32(const tbg_wgrad_desc *d, const float *S, 
   p.addw = addw; p.addq = addq; p.gamma = gamma;
   const size_t wsb = workspace_bytes < 0 ? 0 : (size_t)workspace_bytes;
   return wgrad_select(p, d->KH * d->KW, PIX, tbg_stream(stream), wsb, nullptr);
+}
+
+// bf16 form: tile rows of >= 8 pixels take conv_wgrad_bf16_kernel; narrower maps (Ws <= 4: the 4x4 head) keep the exact fp32
+// kernel -- they hold a negligible share of the work.  Same workspace size as the fp32 form (same chunking).
+static int wgrad_bf16_select(WgradP &p, int NT, int PIX, int sx, hipStream_t st, size_t wsb, const NameOut *name) {
+  if (NT == 9) {
+    if (PIX == 32) return sx == 2 ? launch_wgrad_bf16<2, 2, 9, 32, 2>(p, st, wsb, name) : launch_wgrad_bf16<2, 2, 9, 32, 1>(p, st, wsb, name);
+    return sx == 2 ? launch_wgrad_bf16<2, 2, 9, 64, 2>(p, st, wsb, name) : launch_wgrad_bf16<2, 2, 9, 64, 1>(p, st, wsb, name);
+  }
+  if (PIX == 32) return sx == 2 ? launch_wgrad_bf16<2, 2, 1, 32, 2>(p, st, wsb, name) : launch_wgrad_bf16<2, 2, 1, 32, 1>(p, st, wsb, name);
+  return sx == 2 ? launch_wgrad_bf16<2, 2, 1, 64, 2>(p, st, wsb, name) : launch_wgrad_bf16<2, 2, 1, 64, 1>(p, st, wsb, name);
+}
+
+extern "C" int tbg_conv2d_wgrad_bf16(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
+                                     const float *s_scale, const float *l_scale, const float *addw, const float *addq,
+                                     float gamma, float *workspace, long long workspace_bytes, void *stream) {
+  if (!d || !S || !L || !dW || !workspace || ((addw == nullptr) != (addq == nullptr))) return TBG_EINVAL;
+  WgradP p;
+  int PIX;
+  int rc = wgrad_geometry(d, p, PIX, true);
+  if (rc != TBG_OK) return rc;
+  p.S = S; p.L = L; p.s_scale = s_scale; p.l_scale = l_scale; p.dW = dW; p.ws = workspace;
+  p.addw = addw; p.addq = addq; p.gamma = gamma;
+  const size_t wsb = workspace_bytes < 0 ? 0 : (size_t)workspace_bytes;
+  if (p.logTW < 3) return wgrad_select(p, d->KH * d->KW, PIX, tbg_stream(stream), wsb, nullptr);
+  return wgrad_bf16_select(p, d->KH * d->KW, PIX, d->sx, tbg_stream(stream), wsb, nullptr);
+}
+
+extern "C" int tbg_conv2d_wgrad_bf16_kernel_name(const tbg_wgrad_desc *d, char *buf, int n) {
+  if (!buf || n < 1) return TBG_EINVAL;
+  buf[0] = 0;
+  WgradP p;
+  int PIX;
+  const int rc = wgrad_geometry(d, p, PIX, true);
+  if (rc != TBG_OK) return rc;
+  NameOut no{buf, n};
+  if (p.logTW < 3) return wgrad_select(p, d->KH * d->KW, PIX, nullptr, 0, &no);
+  return wgrad_bf16_select(p, d->KH * d->KW, PIX, d->sx, nullptr, 0, &no);
 }
 
 extern "C" int tbg_conv2d_wgrad_kernel_name(const tbg_wgrad_desc *d, char *buf, int n) {

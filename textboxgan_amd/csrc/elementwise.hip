@@ -284,6 +284,47 @@ extern "C" int tbg_weight_pack_f32(const float *src, float *dst, int T, int I, i
   return TBG_OK;
 }
 
+// bf16 form of the packed filter (tbg_conv2d_bf16): Wp[T][ceil(C/8)][M][8] bf16 -- a 16-byte unit holds 8 consecutive
+// reduction channels of one output channel (RNE rounding of the fp32 master weight, zero padded past C).
+typedef __bf16 tbg_bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void weight_pack_bf16_kernel(const float *__restrict__ src, tbg_bf16x8 *__restrict__ dst,
+                                                               int T, int I, int O, int transpose, int flip) {
+  const int t = blockIdx.z;
+  const int td = flip ? T - 1 - t : t;
+  const int C = transpose ? O : I, M = transpose ? I : O;
+  const int C8 = (C + 7) >> 3;
+  const int c8 = blockIdx.y;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  tbg_bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * c8 + e;
+    const int i = transpose ? m : c, o = transpose ? c : m;
+    v[e] = (__bf16)((c < C) ? src[((size_t)t * I + i) * O + o] : 0.f);
+  }
+  dst[((size_t)td * C8 + c8) * M + m] = v;
+}
+
+extern "C" long long tbg_weight_pack_bf16_bytes(int T, int I, int O, int transpose) {
+  if (T < 1 || I < 1 || O < 1) return -1;
+  const long long C = transpose ? O : I, M = transpose ? I : O;
+  return (long long)T * ((C + 7) / 8) * M * 16;
+}
+
+extern "C" int tbg_weight_pack_bf16(const float *src, void *dst, int T, int I, int O, int transpose, int flip,
+                                    void *stream) {
+  if (!src || !dst || T < 1 || I < 1 || O < 1) return TBG_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) != 0) return TBG_EINVAL;
+  const int C = transpose ? O : I, M = transpose ? I : O;
+  dim3 grid((M + 255) / 256, (C + 7) / 8, T);
+  hipLaunchKernelGGL(weight_pack_bf16_kernel, grid, dim3(256), 0, tbg_stream(stream), src,
+                     reinterpret_cast<tbg_bf16x8 *>(dst), T, I, O, transpose, flip);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
 // ============================================================================================
 // Adam (Keras / ResourceApplyAdam semantics) and EMA lerp over flat buffers
 // ============================================================================================
@@ -409,7 +450,7 @@ extern "C" int tbg_demod_coefs_f32(const float *s, const float *w, float *wsq, f
 }
 
 // ============================================================================================
-extern "C" int tbg_version(void) { return 100; }
+extern "C" int tbg_version(void) { return 200; }
 
 extern "C" const char *tbg_strerror(int code) {
   switch (code) {

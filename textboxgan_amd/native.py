@@ -21,7 +21,7 @@ SQRT2 = 1.4142135623730951
 
 EXPORTS = [
     "tbg_version", "tbg_strerror", "tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_upfirdn2d_sep_f32", "tbg_conv2d_f32",
-    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_conv2d_kernel_name", "tbg_conv2d_wgrad_kernel_name", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_attn_ctx_fwd_f32", "tbg_attn_ctx_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
+    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_conv2d_kernel_name", "tbg_conv2d_wgrad_kernel_name", "tbg_weight_pack_bf16_bytes", "tbg_weight_pack_bf16", "tbg_conv2d_bf16", "tbg_conv2d_bf16_kernel_name", "tbg_conv2d_wgrad_bf16", "tbg_conv2d_wgrad_bf16_kernel_name", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_attn_ctx_fwd_f32", "tbg_attn_ctx_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
     "tbg_bias_act_bwd_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -78,6 +78,13 @@ def lib():
         l.tbg_attn_ctx_fwd_f32.argtypes = [vp] * 6 + [ci] * 4 + [vp]
         l.tbg_attn_ctx_bwd_f32.argtypes = [vp] * 9 + [ci] * 4 + [vp]
         l.tbg_conv2d_kernel_name.argtypes = [C.POINTER(ConvDesc), ci, C.c_char_p, ci]
+        l.tbg_conv2d_bf16_kernel_name.argtypes = [C.POINTER(ConvDesc), ci, C.c_char_p, ci]
+        l.tbg_conv2d_wgrad_bf16_kernel_name.argtypes = [C.POINTER(WgradDesc), C.c_char_p, ci]
+        l.tbg_conv2d_bf16.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(Epilogue), vp]
+        l.tbg_conv2d_wgrad_bf16.argtypes = [C.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, vp, cf, vp, ll, vp]
+        l.tbg_weight_pack_bf16.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+        l.tbg_weight_pack_bf16_bytes.argtypes = [ci, ci, ci, ci]
+        l.tbg_weight_pack_bf16_bytes.restype = C.c_longlong
         l.tbg_conv2d_wgrad_kernel_name.argtypes = [C.POINTER(WgradDesc), C.c_char_p, ci]
         l.tbg_bias_act_fwd_f32.argtypes = [vp, vp, ci, ci, ci, C.POINTER(Epilogue), vp]
         l.tbg_slab_epilogue_f32.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(Epilogue), vp]
@@ -101,7 +108,7 @@ def ptr(t: Optional[torch.Tensor]):
         return None
     if not t.is_cuda:
         raise TbgError("libtbg_hip kernels need device tensors (no CPU path in the product)")
-    if t.dtype != torch.float32 and t.dtype != torch.int64:
+    if t.dtype not in (torch.float32, torch.int64, torch.bfloat16):
         raise TbgError(f"unsupported dtype {t.dtype}")
     if not t.is_contiguous():
         raise TbgError("tensor must be contiguous")
@@ -120,13 +127,15 @@ def epilogue(out_scale=None, bias=None, noise=None, strength=None, residual=None
                     res_scale, act, res_first)
 
 
-def conv_kernel_name(desc: ConvDesc, has_in_scale: bool) -> str:
+def conv_kernel_name(desc: ConvDesc, has_in_scale: bool, bf16: bool = False) -> str:
     buf = C.create_string_buffer(128)
-    check(lib().tbg_conv2d_kernel_name(C.byref(desc), int(has_in_scale), buf, 128), "tbg_conv2d_kernel_name")
+    fn = lib().tbg_conv2d_bf16_kernel_name if bf16 else lib().tbg_conv2d_kernel_name
+    check(fn(C.byref(desc), int(has_in_scale), buf, 128), "tbg_conv2d_kernel_name")
     return buf.value.decode()
 
 
-def wgrad_kernel_name(desc: WgradDesc) -> str:
+def wgrad_kernel_name(desc: WgradDesc, bf16: bool = False) -> str:
     buf = C.create_string_buffer(128)
-    check(lib().tbg_conv2d_wgrad_kernel_name(C.byref(desc), buf, 128), "tbg_conv2d_wgrad_kernel_name")
+    fn = lib().tbg_conv2d_wgrad_bf16_kernel_name if bf16 else lib().tbg_conv2d_wgrad_kernel_name
+    check(fn(C.byref(desc), buf, 128), "tbg_conv2d_wgrad_kernel_name")
     return buf.value.decode()

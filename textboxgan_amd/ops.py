@@ -39,6 +39,35 @@ class _Flags:
 FLAGS = _Flags()
 
 
+# ----------------------------------------------------------------------------------------
+# arithmetic type of the MFMA contractions: "f32" (v_mfma_f32_32x32x2_f32, exact) or "bf16" (bf16 operands rounded while
+# staging, fp32 accumulate: BASELINE configs[2]).  HBM tensors, epilogues, master weights and Adam stay fp32 either way.
+# ----------------------------------------------------------------------------------------
+_COMPUTE_BF16 = False
+
+
+class compute_dtype:
+    """``with ops.compute_dtype("bf16"): ...`` -- scope in which conv / filter-gradient launches use the bf16 entries."""
+
+    def __init__(self, dtype: str):
+        assert dtype in ("f32", "bf16"), dtype
+        self.bf16 = dtype == "bf16"
+
+    def __enter__(self):
+        global _COMPUTE_BF16
+        self._prev, _COMPUTE_BF16 = _COMPUTE_BF16, self.bf16
+        return self
+
+    def __exit__(self, *exc):
+        global _COMPUTE_BF16
+        _COMPUTE_BF16 = self._prev
+        return False
+
+
+def is_bf16() -> bool:
+    return _COMPUTE_BF16
+
+
 class _Profile:
     """bench.py's roofline pass: bracket kernel launches with HIP events on the stream the kernel is enqueued on and
     attribute their ALGORITHMIC work to the kernel that ran: FLOPs (2 x MACs of the dense contraction) for the MFMA
@@ -177,9 +206,11 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         w = pack_filter(w.reshape(KH * KW, Cc, ldw), transpose=False, flip=False)
     assert w.C == Cc and w.M >= M and w.T == KH * KW, "packed filter does not match the convolution"
     ldw = w.M
+    bf16 = w.bf16
+    _conv = N.lib().tbg_conv2d_bf16 if bf16 else N.lib().tbg_conv2d_f32
     w = w.data
     Hout, Wout = out_hw
-    nchunks = math.ceil(Cc / 8)
+    nchunks = math.ceil(Cc / (16 if bf16 else 8))
     ksplit = 1
     _npix = B * (math.ceil(Hout / stride[0]) * math.ceil(Wout / stride[1]) if transposed else Hout * Wout)
     if allow_split:
@@ -199,13 +230,13 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
              f"p={tuple(pad)} T={int(transposed)} ldw={ldw} ksplit={ksplit}]")
     _flops = 2.0 * B * M * Cc * KH * KW * (Hin * Win if transposed else Hout * Wout)
     _bytes = 4.0 * (B * Cc * Hin * Win + B * M * Hout * Wout * ksplit + KH * KW * Cc * M)  # x + y (slabs) + filter, once each
-    _kname = lambda: N.conv_kernel_name(d, in_scale is not None)
+    _kname = lambda: N.conv_kernel_name(d, in_scale is not None, bf16)
     if ksplit > 1:
         # split-K: every split stores alpha*acc into its own slab (no zero-fill, no atomics); one flat pass sums the
         # slabs and applies the real epilogue
         slabs = torch.empty((ksplit, B, M, Hout, Wout), device=x.device, dtype=torch.float32)
         e0 = N.epilogue(alpha=epi.alpha)
-        N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
+        N.check(PROFILE.launch(_kname, _flops, lambda: _conv(
             C.byref(d), N.ptr(x), N.ptr(w), N.ptr(slabs), N.ptr(in_scale), C.byref(e0), N.stream()), _what, _bytes), _what)
         e1 = N.Epilogue.from_buffer_copy(epi)
         e1.alpha = 1.0
@@ -226,7 +257,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         epi = N.Epilogue.from_buffer_copy(epi)
         epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(dot[1])
     y = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
-    N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_f32(
+    N.check(PROFILE.launch(_kname, _flops, lambda: _conv(
         C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream()), _what, _bytes), _what)
     return y
 
@@ -251,9 +282,11 @@ def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, o
         raise N.TbgError("tbg_conv2d_wgrad: unsupported geometry")
     ws = _workspace(S.device, nbytes)
     _flops = 2.0 * B * CS * CL * Hs * Ws * KH * KW
-    _kname = lambda: N.wgrad_kernel_name(d)
+    bf16 = _COMPUTE_BF16
+    _kname = lambda: N.wgrad_kernel_name(d, bf16)
+    _wg = N.lib().tbg_conv2d_wgrad_bf16 if bf16 else N.lib().tbg_conv2d_wgrad_ex_f32
     addw, addq, gamma = add if add is not None else (None, None, 0.0)
-    N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_wgrad_ex_f32(
+    N.check(PROFILE.launch(_kname, _flops, lambda: _wg(
         C.byref(d), N.ptr(S), N.ptr(L), N.ptr(out) + 4 * out_offset, N.ptr(s_scale), N.ptr(l_scale),
         (N.ptr(addw) + 4 * out_offset) if addw is not None else None, N.ptr(addq), gamma, N.ptr(ws),
         ws.numel() * 4, N.stream()), f"wgrad[B={B} CS={CS} CL={CL} S={Hs}x{Ws} L={Hl}x{Wl} k={KH} s={tuple(stride)}]",
@@ -262,11 +295,13 @@ def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, o
 
 
 class PackedFilter(NamedTuple):
-    """Wp[T][ceil(C/4)][M][4] (tbg_weight_pack_f32): the filter format of tbg_conv2d_f32."""
+    """Wp[T][ceil(C/4)][M][4] fp32 (tbg_weight_pack_f32) or Wp[T][ceil(C/8)][M][8] bf16 (tbg_weight_pack_bf16): the filter
+    formats of tbg_conv2d_f32 / tbg_conv2d_bf16."""
     data: torch.Tensor
     T: int
     C: int
     M: int
+    bf16: bool = False
 
 
 _PACK_STEP: Optional[dict] = None  # live only inside filter_cache(): weights are constant within one step's passes
@@ -289,8 +324,10 @@ class filter_cache:
         return False
 
 
-def pack_filter(w: torch.Tensor, transpose: bool, flip: bool) -> PackedFilter:
-    """HWIO [KH,KW,I,O] / [T,I,O] parameter -> PackedFilter.  transpose: C = O, M = I (data gradient)."""
+def pack_filter(w: torch.Tensor, transpose: bool, flip: bool, bf16: Optional[bool] = None) -> PackedFilter:
+    """HWIO [KH,KW,I,O] / [T,I,O] parameter -> PackedFilter.  transpose: C = O, M = I (data gradient).
+    bf16 = None: the current ops.compute_dtype."""
+    bf16 = _COMPUTE_BF16 if bf16 is None else bool(bf16)
     if w.dim() == 4:
         T, I, O = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
     else:
@@ -298,15 +335,21 @@ def pack_filter(w: torch.Tensor, transpose: bool, flip: bool) -> PackedFilter:
     cache = None
     if _PACK_STEP is not None and w.is_leaf and w.requires_grad:  # live parameters only: the key is an address
         cache = _PACK_STEP
-    key = (w.data_ptr(), T, I, O, bool(transpose), bool(flip), w._version)
+    key = (w.data_ptr(), T, I, O, bool(transpose), bool(flip), w._version, bf16)
     if cache is not None and key in cache:
         return cache[key]
     w = w.contiguous()
-    n = N.lib().tbg_weight_pack_floats(T, I, O, int(transpose))
-    out = torch.empty(n, device=w.device, dtype=torch.float32)
-    N.check(N.lib().tbg_weight_pack_f32(N.ptr(w), N.ptr(out), T, I, O, int(transpose), int(flip), N.stream()),
-            "tbg_weight_pack")
-    pf = PackedFilter(out, T, O if transpose else I, I if transpose else O)
+    if bf16:
+        nb = N.lib().tbg_weight_pack_bf16_bytes(T, I, O, int(transpose))
+        out = torch.empty(nb // 2, device=w.device, dtype=torch.bfloat16)
+        N.check(N.lib().tbg_weight_pack_bf16(N.ptr(w), N.ptr(out), T, I, O, int(transpose), int(flip), N.stream()),
+                "tbg_weight_pack_bf16")
+    else:
+        n = N.lib().tbg_weight_pack_floats(T, I, O, int(transpose))
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
+        N.check(N.lib().tbg_weight_pack_f32(N.ptr(w), N.ptr(out), T, I, O, int(transpose), int(flip), N.stream()),
+                "tbg_weight_pack")
+    pf = PackedFilter(out, T, O if transpose else I, I if transpose else O, bf16)
     if cache is not None:
         cache[key] = pf
     return pf

@@ -56,7 +56,8 @@ def mean_squared_loss(y_a, y_b, batch_size):
 class TrainingStep:
     def __init__(self, generator: Generator, discriminator: Discriminator, aster_ocr, g_optimizer: AdamTF,
                  ocr_optimizer: AdamTF, d_optimizer: AdamTF, g_reg_interval: int, d_reg_interval: int,
-                 pl_mean: torch.Tensor, cfg: Config = default_cfg, process_group=None, use_graphs: bool = False):
+                 pl_mean: torch.Tensor, cfg: Config = default_cfg, process_group=None, use_graphs: bool = False,
+                 compute_dtype: str = "f32"):
         self.generator, self.discriminator, self.aster_ocr = generator, discriminator, aster_ocr
         self.g_optimizer, self.ocr_optimizer, self.d_optimizer = g_optimizer, ocr_optimizer, d_optimizer
         self.g_reg_interval, self.d_reg_interval = g_reg_interval, d_reg_interval
@@ -70,6 +71,10 @@ class TrainingStep:
         self.pl_noise_scaler = 1.0 / math.sqrt(float(cfg.image_width) * float(cfg.char_height))
         self.pg = process_group
         self.use_graphs = use_graphs
+        # "f32": exact fp32 MFMA contractions (BASELINE configs[1]).  "bf16": conv / filter-gradient operands rounded to
+        # bf16 on their way into LDS, fp32 accumulate, fp32 master weights + Adam (BASELINE configs[2]).
+        assert compute_dtype in ("f32", "bf16")
+        self.compute_dtype = compute_dtype
         # OCR branch (forward + its own backward) on a second HIP stream.  Worth ~1% only (415 -> 418-420 text-boxes/s):
         # tools/graph_branch_test.py shows that on MI355X / ROCm 7.2 neither eager streams nor captured fork/join branches
         # overlap a chain of small kernels with a large kernel to any useful degree (7.67 vs 7.96 ms).
@@ -257,7 +262,8 @@ class TrainingStep:
         return outs
 
     def _compute_grads(self, *args, **kw):
-        with ops.filter_cache():  # packed filters are shared by the forward and the three backward passes
+        # packed filters are shared by the forward and the three backward passes
+        with ops.filter_cache(), ops.compute_dtype(self.compute_dtype):
             return self._compute_grads_impl(*args, **kw)
 
     def _compute_grads_impl(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg, do_pl_reg,
@@ -394,7 +400,7 @@ class TrainingStep:
 
 
 def build_trainer_state(cfg: Config, device, aster_ocr=None, seed: int = 0, process_group=None,
-                        use_graphs: bool = False):
+                        use_graphs: bool = False, compute_dtype: str = "f32"):
     """The wiring of reference train.py:25-108 / model_loader.py:13-20: models (g_clone starts as a
     copy of G), lazy-reg-rescaled optimiser settings, three Adam states, pl_mean, TrainingStep."""
     from .aster import AsterInferer
@@ -417,7 +423,7 @@ def build_trainer_state(cfg: Config, device, aster_ocr=None, seed: int = 0, proc
                                  max_char_number=cfg.max_char_number, image_dims=cfg.aster_image_dims)
     aster_ocr = aster_ocr.to(device)
     step = TrainingStep(G, D, aster_ocr, g_optimizer, ocr_optimizer, d_optimizer, cfg.g_opt.reg_interval,
-                        cfg.d_opt.reg_interval, pl_mean, cfg, process_group, use_graphs)
+                        cfg.d_opt.reg_interval, pl_mean, cfg, process_group, use_graphs, compute_dtype)
     # Replicas must start from IDENTICAL weights (same seed above) but draw INDEPENDENT z / z2 / mixing cut-off / noise /
     # dropout / pl_z / pl_noise afterwards, as MirroredStrategy's replicas do (training_step.py:147, latent_encoder.py:47-60,
     # noise.py:16-19): reseed every device generator per rank once the models exist.  The captured HIP graphs read the
