@@ -41,6 +41,11 @@ extern "C" {
 int tbg_version(void);
 const char *tbg_strerror(int code);
 
+/* HOST helper (no device work, `data` is a host pointer): CRC-32C (Castagnoli) of data[0..n) continuing from `crc`
+ * (0 to start) -- the checksum of TensorFlow's TensorBundle checkpoint files (tensorflow/core/lib/hash/crc32c.h), used
+ * by textboxgan_amd/tf_checkpoint.py to read/write the reference's checkpoint layout (models/model_loader.py:57-81). */
+unsigned int tbg_crc32c(const void *data, long long n, unsigned int crc);
+
 /* Fused epilogue shared by the conv / FIR / bias_act kernels.  For an accumulator value
  * `acc` at (sample b, channel m, pixel p):
  *   v   = acc * alpha * (out_scale ? out_scale[b*M + m] : 1)

@@ -1,0 +1,60 @@
+// Host-side helpers of libtbg_hip.so (no device code): CRC-32C for the TensorBundle checkpoint files
+// (textboxgan_amd/tf_checkpoint.py -- the counterpart of tensorflow/core/lib/hash/crc32c.cc, which TF also keeps native).
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+static uint32_t g_table[8][256];
+static bool g_table_ready = false;
+
+static void build_table() {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+    g_table[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t) g_table[t][i] = (g_table[t - 1][i] >> 8) ^ g_table[0][g_table[t - 1][i] & 0xFF];
+  g_table_ready = true;
+}
+
+// slicing-by-8 software path
+static uint32_t crc_sw(const uint8_t *p, size_t n, uint32_t c) {
+  if (!g_table_ready) build_table();
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    w ^= c;
+    c = g_table[7][w & 0xFF] ^ g_table[6][(w >> 8) & 0xFF] ^ g_table[5][(w >> 16) & 0xFF] ^ g_table[4][(w >> 24) & 0xFF] ^
+        g_table[3][(w >> 32) & 0xFF] ^ g_table[2][(w >> 40) & 0xFF] ^ g_table[1][(w >> 48) & 0xFF] ^ g_table[0][w >> 56];
+    p += 8; n -= 8;
+  }
+  while (n--) c = g_table[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return c;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) static uint32_t crc_hw(const uint8_t *p, size_t n, uint32_t c) {
+  uint64_t c64 = c;
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    c64 = __builtin_ia32_crc32di(c64, w);
+    p += 8; n -= 8;
+  }
+  c = (uint32_t)c64;
+  while (n--) c = __builtin_ia32_crc32qi(c, *p++);
+  return c;
+}
+#endif
+
+// CRC-32C (Castagnoli, reflected, init/xorout 0xFFFFFFFF) of data[0..n), continuing from `crc` (0 to start).
+extern "C" uint32_t tbg_crc32c(const void *data, long long n, uint32_t crc) {
+  if (!data || n <= 0) return crc;
+  const uint8_t *p = static_cast<const uint8_t *>(data);
+  uint32_t c = crc ^ 0xFFFFFFFFu;
+#if defined(__x86_64__)
+  if (__builtin_cpu_supports("sse4.2")) return crc_hw(p, (size_t)n, c) ^ 0xFFFFFFFFu;
+#endif
+  return crc_sw(p, (size_t)n, c) ^ 0xFFFFFFFFu;
+}
