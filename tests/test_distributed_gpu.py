@@ -1,6 +1,8 @@
-"""-m gpu: the data-parallel step with world_size 2 (two processes sharing cuda:0, gloo collectives --
-the same code path bench.py drives with RCCL): replicas stay bit-identical, losses are SUM-reduced,
-and the summed gradient equals the sum of the per-rank gradients."""
+"""-m gpu: the data-parallel step with world_size 2 (two processes; gloo collectives on one shared GPU, or RCCL when the
+box has two GPUs -- the same code path bench.py drives): replicas stay bit-identical, losses are SUM-reduced, and the
+exchanged flat gradient buffers equal the SUM of the per-replica gradients of the CPU oracle (each replica: its own
+shard, its own randomness, minibatch-std inside the replica, losses divided by the GLOBAL batch -- exactly what
+MirroredStrategy does in the reference, training_step.py:91-136,233-235)."""
 import os
 import socket
 
@@ -56,3 +58,110 @@ def test_two_rank_step_keeps_replicas_identical(dev, use_graphs):
     n = 5 if use_graphs else 2
     assert it0 == it1 == n and s0 == s1 == n
     assert all(abs(v) < 1e6 for v in l0)
+
+
+def _grad_worker(rank, world, port, backend, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from oracle import ref_model as M
+    from textboxgan_amd.config import small_config
+    from textboxgan_amd.training_step import build_trainer_state
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = small_config(4, num_replicas=world)
+    init = M.make_state(cfg, seed=0, bench_init=True)
+    st = build_trainer_state(cfg, dev, seed=0)
+    st["generator"].load_state_dict({k: v.clone() for k, v in init["G"].items()})
+    st["discriminator"].load_state_dict({k: v.clone() for k, v in init["D"].items()})
+    ts = st["training_step"]
+    assert ts.distributed and ts.d_cuts, "the bucketed D exchange must be active in a data-parallel run"
+    b = {k: v.to(dev) for k, v in M.make_batch(cfg, seed=1234, rank=rank).items()}
+    rand = M.make_rand(cfg, seed=99 + rank, with_pl=False)
+    rand = {k: ([t.to(dev) for t in v] if isinstance(v, list) else (v.to(dev) if torch.is_tensor(v) else v)) for k, v in rand.items()}
+    losses = ts.dist_train_step(b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False, 1e-4, rand=rand)
+    torch.cuda.synchronize()
+    cat = lambda views: torch.cat([v.reshape(-1) for v in views]).cpu()
+    q.put((rank, cat(ts.g_views), cat(ts.o_views), cat(ts.d_views),
+           [float(x) for x in losses[0]] + [float(x) for x in losses[1]] + [float(losses[2])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _exchange_vs_oracle(backend):
+    import torch.multiprocessing as mp
+    from oracle import ref_model as M
+    from textboxgan_amd.aster import AsterLikeOCR
+    from textboxgan_amd.config import small_config
+    world = 2
+    cfg = small_config(4, num_replicas=world)
+    ocr = AsterLikeOCR(max_steps=cfg.max_char_number)
+    sums, loss_sum = None, None
+    for rank in range(world):  # the oracle, replica by replica, from the same initial weights
+        st = M.make_state(cfg, seed=0, bench_init=True)
+        batch, rand = M.make_batch(cfg, seed=1234, rank=rank), M.make_rand(cfg, seed=99 + rank, with_pl=False)
+        losses, grads = M.training_step(st, cfg, batch["real_images"], batch["ocr_images"], batch["input_words"],
+                                        batch["ocr_labels"], False, False, 1e-4, rand, ocr.serve, return_grads=True)
+        flat = [float(x) for x in losses[0]] + [float(x) for x in losses[1]] + [float(losses[2])]
+        loss_sum = flat if loss_sum is None else [a + b for a, b in zip(loss_sum, flat)]
+        if sums is None:
+            sums = {k: {n: g.clone() for n, g in grads[k].items()} for k in ("g", "ocr", "d")}
+        else:
+            for k in ("g", "ocr", "d"):
+                for n, g in grads[k].items():
+                    sums[k][n] += g
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    [p.join(timeout=120) for p in procs]
+    l2 = lambda a, r: float((a.double() - r.double()).norm() / (r.double().norm() + 1e-30))
+    (_, g0, o0, d0, l0), (_, g1, o1, d1, l1) = res
+    assert torch.equal(g0, g1) and torch.equal(o0, o1) and torch.equal(d0, d1), "ranks hold different exchanged gradients"
+    # the oracle's gradient dicts, concatenated in the order of the product's flat buffers
+    from textboxgan_amd.training_step import build_trainer_state
+    names = build_trainer_state(cfg, torch.device("cpu"), seed=0)
+    gnames = [n for n in names["generator"]._flat.names if n.startswith(("latent_encoder.", "synthesis."))]
+    onames = [n for n in names["generator"]._flat.names if n.startswith(("synthesis.", "word_encoder."))]
+    dnames = names["discriminator"]._flat.names
+    cat = lambda d, order: torch.cat([d[n].reshape(-1) for n in order])
+    assert g0.numel() == cat(sums["g"], gnames).numel() and d0.numel() == cat(sums["d"], dnames).numel()
+    assert l2(g0, cat(sums["g"], gnames)) < 2e-3, "all-reduced G gradient != sum of the per-replica oracle gradients"
+    assert l2(o0, cat(sums["ocr"], onames)) < 1e-2
+    assert l2(d0, cat(sums["d"], dnames)) < 2e-3
+    for a, e in zip(l0, loss_sum):  # strategy.reduce(SUM) of the loss scalars
+        assert abs(a - e) <= 2e-4 * max(1.0, abs(e)), (l0, loss_sum)
+
+
+def test_exchanged_gradients_equal_sum_of_per_replica_oracle_gradients_gloo(dev):
+    _exchange_vs_oracle("gloo")
+
+
+def test_exchanged_gradients_equal_sum_of_per_replica_oracle_gradients_rccl(dev):
+    """the same over RCCL (backend "nccl" IS RCCL on ROCm), one process per GPU -- needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the driver's multi-GPU node); the gloo variant covers the logic on one GPU")
+    _exchange_vs_oracle("nccl")
+
+
+def test_bench_launcher_two_ranks_gloo_smoke(dev):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as the driver launches it, with both ranks
+    on one GPU and gloo collectives (TBG_BENCH_SINGLE_DEVICE / TBG_DIST_BACKEND): one JSON line, whole-job throughput."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TBG_DIST_BACKEND="gloo", TBG_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--no-roofline", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["scaling"] == "weak" and rec["value"] > 0

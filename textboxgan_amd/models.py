@@ -394,12 +394,19 @@ class Discriminator(nn.Module):
         self.last_dense = Dense(fm[-1], 1)
         self.last_bias = BiasAct(1, 1.0, "linear")
 
-    def forward(self, images, mode="fused"):
+    def forward(self, images, mode="fused", cuts=None):
+        """cuts: block indices k -- the activation ENTERING blocks[k] is returned too (``(scores, [h_k...])``), so that a
+        caller can run the backward pass in stages (deep layers first) and exchange each stage's gradients while the next
+        stage still computes (training_step.py: bucketed data-parallel all-reduce)."""
         x = self.initial_fromrgb(images.contiguous(), mode)
-        for block in self.blocks:
+        taps = []
+        for i, block in enumerate(self.blocks):
+            if cuts is not None and i in cuts:
+                taps.append(x)
             x = block(x, mode)
         x = self.last_block(x, mode)
-        return self.last_bias(self.last_dense(x))
+        scores = self.last_bias(self.last_dense(x))
+        return scores if cuts is None else (scores, taps)
 
 
 def mask_text_box(fake_images, input_words, char_width: int):

@@ -95,6 +95,28 @@ class TrainingStep:
         self.g_grad, self.g_views = gf.make_grad_buffer(*self.g_range)
         self.o_grad, self.o_views = gf.make_grad_buffer(*self.o_range)
         self.d_grad, self.d_views = df.make_grad_buffer(0, df.total)
+        # D's gradient exchange in BUCKETS, deepest layers first (SURVEY section 5: the reference hides one 62 MB all-reduce
+        # inside apply_gradients, training_step.py:233-235).  D's backward reaches the deep layers first: at the default
+        # cuts (5, 3) the blocks[5:] + head hold 74% of D's gradient bytes after ~8% of its backward FLOPs and blocks[3:5]
+        # another 20% after ~20%, so their all-reduces run under the backward of the high-resolution blocks, and only the
+        # last 6% of the bytes is exchanged after the pass.  Stage boundaries = activations entering blocks[cut].
+        nb = len(discriminator.blocks)
+        self.d_cuts = tuple(c for c in (5, 3) if 0 < c < nb) if self.distributed else ()
+        self.d_stages = self._d_stage_table(df)
+
+    def _d_stage_table(self, df):
+        """[(parameter list, views, flat slice)] per backward stage, deepest first; the slices tile d_grad."""
+        names = df.names
+        def first_index(prefix):
+            return next(i for i, n in enumerate(names) if n.startswith(prefix))
+        bounds = sorted([first_index(f"blocks.{c}.") for c in self.d_cuts]) + [len(names)]
+        stages, hi = [], len(names)
+        for lo in reversed([0] + bounds[:-1]):
+            b0 = df.offsets[lo]
+            b1 = df.offsets[hi] if hi < len(names) else df.total
+            stages.append((self.d_params[lo:hi], self.d_views[lo:hi], (b0, b1)))
+            hi = lo
+        return stages
 
     # ------------------------------------------------------------------------------------
     def dist_train_step(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg: bool, do_pl_reg: bool,
@@ -186,22 +208,31 @@ class TrainingStep:
             self.exchange.reduce_now((self.g_grad, self.o_grad, self.d_grad))
             graphs[1].replay()
             return fresh(outs)
-        # data-parallel: [fwd + g-pass] -> all-reduce(g) || [ocr-pass] -> all-reduce(ocr) || [d-pass] -> all-reduce(d) -> [Adam x3]
+        # data-parallel: [fwd + g-pass] -> all-reduce(g) || [ocr-pass] -> all-reduce(ocr) || [d stage 0 (deepest)] ->
+        # all-reduce(bucket 0) || [d stage 1] -> all-reduce(bucket 1) || ... -> [Adam x3]
         handles = []
-        for g, buf in zip(graphs[:3], (self.g_grad, self.o_grad, self.d_grad)):
+        for g, buf in zip(graphs[:-1], self._exchange_buffers(do_r1)):
             g.replay()
             handles.append(self.exchange.start(buf))  # ordered after the graph on this stream, runs on the RCCL stream
         for h in handles:
             GradExchange.finish(h)
-        graphs[3].replay()
+        graphs[-1].replay()
         return fresh(outs)
 
+    def _exchange_buffers(self, do_r1):
+        """the flat gradient slices exchanged after each gradient graph, in order."""
+        if self.d_cuts and not do_r1:
+            return [self.g_grad, self.o_grad] + [self.d_grad[b0:b1] for _, _, (b0, b1) in self.d_stages]
+        return [self.g_grad, self.o_grad, self.d_grad]
+
     def _capture_split(self, st, do_r1, do_pl):
-        """Capture the step as FOUR HIP graphs sharing one memory pool (the autograd state of the forward lives across
-        them, as in torch's make_graphed_callables): the three gradient all-reduces (training_step.py:233-235) are issued
-        between the graphs and overlap the next backward pass instead of sitting in front of the Adam updates."""
+        """Capture the step as SEVERAL HIP graphs sharing one memory pool (the autograd state of the forward lives across
+        them, as in torch's make_graphed_callables): [forward + g-pass] [ocr-pass] [d-pass stage 0 .. n-1] [3x Adam].  The
+        gradient all-reduces (training_step.py:233-235) are issued between the graphs and overlap the next backward graph
+        instead of sitting in front of the Adam updates; D's is bucketed by backward stage, deepest layers first."""
         import gc
-        graphs = [torch.cuda.CUDAGraph() for _ in range(4)]
+        n_grad = len(self._exchange_buffers(do_r1))
+        graphs = [torch.cuda.CUDAGraph() for _ in range(n_grad + 1)]
         pool = torch.cuda.graph_pool_handle()
         cap = torch.cuda.Stream()
         torch.cuda.synchronize()
@@ -220,11 +251,12 @@ class TrainingStep:
             try:
                 outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl, st["w"], {},
                                            None, boundary)
-                graphs[2].capture_end()
-                idx[0] = 3
-                graphs[3].capture_begin(pool=pool, capture_error_mode="thread_local")
+                assert idx[0] == n_grad - 1, "one capture boundary per exchanged gradient slice"
+                graphs[idx[0]].capture_end()
+                idx[0] = n_grad
+                graphs[n_grad].capture_begin(pool=pool, capture_error_mode="thread_local")
                 self._apply_updates()
-                graphs[3].capture_end()
+                graphs[n_grad].capture_end()
             except Exception:
                 try:
                     graphs[idx[0]].capture_end()  # leave capture mode before propagating
@@ -295,13 +327,21 @@ class TrainingStep:
                 # in front of the generator's ocr-pass backward; only d(ocr_loss)/d(fake_images) crosses back
                 (dfake_ocr,) = torch.autograd.grad(ocr_loss_w, fake_images, retain_graph=False)
 
-        fake_scores = D(fake_images)
+        staged = bool(self.d_cuts) and not do_r1_reg  # R1 steps (1 in 16) keep the single exchange: their D graph is second order
+        cuts = sorted(self.d_cuts) if staged else None
+        if staged:
+            fake_scores, fake_taps = D(fake_images, cuts=cuts)
+        else:
+            fake_scores = D(fake_images)
         g_loss = generator_loss(fake_scores, self.batch_size)
         pl_penalty = self._path_length_reg(input_words, rand) if do_pl_reg else zero
         reg_g_loss = g_loss + pl_penalty
 
         if do_r1_reg:
             real_scores, r1_penalty = self._r1_reg(real_images)
+        elif staged:
+            real_scores, real_taps = D(real_images, cuts=cuts)
+            r1_penalty = zero
         else:
             real_scores = D(real_images)
             r1_penalty = zero
@@ -344,12 +384,31 @@ class TrainingStep:
 
         ops.FLAGS.skip_image_grad = True
         try:
-            grads = torch.autograd.grad(reg_d_loss, self.d_params, allow_unused=True)
+            if not staged:
+                grads = torch.autograd.grad(reg_d_loss, self.d_params, allow_unused=True)
+                write_grads(self.d_views, grads)
+                if handles is not None:
+                    handles.append(self._all_reduce_async(self.d_grad))
+            else:
+                # staged backward, deepest layers first: stage i yields its parameters' gradients plus the gradients of the
+                # activations entering it (the "taps"), from which stage i+1 continues; each bucket's all-reduce is
+                # issued as soon as the stage has written it (eager: async handles; HIP graphs: a capture boundary)
+                outs, gouts = [reg_d_loss], None
+                for si, (params, views, (b0, b1)) in enumerate(self.d_stages):
+                    last = si == len(self.d_stages) - 1
+                    k = len(cuts) - 1 - si  # taps feeding this stage sit at cuts[k] (none for the last stage)
+                    taps = [] if last else [fake_taps[k], real_taps[k]]
+                    grads = torch.autograd.grad(outs, list(params) + taps, grad_outputs=gouts, retain_graph=not last,
+                                                allow_unused=True)
+                    write_grads(views, grads[:len(params)])
+                    if handles is not None:
+                        handles.append(self._all_reduce_async(self.d_grad[b0:b1]))
+                    if not last:
+                        outs, gouts = taps, list(grads[len(params):])
+                        if boundary is not None:
+                            boundary()
         finally:
             ops.FLAGS.skip_image_grad = False
-        write_grads(self.d_views, grads)
-        if handles is not None:
-            handles.append(self._all_reduce_async(self.d_grad))
 
         if self.overlap_ocr and not ocr_joined:
             main_stream.wait_stream(self._ocr_stream)  # join
@@ -360,9 +419,10 @@ class TrainingStep:
     def _apply_updates(self, handles=None):
         """three Adam updates in the reference's order (g, ocr, d)."""
         hs = list(handles) if handles else [None, None, None]
-        for h, opt, buf in zip(hs, (self.g_optimizer, self.ocr_optimizer, self.d_optimizer),
-                               (self.g_grad, self.o_grad, self.d_grad)):
-            GradExchange.finish(h)
+        for i, (opt, buf) in enumerate(zip((self.g_optimizer, self.ocr_optimizer, self.d_optimizer),
+                                           (self.g_grad, self.o_grad, self.d_grad))):
+            for h in (hs[i:i + 1] if i < 2 else hs[2:]):  # D's exchange may be several bucket handles
+                GradExchange.finish(h)
             opt.apply_gradients(buf)
 
     # ------------------------------------------------------------------------------------
