@@ -84,7 +84,7 @@ def _grad_worker(rank, world, port, backend, q):
     rand = {k: ([t.to(dev) for t in v] if isinstance(v, list) else (v.to(dev) if torch.is_tensor(v) else v)) for k, v in rand.items()}
     losses = ts.dist_train_step(b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False, 1e-4, rand=rand)
     torch.cuda.synchronize()
-    cat = lambda views: torch.cat([v.reshape(-1) for v in views]).cpu()
+    cat = lambda views: torch.cat([v.reshape(-1) for v in views]).cpu().numpy()  # numpy: pickled by value (no shm fd)
     q.put((rank, cat(ts.g_views), cat(ts.o_views), cat(ts.d_views),
            [float(x) for x in losses[0]] + [float(x) for x in losses[1]] + [float(losses[2])]))
     dist.barrier()
@@ -117,9 +117,10 @@ def _exchange_vs_oracle(backend):
     q, port = ctx.Queue(), _free_port()
     procs = [ctx.Process(target=_grad_worker, args=(r, world, port, backend, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = sorted(q.get(timeout=600) for _ in range(world))
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
     [p.join(timeout=120) for p in procs]
     l2 = lambda a, r: float((a.double() - r.double()).norm() / (r.double().norm() + 1e-30))
+    res = [(r, torch.from_numpy(g), torch.from_numpy(o), torch.from_numpy(d), l) for r, g, o, d, l in res]
     (_, g0, o0, d0, l0), (_, g1, o1, d1, l1) = res
     assert torch.equal(g0, g1) and torch.equal(o0, o1) and torch.equal(d0, d1), "ranks hold different exchanged gradients"
     # the oracle's gradient dicts, concatenated in the order of the product's flat buffers

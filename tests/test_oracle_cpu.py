@@ -272,3 +272,29 @@ def test_hand_evaluated_literal_vectors_pin_the_oracle():
     th = {"p": torch.tensor([1.0], dtype=torch.float64)}
     opt.apply(th, ["p"], [torch.tensor([0.5], dtype=torch.float64)])
     assert abs(float(th["p"]) - (1.0 - 0.0002 * 0.5 / (0.05 + 1e-8))) < 1e-12
+
+
+def test_projector_oracle_known_answers():
+    """oracle/ref_projector.py pinned by hand-computable facts (projector.py:65-83, lpips_tensorflow.py:9-18,41-71)."""
+    from oracle import ref_projector as RP
+    # learning-rate schedule: warm-up over the first 5%, flat, cosine ramp-down over the last 25%
+    assert abs(RP.get_lr(0.025) - 0.05) < 1e-12 and abs(RP.get_lr(0.05) - 0.1) < 1e-12 and abs(RP.get_lr(0.5) - 0.1) < 1e-12
+    assert abs(RP.get_lr(0.9) - 0.1 * (0.5 - 0.5 * math.cos(0.4 * math.pi))) < 1e-12 and RP.get_lr(1.0) == 0.0
+    # preprocessing: grey 127.5 -> 0 -> (0 - shift) / scale
+    img = torch.full((1, 2, 2, 3), 127.5, dtype=torch.float64)
+    np.testing.assert_allclose(RP.image_preprocess(img)[0, 0, 0].numpy(), [0.030 / 0.458, 0.088 / 0.448, 0.188 / 0.450], rtol=1e-12)
+    # the metric: zero on identical images, symmetric, and for ONE tap = mean_p sum_c lin_c (a_c/|a| - b_c/|b|)^2
+    from textboxgan_amd.projector import LPIPS
+    P = {k: v.double() for k, v in LPIPS().state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(1, 32, 64, 3, generator=g, dtype=torch.float64) * 255
+    b = torch.rand(1, 32, 64, 3, generator=g, dtype=torch.float64) * 255
+    assert float(RP.lpips(P, a, a)) == 0.0
+    assert abs(float(RP.lpips(P, a, b)) - float(RP.lpips(P, b, a))) < 1e-12 and float(RP.lpips(P, a, b)) > 0
+    fa, fb = RP.vgg_features(P, a), RP.vgg_features(P, b)
+    assert [f.shape[1:] for f in fa] == [(64, 32, 64), (128, 16, 32), (256, 8, 16), (512, 4, 8), (512, 2, 4)]
+    manual = 0.0
+    for i, (x, y) in enumerate(zip(fa, fb)):
+        xn, yn = x / x.norm(dim=1, keepdim=True), y / y.norm(dim=1, keepdim=True)
+        manual += float((((xn - yn) ** 2) * P[f"lins.{i}.kernel"].reshape(1, -1, 1, 1)).sum(dim=1).mean())
+    assert abs(manual - float(RP.lpips(P, a, b))) < 1e-10

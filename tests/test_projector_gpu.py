@@ -1,0 +1,92 @@
+"""-m gpu: projector (BASELINE configs[4]) on the HIP path vs the CPU restatement oracle/ref_projector.py: LPIPS forward +
+image gradient, three projector steps with injected randomness, and a full-width smoke run."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model as M, ref_projector as RP
+from textboxgan_amd.config import Config, small_config
+
+pytestmark = pytest.mark.gpu
+
+
+def l2_err(a, ref):
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return float((a - ref).norm() / (ref.norm() + 1e-30))
+
+
+def test_lpips_forward_and_image_gradient(dev):
+    from textboxgan_amd.projector import LPIPS
+    lp = LPIPS()
+    P = {k: v.clone() for k, v in lp.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    target = torch.randint(0, 256, (1, 64, 160, 3), generator=g).float()
+    gen = (torch.rand(1, 64, 160, 3, generator=g) * 255.0).requires_grad_(True)
+    ref = RP.lpips(P, target, gen)
+    (gref,) = torch.autograd.grad(ref, gen)
+    lpd = lp.to(dev)
+    gend = gen.detach().to(dev).requires_grad_(True)
+    out = lpd(target.to(dev), gend)
+    (gd,) = torch.autograd.grad(out, gend)
+    assert out.dim() == 0 and abs(float(out) - float(ref)) <= 2e-4 * abs(float(ref))
+    assert l2_err(gd, gref) < 2e-3
+    assert float(lpd(target.to(dev), target.to(dev))) == 0.0  # identical images
+    with pytest.raises(RuntimeError):
+        lp.cpu()(target, target)  # no CPU path in the product
+
+
+def _rand(cfg, steps, n_latent, seed):
+    g = np.random.default_rng(seed)
+    nrm = lambda *s: torch.from_numpy(g.standard_normal(size=s).astype(np.float32))
+    res = cfg.generator_resolutions[1:]
+    return dict(z_latent=nrm(n_latent, cfg.z_dim), w_noise=[nrm(1, cfg.style_dim) for _ in range(steps)],
+                noises=[[nrm(1, 1, h, w) for (h, w) in res for _ in range(2)] for _ in range(steps)])
+
+
+def test_projector_steps_match_oracle(dev):
+    from textboxgan_amd.aster import AsterInferer, AsterLikeOCR, AsterLikeOCRHip
+    from textboxgan_amd.models import Generator
+    from textboxgan_amd.projector import LPIPS, Projector
+    cfg = small_config(4)
+    G = M.init_generator(cfg, seed=3, bench_init=True)
+    gen = Generator(cfg)
+    gen.load_state_dict({k: v.clone() for k, v in G.items()})
+    gen = gen.to(dev)
+    lp = LPIPS()
+    LP = {k: v.clone() for k, v in lp.state_dict().items()}
+    text, steps = "Hello", 3
+    rand = _rand(cfg, steps, 64, 11)
+    tg = torch.Generator().manual_seed(9)
+    target = torch.randint(0, 256, (1, cfg.char_height, cfg.char_width * len(text), 3), generator=tg).float()
+    ocr_cpu = AsterLikeOCR(max_steps=cfg.max_char_number)
+    w_ref, loss_ref = RP.project(G, LP, cfg, text, target, ocr_cpu.serve, rand, steps)
+    w0_ref = RP.compute_w_latent(G, cfg, rand["z_latent"])[1]
+
+    proj = Projector(text, gen, AsterInferer(model=AsterLikeOCRHip(max_steps=cfg.max_char_number)).to(dev), cfg, lp, dev)
+    assert abs(proj._get_lr(0.05) - 0.1) < 1e-12 and abs(proj._get_lr(0.025) - 0.05) < 1e-12 and proj._get_lr(1.0) == 0.0
+    w, saved, losses = proj.main(target, num_steps=steps, rand={k: v for k, v in rand.items()})
+    for a, e in zip(losses, loss_ref):
+        assert abs(float(a) - e) <= 1e-3 * max(1.0, abs(e)), (losses, loss_ref)
+    upd, upd_ref = (w.cpu() - w0_ref), (w_ref - w0_ref)
+    assert float(upd_ref.norm()) > 0 and l2_err(upd, upd_ref) < 5e-2
+    assert saved == []  # save_and_log_frequency = 100
+
+
+def test_projector_full_width_smoke_and_chosen_words(dev):
+    from textboxgan_amd.aster import AsterInferer, AsterLikeOCRHip
+    from textboxgan_amd.models import Generator
+    from textboxgan_amd.projector import Projector
+    from textboxgan_amd.validation_step import generate_chosen_words
+    cfg = Config(batch_size_per_gpu=4)
+    torch.manual_seed(0)
+    gen = Generator(cfg).to(dev)
+    proj = Projector("GAN", gen, AsterInferer(model=AsterLikeOCRHip()).to(dev), cfg, device=dev)
+    proj.n_mean_latent = 256
+    target = torch.randint(0, 256, (1, 64, 96, 3)).float()
+    w, _, losses = proj.main(target, num_steps=2)
+    assert w.shape == (1, cfg.style_dim) and all(math.isfinite(float(l)) for l in losses)
+    imgs = generate_chosen_words(gen, ["GAN"], cfg, w_latents=w)
+    assert imgs[0].shape == (64, 96, 3) and imgs[0].dtype == np.uint8

@@ -609,7 +609,9 @@ class _ModConvFused(torch.autograd.Function):
         ds = torch.zeros_like(s)
         dx = _bwd_data_launch(dpre, w, g, in_scale=d, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds))
         ds, dwsq = _demod_backward(pdy, d, s, wsq, ds)
-        dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef, x_scale=s, dy_scale=d, add=(w, dwsq, -coef * coef))
+        dw = None
+        if ctx.needs_input_grad[1]:  # frozen generator (projector.py: only the latent is optimised): no filter gradient
+            dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef, x_scale=s, dy_scale=d, add=(w, dwsq, -coef * coef))
         return dx, dw, ds, None, dstrength, db
 
 
@@ -652,11 +654,13 @@ class _ModConvUpFused(torch.autograd.Function):
         dx = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0),
                         epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds))
         ds, dwsq = _demod_backward(pdy, d, s, wsq, ds)
-        dw = torch.empty_like(w)
-        T = KH * KW
-        # dW_t[t][i][o] = sum x*s . dy_up shifted;  w = flip(w_t)  -> write tap t at T-1-t
-        wgrad_raw(x, dy_up, KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O,
-                  add=(w, dwsq, -coef * coef))
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            T = KH * KW
+            # dW_t[t][i][o] = sum x*s . dy_up shifted;  w = flip(w_t)  -> write tap t at T-1-t
+            wgrad_raw(x, dy_up, KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O,
+                      add=(w, dwsq, -coef * coef))
         return dx, dw, ds, None, dstrength, db
 
 
@@ -685,7 +689,7 @@ class _ToRGBFused(torch.autograd.Function):
         dx, G = rgb_backproject_raw(x, dy, w, s, ctx.coef, want_dx=True, want_G=True)  # G[b,c,o] = sum_p x*dy
         w2 = w.reshape(I, O)
         ds = ctx.coef * (G * w2[None]).sum(dim=2)
-        dw = (ctx.coef * (G * s[:, :, None]).sum(dim=0)).reshape(w.shape)
+        dw = (ctx.coef * (G * s[:, :, None]).sum(dim=0)).reshape(w.shape) if ctx.needs_input_grad[1] else None
         return dx, dw, ds, db, (dy if ctx.has_skip else None)
 
 

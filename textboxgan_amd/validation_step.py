@@ -42,10 +42,19 @@ class ValidationStep:
 
 @torch.no_grad()
 def generate_chosen_words(generator: Generator, words: List[str], cfg: Config = default_cfg,
-                          z: Optional[torch.Tensor] = None, truncation_psi: float = 1.0) -> List[np.ndarray]:
-    """-> one uint8 HxWx3 array per word, width = char_width * len(word) (infer.py:84-100)."""
+                          z: Optional[torch.Tensor] = None, truncation_psi: float = 1.0,
+                          w_latents: Optional[torch.Tensor] = None) -> List[np.ndarray]:
+    """-> one uint8 HxWx3 array per word, width = char_width * len(word) (infer.py:37-100).
+    w_latents [1, style_dim]: a style vector (e.g. from the Projector) instead of a random z (infer.py:60-71)."""
     device = next(generator.parameters()).device
     tokens = torch.from_numpy(string_to_main_int_sequence(words, cfg.max_char_number)).to(device)
+    if w_latents is not None:
+        with torch.no_grad():
+            we = generator.word_encoder(tokens, batch_size=len(words))
+            styles = w_latents.to(device).reshape(1, 1, -1).expand(len(words), generator.n_style, -1).contiguous()
+            img = generator.synthesis(we, styles)
+        u8 = generator_output_to_uint8(img).cpu().numpy()
+        return [u8[i, :, : cfg.char_width * min(len(w), cfg.max_char_number)] for i, w in enumerate(words)]
     if z is None:
         z = torch.randn(1, cfg.z_dim, device=device)
     z = z.expand(len(words), -1).contiguous()  # the same style for every word (infer.py:72-76)
