@@ -225,3 +225,36 @@ def test_checkpoint_manager_keeps_five(tmp_path):
     lines = open(os.path.join(d, "checkpoint")).read().splitlines()
     assert lines[0] == 'model_checkpoint_path: "ckpt-70"' and len(lines) == 6
     assert int(T.read_bundle(os.path.join(d, "ckpt-70"), ["save_counter" + T.VAR_SUFFIX])["save_counter" + T.VAR_SUFFIX]) == 7
+
+
+def test_aster_weight_import_from_a_savedmodel_variables_bundle(tmp_path):
+    """AsterLikeOCR.load_weights_tf reads ``<saved_model>/variables/variables.{index,data-*}`` without TensorFlow and
+    converts the TF layouts (HWIO conv, [in,out] dense, fused LSTM kernel with gate order i,j,f,o)."""
+    from textboxgan_amd.aster import AsterLikeOCR
+    net = AsterLikeOCR(max_steps=8)
+    g = np.random.default_rng(0)
+    H = net.hidden
+    conv = g.standard_normal((3, 3, 3, 32)).astype(np.float32)               # stem conv, HWIO
+    dense = g.standard_normal((H, net.num_classes)).astype(np.float32)        # Predictor/dense/kernel [in, out]
+    bias = g.standard_normal((net.num_classes,)).astype(np.float32)
+    n_in = net.cell.weight_ih.shape[1]
+    kernel = g.standard_normal((n_in + H, 4 * H)).astype(np.float32)          # Predictor/lstm_cell/kernel
+    sm = tmp_path / "aster_weights"
+    os.makedirs(sm / "variables")
+    T.write_bundle(str(sm / "variables" / "variables"), {
+        "Forward/Predictor/dense/kernel" + T.VAR_SUFFIX: dense, "Forward/Predictor/dense/bias" + T.VAR_SUFFIX: bias,
+        "Forward/Predictor/lstm_cell/kernel" + T.VAR_SUFFIX: kernel, "FeatureExtractor/stem/kernel" + T.VAR_SUFFIX: conv})
+    listed = AsterLikeOCR.list_tf_variables(str(sm))
+    assert listed["Forward/Predictor/dense/kernel"] == (H, net.num_classes) and len(listed) == 4
+    missing = net.load_weights_tf(str(sm), {
+        "stem.conv.weight": "FeatureExtractor/stem/kernel", "out.weight": "Forward/Predictor/dense/kernel",
+        "out.bias": "Forward/Predictor/dense/bias", "cell.weight_ih": ("Forward/Predictor/lstm_cell/kernel", "lstm_kernel")})
+    assert missing == []
+    assert torch.equal(net.stem.conv.weight, torch.from_numpy(conv).permute(3, 2, 0, 1))
+    assert torch.equal(net.out.weight, torch.from_numpy(dense).t()) and torch.equal(net.out.bias, torch.from_numpy(bias))
+    i, j, f, o = np.split(kernel, 4, axis=1)
+    torch_order = np.concatenate([i, f, j, o], axis=1)                          # torch gates: i, f, g(=j), o
+    assert torch.equal(net.cell.weight_ih, torch.from_numpy(torch_order[:n_in].T.copy()))
+    assert torch.equal(net.cell.weight_hh, torch.from_numpy(torch_order[n_in:].T.copy()))
+    with pytest.raises(KeyError):
+        net.load_weights_tf(str(sm), {"out.bias": "no/such/variable"})

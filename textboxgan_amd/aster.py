@@ -257,6 +257,76 @@ class AsterLikeOCR(nn.Module):
                 sd[k].copy_(a.reshape(sd[k].shape))
         self._invalidate()
 
+    # ---- real-weight import.  The ASTER SavedModel (cfg.aster_weights, aster_inferer.py:24-26) and
+    # the TF1 checkpoint it was converted from (weigths_tf1_to_tf2.py) store their variables as TensorBundle files
+    # (``<dir>/variables/variables.index`` + ``.data-*``, or a name-based ``model.ckpt``): both are read WITHOUT
+    # TensorFlow by textboxgan_amd/tf_checkpoint.py.  Which variable feeds which layer of this stand-in cannot be
+    # derived here (the graph is absent: parity unpinned), so the caller supplies ``name_map``: module parameter name ->
+    # checkpoint variable name (after the renames of weigths_tf1_to_tf2.py:3-19, listed by list_tf_variables).
+    @staticmethod
+    def list_tf_variables(path: str):
+        """{variable name: shape} of a SavedModel directory or a checkpoint prefix."""
+        from . import tf_checkpoint as T
+        import os
+        prefix = os.path.join(path, "variables", "variables") if os.path.isdir(path) else path
+        _, entries = T.read_bundle_index(prefix)
+        strip = lambda k: k[: -len(T.VAR_SUFFIX)] if k.endswith(T.VAR_SUFFIX) else k
+        return {strip(k): e.shape for k, e in entries.items() if k != T.OBJECT_GRAPH_KEY}
+
+    @staticmethod
+    def tf_to_torch_layout(a: np.ndarray, kind: str, hidden: int = 0) -> np.ndarray:
+        """TF variable -> the layout of the matching torch parameter.
+        "conv"  HWIO [kh,kw,I,O] -> OIHW;   "dense" [in,out] -> [out,in];   "same": unchanged;
+        "lstm_kernel" [in+hidden, 4*hidden] with TF gate order (i, j, f, o) -> (weight_ih [4h,in], weight_hh [4h,hidden]) in
+        torch order (i, f, g, o);   "lstm_bias" [4h] (i, j, f, o) -> [4h] (i, f, g, o) (TF's forget_bias is NOT added here)."""
+        if kind == "conv":
+            return np.ascontiguousarray(a.transpose(3, 2, 0, 1))
+        if kind == "dense":
+            return np.ascontiguousarray(a.T)
+        if kind == "same":
+            return a
+        if kind in ("lstm_kernel", "lstm_bias"):
+            h = hidden or a.shape[-1] // 4
+            i, j, f, o = np.split(a, 4, axis=-1)
+            re = np.concatenate([i, f, j, o], axis=-1)
+            if kind == "lstm_bias":
+                return re
+            n_in = a.shape[0] - h
+            return np.ascontiguousarray(re[:n_in].T), np.ascontiguousarray(re[n_in:].T)
+        raise ValueError(kind)
+
+    def load_weights_tf(self, path: str, name_map: dict, strict: bool = True):
+        """Import variables of a SavedModel directory / checkpoint prefix.  name_map: parameter name -> variable name or
+        (variable name, kind) with kind as in tf_to_torch_layout (default: "conv" for 4-D, "dense" for 2-D, else "same").
+        An LSTM's fused kernel maps from its ``weight_ih`` name and fills the matching ``weight_hh`` too."""
+        from . import tf_checkpoint as T
+        import os
+        prefix = os.path.join(path, "variables", "variables") if os.path.isdir(path) else path
+        _, entries = T.read_bundle_index(prefix)
+        key_of = {}
+        for k in entries:
+            key_of[k[: -len(T.VAR_SUFFIX)] if k.endswith(T.VAR_SUFFIX) else k] = k
+        sd = self.state_dict()
+        missing = []
+        with torch.no_grad():
+            for pname, spec in name_map.items():
+                vname, kind = spec if isinstance(spec, tuple) else (spec, None)
+                if vname not in key_of:
+                    missing.append(vname)
+                    continue
+                a = T.read_bundle(prefix, [key_of[vname]])[key_of[vname]]
+                kind = kind or ("conv" if a.ndim == 4 else "dense" if a.ndim == 2 else "same")
+                conv = self.tf_to_torch_layout(a, kind, self.hidden)
+                if kind == "lstm_kernel":
+                    sd[pname].copy_(torch.from_numpy(conv[0]))
+                    sd[pname.replace("weight_ih", "weight_hh")].copy_(torch.from_numpy(conv[1]))
+                else:
+                    sd[pname].copy_(torch.from_numpy(np.ascontiguousarray(conv)).reshape(sd[pname].shape))
+        if missing and strict:
+            raise KeyError(f"variables not found in {path}: {missing[:5]}")
+        self._invalidate()
+        return missing
+
     def _invalidate(self):
         pass
 

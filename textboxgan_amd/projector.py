@@ -167,6 +167,7 @@ class Projector:
         """projector.py:85-103: mean style of n_mean_latent random latents and its scalar spread."""
         if z_latent is None:
             z_latent = torch.randn(self.n_mean_latent, self.cfg.z_dim, device=self.device)
+        z_latent = z_latent.to(self.device)
         w_latent = self.generator.latent_encoder(z_latent, training=False)[:, 1, :]
         w_mean = w_latent.mean(dim=0, keepdim=True)
         w_std = ((w_latent - w_mean).square().sum() / z_latent.shape[0]).sqrt()
