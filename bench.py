@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="SURVEY 8(d) protocol instead of the bounded sample: batch 16, 3 warm-up + 10 timed steps at all "
                          "cores, plus a batch-4 1+3-step run at 8 threads (takes ~15 min of host time)")
+    ap.add_argument("--tiny-ocr", action="store_true",
+                    help="profiling aid: run the MAIN loop with the OCR network replaced by the trivial stand-in (the "
+                         "G + D part of the step alone); the printed line is then not the BASELINE metric")
     ap.add_argument("--no-ocr-excluded", action="store_true",
                     help="skip the second timed loop that replaces the (guessed) OCR network by a trivial stand-in")
     ap.add_argument("--no-roofline", action="store_true")
@@ -239,7 +242,12 @@ def main():
     from textboxgan_amd.training_step import build_trainer_state
 
     cfg = Config(batch_size_per_gpu=args.batch, num_replicas=world)
-    state = build_trainer_state(cfg, device, seed=0, use_graphs=not args.no_graphs,  # identical replicas on every rank
+    tiny = None
+    if args.tiny_ocr:
+        from textboxgan_amd.aster import AsterInferer
+        tiny = AsterInferer(model=_TinyOCR(cfg.max_char_number))
+        args.no_ocr_excluded = True
+    state = build_trainer_state(cfg, device, aster_ocr=tiny, seed=0, use_graphs=not args.no_graphs,  # identical replicas
                                 compute_dtype=args.dtype)
     bench_init_(state)
     batch = synthetic_batch(cfg, device, 1234 + rank)
@@ -281,7 +289,8 @@ def main():
     if rank == 0:
         value = args.batch * world * args.steps / dt
         out = {
-            "metric": "text-boxes/sec (G+D+OCR training_step)", "value": round(value, 2), "unit": "text-boxes/s",
+            "metric": "text-boxes/sec (G+D+OCR training_step)" + (" [OCR NETWORK EXCLUDED: --tiny-ocr]" if args.tiny_ocr else ""),
+            "value": round(value, 2), "unit": "text-boxes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"training_step G+D+OCR, bs={args.batch}/GPU, 64x256 boxes, max_char_number=8, " +
