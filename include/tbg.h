@@ -201,6 +201,17 @@ int tbg_conv2d_wgrad_bf16(const tbg_wgrad_desc *d, const float *S, const float *
                           long long workspace_bytes, void *stream);
 int tbg_conv2d_wgrad_bf16_kernel_name(const tbg_wgrad_desc *d, char *buf, int n);
 
+/* Multi-tensor filter packing: items_dev is a DEVICE array of n_items descriptors; item k is packed exactly as
+ * tbg_weight_pack_f32 (bf16 = 0) / tbg_weight_pack_bf16 (bf16 = 1) would pack (src, dst, T, I, O, transpose, flip).
+ * One launch for all filters of a model (the training step refreshes its packed filters once per step). */
+typedef struct tbg_pack_item {
+  const float *src; /* HWIO parameter [T][I][O] */
+  void *dst;        /* packed filter, 16-byte aligned */
+  int T, I, O;
+  int transpose, flip, bf16;
+} tbg_pack_item;
+int tbg_weight_pack_multi(const tbg_pack_item *items_dev, int n_items, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * One time step of a frozen (bi)directional LSTM layer, pointwise part for all directions in one launch -- the
  * recurrent encoder of the OCR branch (aster_inferer.py:28-190 runs the ASTER SavedModel: 2x BiLSTM).  The step's

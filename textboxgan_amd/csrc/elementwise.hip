@@ -325,6 +325,46 @@ extern "C" int tbg_weight_pack_bf16(const float *src, void *dst, int T, int I, i
   return TBG_OK;
 }
 
+// Multi-tensor form: ONE launch packs every filter of a model (both orientations, either format) from a device table
+// -- the training step refreshes all its packed filters at the start of a step instead of ~140 small launches.
+__global__ __launch_bounds__(256) void weight_pack_multi_kernel(const tbg_pack_item *__restrict__ items) {
+  const tbg_pack_item it = items[blockIdx.y];
+  const int C = it.transpose ? it.O : it.I, M = it.transpose ? it.I : it.O;
+  const int KP = it.bf16 ? 8 : 4;
+  const int CU = (C + KP - 1) / KP;
+  const long long units = (long long)it.T * CU * M;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+    const int m = (int)(u % M);
+    const long long r = u / M;
+    const int cu = (int)(r % CU), t = (int)(r / CU);
+    const int td = it.flip ? it.T - 1 - t : t;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = KP * cu + e;
+      const int i = it.transpose ? m : c, o = it.transpose ? c : m;
+      v[e] = (e < KP && c < C) ? it.src[((size_t)t * it.I + i) * it.O + o] : 0.f;
+    }
+    const size_t d = ((size_t)td * CU + cu) * M + m;
+    if (it.bf16) {
+      tbg_bf16x8 b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b[e] = (__bf16)v[e];
+      reinterpret_cast<tbg_bf16x8 *>(it.dst)[d] = b;
+    } else {
+      reinterpret_cast<float4 *>(it.dst)[d] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+extern "C" int tbg_weight_pack_multi(const tbg_pack_item *items_dev, int n_items, void *stream) {
+  if (!items_dev || n_items < 1) return TBG_EINVAL;
+  if (n_items > 65535) return TBG_ERANGE;
+  hipLaunchKernelGGL(weight_pack_multi_kernel, dim3(64, n_items), dim3(256), 0, tbg_stream(stream), items_dev);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
 // ============================================================================================
 // Adam (Keras / ResourceApplyAdam semantics) and EMA lerp over flat buffers
 // ============================================================================================

@@ -21,7 +21,7 @@ SQRT2 = 1.4142135623730951
 
 EXPORTS = [
     "tbg_version", "tbg_strerror", "tbg_crc32c", "tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_upfirdn2d_sep_f32", "tbg_conv2d_f32",
-    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_conv2d_kernel_name", "tbg_conv2d_wgrad_kernel_name", "tbg_weight_pack_bf16_bytes", "tbg_weight_pack_bf16", "tbg_conv2d_bf16", "tbg_conv2d_bf16_kernel_name", "tbg_conv2d_wgrad_bf16", "tbg_conv2d_wgrad_bf16_kernel_name", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_attn_ctx_fwd_f32", "tbg_attn_ctx_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
+    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_conv2d_kernel_name", "tbg_conv2d_wgrad_kernel_name", "tbg_weight_pack_bf16_bytes", "tbg_weight_pack_bf16", "tbg_weight_pack_multi", "tbg_conv2d_bf16", "tbg_conv2d_bf16_kernel_name", "tbg_conv2d_wgrad_bf16", "tbg_conv2d_wgrad_bf16_kernel_name", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_attn_ctx_fwd_f32", "tbg_attn_ctx_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
     "tbg_bias_act_bwd_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -34,6 +34,11 @@ class Epilogue(C.Structure):
     _fields_ = [("out_scale", C.c_void_p), ("bias", C.c_void_p), ("noise", C.c_void_p), ("strength", C.c_void_p),
                 ("residual", C.c_void_p), ("dot_aux", C.c_void_p), ("dot_out", C.c_void_p), ("alpha", C.c_float), ("bias_mul", C.c_float), ("slope", C.c_float),
                 ("gain", C.c_float), ("res_scale", C.c_float), ("act", C.c_int), ("res_first", C.c_int)]
+
+
+class PackItem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("T", C.c_int), ("I", C.c_int), ("O", C.c_int),
+                ("transpose", C.c_int), ("flip", C.c_int), ("bf16", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -83,6 +88,7 @@ def lib():
         l.tbg_conv2d_bf16.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(Epilogue), vp]
         l.tbg_conv2d_wgrad_bf16.argtypes = [C.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, vp, cf, vp, ll, vp]
         l.tbg_weight_pack_bf16.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+        l.tbg_weight_pack_multi.argtypes = [vp, ci, vp]
         l.tbg_weight_pack_bf16_bytes.argtypes = [ci, ci, ci, ci]
         l.tbg_weight_pack_bf16_bytes.restype = C.c_longlong
         l.tbg_conv2d_wgrad_kernel_name.argtypes = [C.POINTER(WgradDesc), C.c_char_p, ci]

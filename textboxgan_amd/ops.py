@@ -305,6 +305,79 @@ class PackedFilter(NamedTuple):
 
 
 _PACK_STEP: Optional[dict] = None  # live only inside filter_cache(): weights are constant within one step's passes
+_PACK_STORE: Optional["PackedStore"] = None  # live only inside PackedStore.scope(): persistent packs of a training step
+
+
+class PackedStore:
+    """Persistent packed filters of ONE training step object, refreshed by ONE multi-tensor launch per step
+    (tbg_weight_pack_multi) instead of ~140 small pack launches.
+
+    Contract: the owner calls ``refresh()`` at the START of every step (after the previous optimiser update, before the
+    forward) and keeps the weights constant until the step's backward passes are done -- exactly the lifetime of
+    ``filter_cache()``.  Inside ``scope()`` a ``pack_filter`` of a live parameter returns its persistent pack; the first time a
+    (parameter, orientation, format) is seen it is registered and packed on the spot (so the step that discovers it is
+    correct too) and joins the table for the following steps.  Nothing is served outside ``scope()``, so code that changes
+    weights without going through the owner (load_state_dict, tests) can never meet a stale pack."""
+
+    def __init__(self):
+        self.items = {}        # key -> (PackedFilter, PackItem fields)
+        self._table = None     # device uint8 tensor holding the tbg_pack_item array
+        self._n = 0
+        self._keep = []        # superseded tables: HIP graphs captured earlier still read them
+        self._fresh = False    # set by refresh(), cleared when the scope ends
+
+    def scope(self):
+        store = self
+
+        class _Scope:
+            def __enter__(self_):
+                global _PACK_STORE
+                self_._outer, _PACK_STORE = _PACK_STORE, store
+                return store
+
+            def __exit__(self_, *exc):
+                global _PACK_STORE
+                _PACK_STORE = self_._outer
+                store._fresh = False
+                # a step that discovered new filters (always an EAGER step: get() never registers during capture) rebuilds the
+                # device table here, outside any capture, so that refresh() never has to copy from the host inside one
+                if store.items and store._n != len(store.items) and not torch.cuda.is_current_stream_capturing():
+                    store._build_table()
+                return False
+        return _Scope()
+
+    def _build_table(self):
+        arr = (N.PackItem * len(self.items))()
+        for k, (pf, f) in enumerate(self.items.values()):
+            arr[k] = N.PackItem(*f)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        dev = next(iter(self.items.values()))[0].data.device
+        if self._table is not None:
+            self._keep.append(self._table)
+        self._table, self._n = host.to(dev), len(self.items)
+
+    def refresh(self):
+        """pack every registered filter from the current weights (one launch); call before the step's forward."""
+        if self.items:
+            if self._table is None:
+                self._build_table()
+            N.check(N.lib().tbg_weight_pack_multi(self._table.data_ptr(), self._n, N.stream()), "tbg_weight_pack_multi")
+        self._fresh = True
+
+    def get(self, w, T, I, O, transpose, flip, bf16):
+        if not self._fresh:
+            return None
+        key = (w.data_ptr(), T, I, O, bool(transpose), bool(flip), bool(bf16))
+        hit = self.items.get(key)
+        if hit is not None:
+            # in the table since an earlier step -> refreshed this step (entries added after this step's refresh carry
+            # their own on-the-spot pack, see below)
+            return hit[0]
+        if torch.cuda.is_current_stream_capturing():
+            return None  # never grow the table while a graph is being captured: the caller packs on demand
+        pf = _pack_now(w, T, I, O, transpose, flip, bf16)
+        self.items[key] = (pf, (w.data_ptr(), pf.data.data_ptr(), T, I, O, int(transpose), int(flip), int(bf16)))
+        return pf
 
 
 class filter_cache:
@@ -338,7 +411,17 @@ def pack_filter(w: torch.Tensor, transpose: bool, flip: bool, bf16: Optional[boo
     key = (w.data_ptr(), T, I, O, bool(transpose), bool(flip), w._version, bf16)
     if cache is not None and key in cache:
         return cache[key]
-    w = w.contiguous()
+    if cache is not None and _PACK_STORE is not None and w.is_contiguous():
+        pf = _PACK_STORE.get(w, T, I, O, transpose, flip, bf16)
+        if pf is not None:
+            return pf
+    pf = _pack_now(w.contiguous(), T, I, O, transpose, flip, bf16)
+    if cache is not None:
+        cache[key] = pf
+    return pf
+
+
+def _pack_now(w, T, I, O, transpose, flip, bf16) -> PackedFilter:
     if bf16:
         nb = N.lib().tbg_weight_pack_bf16_bytes(T, I, O, int(transpose))
         out = torch.empty(nb // 2, device=w.device, dtype=torch.bfloat16)
@@ -349,10 +432,7 @@ def pack_filter(w: torch.Tensor, transpose: bool, flip: bool, bf16: Optional[boo
         out = torch.empty(n, device=w.device, dtype=torch.float32)
         N.check(N.lib().tbg_weight_pack_f32(N.ptr(w), N.ptr(out), T, I, O, int(transpose), int(flip), N.stream()),
                 "tbg_weight_pack")
-    pf = PackedFilter(out, T, O if transpose else I, I if transpose else O, bf16)
-    if cache is not None:
-        cache[key] = pf
-    return pf
+    return PackedFilter(out, T, O if transpose else I, I if transpose else O, bf16)
 
 
 def bias_act_bwd_raw(dout, out_act, epi: N.Epilogue, want_dx=False, want_dpre=True, want_db=True, want_dn=False,

@@ -81,6 +81,7 @@ class TrainingStep:
         self.overlap_ocr = True
         self._ocr_stream = None
         self._graphs = {}
+        self._packs = ops.PackedStore()
         self._warmed = set()
         self._static = None
         self.exchange = GradExchange(process_group)
@@ -295,7 +296,8 @@ class TrainingStep:
 
     def _compute_grads(self, *args, **kw):
         # packed filters are shared by the forward and the three backward passes
-        with ops.filter_cache(), ops.compute_dtype(self.compute_dtype):
+        with ops.filter_cache(), ops.compute_dtype(self.compute_dtype), self._packs.scope():
+            self._packs.refresh()  # ONE launch re-packs every filter from the weights the last update left
             return self._compute_grads_impl(*args, **kw)
 
     def _compute_grads_impl(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg, do_pl_reg,
