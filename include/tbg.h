@@ -280,6 +280,27 @@ int tbg_bias_act_bwd_f32(const float *dout, const float *out_act, float *dx, flo
                          const tbg_epilogue *epi, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Small-tensor tails of the layer gradients: one launch each instead of a chain of tiny reductions / GEMMs.
+ * tbg_modconv_bwd_smalls_f32 (modulated_conv2d.py:78-82, activation-scaling form), from the partial sums of
+ * tbg_bias_act_bwd_f32 (pdb, pdn, pdy: [B,O,nch]), d [B,O], s [B,I], wsq [I,O] and the conv's style-dot ds_conv [B,I]:
+ *   t[b,o] = (sum_ch pdy) d^2;  ds[b,i] = ds_conv - s * sum_o t wsq[i,o];  dwsq[i,o] = sum_b s^2 t;
+ *   db[o] = sum pdb;  dstrength = sum pdn (pdn / dstrength may both be NULL).
+ * tbg_torgb_bwd_smalls_f32 (to_rgb.py:28-33), from the Gram G [B,C,O] of tbg_rgb_backproject_f32:
+ *   ds[b,c] = coef sum_o G w[c,o];  dw[c,o] = coef sum_b G s[b,c].
+ * tbg_minibatch_std_{fwd,bwd}_f32 (mini_batch_std.py:10-35, first order): x [B,C,HW] -> y [B,C+1,HW]; groups of
+ * min(group, B) samples {g*M + m}; B must be a multiple of the group size (EINVAL otherwise, as the reference's reshape).
+ * ---------------------------------------------------------------------------------------- */
+int tbg_modconv_bwd_smalls_f32(const float *pdb, const float *pdn, const float *pdy, const float *d,
+                               const float *s, const float *wsq, const float *ds_conv, float *db,
+                               float *dstrength, float *ds, float *dwsq, int B, int I, int O, int nch,
+                               void *stream);
+int tbg_torgb_bwd_smalls_f32(const float *G, const float *w, const float *s, float *ds, float *dw, int B,
+                             int C, int O, float coef, void *stream);
+int tbg_minibatch_std_fwd_f32(const float *x, float *y, int B, int C, int HW, int group, void *stream);
+int tbg_minibatch_std_bwd_f32(const float *x, const float *dy, float *dx, int B, int C, int HW, int group,
+                              void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimiser / EMA (multi-tensor over one flat buffer).
  * Keras Adam (reference train.py:58-75 -> ResourceApplyAdam): m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2;
  * theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps).  `step` is a DEVICE int64 holding t-1

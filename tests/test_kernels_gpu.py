@@ -482,3 +482,48 @@ def test_demod_coefs(dev):
     dd = ops.demod_coefs(sd, wd)
     gsd, gwd = torch.autograd.grad(dd, (sd, wd), gd.float().to(dev))
     assert rel_err(dd, d) < 1e-5 and rel_err(gsd, gs) < 1e-4 and rel_err(gwd, gw) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------- small-tensor tails
+def test_modconv_bwd_smalls(dev):
+    """tbg_modconv_bwd_smalls_f32 == the torch composition it replaces (modulated_conv2d.py:78-82), float64."""
+    from textboxgan_amd import ops
+    for B, I, O, nch in ((16, 512, 512, 1), (5, 24, 40, 3), (32, 128, 128, 4)):
+        pdb, pdn, pdy = rnd(B, O, nch, seed=90), rnd(B, O, nch, seed=91), rnd(B, O, nch, seed=92)
+        d, s = rnd(B, O, seed=93).abs() + 0.5, rnd(B, I, seed=94) + 1.0
+        wsq, ds_conv = rnd(I, O, seed=95).abs(), rnd(B, I, seed=96)
+        t = pdy.sum(dim=2) * d.square()
+        ds_ref = ds_conv - s * (t @ wsq.t())
+        dwsq_ref = s.square().t() @ t
+        f = lambda a: a.float().to(dev).contiguous()
+        db, dstr, ds, dwsq = ops.modconv_bwd_smalls_raw(f(pdb), f(pdn), f(pdy), f(d), f(s), f(wsq), f(ds_conv))
+        assert rel_err(db, pdb.sum(dim=(0, 2))) < 1e-5 and rel_err(dstr, pdn.sum()) < 1e-4
+        assert rel_err(ds, ds_ref) < 2e-5 and rel_err(dwsq, dwsq_ref) < 2e-5
+
+
+def test_torgb_bwd_smalls(dev):
+    from textboxgan_amd import ops
+    B, Cc, O, coef = 7, 130, 3, 0.25
+    G, w, s = rnd(B, Cc, O, seed=97), rnd(Cc, O, seed=98), rnd(B, Cc, seed=99)
+    f = lambda a: a.float().to(dev).contiguous()
+    ds, dw = ops.torgb_bwd_smalls_raw(f(G), f(w), f(s), coef)
+    assert rel_err(ds, coef * (G * w[None]).sum(dim=2)) < 1e-5
+    assert rel_err(dw, coef * (G * s[:, :, None]).sum(dim=0)) < 1e-5
+
+
+@pytest.mark.parametrize("B", [16, 4, 2, 32], ids=lambda b: f"B{b}")
+def test_minibatch_std_fused_fwd_bwd(dev, B):
+    """mini_batch_std.py:10-35: forward and first-order gradient vs autograd through the float64 oracle."""
+    from textboxgan_amd import ops
+    x = rnd(B, 48, 4, 4, seed=101).requires_grad_(True)
+    y = R.t_minibatch_std(x, 4)
+    dy = rnd(*y.shape, seed=102)
+    (gx,) = torch.autograd.grad(y, x, dy)
+    xd = x.detach().float().to(dev).requires_grad_(True)
+    yd = ops.minibatch_std_fused(xd, 4)
+    (gxd,) = torch.autograd.grad(yd, xd, dy.float().to(dev))
+    assert rel_err(yd, y) < 1e-5 and rel_err(gxd, gx) < 2e-5
+    from textboxgan_amd import native as N
+    bad = torch.zeros(6, 8, 4, 4, device=dev)
+    out = torch.zeros(6, 9, 4, 4, device=dev)
+    assert N.lib().tbg_minibatch_std_fwd_f32(N.ptr(bad), N.ptr(out), 6, 8, 16, 4, N.stream()) == -1  # 6 % 4 != 0

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtbg_hip.so")
-SOURCES = ["elementwise.hip", "upfirdn.hip", "conv.hip", "rgb.hip", "lstm.hip", "host_util.hip"]
+SOURCES = ["elementwise.hip", "upfirdn.hip", "conv.hip", "rgb.hip", "lstm.hip", "smalls.hip", "host_util.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
 
 

@@ -1,0 +1,211 @@
+// Small-tensor tails of the layer gradients (gfx950).  Each of these replaces a chain of 6-25 tiny framework launches
+// (reductions, squares, small GEMMs, fills) that cost ~5 us apiece whatever their size: on this path ~1600 of the ~2100
+// launches of a G+D step were such tails (profiles/r02_census_gd.txt), 9 ms of a 33 ms step.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// tail of the modulated-conv backward (modulated_conv2d.py:78-82 in the activation-scaling form):
+//   t[b,o]    = (sum_ch pdy[b,o,ch]) * d[b,o]^2                 pdy: partial sums of dpre * y_rec from bias_act_bwd
+//   ds[b,i]   = ds_conv[b,i] - s[b,i] * sum_o t[b,o] wsq[i,o]   (gradient of the style scale, incl. the demod term)
+//   dwsq[i,o] = sum_b s[b,i]^2 t[b,o]                           (enters dW through tbg_conv2d_wgrad_ex_f32's addq)
+//   db[o]     = sum_{b,ch} pdb[b,o,ch];   dstrength = sum pdn
+// grid: ceil(I / 16) blocks own 16 input channels each (all b, all o) + one last block for db / dstrength.
+// ---------------------------------------------------------------------------------------------------------------
+struct ModSmallP {
+  const float *pdb, *pdn, *pdy, *d, *s, *wsq, *ds_conv;
+  float *db, *dstrength, *ds, *dwsq;
+  int B, I, O, nch;
+};
+
+#define MS_IT 16
+
+__global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x;
+  const int nI = (p.I + MS_IT - 1) / MS_IT;
+  if ((int)blockIdx.x == nI) {  // ---- bias / noise-strength gradients
+    __shared__ float red[4];
+    for (int o = tid; o < p.O; o += 256) {
+      float a = 0.f;
+      for (int b = 0; b < p.B; ++b)
+        for (int c = 0; c < p.nch; ++c) a += p.pdb[((size_t)b * p.O + o) * p.nch + c];
+      p.db[o] = a;
+    }
+    float a = 0.f;
+    if (p.pdn)
+      for (int i = tid; i < p.B * p.O * p.nch; i += 256) a += p.pdn[i];
+    a = wave_sum(a);
+    if ((tid & 63) == 0) red[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0 && p.dstrength) p.dstrength[0] = red[0] + red[1] + red[2] + red[3];
+    return;
+  }
+  float *t = sm;                          // [B][O]
+  float *wq = t + p.B * p.O;              // [MS_IT][O + 1]
+  float *s2 = wq + MS_IT * (p.O + 1);     // [B][MS_IT]  s
+  const int i0 = blockIdx.x * MS_IT;
+  for (int e = tid; e < p.B * p.O; e += 256) {
+    float a = 0.f;
+    for (int c = 0; c < p.nch; ++c) a += p.pdy[(size_t)e * p.nch + c];
+    const float dv = p.d[e];
+    t[e] = a * dv * dv;
+  }
+  for (int e = tid; e < MS_IT * p.O; e += 256) {
+    const int ii = e / p.O, o = e - ii * p.O;
+    wq[ii * (p.O + 1) + o] = (i0 + ii < p.I) ? p.wsq[(size_t)(i0 + ii) * p.O + o] : 0.f;
+  }
+  for (int e = tid; e < p.B * MS_IT; e += 256) {
+    const int b = e / MS_IT, ii = e - b * MS_IT;
+    s2[e] = (i0 + ii < p.I) ? p.s[(size_t)b * p.I + i0 + ii] : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < p.B * MS_IT; e += 256) {  // ds
+    const int b = e / MS_IT, ii = e - b * MS_IT;
+    if (i0 + ii < p.I) {
+      const float *tb = t + b * p.O, *wr = wq + ii * (p.O + 1);
+      float a = 0.f;
+      for (int o = 0; o < p.O; ++o) a += tb[o] * wr[o];
+      const size_t idx = (size_t)b * p.I + i0 + ii;
+      p.ds[idx] = p.ds_conv[idx] - s2[e] * a;
+    }
+  }
+  for (int e = tid; e < MS_IT * p.O; e += 256) {  // dwsq
+    const int ii = e / p.O, o = e - ii * p.O;
+    if (i0 + ii < p.I) {
+      float a = 0.f;
+      for (int b = 0; b < p.B; ++b) {
+        const float sv = s2[b * MS_IT + ii];
+        a += sv * sv * t[b * p.O + o];
+      }
+      p.dwsq[(size_t)(i0 + ii) * p.O + o] = a;
+    }
+  }
+}
+
+extern "C" int tbg_modconv_bwd_smalls_f32(const float *pdb, const float *pdn, const float *pdy, const float *d,
+                                          const float *s, const float *wsq, const float *ds_conv, float *db,
+                                          float *dstrength, float *ds, float *dwsq, int B, int I, int O, int nch,
+                                          void *stream) {
+  if (!pdb || !pdy || !d || !s || !wsq || !ds_conv || !db || !ds || !dwsq) return TBG_EINVAL;
+  if (B < 1 || I < 1 || O < 1 || nch < 1 || ((pdn == nullptr) != (dstrength == nullptr))) return TBG_EINVAL;
+  const size_t lds = ((size_t)B * O + (size_t)MS_IT * (O + 1) + (size_t)B * MS_IT) * sizeof(float);
+  if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(modconv_bwd_smalls_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return TBG_EHIP;
+  ModSmallP p{pdb, pdn, pdy, d, s, wsq, ds_conv, db, dstrength, ds, dwsq, B, I, O, nch};
+  hipLaunchKernelGGL(modconv_bwd_smalls_kernel, dim3((I + MS_IT - 1) / MS_IT + 1), dim3(256), lds, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tail of the toRGB backward (to_rgb.py:28-33): from the channel Gram G[b,c,o] = sum_p x[b,c,p] dy[b,o,p]
+//   ds[b,c] = coef * sum_o G[b,c,o] w[c,o];     dw[c,o] = coef * sum_b G[b,c,o] s[b,c]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void torgb_bwd_smalls_kernel(const float *__restrict__ G, const float *__restrict__ w,
+                                                              const float *__restrict__ s, float *__restrict__ ds,
+                                                              float *__restrict__ dw, int B, int C, int O, float coef) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < B * C) {
+    const int c = e % C;
+    float a = 0.f;
+    for (int o = 0; o < O; ++o) a += G[(size_t)e * O + o] * w[c * O + o];
+    ds[e] = a * coef;
+  }
+  if (e < C * O) {
+    const int c = e / O, o = e - c * O;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += G[((size_t)b * C + c) * O + o] * s[(size_t)b * C + c];
+    dw[e] = a * coef;
+  }
+}
+
+extern "C" int tbg_torgb_bwd_smalls_f32(const float *G, const float *w, const float *s, float *ds, float *dw, int B, int C,
+                                        int O, float coef, void *stream) {
+  if (!G || !w || !s || !ds || !dw || B < 1 || C < 1 || O < 1) return TBG_EINVAL;
+  const int n = B * C > C * O ? B * C : C * O;
+  hipLaunchKernelGGL(torgb_bwd_smalls_kernel, dim3((n + 255) / 256), dim3(256), 0, tbg_stream(stream), G, w, s, ds, dw, B, C, O,
+                     coef);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// minibatch standard deviation (mini_batch_std.py:10-35), first order.  x [B,C,HW] with B = G*M (G = min(4, B) samples per
+// statistics group, group member g of group m is sample g*M + m):
+//   std[m,e] = sqrt(mean_g (x[g,m,e] - mean_g x)^2 + 1e-8);  stat[m] = mean_e std[m,e]
+//   y [B, C+1, HW] = cat(x, stat[n mod M] broadcast)
+// backward: dstat[m] = sum_{g,p} dy[g*M+m, C, p];  dx[g,m,e] = dy[g,m,e] + dstat[m]/(E*G) * (x[g,m,e] - mean)/std[m,e]
+// One block per statistics group m.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float *red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int G, int M, int C,
+                                                       int HW) {
+  __shared__ float red[4];
+  const int m = blockIdx.x, E = C * HW;
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float v[4], mean = 0.f;
+    for (int g = 0; g < G; ++g) { v[g] = x[(size_t)(g * M + m) * E + e]; mean += v[g]; }
+    mean /= G;
+    float var = 0.f;
+    for (int g = 0; g < G; ++g) { const float dlt = v[g] - mean; var += dlt * dlt; }
+    acc += sqrtf(var / G + 1e-8f);
+    for (int g = 0; g < G; ++g) y[(size_t)(g * M + m) * (E + HW) + e] = v[g];
+  }
+  const float stat = block_sum(acc, red) / E;
+  for (int i = threadIdx.x; i < G * HW; i += 256) {
+    const int g = i / HW, px = i - g * HW;
+    y[(size_t)(g * M + m) * (E + HW) + E + px] = stat;
+  }
+}
+
+__global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                       float *__restrict__ dx, int G, int M, int C, int HW) {
+  __shared__ float red[4];
+  const int m = blockIdx.x, E = C * HW;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < G * HW; i += 256) {
+    const int g = i / HW, px = i - g * HW;
+    a += dy[(size_t)(g * M + m) * (E + HW) + E + px];
+  }
+  const float k = block_sum(a, red) / ((float)E * G);
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float v[4], mean = 0.f;
+    for (int g = 0; g < G; ++g) { v[g] = x[(size_t)(g * M + m) * E + e]; mean += v[g]; }
+    mean /= G;
+    float var = 0.f;
+    for (int g = 0; g < G; ++g) { const float dlt = v[g] - mean; var += dlt * dlt; }
+    const float inv = k / sqrtf(var / G + 1e-8f);
+    for (int g = 0; g < G; ++g) dx[(size_t)(g * M + m) * E + e] = dy[(size_t)(g * M + m) * (E + HW) + e] + (v[g] - mean) * inv;
+  }
+}
+
+extern "C" int tbg_minibatch_std_fwd_f32(const float *x, float *y, int B, int C, int HW, int group, void *stream) {
+  if (!x || !y || B < 1 || C < 1 || HW < 1 || group < 1) return TBG_EINVAL;
+  const int G = group < B ? group : B;
+  if (G > 4 || B % G != 0) return TBG_EINVAL;  // mini_batch_std.py: the batch must be a multiple of the group size
+  hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(B / G), dim3(256), 0, tbg_stream(stream), x, y, G, B / G, C, HW);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_minibatch_std_bwd_f32(const float *x, const float *dy, float *dx, int B, int C, int HW, int group,
+                                         void *stream) {
+  if (!x || !dy || !dx || B < 1 || C < 1 || HW < 1 || group < 1) return TBG_EINVAL;
+  const int G = group < B ? group : B;
+  if (G > 4 || B % G != 0) return TBG_EINVAL;
+  hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(B / G), dim3(256), 0, tbg_stream(stream), x, dy, dx, G, B / G, C, HW);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}

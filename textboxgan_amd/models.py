@@ -373,11 +373,14 @@ class DiscriminatorLastBlock(nn.Module):
         self.apply_bias_act_1 = BiasAct(n_f1, 1.0, "lrelu")
 
     def forward(self, x, mode="fused"):
-        x = minibatch_std(x, 4).contiguous()
-        if mode == "fused":
+        if mode == "fused":  # one launch each: statistics layer, conv + bias + lrelu, dense + bias + lrelu
+            x = ops.minibatch_std_fused(x, 4)
             x = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1), role="d")
-        else:
-            x = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w * _coef(self.conv_0.w.shape), (1, 1), (1, 1)))
+            return ops.dense_bias_act(x.reshape(x.shape[0], -1), self.dense_1.w, self.apply_bias_act_1.b,
+                                      _coef(self.dense_1.w.shape, self.dense_1.gain, self.dense_1.lrmul),
+                                      self.apply_bias_act_1.lrmul, lrelu=True)
+        x = minibatch_std(x, 4).contiguous()
+        x = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w * _coef(self.conv_0.w.shape), (1, 1), (1, 1)))
         return self.apply_bias_act_1(self.dense_1(x))
 
 
@@ -405,7 +408,12 @@ class Discriminator(nn.Module):
                 taps.append(x)
             x = block(x, mode)
         x = self.last_block(x, mode)
-        scores = self.last_bias(self.last_dense(x))
+        if mode == "fused":
+            scores = ops.dense_bias_act(x, self.last_dense.w, self.last_bias.b,
+                                        _coef(self.last_dense.w.shape, self.last_dense.gain, self.last_dense.lrmul),
+                                        self.last_bias.lrmul, lrelu=False)
+        else:
+            scores = self.last_bias(self.last_dense(x))
         return scores if cuts is None else (scores, taps)
 
 

@@ -482,6 +482,30 @@ def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True):
     return dx, G
 
 
+def modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv):
+    """one launch for the small-tensor tail of a modulated-conv backward: (db [O], dstrength [], ds [B,I], dwsq [I,O])."""
+    B, O, nch = pdy.shape
+    I = s.shape[1]
+    dev = s.device
+    db = torch.empty(O, device=dev, dtype=torch.float32)
+    dstrength = torch.empty((), device=dev, dtype=torch.float32) if pdn is not None else None
+    ds = torch.empty_like(s)
+    dwsq = torch.empty((I, O), device=dev, dtype=torch.float32)
+    N.check(N.lib().tbg_modconv_bwd_smalls_f32(N.ptr(pdb), N.ptr(pdn), N.ptr(pdy), N.ptr(d), N.ptr(s), N.ptr(wsq),
+                                               N.ptr(ds_conv), N.ptr(db), N.ptr(dstrength), N.ptr(ds), N.ptr(dwsq), B, I, O,
+                                               nch, N.stream()), "tbg_modconv_bwd_smalls")
+    return db, dstrength, ds, dwsq
+
+
+def torgb_bwd_smalls_raw(G, w2d, s, coef):
+    B, Cc, O = G.shape
+    ds = torch.empty((B, Cc), device=G.device, dtype=torch.float32)
+    dw = torch.empty((Cc, O), device=G.device, dtype=torch.float32)
+    N.check(N.lib().tbg_torgb_bwd_smalls_f32(N.ptr(G), N.ptr(w2d), N.ptr(s), N.ptr(ds), N.ptr(dw), B, Cc, O, coef, N.stream()),
+            "tbg_torgb_bwd_smalls")
+    return ds, dw
+
+
 def demod_coefs_raw(s: torch.Tensor, w: torch.Tensor, coef: float):
     KH, KW, I, O = w.shape
     B = s.shape[0]
@@ -683,12 +707,10 @@ class _ModConvFused(torch.autograd.Function):
         coef = ctx.coef
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
         _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
-        db = pdb.sum(dim=(0, 2))
-        dstrength = pdn.sum()
         g = _Geom((1, 1), (KH // 2, KW // 2), KH, KW, (x.shape[2], x.shape[3]), (out.shape[2], out.shape[3]))
-        ds = torch.zeros_like(s)
-        dx = _bwd_data_launch(dpre, w, g, in_scale=d, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds))
-        ds, dwsq = _demod_backward(pdy, d, s, wsq, ds)
+        ds_conv = torch.zeros_like(s)
+        dx = _bwd_data_launch(dpre, w, g, in_scale=d, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
+        db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)
         dw = None
         if ctx.needs_input_grad[1]:  # frozen generator (projector.py: only the latent is optimised): no filter gradient
             dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef, x_scale=s, dy_scale=d, add=(w, dwsq, -coef * coef))
@@ -725,15 +747,13 @@ class _ModConvUpFused(torch.autograd.Function):
         H, W = x.shape[2], x.shape[3]
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
         _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
-        db = pdb.sum(dim=(0, 2))
-        dstrength = pdn.sum()
         k = fir_kernel(x.device, gain=4.0)  # symmetric: flipped == itself
         dy_up = upfirdn2d_raw(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))  # [B,O,2H+1,2W+1]
         wt = pack_filter(w, transpose=True, flip=True)
-        ds = torch.zeros_like(s)
+        ds_conv = torch.zeros_like(s)
         dx = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0),
-                        epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds))
-        ds, dwsq = _demod_backward(pdy, d, s, wsq, ds)
+                        epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
+        db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -767,10 +787,8 @@ class _ToRGBFused(torch.autograd.Function):
         dy = dy.contiguous()
         db = dy.sum(dim=(0, 2, 3))
         dx, G = rgb_backproject_raw(x, dy, w, s, ctx.coef, want_dx=True, want_G=True)  # G[b,c,o] = sum_p x*dy
-        w2 = w.reshape(I, O)
-        ds = ctx.coef * (G * w2[None]).sum(dim=2)
-        dw = (ctx.coef * (G * s[:, :, None]).sum(dim=0)).reshape(w.shape) if ctx.needs_input_grad[1] else None
-        return dx, dw, ds, db, (dy if ctx.has_skip else None)
+        ds, dw = torgb_bwd_smalls_raw(G, w.reshape(I, O), s, ctx.coef)
+        return dx, dw.reshape(w.shape), ds, db, (dy if ctx.has_skip else None)
 
 
 class _ConvBiasActFused(torch.autograd.Function):
@@ -873,6 +891,35 @@ class _DemodCoefs(torch.autograd.Function):
 
 def demod_coefs(s, w):
     return _DemodCoefs.apply(s, w)
+
+
+class _MinibatchStd(torch.autograd.Function):
+    """mini_batch_std.py:10-35 as one launch forward and one backward (first order: the R1 pass, which needs the second-
+    order term, keeps the torch composition in models.minibatch_std)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        y = torch.empty((B, Cc + 1, H, W), device=x.device, dtype=torch.float32)
+        N.check(N.lib().tbg_minibatch_std_fwd_f32(N.ptr(x), N.ptr(y), B, Cc, H * W, group, N.stream()), "tbg_minibatch_std_fwd")
+        ctx.save_for_backward(x)
+        ctx.group = group
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        dx = torch.empty_like(x)
+        N.check(N.lib().tbg_minibatch_std_bwd_f32(N.ptr(x), N.ptr(dy.contiguous()), N.ptr(dx), B, Cc, H * W, ctx.group,
+                                                  N.stream()), "tbg_minibatch_std_bwd")
+        return dx, None
+
+
+def minibatch_std_fused(x, group=4):
+    return _MinibatchStd.apply(x, int(group))
 
 
 # ----------------------------------------------------------------------------------------
