@@ -138,6 +138,11 @@ int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float
  * environment knobs and the library keeps no mutable state.  Profiling aid (bench.py attributes HIP-event timings to
  * rocprofv3 kernel names with it; tests use it to prove every instantiation is compared with the oracle). */
 int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
+/* tbg_conv2d_f32 with an EXPLICIT instantiation family for 3x3 / 1x1 non-transposed-class launches (tuning and test aid):
+ * variant 0 = the library's choice, 1 = software-pipelined (double-buffered LDS), 2 = plain 8-channel chunks,
+ * 3 = 4-channel chunks at 4 waves/SIMD (128x128 tile only).  TBG_EUNSUPPORTED if the descriptor cannot take it. */
+int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, const float *w, float *y,
+                           const float *in_scale, const tbg_epilogue *epi, int variant, void *stream);
 
 /* Weight gradient:  dW[t*st_t + cl*st_l + cs*st_s] = alpha * sum_{b,u,v}
  *     S[b,cs,u,v]*s_scale[b,cs] * L[b,cl,u*sy-py+kh,v*sx-px+kw]*l_scale[b,cl]

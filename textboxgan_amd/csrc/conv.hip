@@ -501,7 +501,7 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
 
 
 static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, float *y, const float *in_scale,
-                       const tbg_epilogue *epi, void *stream, const NameOut *name, bool bf = false) {
+                       const tbg_epilogue *epi, void *stream, const NameOut *name, bool bf = false, int variant = 0) {
   if (!d || !epi_valid(epi)) return TBG_EINVAL;
   if (!name && (!x || !w || !y)) return TBG_EINVAL;
   if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1 || d->Hout < 1 || d->Wout < 1) return TBG_EINVAL;
@@ -634,6 +634,23 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
     return launch_fprop<2, 2, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
   }
+  if (variant != 0) {  // explicit instantiation choice (tbg_conv2d_f32_variant: tuning / test aid, stateless)
+    if (variant == 1 && p.NJ <= 3) {  // software-pipelined
+      if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
+      if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
+      if (BM == 64) return launch_fprop<1, 4, 2, 2, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
+      return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
+    }
+    if (variant == 2) {  // plain CK = 8
+      if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
+      if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
+      if (BM == 64) return launch_fprop<1, 4, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
+      return launch_fprop<2, 2, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
+    }
+    if (variant == 3 && BM == 128 && BN == 128 && p.NJ <= 3 && p.ksplit == 1)  // CK = 4 at 4 waves/SIMD
+      return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 0, 4>(p, st, maxtaps, maxTilesN, name);
+    return TBG_EUNSUPPORTED;
+  }
   // Software-pipelined variant (double-buffered LDS, one barrier per chunk).  Measured (tools/bench_conv.py): +12% on
   // the 64x256 tile (76 -> 86 TFLOP/s), neutral on 128x128, -5..10% on the small-spatial 64x64 tile -> 64x256 only.
   if (p.NJ <= 3 && BM == 64 && BN == 256) return launch_fprop<1, 4, 2, 2, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
@@ -651,6 +668,12 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
 extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                               const float *in_scale, const tbg_epilogue *epi, void *stream) {
   return conv2d_impl(d, x, w, y, in_scale, epi, stream, nullptr);
+}
+
+extern "C" int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, const float *w, float *y,
+                                      const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
+  if (variant < 0 || variant > 3) return TBG_EINVAL;
+  return conv2d_impl(d, x, w, y, in_scale, epi, stream, nullptr, false, variant);
 }
 
 extern "C" int tbg_conv2d_bf16(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,

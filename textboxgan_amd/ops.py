@@ -187,6 +187,7 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
 
 
 FORCE_KSPLIT = None  # experiment knob (tools/bench_ksplit.py)
+FORCE_VARIANT = 0    # experiment knob (tools/bench_variants_conv.py): tbg_conv2d_f32_variant's instantiation family
 
 
 def _conv_tiles(M, npix):
@@ -208,6 +209,9 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     ldw = w.M
     bf16 = w.bf16
     _conv = N.lib().tbg_conv2d_bf16 if bf16 else N.lib().tbg_conv2d_f32
+    if FORCE_VARIANT and not bf16:
+        _v = FORCE_VARIANT
+        _conv = lambda d_, x_, w_, y_, s_, e_, st_: N.lib().tbg_conv2d_f32_variant(d_, x_, w_, y_, s_, e_, _v, st_)
     w = w.data
     Hout, Wout = out_hw
     nchunks = math.ceil(Cc / (16 if bf16 else 8))
