@@ -198,6 +198,9 @@ int tbg_weight_pack_bf16(const float *src, void *dst, int T, int I, int O, int t
 int tbg_conv2d_bf16(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                     const float *in_scale, const tbg_epilogue *epi, void *stream);
 int tbg_conv2d_bf16_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
+/* explicit instantiation family (tuning / test aid): 0 = library's choice, 1 = 128x256 tile, 2 = 32-channel chunks. */
+int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
+                            const float *in_scale, const tbg_epilogue *epi, int variant, void *stream);
 /* filter gradient; tile rows narrower than 8 pixels (Ws <= 4) fall back to the exact fp32 kernel.  Workspace size =
  * tbg_conv2d_wgrad_workspace_bytes(d). */
 int tbg_conv2d_wgrad_bf16(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,

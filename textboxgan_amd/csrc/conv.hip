@@ -615,6 +615,29 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   p.slab = (long long)d->B * d->M * d->Hout * d->Wout;
   hipStream_t st = tbg_stream(stream);
   if (bf) {  // bf16-in MFMA: chunks of 16 channels (32 for the few-tap classes), the same four tile shapes
+    if (variant == 1 && BM == 128 && BN == 128 && maxtaps > 4) {  // 128x256 tile: every filter byte feeds 256 pixels
+      // re-derive the pixel tiling for BN = 256 (same rules as above)
+      const int TR = 256 / TW;
+      THs = pow2ceil(maxUg) < TR ? pow2ceil(maxUg) : TR;
+      p.logTHs = ilog2(THs); p.NSEG = TR / THs;
+      p.IHs = (THs - 1) * p.sy + maxKH;
+      p.planeStride = p.NSEG * p.IHs * p.IWp;
+      p.ppc = p.NSEG * p.IHs * p.IWs;
+      p.NJ = ceil_div(p.ppc, 256);
+      if (p.NJ > MAXNJ) return TBG_EUNSUPPORTED;
+      p.nBG = ceil_div(p.B, p.NSEG);
+      maxTilesN = 0;
+      for (int k = 0; k < p.nclass; ++k) {
+        ClassInfo &c = p.cls[k];
+        c.tilesU = c.Ug > 0 ? ceil_div(c.Ug, THs) : 1;
+        const int tiles = c.tilesU * c.tilesV * p.nBG;
+        if (tiles > maxTilesN) maxTilesN = tiles;
+      }
+      return launch_fprop<2, 2, 2, 4, 16, MAXTAPS, 0, 2, true>(p, st, maxtaps, maxTilesN, name);
+    }
+    if (variant == 2 && BM == 128 && BN == 128 && maxtaps > 4)  // 32-channel chunks: half the barriers
+      return launch_fprop<2, 2, 2, 2, 32, MAXTAPS, 0, 2, true>(p, st, maxtaps, maxTilesN, name);
+    if (variant != 0) return TBG_EUNSUPPORTED;
     if (maxtaps > 1 && maxtaps <= 4) {
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
@@ -674,6 +697,12 @@ extern "C" int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, co
                                       const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
   if (variant < 0 || variant > 3) return TBG_EINVAL;
   return conv2d_impl(d, x, w, y, in_scale, epi, stream, nullptr, false, variant);
+}
+
+extern "C" int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
+                                       const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
+  if (variant < 0 || variant > 2) return TBG_EINVAL;
+  return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, true, variant);
 }
 
 extern "C" int tbg_conv2d_bf16(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,

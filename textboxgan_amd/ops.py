@@ -209,9 +209,9 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     ldw = w.M
     bf16 = w.bf16
     _conv = N.lib().tbg_conv2d_bf16 if bf16 else N.lib().tbg_conv2d_f32
-    if FORCE_VARIANT and not bf16:
-        _v = FORCE_VARIANT
-        _conv = lambda d_, x_, w_, y_, s_, e_, st_: N.lib().tbg_conv2d_f32_variant(d_, x_, w_, y_, s_, e_, _v, st_)
+    if FORCE_VARIANT:
+        _v, _fn = FORCE_VARIANT, (N.lib().tbg_conv2d_bf16_variant if bf16 else N.lib().tbg_conv2d_f32_variant)
+        _conv = lambda d_, x_, w_, y_, s_, e_, st_: _fn(d_, x_, w_, y_, s_, e_, _v, st_)
     w = w.data
     Hout, Wout = out_hw
     nchunks = math.ceil(Cc / (16 if bf16 else 8))
