@@ -1,0 +1,24 @@
+"""profiles/<tag>_pmc_report.txt (tools/pmc_report.sh) -> profiles/latest_traffic.json, the file bench.py reads
+roofline.traffic / mfma_busy_pmc from (PMC counters cannot be read from inside the process).
+usage: python tools/make_traffic_json.py profiles/r02_pmc_report.txt"""
+import json, re, sys
+src = sys.argv[1]
+kern = {}
+for line in open(src):
+    if line.startswith("#") or line.startswith("kernel") or not line.strip():
+        continue
+    name, rest = line[:66].strip(), line[66:].split()
+    if len(rest) < 7:
+        continue
+    calls, avg, tot, mb, gbs, frac, busy = rest[:7]
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\((ConvP|WgradP)\)?$", "", name).strip()
+    if "conv_" not in name or mb == "nan":
+        continue
+    kern[name] = {"launches": int(calls), "avg_us": float(avg), "hbm_bytes_per_launch": int(float(mb) * 1e6),
+                  "hbm_GBps": float(gbs), "mfma_busy": None if busy == "nan" else float(busy)}
+json.dump({"source": src, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE "
+           "(separate passes) -- python bench.py --roofline-only --steps 2 --warmup 1",
+           "correction": "(2 x FETCH_SIZE + WRITE_SIZE) KiB -> bytes, MI355X_MICROARCH.md HBM section", "kernels": kern},
+          open("profiles/latest_traffic.json", "w"), indent=1)
+print(len(kern), "kernels")
