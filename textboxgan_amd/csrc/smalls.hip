@@ -17,32 +17,35 @@ struct ModSmallP {
   int B, I, O, nch;
 };
 
-#define MS_IT 16
+#define MS_IT 4  // input channels per block: 128 blocks at I = 512 (the first version's 16 gave 33 blocks and 30 us)
 
 __global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x;
   const int nI = (p.I + MS_IT - 1) / MS_IT;
-  if ((int)blockIdx.x == nI) {  // ---- bias / noise-strength gradients
+  if ((int)blockIdx.x >= nI) {  // ---- bias / noise-strength gradients: blocks nI .. nI + ceil(O/256) - 1
     __shared__ float red[4];
-    for (int o = tid; o < p.O; o += 256) {
+    const int o = ((int)blockIdx.x - nI) * 256 + tid;
+    if (o < p.O) {
       float a = 0.f;
       for (int b = 0; b < p.B; ++b)
         for (int c = 0; c < p.nch; ++c) a += p.pdb[((size_t)b * p.O + o) * p.nch + c];
       p.db[o] = a;
     }
-    float a = 0.f;
-    if (p.pdn)
+    if ((int)blockIdx.x == nI && p.pdn) {
+      float a = 0.f;
       for (int i = tid; i < p.B * p.O * p.nch; i += 256) a += p.pdn[i];
-    a = wave_sum(a);
-    if ((tid & 63) == 0) red[tid >> 6] = a;
-    __syncthreads();
-    if (tid == 0 && p.dstrength) p.dstrength[0] = red[0] + red[1] + red[2] + red[3];
+      a = wave_sum(a);
+      if ((tid & 63) == 0) red[tid >> 6] = a;
+      __syncthreads();
+      if (tid == 0) p.dstrength[0] = red[0] + red[1] + red[2] + red[3];
+    }
     return;
   }
   float *t = sm;                          // [B][O]
-  float *wq = t + p.B * p.O;              // [MS_IT][O + 1]
-  float *s2 = wq + MS_IT * (p.O + 1);     // [B][MS_IT]  s
+  float *wq = t + p.B * p.O;              // [MS_IT][O]
+  float *s2 = wq + MS_IT * p.O;           // [B][MS_IT]
+  float *part = s2 + p.B * MS_IT;         // [B][MS_IT][4] partial dots
   const int i0 = blockIdx.x * MS_IT;
   for (int e = tid; e < p.B * p.O; e += 256) {
     float a = 0.f;
@@ -52,21 +55,29 @@ __global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP
   }
   for (int e = tid; e < MS_IT * p.O; e += 256) {
     const int ii = e / p.O, o = e - ii * p.O;
-    wq[ii * (p.O + 1) + o] = (i0 + ii < p.I) ? p.wsq[(size_t)(i0 + ii) * p.O + o] : 0.f;
+    wq[e] = (i0 + ii < p.I) ? p.wsq[(size_t)(i0 + ii) * p.O + o] : 0.f;
   }
   for (int e = tid; e < p.B * MS_IT; e += 256) {
     const int b = e / MS_IT, ii = e - b * MS_IT;
     s2[e] = (i0 + ii < p.I) ? p.s[(size_t)b * p.I + i0 + ii] : 0.f;
   }
   __syncthreads();
-  for (int e = tid; e < p.B * MS_IT; e += 256) {  // ds
-    const int b = e / MS_IT, ii = e - b * MS_IT;
+  // ds: (b, ii) pairs x 4 lanes that split the o range (consecutive lanes -> consecutive o: conflict-free LDS reads)
+  for (int e = tid; e < p.B * MS_IT * 4; e += 256) {
+    const int q = e & 3, pair = e >> 2;
+    const int b = pair / MS_IT, ii = pair - b * MS_IT;
+    const float *tb = t + b * p.O, *wr = wq + ii * p.O;
+    float a = 0.f;
+    for (int o = q; o < p.O; o += 4) a += tb[o] * wr[o];
+    part[e] = a;
+  }
+  __syncthreads();
+  for (int pair = tid; pair < p.B * MS_IT; pair += 256) {
+    const int b = pair / MS_IT, ii = pair - b * MS_IT;
     if (i0 + ii < p.I) {
-      const float *tb = t + b * p.O, *wr = wq + ii * (p.O + 1);
-      float a = 0.f;
-      for (int o = 0; o < p.O; ++o) a += tb[o] * wr[o];
+      const float a = part[4 * pair] + part[4 * pair + 1] + part[4 * pair + 2] + part[4 * pair + 3];
       const size_t idx = (size_t)b * p.I + i0 + ii;
-      p.ds[idx] = p.ds_conv[idx] - s2[e] * a;
+      p.ds[idx] = p.ds_conv[idx] - s2[pair] * a;
     }
   }
   for (int e = tid; e < MS_IT * p.O; e += 256) {  // dwsq
@@ -88,14 +99,15 @@ extern "C" int tbg_modconv_bwd_smalls_f32(const float *pdb, const float *pdn, co
                                           void *stream) {
   if (!pdb || !pdy || !d || !s || !wsq || !ds_conv || !db || !ds || !dwsq) return TBG_EINVAL;
   if (B < 1 || I < 1 || O < 1 || nch < 1 || ((pdn == nullptr) != (dstrength == nullptr))) return TBG_EINVAL;
-  const size_t lds = ((size_t)B * O + (size_t)MS_IT * (O + 1) + (size_t)B * MS_IT) * sizeof(float);
+  const size_t lds = ((size_t)B * O + (size_t)MS_IT * O + (size_t)B * MS_IT * 5) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void *>(modconv_bwd_smalls_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
     return TBG_EHIP;
   ModSmallP p{pdb, pdn, pdy, d, s, wsq, ds_conv, db, dstrength, ds, dwsq, B, I, O, nch};
-  hipLaunchKernelGGL(modconv_bwd_smalls_kernel, dim3((I + MS_IT - 1) / MS_IT + 1), dim3(256), lds, tbg_stream(stream), p);
+  const int blocks = (I + MS_IT - 1) / MS_IT + (O + 255) / 256;
+  hipLaunchKernelGGL(modconv_bwd_smalls_kernel, dim3(blocks), dim3(256), lds, tbg_stream(stream), p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
@@ -149,25 +161,36 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
   return r;
 }
 
+#define MB_NCH 16  // element chunks per statistics group: M x 16 blocks (one block per group took 100 us at M = 4)
+
 __global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int G, int M, int C,
                                                        int HW) {
   __shared__ float red[4];
   const int m = blockIdx.x, E = C * HW;
-  float acc = 0.f;
-  for (int e = threadIdx.x; e < E; e += 256) {
-    float v[4], mean = 0.f;
-    for (int g = 0; g < G; ++g) { v[g] = x[(size_t)(g * M + m) * E + e]; mean += v[g]; }
-    mean /= G;
-    float var = 0.f;
-    for (int g = 0; g < G; ++g) { const float dlt = v[g] - mean; var += dlt * dlt; }
-    acc += sqrtf(var / G + 1e-8f);
-    for (int g = 0; g < G; ++g) y[(size_t)(g * M + m) * (E + HW) + e] = v[g];
+  // chunk 0 of a group computes the group's statistic (a small, L2-resident reduction over all E) and writes the extra
+  // channel; the other chunks only copy their share of x
+  float stat = 0.f;
+  if (blockIdx.y == 0) {
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < E; e += 256) {
+      float v[4], mean = 0.f;
+      for (int g = 0; g < G; ++g) { v[g] = x[(size_t)(g * M + m) * E + e]; mean += v[g]; }
+      mean /= G;
+      float var = 0.f;
+      for (int g = 0; g < G; ++g) { const float dlt = v[g] - mean; var += dlt * dlt; }
+      acc += sqrtf(var / G + 1e-8f);
+    }
+    stat = block_sum(acc, red) / E;
   }
-  const float stat = block_sum(acc, red) / E;
-  for (int i = threadIdx.x; i < G * HW; i += 256) {
-    const int g = i / HW, px = i - g * HW;
-    y[(size_t)(g * M + m) * (E + HW) + E + px] = stat;
-  }
+  const int per = (E + MB_NCH - 1) / MB_NCH, e0 = blockIdx.y * per, e1 = min(e0 + per, E);
+  for (int g = 0; g < G; ++g)
+    for (int e = e0 + threadIdx.x; e < e1; e += 256)
+      y[(size_t)(g * M + m) * (E + HW) + e] = x[(size_t)(g * M + m) * E + e];
+  if (blockIdx.y == 0)
+    for (int i = threadIdx.x; i < G * HW; i += 256) {
+      const int g = i / HW, px = i - g * HW;
+      y[(size_t)(g * M + m) * (E + HW) + E + px] = stat;
+    }
 }
 
 __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
@@ -180,7 +203,8 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float *__restrict_
     a += dy[(size_t)(g * M + m) * (E + HW) + E + px];
   }
   const float k = block_sum(a, red) / ((float)E * G);
-  for (int e = threadIdx.x; e < E; e += 256) {
+  const int per = (E + MB_NCH - 1) / MB_NCH, e0 = blockIdx.y * per, e1 = min(e0 + per, E);
+  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
     float v[4], mean = 0.f;
     for (int g = 0; g < G; ++g) { v[g] = x[(size_t)(g * M + m) * E + e]; mean += v[g]; }
     mean /= G;
@@ -195,7 +219,7 @@ extern "C" int tbg_minibatch_std_fwd_f32(const float *x, float *y, int B, int C,
   if (!x || !y || B < 1 || C < 1 || HW < 1 || group < 1) return TBG_EINVAL;
   const int G = group < B ? group : B;
   if (G > 4 || B % G != 0) return TBG_EINVAL;  // mini_batch_std.py: the batch must be a multiple of the group size
-  hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(B / G), dim3(256), 0, tbg_stream(stream), x, y, G, B / G, C, HW);
+  hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(B / G, MB_NCH), dim3(256), 0, tbg_stream(stream), x, y, G, B / G, C, HW);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
@@ -205,7 +229,7 @@ extern "C" int tbg_minibatch_std_bwd_f32(const float *x, const float *dy, float 
   if (!x || !dy || !dx || B < 1 || C < 1 || HW < 1 || group < 1) return TBG_EINVAL;
   const int G = group < B ? group : B;
   if (G > 4 || B % G != 0) return TBG_EINVAL;
-  hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(B / G), dim3(256), 0, tbg_stream(stream), x, dy, dx, G, B / G, C, HW);
+  hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(B / G, MB_NCH), dim3(256), 0, tbg_stream(stream), x, dy, dx, G, B / G, C, HW);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }

@@ -54,16 +54,41 @@ class FlatParams:
         return buf, views
 
 
+_WG_CACHE: Dict[int, tuple] = {}
+
+
 def write_grads(views: List[torch.Tensor], grads) -> None:
-    dst, src = [], []
-    for v, g in zip(views, grads):
+    """gradients -> the flat buffer slice the consecutive ``views`` tile (16-byte alignment gaps between them).  ONE
+    ``torch.cat(..., out=slice)`` (a batched copy kernel over up to 128 tensors per launch) instead of one copy per
+    parameter: ``_foreach_copy_`` lowered to ~320 separate D2D copies per step (profiles/r02_pmc_report.txt)."""
+    if not views:
+        return
+    key = id(views)
+    hit = _WG_CACHE.get(key)
+    if hit is None or hit[0] is not views:
+        base = views[0]._base if views[0]._base is not None else views[0]
+        starts = [v.storage_offset() for v in views]
+        ends = [o + v.numel() for o, v in zip(starts, views)]
+        gaps = [(starts[i + 1] - ends[i]) if i + 1 < len(views) else 0 for i in range(len(views))]
+        assert all(g >= 0 for g in gaps), "views must be consecutive slices of one flat buffer"
+        dev = views[0].device
+        pads = {g: torch.zeros(g, device=dev) for g in set(gaps) if g > 0}
+        zeros = {}
+        hit = (views, base.view(-1)[starts[0]:ends[-1]], gaps, pads, zeros)
+        _WG_CACHE[key] = hit
+    _, out, gaps, pads, zeros = hit
+    pieces = []
+    for i, (v, g) in enumerate(zip(views, grads)):
         if g is None:
-            v.zero_()
+            z = zeros.get(v.numel())
+            if z is None:
+                z = zeros[v.numel()] = torch.zeros(v.numel(), device=v.device)
+            pieces.append(z)
         else:
-            dst.append(v)
-            src.append(g)
-    if dst:
-        torch._foreach_copy_(dst, src)
+            pieces.append(g.reshape(-1))
+        if gaps[i]:
+            pieces.append(pads[gaps[i]])
+    torch.cat(pieces, out=out)
 
 
 class AdamTF:
