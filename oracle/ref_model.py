@@ -287,14 +287,43 @@ def mean_squared_loss(y_a, y_b, batch_size):
     return (y_a - y_b).square().mean(dim=-1).sum() / batch_size
 
 
-def ocr_call(inputs_nhwc: torch.Tensor, serve_fn: Callable, max_char_number=8):
+def ocr_combine_logits(forward_logits, backward_logits):
+    """aster_inferer.py:84-114."""
+    forward_mask = ~(forward_logits.argmax(dim=2) == 1)
+    backward_mask = ~(backward_logits.argmax(dim=2) == 1)
+    masked_forward = forward_logits[forward_mask]
+    masked_backward = torch.flip(backward_logits[backward_mask], (0,))
+    crop_masked_forward = masked_forward[: masked_backward.shape[0]]
+    crop_masked_backward = masked_backward[: masked_forward.shape[0]]
+    forward_max = crop_masked_forward.max(dim=1).values
+    backward_max = crop_masked_backward.max(dim=1).values
+    combined = torch.where(forward_max[:, None] > backward_max[:, None], crop_masked_forward, crop_masked_backward)
+    return combined[None]
+
+
+def ocr_postprocess_combine(prediction: dict, max_char_number=8):
+    """aster_inferer.py:39-82."""
+    forward_logits = prediction["forward_logits"][:, :max_char_number]
+    backward_logits = prediction["backward_logits"][:, :max_char_number]
+    combined_logits = ocr_combine_logits(forward_logits, backward_logits)
+    remaining_logits = forward_logits[:, combined_logits.shape[1]:, :]
+    padding_len = max_char_number - forward_logits.shape[1]
+    padding = torch.zeros(1, padding_len, combined_logits.shape[2], dtype=forward_logits.dtype)
+    padding[:, :, 1] = 1000.0
+    return torch.cat([combined_logits, remaining_logits, padding], dim=1)
+
+
+def ocr_call(inputs_nhwc: torch.Tensor, serve_fn: Callable, max_char_number=8, combine_forward_and_backward=False):
     """AsterInferer.call, aster_inferer.py:28-37: the SavedModel is called ONE SAMPLE AT A TIME; each sample's
     ``forward_logits`` [1, T_i, C] (T_i = that sample's own dynamic-decode length) is post-processed and the rows are
     concatenated.  ``serve_fn``: NHWC [1,64,256,3] -> {"forward_logits": [1,T,C]} (the serving signature)."""
     rows = []
     for i in range(inputs_nhwc.shape[0]):
         prediction = serve_fn(inputs_nhwc[i:i + 1])
-        rows.append(ocr_postprocess_simple(prediction["forward_logits"], max_char_number))
+        if combine_forward_and_backward:
+            rows.append(ocr_postprocess_combine(prediction, max_char_number))
+        else:
+            rows.append(ocr_postprocess_simple(prediction["forward_logits"], max_char_number))
     return torch.cat(rows, dim=0)
 
 

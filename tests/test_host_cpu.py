@@ -169,3 +169,34 @@ def test_grad_exchange_is_a_noop_single_process():
     assert ex.start(b) is None and ex.world_size() == 1
     ex.reduce_now([b])
     assert float(b.sum()) == 5.0 and [float(v) for v in ex.reduce_scalars([torch.tensor(2.0)])] == [2.0]
+
+
+def test_aster_wrapper_combine_forward_and_backward_matches_oracle_on_cpu():
+    """combine_forward_and_backward=True (aster_inferer.py:39-114): hand-made logits with a known answer, then the whole
+    wrapper against the oracle's per-sample restatement."""
+    from oracle import ref_model as M
+    from textboxgan_amd.aster import AsterInferer, AsterLikeOCR
+    C = 7
+    def row(cls, conf):
+        r = torch.zeros(C); r[cls] = conf; return r
+    # forward predictor: "ab" then blank; backward predictor (reads right-to-left): "b"(conf 9), "a"(conf 1), blank
+    fwd = torch.stack([row(2, 3.0), row(3, 4.0), row(1, 5.0)])[None]
+    bwd = torch.stack([row(3, 9.0), row(2, 1.0), row(1, 5.0)])[None]
+    out = AsterInferer._combine_logits(fwd, bwd)
+    # step 0: forward 3.0 vs reversed-backward 1.0 -> forward; step 1: 4.0 vs 9.0 -> backward
+    assert out.shape == (1, 2, C) and torch.equal(out[0, 0], row(2, 3.0)) and torch.equal(out[0, 1], row(3, 9.0))
+    assert torch.equal(out, M.ocr_combine_logits(fwd, bwd))
+    net = AsterLikeOCR(max_steps=8, backward_predictor=True)
+    plain = AsterLikeOCR(max_steps=8)
+    assert torch.equal(net.out.weight, plain.out.weight) and torch.equal(net.cell.weight_ih, plain.cell.weight_ih)
+    o = AsterInferer(model=net, combine_forward_and_backward=True)
+    x = torch.randn(2, 64, 256, 3, generator=torch.Generator().manual_seed(3)) * 0.5
+    with torch.no_grad():
+        got = o(x)
+        exp = M.ocr_call(x, net.serve, 8, combine_forward_and_backward=True)
+    assert got.shape == (2, 8, 97)
+    np.testing.assert_allclose(got.numpy(), exp.numpy(), atol=1e-5)
+    full = o._postprocess_combine({"forward_logits": fwd, "backward_logits": bwd})
+    assert full.shape == (1, 8, C) and torch.equal(full[0, 2], row(1, 5.0)) and float(full[0, 3, 1]) == 1000.0
+    with pytest.raises(ValueError):
+        AsterInferer(model=plain, combine_forward_and_backward=True)

@@ -59,9 +59,12 @@ class AsterInferer(nn.Module):
     def __init__(self, model: Optional[nn.Module] = None, char_width: int = 32, max_char_number: int = 8,
                  image_dims=(64, 256), combine_forward_and_backward: bool = False):
         super().__init__()
-        if combine_forward_and_backward:
-            raise NotImplementedError("reference default is forward logits only (aster_inferer.py:19)")
-        self.model = model if model is not None else AsterLikeOCR(max_steps=max_char_number)
+        self.combine_forward_and_backward = combine_forward_and_backward
+        if model is None:
+            model = AsterLikeOCR(max_steps=max_char_number, backward_predictor=combine_forward_and_backward)
+        if combine_forward_and_backward and not getattr(model, "has_backward_predictor", False):
+            raise ValueError("combine_forward_and_backward needs a network with a backward predictor (backward_logits)")
+        self.model = model
         for p in self.model.parameters():
             p.requires_grad_(False)
         self.model.train(False)
@@ -92,9 +95,42 @@ class AsterInferer(nn.Module):
         return out.permute(0, 2, 3, 1)
 
     def forward(self, inputs_nhwc: torch.Tensor) -> torch.Tensor:
-        """aster_inferer.py:28-37 (``call``), batched: ``forward_logits`` of every sample, post-processed."""
+        """aster_inferer.py:28-37 (``call``), batched: ``forward_logits`` of every sample, post-processed.
+        combine_forward_and_backward (off by default, as in the reference :12-15,19): the literal per-sample loop with
+        data-dependent shapes -- eager only (not HIP-graph capturable)."""
+        if self.combine_forward_and_backward:
+            rows = []
+            for i in range(inputs_nhwc.shape[0]):
+                rows.append(self._postprocess_combine(self.model.serve(inputs_nhwc[i:i + 1])))
+            return torch.cat(rows, dim=0)
         logits, lengths = self.model.forward_logits(inputs_nhwc.permute(0, 3, 1, 2))  # [B, S, C], [B] (T_i of sample i)
         return self._postprocess_simple(logits, lengths)
+
+    def _postprocess_combine(self, logits: dict) -> torch.Tensor:
+        """aster_inferer.py:39-82 for ONE sample's {"forward_logits", "backward_logits"} [1, T, C]."""
+        forward_logits = logits["forward_logits"][:, : self.max_char_number]
+        backward_logits = logits["backward_logits"][:, : self.max_char_number]
+        combined = self._combine_logits(forward_logits, backward_logits)
+        remaining = forward_logits[:, combined.shape[1]:, :]
+        padding_len = self.max_char_number - forward_logits.shape[1]
+        C = combined.shape[2]
+        pad_row = (torch.arange(C, device=combined.device) == EOS).to(combined.dtype) * 1000.0
+        return torch.cat([combined, remaining, pad_row.expand(1, padding_len, C)], dim=1)
+
+    @staticmethod
+    def _combine_logits(forward_logits: torch.Tensor, backward_logits: torch.Tensor) -> torch.Tensor:
+        """aster_inferer.py:84-114: drop the steps that predict blank, reverse the backward predictor's steps, and per step
+        keep whichever predictor is more confident (larger maximum logit)."""
+        forward_mask = forward_logits.argmax(dim=2) != EOS
+        backward_mask = backward_logits.argmax(dim=2) != EOS
+        masked_forward = forward_logits[forward_mask]
+        masked_backward = backward_logits[backward_mask].flip(0)
+        crop_forward = masked_forward[: masked_backward.shape[0]]
+        crop_backward = masked_backward[: masked_forward.shape[0]]
+        forward_max = crop_forward.max(dim=1).values
+        backward_max = crop_backward.max(dim=1).values
+        combined = torch.where(forward_max[:, None] > backward_max[:, None], crop_forward, crop_backward)
+        return combined[None]
 
     def _postprocess_simple(self, logits: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
         """aster_inferer.py:116-151 for a batch of samples whose own logits have ``lengths[i]`` time steps (``None``:
@@ -182,8 +218,9 @@ class _ResUnit(nn.Module):
 
 class AsterLikeOCR(nn.Module):
     def __init__(self, num_classes: int = 97, max_steps: int = 8, hidden: int = 256, num_ctrl: int = 20,
-                 rect_hw=(32, 100), seed: int = 20180625):
+                 rect_hw=(32, 100), seed: int = 20180625, backward_predictor: bool = False):
         super().__init__()
+        self.has_backward_predictor = backward_predictor
         self.num_classes, self.max_steps, self.hidden = num_classes, max_steps, hidden
         self.rect_hw = rect_hw
         # --- rectification (STN): localisation CNN on a 32x64 thumbnail -> 2K control coordinates
@@ -211,6 +248,12 @@ class AsterLikeOCR(nn.Module):
         self.att_v = nn.Linear(hidden, 1, bias=False)
         self.cell = nn.LSTMCell(2 * hidden + hidden, hidden)
         self.out = nn.Linear(hidden, num_classes)
+        if backward_predictor:  # ASTER's second predictor (weigths_tf1_to_tf2.py:8-13 "Backward/Predictor"): the same decoder
+            # on the time-reversed encoder features; registered LAST so the forward network's synthetic weights are unchanged
+            self.bwd = nn.ModuleDict(dict(emb=nn.Embedding(num_classes + 1, hidden),
+                                          att_enc=nn.Linear(2 * hidden, hidden, bias=False), att_dec=nn.Linear(hidden, hidden),
+                                          att_v=nn.Linear(hidden, 1, bias=False), cell=nn.LSTMCell(2 * hidden + hidden, hidden),
+                                          out=nn.Linear(hidden, num_classes)))
         self._synthetic_init(seed)
         self.train(False)
 
@@ -383,25 +426,37 @@ class AsterLikeOCR(nn.Module):
 
     def serve(self, inputs_nhwc: torch.Tensor) -> dict:
         """The SavedModel's serving signature as the reference calls it (aster_inferer.py:31, batch 1):
-        NHWC [1,64,256,3] -> {"forward_logits": [1, T, C]} with the decode's own length T."""
+        NHWC [1,64,256,3] -> {"forward_logits": [1, T, C]} (+ "backward_logits" when the network has the backward
+        predictor) with the decode's own length T."""
         assert inputs_nhwc.shape[0] == 1, "the reference calls the SavedModel one sample at a time"
-        logits, lengths = self.forward_logits(inputs_nhwc.permute(0, 3, 1, 2))
-        return {"forward_logits": logits[:, : int(lengths[0])]}
+        if not self.has_backward_predictor:
+            logits, lengths = self.forward_logits(inputs_nhwc.permute(0, 3, 1, 2))
+            return {"forward_logits": logits[:, : int(lengths[0])]}
+        x = self.encode(self.rectify(inputs_nhwc.permute(0, 3, 1, 2)))
+        enc = self._encode_rnn(x.squeeze(2).permute(0, 2, 1))
+        fwd = self._decode(enc)
+        bwd = self._decode_with(enc.flip(1), self.bwd.emb, self.bwd.att_enc, self.bwd.att_dec, self.bwd.att_v, self.bwd.cell,
+                                self.bwd.out)
+        return {"forward_logits": fwd[:, : int(self.decode_lengths(fwd.detach())[0])],
+                "backward_logits": bwd[:, : int(self.decode_lengths(bwd.detach())[0])]}
 
     def _decode(self, enc):
         """Bahdanau-attention LSTM decoder, greedy feedback (overridden by the HIP subclass)."""
+        return self._decode_with(enc, self.emb, self.att_enc, self.att_dec, self.att_v, self.cell, self.out)
+
+    def _decode_with(self, enc, emb, att_enc, att_dec, att_v, cell, out):
         B = enc.shape[0]
-        enc_proj = self.att_enc(enc)
+        enc_proj = att_enc(enc)
         h = enc.new_zeros(B, self.hidden)
         c = enc.new_zeros(B, self.hidden)
         prev = torch.full((B,), self.num_classes, dtype=torch.long, device=enc.device)  # GO
         outs = []
         for _ in range(self.max_steps):
-            e = self.att_v(torch.tanh(enc_proj + self.att_dec(h)[:, None, :])).squeeze(2)
+            e = att_v(torch.tanh(enc_proj + att_dec(h)[:, None, :])).squeeze(2)
             a = torch.softmax(e, dim=1)
             ctx = torch.bmm(a[:, None, :], enc).squeeze(1)
-            h, c = self.cell(torch.cat([ctx, self.emb(prev)], dim=1), (h, c))
-            logit = self.out(h)
+            h, c = cell(torch.cat([ctx, emb(prev)], dim=1), (h, c))
+            logit = out(h)
             outs.append(logit)
             prev = logit.argmax(dim=1)  # greedy feedback (non-differentiable, as in the TF decoder)
         return torch.stack(outs, dim=1)
