@@ -12,7 +12,8 @@
 //   * upfirdn2d_tile_kernel<UPX,UPY,DNX,DNY,RX,RY,SEP>: the model's forms (filters <= 4x4, factors <= 2, minor == 1).
 //     NO LDS and no barriers: one lane owns a 4 (x) x 4 (y) patch of outputs; its input window rows arrive as 16-byte
 //     global loads (a row is only 4-byte aligned: e.g. 257-float rows -- global_load_dwordx4 needs no more) that are all in
-//     flight together, outputs leave as 16-byte stores.  Because a lane's first output is a multiple of 4 and the
+//     flight together -- plane edges included: the loads are branch-free, padding is zeroed by selects afterwards -- and
+//     outputs leave as 16-byte stores.  Because a lane's first output is a multiple of 4 and the
 //     up-factors are 1 or 2, which taps meet which window element depends only on (pad0 mod UP) -- template parameters
 //     RX/RY -- so every register index is a compile-time constant and the taps sit in SGPRs.
 //     SEP: k = ky (x) kx (the model's [1,3,3,1] (x) [1,3,3,1]): a horizontal pass over the window rows, then a vertical
@@ -86,34 +87,49 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(const UpfirdnP p) {
   const int ix0 = (ox0 * DNX) / UPX + AX::base - qx;
   const int iy0 = (oy0 * DNY) / UPY + AY::base - qy;
   const float *xin = p.x + (size_t)plane * p.inH * p.inW;
-  // A lane takes ONE of two straight-line load sequences for its whole window (a branch per row would expose one
-  // memory round trip per row): interior lanes NIY*NV 16-byte loads, plane-edge lanes NIY*NIX clamped 4-byte loads with
-  // the out-of-plane elements zeroed afterwards.  Either way every load of the window is in flight at once.
-  const bool interior = ix0 >= 0 && ix0 + NIXP <= p.inW && iy0 >= 0 && iy0 + NIY <= p.inH;
+  // Window loads are branch-free for every lane whose window lies inside the TENSOR (not merely inside its plane row): the
+  // 16-byte loads are issued at the true addresses -- a window that hangs over the left / right end of a row reads the
+  // neighbouring row's elements, one that hangs over the top / bottom of the plane reads a clamped row -- and the elements
+  // that are padding are zeroed afterwards with selects (plane edges are NOT a slow path: the first version sent every
+  // wave of a 256-wide plane through a second, divergent load sequence for its two edge lanes).  Only the few lanes
+  // whose window would leave the allocation itself (first / last elements of the whole tensor) load element by element.
+  const long long plane_off = (long long)plane * p.inH * p.inW;
+  const long long n_total = (long long)p.major * p.inH * p.inW;
+  const int iy_lo = min(max(iy0, 0), p.inH - 1), iy_hi = min(max(iy0 + NIY - 1, 0), p.inH - 1);
+  const bool safe = plane_off + (long long)iy_lo * p.inW + ix0 >= 0 &&
+                    plane_off + (long long)iy_hi * p.inW + ix0 + NIXP <= n_total;
   float w[NIY][NIXP];
-  if (interior) {
-    const float *src = xin + (size_t)iy0 * p.inW + ix0;
+  if (safe) {
 #pragma unroll
-    for (int m = 0; m < NIY; ++m)
+    for (int m = 0; m < NIY; ++m) {
+      const int iyc = min(max(iy0 + m, 0), p.inH - 1);
+      const float *src = xin + (long long)iyc * p.inW + ix0;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        const f32x4u t = *reinterpret_cast<const f32x4u *>(src + (size_t)m * p.inW + 4 * v);
+        const f32x4u t = *reinterpret_cast<const f32x4u *>(src + 4 * v);
         w[m][4 * v] = t.x; w[m][4 * v + 1] = t.y; w[m][4 * v + 2] = t.z; w[m][4 * v + 3] = t.w;
       }
+    }
   } else {
 #pragma unroll
     for (int m = 0; m < NIY; ++m) {
-      const int iy = iy0 + m;
-      const bool row_ok = iy >= 0 && iy < p.inH;
-      const float *row = xin + (size_t)(row_ok ? iy : 0) * p.inW;
+      const int iyc = min(max(iy0 + m, 0), p.inH - 1);
+      const float *row = xin + (size_t)iyc * p.inW;
 #pragma unroll
       for (int e = 0; e < NIXP; ++e) {
         const int ix = ix0 + e;
-        const bool ok = row_ok && e < NIX && ix >= 0 && ix < p.inW;
-        const float t = e < NIX ? row[ok ? ix : 0] : 0.f;
-        w[m][e] = ok ? t : 0.f;
+        w[m][e] = row[min(max(ix, 0), p.inW - 1)];
       }
     }
+  }
+  bool col_ok[NIXP];
+#pragma unroll
+  for (int e = 0; e < NIXP; ++e) col_ok[e] = e < NIX && ix0 + e >= 0 && ix0 + e < p.inW;
+#pragma unroll
+  for (int m = 0; m < NIY; ++m) {
+    const bool row_ok = iy0 + m >= 0 && iy0 + m < p.inH;
+#pragma unroll
+    for (int e = 0; e < NIXP; ++e) w[m][e] = (row_ok && col_ok[e]) ? w[m][e] : 0.f;
   }
 
   float out[NOY][NOX];
