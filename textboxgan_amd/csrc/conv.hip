@@ -75,9 +75,17 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // bf16 (RNE) on their way into LDS, the filter arrives pre-packed in bf16 (tbg_weight_pack_bf16) and the contraction runs on
 // v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate).  A 16-byte LDS unit then holds 8 channels instead of 4, so the
 // same tile geometry / DMA / operand-read code serves both: only the unit width KP and the MFMA differ.
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF, int OCC = 3, bool BF = false>
+// TM = true: MERGED stride-2 transposed 3x3 convolution (up-conv forward, data gradient of the stride-2 convs).  The four
+// output-parity classes of y[2a+kh, 2b+kw] += x[a,b] w[kh,kw] are computed by ONE block from ONE staged halo tile: the tile
+// indexes INPUT positions (u,v) (halo: one row above, one column left), the 9 taps are unrolled statically and tap (kh,kw)
+// accumulates into class (kh&1, kw&1) -- 4 x (WTM x WTN) accumulator tiles -- reading x[u - (kh==2), v - (kw==2)].  Same MFMA
+// count as a 3x3 stride-1 convolution on the input grid and no per-class re-staging (the class-per-block form staged the
+// halo four times and ran 1/2/2/4-tap K loops).  Store-only epilogue (alpha * acc; split-K slabs allowed).
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF, int OCC = 3, bool BF = false, bool TM = false>
 __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   constexpr int BM = WGM * WTM * 32;
+  constexpr int NC = TM ? 4 : 1;            // accumulator sets (output-parity classes of the merged transposed form)
+  static_assert(!TM || (PF == 0 && CK >= 8 && MT == 9), "merged transposed form: 9 taps, plain K loop");
   constexpr int KP = BF ? 8 : 4;            // channels per 16-byte unit
   constexpr int G4 = (CK + KP - 1) / KP;    // units (fp32: channel quads, bf16: octets) per chunk
   constexpr int CB = CK < 8 ? CK : 8;       // channels per halo load batch
@@ -162,13 +170,15 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   const int abytes = CK == 4 ? (wm * (WTM * 32) + (lane & 31)) * 16 + half * 8
                              : (half * BM + wm * (WTM * 32) + (lane & 31)) * 16;
 
-  f32x16 acc[WTM][WTN];
+  f32x16 acc[NC][WTM][WTN];
 #pragma unroll
-  for (int i = 0; i < WTM; ++i)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int j = 0; j < WTN; ++j)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
   const int HWin = p.Hin * p.Win;
   const int kbeg = ks * p.cps;
@@ -238,6 +248,50 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   auto mfma_taps = [&](const float *Abuf, const float *Xbuf) {
     const char *Ab = reinterpret_cast<const char *>(Abuf) + abytes;
     const char *Xb = reinterpret_cast<const char *>(Xbuf);
+    if constexpr (TM) {
+      const int rowb = p.IWp * 16;  // one halo row, in bytes
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int t = kh * 3 + kw;
+          const int c = (kh & 1) * 2 + (kw & 1);
+          const int toffb = (kh == 2 ? 0 : rowb) + (kw == 2 ? 0 : 16);  // x[u - (kh==2), v - (kw==2)] inside the halo tile
+#pragma unroll
+          for (int o = 0; o < CK / (2 * KP); ++o) {
+            if constexpr (BF) {
+              bf16x8 a[WTM], b[WTN];
+#pragma unroll
+              for (int i = 0; i < WTM; ++i)
+                a[i] = *reinterpret_cast<const bf16x8 *>(Ab + ((t * G4 + o * 2) * BM + i * 32) * 16);
+#pragma unroll
+              for (int j = 0; j < WTN; ++j)
+                b[j] = *reinterpret_cast<const bf16x8 *>(Xb + (bbytes[j] + toffb + o * 2 * p.planeStride * 16));
+#pragma unroll
+              for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j)
+                  acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[c][i][j], 0, 0, 0);
+            } else {
+              f32x4 a[WTM], b[WTN];
+#pragma unroll
+              for (int i = 0; i < WTM; ++i)
+                a[i] = *reinterpret_cast<const f32x4 *>(Ab + ((t * G4 + o * 2) * BM + i * 32) * 16);
+#pragma unroll
+              for (int j = 0; j < WTN; ++j)
+                b[j] = *reinterpret_cast<const f32x4 *>(Xb + (bbytes[j] + toffb + o * 2 * p.planeStride * 16));
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                  for (int j = 0; j < WTN; ++j)
+                    acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[c][i][j], 0, 0, 0);
+            }
+          }
+        }
+      return;
+    }
     for (int t = 0; t < ntaps; ++t) {
       const int toffb = __builtin_amdgcn_readlane(tofft, t);  // tap shift in bytes (lane t of the table)
       if constexpr (BF) {
@@ -254,7 +308,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
           for (int i = 0; i < WTM; ++i)
 #pragma unroll
             for (int j = 0; j < WTN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+              acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[0][i][j], 0, 0, 0);
         }
       } else if constexpr (CK == 4) {
         f32x2 a[WTM], b[WTN];
@@ -268,7 +322,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
           for (int i = 0; i < WTM; ++i)
 #pragma unroll
             for (int j = 0; j < WTN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+              acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[0][i][j], 0, 0, 0);
       } else {
 #pragma unroll
         for (int o = 0; o < CK / 8; ++o) {
@@ -285,7 +339,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
             for (int i = 0; i < WTM; ++i)
 #pragma unroll
               for (int j = 0; j < WTN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[0][i][j], 0, 0, 0);
         }
       }
     }
@@ -363,6 +417,32 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   // version interleaved kernarg reloads, loads and stores element by element (521 s_waitcnt in 6.8k instructions) and
   // cost 45-80 us per large launch -- more than the output write itself (a 134 MB fill takes 21 us).
   const int HWout = p.Hout * p.Wout;
+  if constexpr (TM) {  // the four classes of input position (u, v) land on outputs (2u + cy, 2v + cx)
+    float *const yb = p.ksplit > 1 ? p.y + (size_t)ks * p.slab : p.y;
+    const float alpha = p.e.alpha;
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int n = (wn * WTN + j) * 32 + (lane & 31);
+      const int q = n & TWm, rr = n >> p.logTW;
+      const int seg = rr >> p.logTHs, r = rr & THm;
+      const int b = bg * p.NSEG + seg, u = u0 + r, v = v0 + q;
+      const bool okp = b < p.B && u < ci.Ug && v < ci.Vg;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int Y = 2 * u + (c >> 1), X = 2 * v + (c & 1);
+        const bool ok = okp && Y < p.Hout && X < p.Wout;
+        const int pix = Y * p.Wout + X;
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int r16 = 0; r16 < 16; ++r16) {
+            const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+            if (ok && m < p.M) yb[(b * p.M + m) * HWout + pix] = acc[c][i][j][r16] * alpha;
+          }
+      }
+    }
+    return;
+  }
   const float *const e_os = p.e.out_scale, *const e_bias = p.e.bias, *const e_res = p.e.residual, *const e_aux = p.e.dot_aux;
   float *const e_dot = p.e.dot_out;
   const float e_alpha = p.e.alpha, e_bmul = p.e.bias_mul, e_slope = p.e.slope, e_gain = p.e.gain, e_rscale = p.e.res_scale;
@@ -395,7 +475,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
         const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
 #pragma unroll
         for (int j = 0; j < WTN; ++j)
-          if (m < M && e_pix[j] >= 0) ybase[(e_b[j] * M + m) * HWout + e_pix[j]] = acc[i][j][r16] * e_alpha;
+          if (m < M && e_pix[j] >= 0) ybase[(e_b[j] * M + m) * HWout + e_pix[j]] = acc[0][i][j][r16] * e_alpha;
       }
     return;
   }
@@ -445,7 +525,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
 #pragma unroll
         for (int j = 0; j < WTN; ++j) {
           const bool okq = idx[q][j] >= 0;
-          float val = acc[i][j][r0 + q] * e_alpha;
+          float val = acc[0][i][j][r0 + q] * e_alpha;
           if (do_dot) {
             const float pv = okq ? val * axv[q][j] : 0.f;
             if (NSEGr == 1) dsum += pv;
@@ -470,7 +550,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
 // name-only mode (name != NULL): write the instantiation the descriptor selects (rocprofv3 spelling) and launch nothing
 struct NameOut { char *buf; int n; };
 
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false, bool TM = false>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, const NameOut *name) {
   constexpr int BM = WGM * WTM * 32;
   constexpr int G4 = (CK + (BF ? 7 : 3)) / (BF ? 8 : 4);
@@ -484,11 +564,11 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   if (maxtaps > MT) return TBG_EUNSUPPORTED;
   if (name) {
-    snprintf(name->buf, name->n, "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC,
-             BF ? "true" : "false");
+    snprintf(name->buf, name->n, "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC,
+             BF ? "true" : "false", TM ? "true" : "false");
     return TBG_OK;
   }
-  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF, OCC, BF>;
+  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF, OCC, BF, TM>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TBG_EHIP;
@@ -527,6 +607,11 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   p.ldw = d->ldw;
   p.e = make_epi(epi);
   const int T = d->KH * d->KW;
+  // merged form of the stride-2 transposed 3x3 convolution (see the TM template parameter): store-only epilogues
+  const bool plain_epi = !epi || (!epi->out_scale && !epi->bias && !epi->noise && !epi->residual && !epi->dot_aux &&
+                                  epi->act == TBG_ACT_LINEAR && epi->gain == 1.f);
+  const bool merged = d->transposed && d->sy == 2 && d->sx == 2 && d->KH == 3 && d->KW == 3 && plain_epi && variant != 4 &&
+                      d->M > 32;
   int maxUg = 0, maxVg = 0, maxKH = 0, maxKW = 0, maxtaps = 0;
   if (!d->transposed) {
     p.sy = d->sy; p.sx = d->sx; p.osy = 1; p.osx = 1; p.nclass = 1;
@@ -534,6 +619,14 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     c.ntaps = T; c.KWc = d->KW; c.py = d->py; c.px = d->px; c.ooy = 0; c.oox = 0; c.Ug = d->Hout; c.Vg = d->Wout;
     for (int t = 0; t < T; ++t) c.wtap[t] = d->flip ? T - 1 - t : t;
     maxUg = c.Ug; maxVg = c.Vg; maxKH = d->KH; maxKW = d->KW; maxtaps = T;
+  } else if (merged) {
+    // one "class" that carries all 9 taps: the tile indexes input positions (u, v), halo = one row above / one column left
+    p.sy = 1; p.sx = 1; p.osy = 2; p.osx = 2; p.nclass = 1;
+    ClassInfo &c = p.cls[0];
+    c.ntaps = 9; c.KWc = 3; c.py = 1; c.px = 1; c.ooy = 0; c.oox = 0;
+    c.Ug = ceil_div(d->Hout, 2); c.Vg = ceil_div(d->Wout, 2);
+    for (int t = 0; t < 9; ++t) c.wtap[t] = d->flip ? 8 - t : t;
+    maxUg = c.Ug; maxVg = c.Vg; maxKH = 2; maxKW = 2; maxtaps = 9;
   } else {
     p.sy = 1; p.sx = 1; p.osy = d->sy; p.osx = d->sx; p.nclass = d->sy * d->sx;
     int k = 0;
@@ -566,7 +659,8 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
 
   // tile configuration
   int BM, BN;
-  {
+  if (merged) { BM = 64; BN = 128; }  // 4 classes x (1 x 2) MFMA tiles per wave = 128 accumulators
+  else {
     const long long npix = (long long)d->B * maxUg * maxVg;  // N of the (largest class) GEMM
     if (d->M <= 32) { BM = 32; BN = 256; }
     else if (d->M <= 64) { BM = 64; BN = (npix + 255) / 256 < 96 ? 64 : 256; }
@@ -599,7 +693,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     if (p.NJ <= MAXNJ) break;
     // very narrow maps pack many images into a 256-pixel tile and the halo of all of them exceeds what a thread can
     // describe: fall back to the 64x64 tile once
-    if (attempt == 0 && BN > 64) { BM = 64; BN = 64; continue; }
+    if (attempt == 0 && BN > 64 && !merged) { BM = 64; BN = 64; continue; }
     return TBG_EUNSUPPORTED;
   }
   p.nBG = ceil_div(p.B, p.NSEG);
@@ -614,6 +708,10 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   p.ksplit = d->ksplit;
   p.slab = (long long)d->B * d->M * d->Hout * d->Wout;
   hipStream_t st = tbg_stream(stream);
+  if (merged) {
+    if (bf) return launch_fprop<2, 2, 1, 2, 16, MAXTAPS, 0, 2, true, true>(p, st, maxtaps, maxTilesN, name);
+    return launch_fprop<2, 2, 1, 2, 8, MAXTAPS, 0, 2, false, true>(p, st, maxtaps, maxTilesN, name);
+  }
   if (bf) {  // bf16-in MFMA: chunks of 16 channels (32 for the few-tap classes), the same four tile shapes
     if (variant == 1 && BM == 128 && BN == 128 && maxtaps > 4) {  // 128x256 tile: every filter byte feeds 256 pixels
       // re-derive the pixel tiling for BN = 256 (same rules as above)
@@ -637,7 +735,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     }
     if (variant == 2 && BM == 128 && BN == 128 && maxtaps > 4)  // 32-channel chunks: half the barriers
       return launch_fprop<2, 2, 2, 2, 32, MAXTAPS, 0, 2, true>(p, st, maxtaps, maxTilesN, name);
-    if (variant != 0) return TBG_EUNSUPPORTED;
+    if (variant != 0 && variant != 4) return TBG_EUNSUPPORTED;
     if (maxtaps > 1 && maxtaps <= 4) {
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
@@ -657,7 +755,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
     return launch_fprop<2, 2, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
   }
-  if (variant != 0) {  // explicit instantiation choice (tbg_conv2d_f32_variant: tuning / test aid, stateless)
+  if (variant != 0 && variant != 4) {  // explicit instantiation choice (tbg_conv2d_f32_variant: tuning / test aid, stateless)
     if (variant == 1 && p.NJ <= 3) {  // software-pipelined
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
@@ -695,13 +793,13 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
 
 extern "C" int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                                       const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant < 0 || variant > 3) return TBG_EINVAL;
+  if (variant < 0 || variant > 4) return TBG_EINVAL;
   return conv2d_impl(d, x, w, y, in_scale, epi, stream, nullptr, false, variant);
 }
 
 extern "C" int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                                        const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant < 0 || variant > 2) return TBG_EINVAL;
+  if (variant < 0 || (variant > 2 && variant != 4)) return TBG_EINVAL;
   return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, true, variant);
 }
 
