@@ -140,8 +140,9 @@ int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float
 int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
 /* tbg_conv2d_f32 with an EXPLICIT instantiation family for 3x3 / 1x1 non-transposed-class launches (tuning and test aid):
  * variant 0 = the library's choice, 1 = software-pipelined (double-buffered LDS), 2 = plain 8-channel chunks,
- * 3 = 4-channel chunks at 4 waves/SIMD (128x128 tile only), 4 = stride-2 transposed 3x3 as one launch per output-parity
- * class (round 1's form) instead of the merged-class kernel.  TBG_EUNSUPPORTED if the descriptor cannot take it. */
+ * 3 = 4-channel chunks at 4 waves/SIMD (128x128 tile only), 4 / 5 = stride-2 transposed 3x3 as one block per output-parity
+ * class / as the merged-class kernel (all four classes from one staged halo tile).  TBG_EUNSUPPORTED if the descriptor
+ * cannot take it. */
 int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                            const float *in_scale, const tbg_epilogue *epi, int variant, void *stream);
 
@@ -200,7 +201,7 @@ int tbg_conv2d_bf16(const tbg_conv_desc *d, const float *x, const void *w, float
                     const float *in_scale, const tbg_epilogue *epi, void *stream);
 int tbg_conv2d_bf16_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
 /* explicit instantiation family (tuning / test aid): 0 = library's choice, 1 = 128x256 tile, 2 = 32-channel chunks,
- * 4 = class-per-block transposed form. */
+ * 4 / 5 = class-per-block / merged-class transposed form. */
 int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                             const float *in_scale, const tbg_epilogue *epi, int variant, void *stream);
 /* filter gradient; tile rows narrower than 8 pixels (Ws <= 4) fall back to the exact fp32 kernel.  Workspace size =

@@ -276,3 +276,40 @@ def test_config3_step_bs32_bf16_runs_and_tracks_fp32(dev):
         torch.cuda.empty_cache()
     for name, a, e in zip(("reg_g", "g", "pl", "reg_d", "d", "r1", "ocr"), first["bf16"], first["f32"]):
         assert abs(a - e) <= 3e-2 * max(1.0, abs(e)), (name, a, e)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 128, 128, 16, 64), (3, 512, 256, 4, 16), (2, 40, 72, 9, 13), (8, 64, 64, 32, 128)],
+                         ids=["16x64", "4x16-splitk", "odd", "bf16-auto-size"])
+def test_merged_class_transposed_kernel(dev, case, bf16):
+    """the merged-class form of the stride-2 transposed 3x3 convolution (all four output-parity classes from one staged halo
+    tile; tbg_conv2d_*_variant 5, and the library's own choice for large bf16 launches) == conv_transpose2d, natural and
+    padded output sizes, with the style modulation applied while staging."""
+    from textboxgan_amd import ops
+    B, Cc, Mo, H, W = case
+    x = rnd(B, Cc, H, W, seed=41)
+    w = rnd(3, 3, Cc, Mo, seed=42) / math.sqrt(9 * Cc)
+    s = rnd(B, Cc, seed=43) + 1.0
+    xs = x.float() * s.float()[:, :, None, None]
+    xr, wr = (bf(xs.double()), bf(w)) if bf16 else (xs.double(), w.float().double())
+    ref = F.conv_transpose2d(xr, wr.permute(2, 3, 0, 1), stride=2)
+    f = lambda t: t.float().to(dev).contiguous()
+    try:
+        ops.FORCE_VARIANT = 5
+        with ops.compute_dtype("bf16" if bf16 else "f32"):
+            y = ops.conv2d_raw(f(x), f(w), Mo, 3, 3, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, in_scale=f(s))
+            y2 = ops.conv2d_raw(f(x), f(w), Mo, 3, 3, (2 * H + 2, 2 * W + 2), (2, 2), (0, 0), transposed=True, in_scale=f(s))
+            yflip = ops.conv2d_raw(f(x), f(w), Mo, 3, 3, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, flip=True,
+                                   in_scale=f(s))
+    finally:
+        ops.FORCE_VARIANT = 0
+    assert rel_err(y, ref) < 3e-5
+    assert rel_err(y2, F.pad(ref, (0, 1, 0, 1))) < 3e-5
+    assert rel_err(yflip, F.conv_transpose2d(xr, torch.flip(wr, (0, 1)).permute(2, 3, 0, 1), stride=2)) < 3e-5
+    if bf16 and B * H * W >= 16384:  # the library picks the merged form by itself here
+        from textboxgan_amd import native as N
+        d = N.ConvDesc(B, Cc, Mo, H, W, 2 * H + 1, 2 * W + 1, 3, 3, 2, 2, 0, 0, 1, 0, Mo, 1)
+        assert N.conv_kernel_name(d, True, True).endswith("true, true>")
+        with ops.compute_dtype("bf16"):
+            y3 = ops.conv2d_raw(f(x), f(w), Mo, 3, 3, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, in_scale=f(s))
+        assert rel_err(y3, ref) < 3e-5

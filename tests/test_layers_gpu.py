@@ -67,11 +67,12 @@ def test_modconv_fused_fwd_bwd(dev, up, shape):
     assert rel_err(outd, out) < 3e-5
     gd = torch.autograd.grad(outd, (xd, wd, mwd, mbd, std, bd), f(dout))
     for name, a, b in zip(("dx", "dw", "dmod_w", "dmod_b", "dstrength", "dbias"), gd, grads):
-        # relative L2 is the stable measure: ONE pre-activation within rounding of zero can take the other LeakyReLU branch
-        # under a different (equally valid) fp32 summation order, which changes dx by ~2e-2 of max at a handful of positions
-        # (observed when the merged-class transposed kernel replaced the class-per-launch form: 445 of 262144 elements)
-        da, db_ = a.detach().double().cpu(), b.detach().double()
-        assert float((da - db_).norm() / (db_.norm() + 1e-30)) < 3e-4 and rel_err(a, b) < 5e-2, name
+        # strict on the bulk, tolerant of LeakyReLU branch flips: ONE pre-activation within rounding of zero can take the other
+        # branch under a different (equally valid) fp32 summation order, which changes dx by ~2e-2 of max at a handful of
+        # positions (seen with the merged-class transposed kernel: 445 of 262144 elements)
+        err = (a.detach().double().cpu() - b.detach().double()).abs() / (b.detach().double().abs().max() + 1e-30)
+        n_bad = int((err > 2e-4).sum())
+        assert n_bad <= 0.005 * err.numel() and float(err.max()) < 5e-2, (name, n_bad, float(err.max()))
 
 
 def test_dense_bias_act(dev):

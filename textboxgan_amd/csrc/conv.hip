@@ -610,8 +610,13 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   // merged form of the stride-2 transposed 3x3 convolution (see the TM template parameter): store-only epilogues
   const bool plain_epi = !epi || (!epi->out_scale && !epi->bias && !epi->noise && !epi->residual && !epi->dot_aux &&
                                   epi->act == TBG_ACT_LINEAR && epi->gain == 1.f);
+  // Measured (tools/bench_transposed.py, profiles/r02_transposed_forms.txt): in bf16 the merged form wins on the large maps
+  // (216 vs 158 TFLOP/s on 32x128 128->128, 232 vs 124 on the 128->64 data gradient: the per-class form re-stages the halo
+  // four times and bf16 launches are staging bound) and loses below ~16k input pixels; in fp32 (MFMA bound) the per-class
+  // form's 128x128 tiles at 3 waves/SIMD beat the merged form's 64x128 tiles at 2 waves/SIMD everywhere (76 vs 68).
+  // variant 5 forces the merged form, variant 4 the per-class form.
   const bool merged = d->transposed && d->sy == 2 && d->sx == 2 && d->KH == 3 && d->KW == 3 && plain_epi && variant != 4 &&
-                      d->M > 32;
+                      d->M > 32 && (variant == 5 || (bf && (long long)d->B * d->Hin * d->Win >= 16384));
   int maxUg = 0, maxVg = 0, maxKH = 0, maxKW = 0, maxtaps = 0;
   if (!d->transposed) {
     p.sy = d->sy; p.sx = d->sx; p.osy = 1; p.osx = 1; p.nclass = 1;
@@ -735,7 +740,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     }
     if (variant == 2 && BM == 128 && BN == 128 && maxtaps > 4)  // 32-channel chunks: half the barriers
       return launch_fprop<2, 2, 2, 2, 32, MAXTAPS, 0, 2, true>(p, st, maxtaps, maxTilesN, name);
-    if (variant != 0 && variant != 4) return TBG_EUNSUPPORTED;
+    if (variant != 0 && variant != 4 && variant != 5) return TBG_EUNSUPPORTED;
     if (maxtaps > 1 && maxtaps <= 4) {
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
@@ -755,7 +760,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
     return launch_fprop<2, 2, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
   }
-  if (variant != 0 && variant != 4) {  // explicit instantiation choice (tbg_conv2d_f32_variant: tuning / test aid, stateless)
+  if (variant != 0 && variant != 4 && variant != 5) {  // explicit instantiation choice (tbg_conv2d_f32_variant: tuning / test aid, stateless)
     if (variant == 1 && p.NJ <= 3) {  // software-pipelined
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
@@ -793,13 +798,13 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
 
 extern "C" int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                                       const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant < 0 || variant > 4) return TBG_EINVAL;
+  if (variant < 0 || variant > 5) return TBG_EINVAL;
   return conv2d_impl(d, x, w, y, in_scale, epi, stream, nullptr, false, variant);
 }
 
 extern "C" int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                                        const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant < 0 || (variant > 2 && variant != 4)) return TBG_EINVAL;
+  if (variant < 0 || variant == 3 || variant > 5) return TBG_EINVAL;
   return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, true, variant);
 }
 
