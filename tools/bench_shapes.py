@@ -6,8 +6,10 @@ from textboxgan_amd.config import Config
 from textboxgan_amd.training_step import build_trainer_state
 from bench import synthetic_batch, bench_init_
 dev = torch.device('cuda:0')
-cfg = Config(batch_size_per_gpu=16)
-st = build_trainer_state(cfg, dev, seed=0); bench_init_(st)
+DTYPE = sys.argv[1] if len(sys.argv) > 1 else "f32"
+BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else (32 if DTYPE == "bf16" else 16)
+cfg = Config(batch_size_per_gpu=BATCH)
+st = build_trainer_state(cfg, dev, seed=0, compute_dtype=DTYPE); bench_init_(st)
 b = synthetic_batch(cfg, dev, 1234); ts = st["training_step"]
 args = (b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False, 1e-4)
 for _ in range(2): ts.dist_train_step(*args)
@@ -24,8 +26,10 @@ import re, collections
 cat = collections.defaultdict(lambda: [0.0, 0.0, 0])
 for k, r in recs.items():
     m = re.search(r"in=(\d+)x(\d+)", k) or re.search(r"S=(\d+)x(\d+)", k)
+    if m is None:  # HBM-bound records (FIR, bias_act, adam): not convolutions
+        continue
     h, w_ = int(m.group(1)), int(m.group(2))
-    ocr = (w_ in (25, 50, 100) or (h, w_) in ((32, 64), (16, 32), (8, 16), (4, 8), (2, 4), (1, 2))) and "B=16" in k and not ("C=512 M=512 in=4x8" in k or "C=256 M=256 in=8x16" in k)
+    ocr = (w_ in (25, 50, 100) or (h, w_) in ((32, 64), (16, 32), (8, 16), (4, 8), (2, 4), (1, 2))) and f"B={BATCH}" in k and not ("C=512 M=512 in=4x8" in k or "C=256 M=256 in=8x16" in k)
     if "wgrad" in k:
         c = "wgrad 1x1" if "k=1 " in k else ("wgrad strided" if "s=(1, 1)" not in k else "wgrad 3x3 s1")
     elif ocr: c = "OCR convs"
