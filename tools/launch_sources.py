@@ -1,0 +1,55 @@
+"""Where do the small launches of one training step come from?  One eager step under torch.profiler; every device kernel is
+attributed to the autograd node that launched it (backward) or to the innermost textboxgan_amd source line (forward).
+usage (GPU box): python tools/launch_sources.py [f32|bf16] [batch] [ocr|noocr]"""
+import sys; sys.path.insert(0, '.')
+import collections
+import torch
+from torch.profiler import profile, ProfilerActivity
+from textboxgan_amd.config import Config
+from textboxgan_amd.training_step import build_trainer_state
+from bench import synthetic_batch, bench_init_, _TinyOCR
+
+dev = torch.device('cuda:0')
+DTYPE = sys.argv[1] if len(sys.argv) > 1 else "f32"
+BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+NOOCR = len(sys.argv) > 3 and sys.argv[3] == "noocr"
+cfg = Config(batch_size_per_gpu=BATCH)
+from textboxgan_amd.aster import AsterInferer
+kw = dict(aster_ocr=AsterInferer(model=_TinyOCR(cfg.max_char_number))) if NOOCR else {}
+st = build_trainer_state(cfg, dev, seed=0, compute_dtype=DTYPE, **kw); bench_init_(st)
+b = synthetic_batch(cfg, dev, 1234); ts = st["training_step"]
+args = (b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False, 1e-4)
+for _ in range(2): ts.dist_train_step(*args)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    ts.dist_train_step(*args)
+    torch.cuda.synchronize()
+
+by_src = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])
+n_k = 0
+for e in prof.events():
+    ks = getattr(e, "kernels", None)
+    if not ks or str(e.device_type).endswith("CUDA"):
+        continue
+    # attribute to the outermost autograd node, else to the innermost package frame of the python stack
+    src, p = None, e
+    while p is not None:
+        if p.name.startswith("autograd::engine::evaluate_function:"):
+            src = "bwd " + p.name.split(":", 4)[-1].strip()
+        p = p.cpu_parent
+    if src is None:
+        for fr in (e.stack or []):
+            if "textboxgan_amd/" in fr and "native.py" not in fr:
+                src = "fwd " + fr.split("textboxgan_amd/")[-1]
+                break
+    src = src or "fwd ?"
+    for k in ks:
+        rec = by_src[src]
+        rec[0] += 1; rec[1] += k.duration; rec[2][k.name[:60]] += 1
+        n_k += 1
+tot = sum(r[1] for r in by_src.values())
+print(f"{n_k} launches, {tot/1e3:.2f} ms of kernel time in one eager step ({DTYPE}, B={BATCH}{', no OCR' if NOOCR else ''})")
+print("--- by launch count")
+for src, (n, us, names) in sorted(by_src.items(), key=lambda kv: -kv[1][0])[:70]:
+    top = ", ".join(f"{c}x {nm.split('<')[0].split('::')[-1][:28]}" for nm, c in names.most_common(3))
+    print(f"{n:5d} launches {us/1e3:7.3f} ms avg {us/n:6.1f} us  {src[:70]:70s} | {top}")
