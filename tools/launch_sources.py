@@ -32,24 +32,26 @@ for e in prof.events():
     if not ks or str(e.device_type).endswith("CUDA"):
         continue
     # attribute to the outermost autograd node, else to the innermost package frame of the python stack
-    src, p = None, e
+    src, p, top = None, e, e
     while p is not None:
         if p.name.startswith("autograd::engine::evaluate_function:"):
             src = "bwd " + p.name.split(":", 4)[-1].strip()
-        p = p.cpu_parent
+        top, p = p, p.cpu_parent
     if src is None:
         for fr in (e.stack or []):
             if "textboxgan_amd/" in fr and "native.py" not in fr:
                 src = "fwd " + fr.split("textboxgan_amd/")[-1]
                 break
-    src = src or "fwd ?"
+    src = src or "fwd " + top.name
     for k in ks:
         rec = by_src[src]
-        rec[0] += 1; rec[1] += k.duration; rec[2][k.name[:60]] += 1
+        rec[0] += 1; rec[1] += k.duration; rec[2][k.name.replace("void ", "").replace("at::native::", "")[:90]] += 1
         n_k += 1
 tot = sum(r[1] for r in by_src.values())
 print(f"{n_k} launches, {tot/1e3:.2f} ms of kernel time in one eager step ({DTYPE}, B={BATCH}{', no OCR' if NOOCR else ''})")
 print("--- by launch count")
 for src, (n, us, names) in sorted(by_src.items(), key=lambda kv: -kv[1][0])[:70]:
-    top = ", ".join(f"{c}x {nm.split('<')[0].split('::')[-1][:28]}" for nm, c in names.most_common(3))
-    print(f"{n:5d} launches {us/1e3:7.3f} ms avg {us/n:6.1f} us  {src[:70]:70s} | {top}")
+    print(f"{n:5d} launches {us/1e3:7.3f} ms avg {us/n:6.1f} us  {src[:70]}")
+    if n >= 20:
+        for nm, c in names.most_common(12):
+            print(f"          {c:4d}x {nm}")
