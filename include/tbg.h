@@ -311,6 +311,18 @@ int tbg_minibatch_std_fwd_f32(const float *x, float *y, int B, int C, int HW, in
 int tbg_minibatch_std_bwd_f32(const float *x, const float *dy, float *dx, int B, int C, int HW, int group,
                               void *stream);
 
+/* Equalised-LR dense layer, one launch per direction (reference layers/dense.py:23-29 + layers/bias_act.py:25-34;
+ * the mapping network mapping_block.py:20-45 and every style affine modulated_conv2d.py:52-56):
+ *   out[r,n] = act(alpha * sum_k x[r,k] w[k,n] + beta * b[n]) + offset      act = leaky_relu(0.2) if lrelu else identity
+ * (the caller folds the sqrt(2) activation gain into alpha / beta: lrelu is positively homogeneous).
+ * backward: gm = dout * act'(out - offset);  dx = alpha gm w^T;  dw = alpha x^T gm;  db = beta sum_r gm.
+ * Any of dx / dw / db may be NULL (not computed); `out` is only read when lrelu != 0.  b may be NULL (no bias). */
+int tbg_dense_fwd_f32(const float *x, const float *w, const float *b, float *out, int R, int K, int N,
+                      float alpha, float beta, int lrelu, float offset, void *stream);
+int tbg_dense_bwd_f32(const float *x, const float *w, const float *out, const float *dout, float *dx, float *dw,
+                      float *db, int R, int K, int N, float alpha, float beta, int lrelu, float offset,
+                      void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimiser / EMA (multi-tensor over one flat buffer).
  * Keras Adam (reference train.py:58-75 -> ResourceApplyAdam): m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2;

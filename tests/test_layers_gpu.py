@@ -75,23 +75,33 @@ def test_modconv_fused_fwd_bwd(dev, up, shape):
         assert n_bad <= 0.005 * err.numel() and float(err.max()) < 5e-2, (name, n_bad, float(err.max()))
 
 
-def test_dense_bias_act(dev):
-    """equalised-LR dense + bias (+lrelu*sqrt2 / +offset): forward and the three gradients vs the oracle layers."""
+@pytest.mark.parametrize("dims", [(5, 24, 40), (32, 256, 256), (16, 256, 512), (64, 100, 130), (16, 512, 1), (33, 96, 65),
+                                  (8, 1536, 48)],
+                         ids=["small", "mapping", "style", "ragged", "head", "rows33", "library-gemm"])
+def test_dense_bias_act(dev, dims):
+    """equalised-LR dense + bias (+lrelu*sqrt2 / +offset): forward and the three gradients vs the oracle layers -- the
+    one-launch kernels (K <= ops.DENSE_SMALL_K) at the step's sizes and ragged ones, and the library-GEMM form above."""
     from textboxgan_amd import ops
-    B, I, O, lrmul = 5, 24, 40, 0.01
+    B, I, O = dims
+    lrmul = 0.01
     x, w, b = rnd(B, I, seed=21), rnd(I, O, seed=22) / lrmul, rnd(O, seed=23) / lrmul
     leaves = [t.requires_grad_(True) for t in (x, w, b)]
     f = lambda t: t.detach().float().to(dev).contiguous().requires_grad_(True)
-    for lrelu, offset in ((True, 0.0), (False, 1.0), (False, 0.0)):
+    for lrelu, offset in ((True, 0.0), (False, 1.0), (False, 0.0), (True, 0.5)):
         ref = R.t_bias_act(R.t_dense(x, w, lrmul=lrmul), b, "lrelu" if lrelu else "linear", lrmul=lrmul) + offset
         dout = rnd(*ref.shape, seed=24)
         grads = torch.autograd.grad(ref, leaves, dout)
         xd, wd, bd = f(x), f(w), f(b)
         out = ops.dense_bias_act(xd, wd, bd, lrmul / math.sqrt(I), lrmul, lrelu=lrelu, offset=offset)
         assert rel_err(out, ref) < 1e-5
-        gd = torch.autograd.grad(out, (xd, wd, bd), dout.float().to(dev))
+        gd = torch.autograd.grad(out, (xd, wd, bd), dout.float().to(dev), retain_graph=True)
         for name, a, b_ in zip(("dx", "dw", "db"), gd, grads):
             assert rel_err(a, b_) < 1e-5, (lrelu, offset, name)
+        # any subset of the three gradients (frozen weights: projector.py; detached input: the mapping network's z)
+        (only_dx,) = torch.autograd.grad(out, (xd,), dout.float().to(dev), retain_graph=True)
+        assert rel_err(only_dx, grads[0]) < 1e-5
+        (only_db,) = torch.autograd.grad(out, (bd,), dout.float().to(dev))
+        assert rel_err(only_db, grads[2]) < 1e-5
 
 
 @pytest.mark.parametrize("dims", [(3, 7, 12, 8), (16, 25, 512, 256)], ids=["small", "ocr-encoder"])

@@ -233,3 +233,163 @@ extern "C" int tbg_minibatch_std_bwd_f32(const float *x, const float *dy, float 
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// equalised-LR dense layers of the mapping network and the per-layer style affines (dense.py:23-29 + bias_act.py:25-34):
+//   out[r,n] = act(alpha * sum_k x[r,k] w[k,n] + beta * b[n]) + offset          R <= a few dozen rows, K, N <= 512
+// These are 1-4 MFLOP problems that went through 3 (forward) and 5 (backward) library launches each -- ~240 of the step's
+// launches.  One launch per direction here; the K (forward) / row (backward) reductions are split over the block's waves.
+// ---------------------------------------------------------------------------------------------------------------
+struct DenseP {
+  const float *x, *w, *b, *out_in, *dout;
+  float *out, *dx, *dw, *db;
+  int R, K, N, lrelu, nb_dw;
+  float alpha, beta, offset;
+};
+
+#define DN_RT 32   // rows per block
+#define DN_KC 128  // K staged per pass
+
+__global__ __launch_bounds__(256) void dense_fwd_kernel(const DenseP p) {
+  __shared__ __attribute__((aligned(16))) float xs[DN_RT][DN_KC + 4];
+  __shared__ float red[3][DN_RT][64];
+  const int tid = threadIdx.x, nl = tid & 63, kq = tid >> 6;
+  const int n = blockIdx.x * 64 + nl, r0 = blockIdx.y * DN_RT;
+  const int nc = min(n, p.N - 1);
+  float acc[DN_RT];
+#pragma unroll
+  for (int r = 0; r < DN_RT; ++r) acc[r] = 0.f;
+  for (int kc = 0; kc < p.K; kc += DN_KC) {
+    __syncthreads();
+    for (int e = tid; e < DN_RT * DN_KC; e += 256) {
+      const int r = e / DN_KC, kk = e - r * DN_KC;
+      xs[r][kk] = (r0 + r < p.R && kc + kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + kc + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int kk = kq * (DN_KC / 4); kk < (kq + 1) * (DN_KC / 4); kk += 4) {
+      float wv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wv[j] = (kc + kk + j < p.K) ? p.w[(size_t)(kc + kk + j) * p.N + nc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < DN_RT; ++r) {
+        const float4 xv = *reinterpret_cast<const float4 *>(&xs[r][kk]);
+        acc[r] += xv.x * wv[0] + xv.y * wv[1] + xv.z * wv[2] + xv.w * wv[3];
+      }
+    }
+  }
+  if (kq > 0) {
+#pragma unroll
+    for (int r = 0; r < DN_RT; ++r) red[kq - 1][r][nl] = acc[r];
+  }
+  __syncthreads();
+  if (kq == 0 && n < p.N) {
+    const float bb = p.b ? p.beta * p.b[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < DN_RT; ++r) {
+      if (r0 + r < p.R) {
+        const float pre = p.alpha * (acc[r] + red[0][r][nl] + red[1][r][nl] + red[2][r][nl]) + bb;
+        p.out[(size_t)(r0 + r) * p.N + n] = ((p.lrelu && pre < 0.f) ? 0.2f * pre : pre) + p.offset;
+      }
+    }
+  }
+}
+
+// gm = dout * act'(pre);   dw[k,n] = alpha sum_r x[r,k] gm[r,n];   db[n] = beta sum_r gm[r,n];   dx[r,k] = alpha sum_n gm[r,n] w[k,n]
+// blocks [0, nb_dw): one 16(k) x 64(n) tile of dw (and db from the k-tile-0 blocks);  blocks [nb_dw, ..): one 32(r) x 64(k) tile of dx
+__global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
+  __shared__ float gs[DN_RT][64];
+  __shared__ float ws[64][65];  // dw role: x tile [DN_RT][16] lives in the first rows
+  const int tid = threadIdx.x, l = tid & 63, q = tid >> 6;
+  const int ntn = (p.N + 63) / 64;
+  auto gmask = [&](int r, int n) -> float {
+    if (r >= p.R || n >= p.N) return 0.f;
+    const size_t i = (size_t)r * p.N + n;
+    const float g = p.dout[i];
+    return (p.lrelu && p.out_in[i] - p.offset <= 0.f) ? 0.2f * g : g;
+  };
+  if ((int)blockIdx.x < p.nb_dw) {
+    const int tn = blockIdx.x % ntn, tk = blockIdx.x / ntn;
+    const int n = tn * 64 + l, k0 = tk * 16 + q * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb = 0.f;
+    float(*xt)[16] = reinterpret_cast<float(*)[16]>(&ws[0][0]);
+    for (int r0 = 0; r0 < p.R; r0 += DN_RT) {
+      __syncthreads();
+      for (int e = tid; e < DN_RT * 64; e += 256) gs[e >> 6][e & 63] = gmask(r0 + (e >> 6), tn * 64 + (e & 63));
+      for (int e = tid; e < DN_RT * 16; e += 256) {
+        const int r = e >> 4, kk = e & 15;
+        xt[r][kk] = (r0 + r < p.R && tk * 16 + kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + tk * 16 + kk] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int r = 0; r < DN_RT; ++r) {
+        const float g = gs[r][l];
+        accb += g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += xt[r][q * 4 + j] * g;
+      }
+    }
+    if (n < p.N) {
+      if (p.dw) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k0 + j < p.K) p.dw[(size_t)(k0 + j) * p.N + n] = p.alpha * acc[j];
+      }
+      if (p.db && tk == 0 && q == 0) p.db[n] = p.beta * accb;
+    }
+    return;
+  }
+  const int bi = blockIdx.x - p.nb_dw;
+  const int ntk = (p.K + 63) / 64;
+  const int tk = bi % ntk, tr = bi / ntk;
+  const int k = tk * 64 + l, r0 = tr * DN_RT;
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+  for (int n0 = 0; n0 < p.N; n0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < DN_RT * 64; e += 256) gs[e >> 6][e & 63] = gmask(r0 + (e >> 6), n0 + (e & 63));
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int i = e >> 6, j = e & 63;
+      ws[i][j] = (tk * 64 + i < p.K && n0 + j < p.N) ? p.w[(size_t)(tk * 64 + i) * p.N + n0 + j] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < 64; ++j) {
+      const float wv = ws[l][j];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] += gs[q * 8 + r][j] * wv;
+    }
+  }
+  if (k < p.K) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (r0 + q * 8 + r < p.R) p.dx[(size_t)(r0 + q * 8 + r) * p.K + k] = p.alpha * acc[r];
+  }
+}
+
+extern "C" int tbg_dense_fwd_f32(const float *x, const float *w, const float *b, float *out, int R, int K, int N,
+                                 float alpha, float beta, int lrelu, float offset, void *stream) {
+  if (!x || !w || !out || R < 1 || K < 1 || N < 1) return TBG_EINVAL;
+  DenseP p = {};
+  p.x = x; p.w = w; p.b = b; p.out = out; p.R = R; p.K = K; p.N = N; p.lrelu = lrelu; p.alpha = alpha; p.beta = beta;
+  p.offset = offset;
+  hipLaunchKernelGGL(dense_fwd_kernel, dim3((N + 63) / 64, (R + DN_RT - 1) / DN_RT), dim3(256), 0, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_dense_bwd_f32(const float *x, const float *w, const float *out, const float *dout, float *dx, float *dw,
+                                 float *db, int R, int K, int N, float alpha, float beta, int lrelu, float offset,
+                                 void *stream) {
+  if (!x || !w || !dout || R < 1 || K < 1 || N < 1 || (lrelu && !out) || (!dx && !dw && !db)) return TBG_EINVAL;
+  DenseP p = {};
+  p.x = x; p.w = w; p.out_in = out; p.dout = dout; p.dx = dx; p.dw = dw; p.db = db; p.R = R; p.K = K; p.N = N;
+  p.lrelu = lrelu; p.alpha = alpha; p.beta = beta; p.offset = offset;
+  const int ntn = (N + 63) / 64;
+  p.nb_dw = dw ? ntn * ((K + 15) / 16) : (db ? ntn : 0);  // db alone: the k-tile-0 row of blocks
+  const int nb_dx = dx ? ((K + 63) / 64) * ((R + DN_RT - 1) / DN_RT) : 0;
+  hipLaunchKernelGGL(dense_bwd_kernel, dim3(p.nb_dw + nb_dx), dim3(256), 0, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}

@@ -930,11 +930,50 @@ def minibatch_std_fused(x, group=4):
 
 
 # ----------------------------------------------------------------------------------------
-# equalised-LR dense layers (torch GEMMs; the Functions only remove the elementwise launches around them)
+# equalised-LR dense layers (1-4 MFLOP each: one hand-written launch per direction instead of 3-5 library launches)
 # ----------------------------------------------------------------------------------------
+DENSE_SMALL_K = 1024  # above: a real GEMM (library); below: launch-bound, one hand-written launch per direction
+
+
 class _DenseBiasAct(torch.autograd.Function):
     """out = act(coef * x @ w + lrmul * b) [* sqrt2 if lrelu] + offset   (dense.py:23-29 + bias_act.py:25-34).
-    lrelu is positively homogeneous, so the sqrt2 gain is folded into the GEMM's alpha/beta: forward = addmm +
+    lrelu is positively homogeneous, so the sqrt2 gain is folded into alpha/beta; one launch forward
+    (tbg_dense_fwd_f32) and one backward (tbg_dense_bwd_f32: mask, dx, dw and db together)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, coef, lrmul, lrelu, offset):
+        g = math.sqrt(2.0) if lrelu else 1.0
+        x = x.contiguous()
+        R, K = x.shape
+        Nn = w.shape[1]
+        out = torch.empty((R, Nn), device=x.device, dtype=torch.float32)
+        N.check(N.lib().tbg_dense_fwd_f32(N.ptr(x), N.ptr(w.contiguous()), N.ptr(b), N.ptr(out), R, K, Nn, coef * g,
+                                          lrmul * g, int(lrelu), offset, N.stream()), "tbg_dense_fwd")
+        ctx.save_for_backward(x, w, out if lrelu else None)
+        ctx.cfgv = (coef * g, lrmul * g, lrelu, offset)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x, w, out = ctx.saved_tensors
+        alpha, beta, lrelu, offset = ctx.cfgv
+        dout = dout.contiguous()
+        R, K = x.shape
+        Nn = w.shape[1]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w, memory_format=torch.contiguous_format) if ctx.needs_input_grad[1] else None
+        db = dout.new_empty(Nn) if ctx.needs_input_grad[2] else None
+        if dx is not None or dw is not None or db is not None:
+            N.check(N.lib().tbg_dense_bwd_f32(N.ptr(x), N.ptr(w.contiguous()), N.ptr(out), N.ptr(dout), N.ptr(dx), N.ptr(dw),
+                                              N.ptr(db), R, K, Nn, alpha, beta, int(lrelu), offset, N.stream()),
+                    "tbg_dense_bwd")
+        return dx, dw, db, None, None, None, None
+
+
+class _DenseBiasActGemm(torch.autograd.Function):
+    """out = act(coef * x @ w + lrmul * b) [* sqrt2 if lrelu] + offset   (dense.py:23-29 + bias_act.py:25-34).
+    Library-GEMM form for the one large layer (the discriminator head's dense_1, K = C*H*W = 32768): forward = addmm +
     leaky_relu, backward = mask + 2 GEMMs + 1 GEMV."""
 
     @staticmethod
@@ -973,7 +1012,8 @@ def b_like(dout):
 
 
 def dense_bias_act(x, w, b, coef, lrmul=1.0, lrelu=False, offset=0.0):
-    return _DenseBiasAct.apply(x, w, b, float(coef), float(lrmul), bool(lrelu), float(offset))
+    fn = _DenseBiasAct if x.shape[1] <= DENSE_SMALL_K else _DenseBiasActGemm
+    return fn.apply(x, w, b, float(coef), float(lrmul), bool(lrelu), float(offset))
 
 
 # ----------------------------------------------------------------------------------------
