@@ -316,7 +316,8 @@ int tbg_minibatch_std_bwd_f32(const float *x, const float *dy, float *dx, int B,
  *   out[r,n] = act(alpha * sum_k x[r,k] w[k,n] + beta * b[n]) + offset      act = leaky_relu(0.2) if lrelu else identity
  * (the caller folds the sqrt(2) activation gain into alpha / beta: lrelu is positively homogeneous).
  * backward: gm = dout * act'(out - offset);  dx = alpha gm w^T;  dw = alpha x^T gm;  db = beta sum_r gm.
- * Any of dx / dw / db may be NULL (not computed); `out` is only read when lrelu != 0.  b may be NULL (no bias). */
+ * Any of dx / dw / db may be NULL (not computed); `out` is only read when lrelu != 0.  b may be NULL (no bias).
+ * tbg_dense_fwd_f32 stages whole rows of x in LDS: K <= 768 (TBG_ERANGE above -- such layers are library GEMMs). */
 int tbg_dense_fwd_f32(const float *x, const float *w, const float *b, float *out, int R, int K, int N,
                       float alpha, float beta, int lrelu, float offset, void *stream);
 int tbg_dense_bwd_f32(const float *x, const float *w, const float *out, const float *dout, float *dx, float *dw,

@@ -76,8 +76,8 @@ def test_modconv_fused_fwd_bwd(dev, up, shape):
 
 
 @pytest.mark.parametrize("dims", [(5, 24, 40), (32, 256, 256), (16, 256, 512), (64, 100, 130), (16, 512, 1), (33, 96, 65),
-                                  (8, 1536, 48)],
-                         ids=["small", "mapping", "style", "ragged", "head", "rows33", "library-gemm"])
+                                  (8, 1536, 48), (4, 768, 20)],
+                         ids=["small", "mapping", "style", "ragged", "head", "rows33", "library-gemm", "k768"])
 def test_dense_bias_act(dev, dims):
     """equalised-LR dense + bias (+lrelu*sqrt2 / +offset): forward and the three gradients vs the oracle layers -- the
     one-launch kernels (K <= ops.DENSE_SMALL_K) at the step's sizes and ragged ones, and the library-GEMM form above."""

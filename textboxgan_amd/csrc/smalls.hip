@@ -247,40 +247,57 @@ struct DenseP {
   float alpha, beta, offset;
 };
 
-#define DN_RT 32   // rows per block
-#define DN_KC 128  // K staged per pass
+#define DN_RT 16   // rows per block
+#define DN_KT 64   // k per thread and pass (all their filter loads are issued before the first use: one latency round)
 
+// block = 64 output columns x 4 k-quarters, DN_RT rows; dynamic LDS: xs[DN_RT][K + 4] + red[3][DN_RT][64]
 __global__ __launch_bounds__(256) void dense_fwd_kernel(const DenseP p) {
-  __shared__ __attribute__((aligned(16))) float xs[DN_RT][DN_KC + 4];
-  __shared__ float red[3][DN_RT][64];
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int KP = ((p.K + 4 * DN_KT - 1) / (4 * DN_KT)) * (4 * DN_KT) + 4;  // whole (zero-filled) passes: no k guards on the reads
+  float *xs = dsm;                    // [DN_RT][KP]
+  float *red = dsm + DN_RT * KP;      // [3][DN_RT][64]
   const int tid = threadIdx.x, nl = tid & 63, kq = tid >> 6;
   const int n = blockIdx.x * 64 + nl, r0 = blockIdx.y * DN_RT;
   const int nc = min(n, p.N - 1);
   float acc[DN_RT];
 #pragma unroll
   for (int r = 0; r < DN_RT; ++r) acc[r] = 0.f;
-  for (int kc = 0; kc < p.K; kc += DN_KC) {
-    __syncthreads();
-    for (int e = tid; e < DN_RT * DN_KC; e += 256) {
-      const int r = e / DN_KC, kk = e - r * DN_KC;
-      xs[r][kk] = (r0 + r < p.R && kc + kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + kc + kk] : 0.f;
+  // first filter pass in flight while x is staged
+  float wv[DN_KT];
+  const int kspan = 4 * DN_KT;
+#pragma unroll
+  for (int j = 0; j < DN_KT; ++j) {
+    const int k = kq * DN_KT + j;
+    wv[j] = (k < p.K) ? p.w[(size_t)k * p.N + nc] : 0.f;
+  }
+  for (int e = tid; e < DN_RT * KP; e += 256) {
+    const int r = e / KP, kk = e - r * KP;
+    xs[e] = (r0 + r < p.R && kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + kk] : 0.f;
+  }
+  __syncthreads();
+  for (int kb = 0; kb < p.K; kb += kspan) {
+    const int k0 = kb + kq * DN_KT;
+    if (k0 < p.K) {  // wave-uniform
+#pragma unroll
+      for (int j = 0; j < DN_KT; j += 4) {
+#pragma unroll
+        for (int r = 0; r < DN_RT; ++r) {
+          const float4 xv = *reinterpret_cast<const float4 *>(&xs[r * KP + k0 + j]);
+          acc[r] += xv.x * wv[j] + xv.y * wv[j + 1] + xv.z * wv[j + 2] + xv.w * wv[j + 3];
+        }
+      }
     }
-    __syncthreads();
-#pragma unroll 2
-    for (int kk = kq * (DN_KC / 4); kk < (kq + 1) * (DN_KC / 4); kk += 4) {
-      float wv[4];
+    if (kb + kspan < p.K) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wv[j] = (kc + kk + j < p.K) ? p.w[(size_t)(kc + kk + j) * p.N + nc] : 0.f;
-#pragma unroll
-      for (int r = 0; r < DN_RT; ++r) {
-        const float4 xv = *reinterpret_cast<const float4 *>(&xs[r][kk]);
-        acc[r] += xv.x * wv[0] + xv.y * wv[1] + xv.z * wv[2] + xv.w * wv[3];
+      for (int j = 0; j < DN_KT; ++j) {
+        const int k = kb + kspan + kq * DN_KT + j;
+        wv[j] = (k < p.K) ? p.w[(size_t)k * p.N + nc] : 0.f;
       }
     }
   }
   if (kq > 0) {
 #pragma unroll
-    for (int r = 0; r < DN_RT; ++r) red[kq - 1][r][nl] = acc[r];
+    for (int r = 0; r < DN_RT; ++r) red[((kq - 1) * DN_RT + r) * 64 + nl] = acc[r];
   }
   __syncthreads();
   if (kq == 0 && n < p.N) {
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const DenseP p) {
 #pragma unroll
     for (int r = 0; r < DN_RT; ++r) {
       if (r0 + r < p.R) {
-        const float pre = p.alpha * (acc[r] + red[0][r][nl] + red[1][r][nl] + red[2][r][nl]) + bb;
+        const float pre = p.alpha * (acc[r] + red[r * 64 + nl] + red[(DN_RT + r) * 64 + nl] + red[(2 * DN_RT + r) * 64 + nl]) + bb;
         p.out[(size_t)(r0 + r) * p.N + n] = ((p.lrelu && pre < 0.f) ? 0.2f * pre : pre) + p.offset;
       }
     }
@@ -296,10 +313,12 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const DenseP p) {
 }
 
 // gm = dout * act'(pre);   dw[k,n] = alpha sum_r x[r,k] gm[r,n];   db[n] = beta sum_r gm[r,n];   dx[r,k] = alpha sum_n gm[r,n] w[k,n]
-// blocks [0, nb_dw): one 16(k) x 64(n) tile of dw (and db from the k-tile-0 blocks);  blocks [nb_dw, ..): one 32(r) x 64(k) tile of dx
+// blocks [0, nb_dw): one 16(k) x 64(n) tile of dw over all rows (and db from the k-tile-0 blocks);
+// blocks [nb_dw, ..): 16 filter rows k (4 per wave) x DN_RT rows of dx: a wave reads its filter rows coalesced along n (all loads
+// issued before the gm tile is staged), accumulates per-lane partial sums for the DN_RT rows and folds them across the wave.
+#define DN_NMAX 512  // columns a dx block keeps in registers per filter row (8 per lane); wider layers loop
 __global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
-  __shared__ float gs[DN_RT][64];
-  __shared__ float ws[64][65];  // dw role: x tile [DN_RT][16] lives in the first rows
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int tid = threadIdx.x, l = tid & 63, q = tid >> 6;
   const int ntn = (p.N + 63) / 64;
   auto gmask = [&](int r, int n) -> float {
@@ -309,24 +328,25 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
     return (p.lrelu && p.out_in[i] - p.offset <= 0.f) ? 0.2f * g : g;
   };
   if ((int)blockIdx.x < p.nb_dw) {
+    float *gs = dsm;             // [32][64]
+    float *xt = dsm + 32 * 64;   // [32][16]
     const int tn = blockIdx.x % ntn, tk = blockIdx.x / ntn;
     const int n = tn * 64 + l, k0 = tk * 16 + q * 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb = 0.f;
-    float(*xt)[16] = reinterpret_cast<float(*)[16]>(&ws[0][0]);
-    for (int r0 = 0; r0 < p.R; r0 += DN_RT) {
+    for (int r0 = 0; r0 < p.R; r0 += 32) {
       __syncthreads();
-      for (int e = tid; e < DN_RT * 64; e += 256) gs[e >> 6][e & 63] = gmask(r0 + (e >> 6), tn * 64 + (e & 63));
-      for (int e = tid; e < DN_RT * 16; e += 256) {
+      for (int e = tid; e < 32 * 64; e += 256) gs[e] = gmask(r0 + (e >> 6), tn * 64 + (e & 63));
+      for (int e = tid; e < 32 * 16; e += 256) {
         const int r = e >> 4, kk = e & 15;
-        xt[r][kk] = (r0 + r < p.R && tk * 16 + kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + tk * 16 + kk] : 0.f;
+        xt[e] = (r0 + r < p.R && tk * 16 + kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + tk * 16 + kk] : 0.f;
       }
       __syncthreads();
 #pragma unroll 8
-      for (int r = 0; r < DN_RT; ++r) {
-        const float g = gs[r][l];
+      for (int r = 0; r < 32; ++r) {
+        const float g = gs[r * 64 + l];
         accb += g;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += xt[r][q * 4 + j] * g;
+        for (int j = 0; j < 4; ++j) acc[j] += xt[r * 16 + q * 4 + j] * g;
       }
     }
     if (n < p.N) {
@@ -340,31 +360,55 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
     return;
   }
   const int bi = blockIdx.x - p.nb_dw;
-  const int ntk = (p.K + 63) / 64;
+  const int ntk = (p.K + 15) / 16;
   const int tk = bi % ntk, tr = bi / ntk;
-  const int k = tk * 64 + l, r0 = tr * DN_RT;
-  float acc[8];
+  const int r0 = tr * DN_RT;
+  float *gs = dsm;  // [DN_RT][NP]   NP = min(N, DN_NMAX) rounded up to 64
+  float acc[4][DN_RT];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
-  for (int n0 = 0; n0 < p.N; n0 += 64) {
-    __syncthreads();
-    for (int e = tid; e < DN_RT * 64; e += 256) gs[e >> 6][e & 63] = gmask(r0 + (e >> 6), n0 + (e & 63));
-    for (int e = tid; e < 64 * 64; e += 256) {
-      const int i = e >> 6, j = e & 63;
-      ws[i][j] = (tk * 64 + i < p.K && n0 + j < p.N) ? p.w[(size_t)(tk * 64 + i) * p.N + n0 + j] : 0.f;
+  for (int kr = 0; kr < 4; ++kr)
+#pragma unroll
+    for (int r = 0; r < DN_RT; ++r) acc[kr][r] = 0.f;
+  for (int n0 = 0; n0 < p.N; n0 += DN_NMAX) {
+    const int nspan = min(DN_NMAX, ((p.N - n0) + 63) & ~63);
+    float wv[4][DN_NMAX / 64];
+#pragma unroll
+    for (int kr = 0; kr < 4; ++kr) {
+      const int k = tk * 16 + q * 4 + kr;
+#pragma unroll
+      for (int c = 0; c < DN_NMAX / 64; ++c) {
+        const int n = n0 + c * 64 + l;
+        wv[kr][c] = (k < p.K && c * 64 < nspan && n < p.N) ? p.w[(size_t)k * p.N + n] : 0.f;
+      }
     }
     __syncthreads();
-#pragma unroll 4
-    for (int j = 0; j < 64; ++j) {
-      const float wv = ws[l][j];
+    for (int e = tid; e < DN_RT * nspan; e += 256) {
+      const int r = e / nspan, nn = e - r * nspan;
+      gs[e] = gmask(r0 + r, n0 + nn);
+    }
+    __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 8; ++r) acc[r] += gs[q * 8 + r][j] * wv;
+    for (int c = 0; c < DN_NMAX / 64; ++c) {
+      if (c * 64 < nspan) {
+#pragma unroll
+        for (int r = 0; r < DN_RT; ++r) {
+          const float g = gs[r * nspan + c * 64 + l];
+#pragma unroll
+          for (int kr = 0; kr < 4; ++kr) acc[kr][r] += g * wv[kr][c];
+        }
+      }
     }
   }
-  if (k < p.K) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-      if (r0 + q * 8 + r < p.R) p.dx[(size_t)(r0 + q * 8 + r) * p.K + k] = p.alpha * acc[r];
+  for (int kr = 0; kr < 4; ++kr) {
+    const int k = tk * 16 + q * 4 + kr;
+    float mine = 0.f;  // lane r keeps row r's total
+#pragma unroll
+    for (int r = 0; r < DN_RT; ++r) {
+      const float s = wave_sum(acc[kr][r]);
+      if (l == r) mine = s;
+    }
+    if (k < p.K && l < DN_RT && r0 + l < p.R) p.dx[(size_t)(r0 + l) * p.K + k] = p.alpha * mine;
   }
 }
 
@@ -374,7 +418,10 @@ extern "C" int tbg_dense_fwd_f32(const float *x, const float *w, const float *b,
   DenseP p = {};
   p.x = x; p.w = w; p.b = b; p.out = out; p.R = R; p.K = K; p.N = N; p.lrelu = lrelu; p.alpha = alpha; p.beta = beta;
   p.offset = offset;
-  hipLaunchKernelGGL(dense_fwd_kernel, dim3((N + 63) / 64, (R + DN_RT - 1) / DN_RT), dim3(256), 0, tbg_stream(stream), p);
+  if (K > 768) return TBG_ERANGE;  // x rows are staged whole in LDS (<= 64 KB); large-K layers are GEMMs, not this kernel's job
+  const size_t KP = (size_t)((K + 4 * DN_KT - 1) / (4 * DN_KT)) * (4 * DN_KT) + 4;
+  const size_t lds = ((size_t)DN_RT * KP + 3 * DN_RT * 64) * sizeof(float);
+  hipLaunchKernelGGL(dense_fwd_kernel, dim3((N + 63) / 64, (R + DN_RT - 1) / DN_RT), dim3(256), lds, tbg_stream(stream), p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
@@ -388,8 +435,11 @@ extern "C" int tbg_dense_bwd_f32(const float *x, const float *w, const float *ou
   p.lrelu = lrelu; p.alpha = alpha; p.beta = beta; p.offset = offset;
   const int ntn = (N + 63) / 64;
   p.nb_dw = dw ? ntn * ((K + 15) / 16) : (db ? ntn : 0);  // db alone: the k-tile-0 row of blocks
-  const int nb_dx = dx ? ((K + 63) / 64) * ((R + DN_RT - 1) / DN_RT) : 0;
-  hipLaunchKernelGGL(dense_bwd_kernel, dim3(p.nb_dw + nb_dx), dim3(256), 0, tbg_stream(stream), p);
+  const int nb_dx = dx ? ((K + 15) / 16) * ((R + DN_RT - 1) / DN_RT) : 0;
+  const int nsp = ((N < DN_NMAX ? N : DN_NMAX) + 63) & ~63;
+  const size_t lds_dx = (size_t)DN_RT * nsp * sizeof(float), lds_dw = (size_t)(32 * 64 + 32 * 16) * sizeof(float);
+  hipLaunchKernelGGL(dense_bwd_kernel, dim3(p.nb_dw + nb_dx), dim3(256), lds_dx > lds_dw ? lds_dx : lds_dw,
+                     tbg_stream(stream), p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }

@@ -932,7 +932,7 @@ def minibatch_std_fused(x, group=4):
 # ----------------------------------------------------------------------------------------
 # equalised-LR dense layers (1-4 MFLOP each: one hand-written launch per direction instead of 3-5 library launches)
 # ----------------------------------------------------------------------------------------
-DENSE_SMALL_K = 1024  # above: a real GEMM (library); below: launch-bound, one hand-written launch per direction
+DENSE_SMALL_K = 768  # above: a real GEMM (library); below: launch-bound, one hand-written launch per direction
 
 
 class _DenseBiasAct(torch.autograd.Function):
