@@ -270,9 +270,18 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const DenseP p) {
     const int k = kq * DN_KT + j;
     wv[j] = (k < p.K) ? p.w[(size_t)k * p.N + nc] : 0.f;
   }
-  for (int e = tid; e < DN_RT * KP; e += 256) {
-    const int r = e / KP, kk = e - r * KP;
-    xs[e] = (r0 + r < p.R && kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + kk] : 0.f;
+  // x rows: batches of 8 loads per lane in flight (a load-store-load-store loop is one HBM round trip per element)
+  for (int e0 = tid; e0 < DN_RT * KP; e0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u;
+      const int r = e / KP, kk = e - r * KP;
+      v[u] = (e < DN_RT * KP && r0 + r < p.R && kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + kk] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + 256 * u < DN_RT * KP) xs[e0 + 256 * u] = v[u];
   }
   __syncthreads();
   for (int kb = 0; kb < p.K; kb += kspan) {
@@ -321,11 +330,24 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int tid = threadIdx.x, l = tid & 63, q = tid >> 6;
   const int ntn = (p.N + 63) / 64;
-  auto gmask = [&](int r, int n) -> float {
-    if (r >= p.R || n >= p.N) return 0.f;
-    const size_t i = (size_t)r * p.N + n;
-    const float g = p.dout[i];
-    return (p.lrelu && p.out_in[i] - p.offset <= 0.f) ? 0.2f * g : g;
+  // gm tile [nrows][ncols] -> LDS, 8 elements (16 loads) per lane in flight
+  auto stage_gm = [&](float *dst, int r0, int nrows, int n0, int ncols) {
+    const int total = nrows * ncols;
+    for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+      float g[8], o[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u;
+        const int r = e / ncols, nn = e - r * ncols;
+        const bool ok = e < total && r0 + r < p.R && n0 + nn < p.N;
+        const size_t i = ok ? (size_t)(r0 + r) * p.N + n0 + nn : 0;
+        g[u] = ok ? p.dout[i] : 0.f;
+        o[u] = (ok && p.lrelu) ? p.out_in[i] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + 256 * u < total) dst[e0 + 256 * u] = (p.lrelu && o[u] - p.offset <= 0.f) ? 0.2f * g[u] : g[u];
+    }
   };
   if ((int)blockIdx.x < p.nb_dw) {
     float *gs = dsm;             // [32][64]
@@ -335,11 +357,14 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb = 0.f;
     for (int r0 = 0; r0 < p.R; r0 += 32) {
       __syncthreads();
-      for (int e = tid; e < 32 * 64; e += 256) gs[e] = gmask(r0 + (e >> 6), tn * 64 + (e & 63));
-      for (int e = tid; e < 32 * 16; e += 256) {
-        const int r = e >> 4, kk = e & 15;
-        xt[e] = (r0 + r < p.R && tk * 16 + kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + tk * 16 + kk] : 0.f;
+      float xv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, r = e >> 4, kk = e & 15;
+        xv[u] = (r0 + r < p.R && tk * 16 + kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + tk * 16 + kk] : 0.f;
       }
+      stage_gm(gs, r0, 32, tn * 64, 64);
+      xt[tid] = xv[0]; xt[tid + 256] = xv[1];
       __syncthreads();
 #pragma unroll 8
       for (int r = 0; r < 32; ++r) {
@@ -382,10 +407,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
       }
     }
     __syncthreads();
-    for (int e = tid; e < DN_RT * nspan; e += 256) {
-      const int r = e / nspan, nn = e - r * nspan;
-      gs[e] = gmask(r0 + r, n0 + nn);
-    }
+    stage_gm(gs, r0, DN_RT, n0, nspan);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < DN_NMAX / 64; ++c) {
