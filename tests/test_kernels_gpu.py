@@ -336,6 +336,38 @@ def test_conv2d_wgrad(dev, case):
     assert rel_err(dw, dw_ref) < 3e-5
 
 
+WGV_CASES = [
+    (3, 40, 72, 5, 36, "ragged: odd rows, a partial 32-wide tile, partial channel tiles"),
+    (2, 64, 64, 8, 32, "exactly one tile per row"),
+    (1, 130, 70, 2, 128, "three / two channel tiles, one row pair"),
+    (2, 64, 64, 3, 100, "W = 100: quads end inside the last tile"),
+]
+
+
+@pytest.mark.parametrize("case", WGV_CASES, ids=[c[-1] for c in WGV_CASES])
+def test_conv2d_wgrad_vector_staging(dev, case):
+    """the float4-staged filter-gradient instance (stride-1 3x3, rows of whole 16-byte units, W >= 32) against a float64
+    reference, with both per-(sample, channel) scale vectors and the fused additive term; and that it IS that instance."""
+    from textboxgan_amd import ops, native as N
+    B, C, M, H, W, _ = case
+    x, dy = rnd(B, C, H, W, seed=40), rnd(B, M, H, W, seed=41)
+    xs, ds = rnd(B, C, seed=42).abs() + 0.5, rnd(B, M, seed=43).abs() + 0.5
+    addw, addq = rnd(3, 3, C, M, seed=44), rnd(C, M, seed=45)
+    w = torch.zeros(3, 3, C, M, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x * xs[:, :, None, None], w.permute(3, 2, 0, 1), padding=1)
+    (ref,) = torch.autograd.grad(y, w, dy * ds[:, :, None, None])
+    ref = 0.7 * ref + 0.3 * addw * addq[None, None]
+    f = lambda t: t.float().to(dev).contiguous()
+    g = ops._Geom((1, 1), (1, 1), 3, 3, (H, W), (H, W))
+    desc = N.WgradDesc(B, M, C, H, W, H, W, 3, 3, 1, 1, 1, 1, C * M, M, 1, 0.7)
+    assert N.wgrad_kernel_name(desc).endswith("true, true>"), N.wgrad_kernel_name(desc)
+    dw = ops._bwd_weight_launch(f(x), f(dy), g, C, M, alpha=0.7, x_scale=f(xs), dy_scale=f(ds), add=(f(addw), f(addq), 0.3))
+    assert rel_err(dw, ref) < 3e-5
+    dw_plain = ops._bwd_weight_launch(f(x), f(dy), g, C, M, alpha=1.0)
+    (ref_plain,) = torch.autograd.grad(F.conv2d(x, w.permute(3, 2, 0, 1), padding=1), w, dy)
+    assert rel_err(dw_plain, ref_plain) < 3e-5
+
+
 def test_conv_random_shapes_all_three_passes(dev):
     """seeded sweep over awkward shapes (channels not multiples of 4 / 32, odd maps, 1- and 2-pixel maps, every stride
     the kernels accept): forward, data gradient and filter gradient against float64 autograd."""

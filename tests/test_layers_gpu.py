@@ -92,8 +92,11 @@ def test_dense_bias_act(dev, dims):
         dout = rnd(*ref.shape, seed=24)
         grads = torch.autograd.grad(ref, leaves, dout)
         xd, wd, bd = f(x), f(w), f(b)
-        out = ops.dense_bias_act(xd, wd, bd, lrmul / math.sqrt(I), lrmul, lrelu=lrelu, offset=offset)
+        # both launch forms are product paths (ops.dense_bias_act routes by activation and K): test each directly
+        form = ops._DenseBiasAct if I <= ops.DENSE_SMALL_K else ops._DenseBiasActGemm
+        out = form.apply(xd, wd, bd, lrmul / math.sqrt(I), lrmul, lrelu, offset)
         assert rel_err(out, ref) < 1e-5
+        assert rel_err(ops.dense_bias_act(xd, wd, bd, lrmul / math.sqrt(I), lrmul, lrelu=lrelu, offset=offset), ref) < 1e-5
         gd = torch.autograd.grad(out, (xd, wd, bd), dout.float().to(dev), retain_graph=True)
         for name, a, b_ in zip(("dx", "dw", "db"), gd, grads):
             assert rel_err(a, b_) < 1e-5, (lrelu, offset, name)

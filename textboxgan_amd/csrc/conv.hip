@@ -844,7 +844,7 @@ struct WgradP {
   int logTW, logTHs, NSEG, IHs, IWs, IWp, HALFW, lplane, ppc, NJ, nBG, tilesU, tilesV, nchunks, ksplit;
 };
 
-template <int WGS, int WGL, int NT, int PIX, bool GRP>
+template <int WGS, int WGL, int NT, int PIX, bool GRP, bool VEC = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   constexpr int BS = WGS * 32, BL = WGL * 32, SP = PIX + 4;  // 16-byte aligned S rows; 68 words = conflict-free b128
   constexpr int KWt = (NT == 9) ? 3 : 1;
@@ -854,10 +854,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   float *Ss = smem;            // [BS][SP]
   float *Ls = smem + BS * SP;  // [BL][lplane]
 
+  // tile geometry: compile-time constants on the VEC path (immediate LDS offsets, no address registers)
+  const int g_IWp = VEC ? 34 : p.IWp, g_lplane = VEC ? 137 : p.lplane, g_logTW = VEC ? 5 : p.logTW;
+  const int g_logTHs = VEC ? 1 : p.logTHs, g_IHs = VEC ? 4 : p.IHs, g_sy = VEC ? 1 : p.sy, g_sx = VEC ? 1 : p.sx;
+  const int g_HALFW = p.HALFW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ws = wave / WGL, wl = wave - ws * WGL;
   const int cs0 = blockIdx.x * BS, cl0 = blockIdx.y * BL;
-  const int TWm = (1 << p.logTW) - 1, THm = (1 << p.logTHs) - 1;
+  const int TWm = (1 << g_logTW) - 1, THm = (1 << g_logTHs) - 1;
 
   // position descriptors inside one L channel plane: a wave stages one channel at a time
   int d_pos[NJC], d_loff[NJC];  // d_pos = seg << 16 | iyl << 8 | ixl, or -1
@@ -865,28 +869,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   for (int j = 0; j < NJC; ++j) {
     d_pos[j] = -1; d_loff[j] = 0;
     const int e = lane + 64 * j;
-    if (j < p.NJ && e < p.ppc) {
-      const int per = p.IHs * p.IWs;
+    if (!VEC && j < p.NJ && e < p.ppc) {
+      const int per = g_IHs * p.IWs;
       const int seg = e / per;
       const int rem = e - seg * per;
       const int iyl = rem / p.IWs;
       const int ixl = rem - iyl * p.IWs;
       d_pos[j] = (seg << 16) | (iyl << 8) | ixl;
-      const int col = (p.sx == 2) ? (ixl & 1) * p.HALFW + (ixl >> 1) : ixl;
-      d_loff[j] = (seg * p.IHs + iyl) * p.IWp + col;
+      const int col = (g_sx == 2) ? (ixl & 1) * g_HALFW + (ixl >> 1) : ixl;
+      d_loff[j] = (seg * g_IHs + iyl) * g_IWp + col;
     }
   }
   // S staging: pixel fixed per thread (256 % PIX == 0)
   const int spix = tid & (PIX - 1);
   const int sch0 = tid / PIX;
-  const int sq = spix & TWm, srr = spix >> p.logTW;
-  const int sseg = srr >> p.logTHs, sr = srr & THm;
+  const int sq = spix & TWm, srr = spix >> g_logTW;
+  const int sseg = srr >> g_logTHs, sr = srr & THm;
 
   int toff[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int kh = t / KWt, kw = t - kh * KWt;
-    toff[t] = kh * p.IWp + (p.sx == 2 ? (kw & 1) * p.HALFW + (kw >> 1) : kw);
+    toff[t] = kh * g_IWp + (g_sx == 2 ? (kw & 1) * g_HALFW + (kw >> 1) : kw);
   }
 
   f32x16 acc[NT];
@@ -903,8 +907,84 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     const int t2 = chunk / p.tilesV;
     const int tu = t2 % p.tilesU;
     const int bg = t2 / p.tilesU;
-    const int u0 = tu << p.logTHs, v0 = tv << p.logTW;
+    const int u0 = tu << g_logTHs, v0 = tv << g_logTW;
     __syncthreads();
+    if constexpr (VEC) {
+      // 32 x 2 pixel tiles of stride-1 3x3 layers whose rows are whole 16-byte units (Ws, Wl % 4 == 0): the S tile and the
+      // interior of the L halo tile are read as float4 (4 + 8 loads per lane instead of 16 + 48), the two halo columns as
+      // scalars, in two rounds of loads issued together -- the scalar form needed six dependent
+      // round trips per chunk and cost a quarter of the kernel (tools/exp_wgrad_split.py: 801 us -> 594 us without staging).
+      static_assert(!VEC || (NT == 9 && PIX == 64 && BS == 64 && BL == 64), "VEC staging: 3x3, 64-pixel chunks, 64x64 tiles");
+      const int b = bg;  // NSEG == 1
+      // scale factors: always loaded (from a valid address), selected afterwards -- no branch around any load
+      const bool hs = p.s_scale != nullptr, hl = p.l_scale != nullptr;
+      const float *ssp = hs ? p.s_scale : p.S, *lsp = hl ? p.l_scale : p.L;
+      // Every address is ONE per-lane base plus a wave-uniform multiple of the channel pitch (lane e = tid + 256 i keeps its
+      // position inside the tile and moves 8 / 16 / 32 channels per step): few live registers next to the 144 accumulators.
+      const int l_ch = tid >> 5, l_row = (tid >> 3) & 3, l_qx = tid & 7;
+      const int l_iy = u0 - p.py + l_row, l_ix = v0 + 4 * l_qx;
+      const bool l_in = l_iy >= 0 && l_iy < p.Hl && l_ix < p.Wl;
+      const unsigned l_g0 = (unsigned)((b * p.CL + cl0 + l_ch) * HWl + l_iy * p.Wl + l_ix);
+      float *l_d0 = Ls + l_ch * g_lplane + l_row * g_IWp + 1 + 4 * l_qx;
+      // two rounds of ~40 staging registers each (the accumulators leave no room for all 56 values at once)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float4 lv[4];
+        float lsc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // L interior: 64 channels x 4 halo rows x 8 quads, half of the channels per round
+          const int ci = 8 * (4 * hf + i);
+          const bool ok = l_in && cl0 + l_ch + ci < p.CL;
+          // branch-free: clamp the address, always load, select 0 (an `ok ? load : 0` is compiled to one branch per load)
+          lv[i] = *reinterpret_cast<const float4 *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl) : 0u));
+          const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
+          lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+        }
+        if (hf == 0) {
+          float4 sv[4];
+          float ssc[4];
+          const int s_ch = tid >> 4, s_pq = (tid & 15) * 4;
+          const int s_u = u0 + (s_pq >> 5), s_v = v0 + (s_pq & 31);
+          const bool s_in = s_u < p.Hs && s_v < p.Ws;
+          const unsigned s_g0 = (unsigned)((b * p.CS + cs0 + s_ch) * HWs + s_u * p.Ws + s_v);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {  // S: 64 channels x 16 quads
+            const bool ok = s_in && cs0 + s_ch + 16 * i < p.CS;
+            sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(16 * i * HWs) : 0u));
+            const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 16 * i) : 0u];
+            ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float4 v = sv[i];
+            v.x *= ssc[i]; v.y *= ssc[i]; v.z *= ssc[i]; v.w *= ssc[i];
+            *reinterpret_cast<float4 *>(Ss + (s_ch + 16 * i) * SP + s_pq) = v;
+          }
+        } else {
+          float ev[2], esc[2];
+          const int e_ch = tid >> 3, e_row = (tid >> 1) & 3, e_side = tid & 1;
+          const int e_iy = u0 - p.py + e_row, e_ix = e_side ? v0 + 32 : v0 - 1;
+          const bool e_in = e_iy >= 0 && e_iy < p.Hl && e_ix >= 0 && e_ix < p.Wl;
+          const unsigned e_g0 = (unsigned)((b * p.CL + cl0 + e_ch) * HWl + e_iy * p.Wl + e_ix);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {  // L halo columns: 64 channels x 4 rows x {left, right}
+            const bool ok = e_in && cl0 + e_ch + 32 * i < p.CL;
+            ev[i] = p.L[ok ? e_g0 + (unsigned)(32 * i * HWl) : 0u];
+            const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch + 32 * i) : 0u];
+            esc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            Ls[(e_ch + 32 * i) * g_lplane + e_row * g_IWp + (e_side ? 33 : 0)] = ev[i] * esc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float *dst = l_d0 + 8 * (4 * hf + i) * g_lplane;
+          dst[0] = lv[i].x * lsc[i]; dst[1] = lv[i].y * lsc[i]; dst[2] = lv[i].z * lsc[i]; dst[3] = lv[i].w * lsc[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the second round's loads behind the first round's LDS writes (registers)
+      }
+    } else {
     // Branch-free staging (same lesson as conv_fprop_kernel): clamp the address, always load, select 0 -- the loads
     // of a batch (and their scale factors) are then in flight together instead of one round trip per `if` block.
     {  // S tile
@@ -935,8 +1015,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
       for (int j = 0; j < NJC; ++j) {
         const int seg = d_pos[j] >> 16, iyl = (d_pos[j] >> 8) & 255, ixl = d_pos[j] & 255;
         const int b = bg * p.NSEG + seg;
-        const int iy = u0 * p.sy - p.py + iyl;
-        const int ix = v0 * p.sx - p.px + ixl;
+        const int iy = u0 * g_sy - p.py + iyl;
+        const int ix = v0 * g_sx - p.px + ixl;
         const bool ok = d_pos[j] >= 0 && b < p.B && iy >= 0 && iy < p.Hl && ix >= 0 && ix < p.Wl;
         g[j] = ok ? (b * p.CL) * HWl + iy * p.Wl + ix : -1;
         bb[j] = ok ? b * p.CL : 0;
@@ -969,9 +1049,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
 #pragma unroll
           for (int j = 0; j < NJC; ++j)
             if (d_pos[j] >= 0 && ch < BL)
-              Ls[ch * p.lplane + d_loff[j]] = (g[j] >= 0 && cl0 + ch < p.CL) ? lv[u][j] : 0.f;
+              Ls[ch * g_lplane + d_loff[j]] = (g[j] >= 0 && cl0 + ch < p.CL) ? lv[u][j] : 0.f;
         }
       }
+    }
     }
     __syncthreads();
     if constexpr (GRP) {
@@ -979,13 +1060,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
       // the A operand of 4 k-steps is ONE aligned ds_read_b128 and the B operands are immediate-offset reads from one
       // base address per tap; the reads of k-step i+1 are issued before the MFMAs of k-step i.
       const float *Sp = Ss + (ws * 32 + (lane & 31)) * SP + 4 * half;
-      const float *Lp = Ls + (wl * 32 + (lane & 31)) * p.lplane;
+      const float *Lp = Ls + (wl * 32 + (lane & 31)) * g_lplane;
 #pragma unroll 2
       for (int gp = 0; gp < PIX / 8; ++gp) {
         const int pp = 8 * gp + 4 * half;
-        const int q = pp & TWm, rr = pp >> p.logTW;
-        const int seg = rr >> p.logTHs, r = rr & THm;
-        const float *Lg = Lp + (seg * p.IHs + r * p.sy) * p.IWp + q;
+        const int q = pp & TWm, rr = pp >> g_logTW;
+        const int seg = rr >> g_logTHs, r = rr & THm;
+        const float *Lg = Lp + (seg * g_IHs + r * g_sy) * g_IWp + q;
         const f32x4 a4 = *reinterpret_cast<const f32x4 *>(Sp + 8 * gp);
         float bq[2][NT];
 #pragma unroll
@@ -1003,13 +1084,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
       }
     } else {  // narrow tiles (Ws <= 2): generic pixel walk
       const float *Sp = Ss + (ws * 32 + (lane & 31)) * SP + half;
-      const float *Lp = Ls + (wl * 32 + (lane & 31)) * p.lplane;
+      const float *Lp = Ls + (wl * 32 + (lane & 31)) * g_lplane;
 #pragma unroll 1
       for (int kp = 0; kp < PIX / 2; ++kp) {
         const int pp = 2 * kp + half;
-        const int q = pp & TWm, rr = pp >> p.logTW;
-        const int seg = rr >> p.logTHs, r = rr & THm;
-        const int poff = (seg * p.IHs + r * p.sy) * p.IWp + q;
+        const int q = pp & TWm, rr = pp >> g_logTW;
+        const int seg = rr >> g_logTHs, r = rr & THm;
+        const int poff = (seg * g_IHs + r * g_sy) * g_IWp + q;
         const float a = Sp[2 * kp];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -1299,17 +1380,18 @@ static int wgrad_ksplit(int tiles, int nchunks) {
   return ksplit;
 }
 
-template <int WGS, int WGL, int NT, int PIX, bool GRP>
+template <int WGS, int WGL, int NT, int PIX, bool GRP, bool VEC = false>
 static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
   constexpr int BS = WGS * 32, BL = WGL * 32;
   if (name) {
-    snprintf(name->buf, name->n, "conv_wgrad_kernel<%d, %d, %d, %d, %s>", WGS, WGL, NT, PIX, GRP ? "true" : "false");
+    snprintf(name->buf, name->n, "conv_wgrad_kernel<%d, %d, %d, %d, %s, %s>", WGS, WGL, NT, PIX, GRP ? "true" : "false",
+             VEC ? "true" : "false");
     return TBG_OK;
   }
   const size_t lds = ((size_t)BS * (PIX + 4) + (size_t)BL * p.lplane) * sizeof(float);
   if (p.NJ > ((NT == 1 && PIX == 64) ? 1 : WG_MAXNJ)) return TBG_EUNSUPPORTED;
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
-  auto kern = conv_wgrad_kernel<WGS, WGL, NT, PIX, GRP>;
+  auto kern = conv_wgrad_kernel<WGS, WGL, NT, PIX, GRP, VEC>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TBG_EHIP;
@@ -1357,6 +1439,12 @@ static int launch_wgrad_bf16(WgradP &p, hipStream_t st, size_t ws_bytes, const N
 
 template <int WGS, int WGL, int NT, int PIX>
 static int launch_wgrad(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
+  if constexpr (NT == 9 && PIX == 64 && WGS == 2 && WGL == 2) {
+    // 32 x 2 pixel tiles of a stride-1 layer with 16-byte-aligned rows: float4 staging
+    if (p.logTW == 5 && p.logTHs == 1 && p.NSEG == 1 && p.sx == 1 && p.sy == 1 && (p.Ws & 3) == 0 && (p.Wl & 3) == 0 &&
+        p.px == 1 && (((uintptr_t)p.S | (uintptr_t)p.L) & 15) == 0)
+      return launch_wgrad_impl<WGS, WGL, NT, PIX, true, true>(p, st, ws_bytes, name);
+  }
   if (p.logTW >= 2) return launch_wgrad_impl<WGS, WGL, NT, PIX, true>(p, st, ws_bytes, name);
   return launch_wgrad_impl<WGS, WGL, NT, PIX, false>(p, st, ws_bytes, name);
 }
@@ -1407,7 +1495,7 @@ static int wgrad_geometry(const tbg_wgrad_desc *d, WgradP &p, int &PIX, bool bf 
 }
 
 extern "C" long long tbg_conv2d_wgrad_workspace_bytes(const tbg_wgrad_desc *d) {
-  WgradP p;
+  WgradP p{};
   int PIX;
   if (wgrad_geometry(d, p, PIX) != TBG_OK) return -1;
   const int tiles = ceil_div(p.CS, 64) * ceil_div(p.CL, 64);
@@ -1434,7 +1522,7 @@ extern "C" int tbg_conv2d_wgrad_ex_f32(const tbg_wgrad_desc *d, const float *S, 
                                        const float *s_scale, const float *l_scale, const float *addw, const float *addq,
                                        float gamma, float *workspace, long long workspace_bytes, void *stream) {
   if (!d || !S || !L || !dW || !workspace || ((addw == nullptr) != (addq == nullptr))) return TBG_EINVAL;
-  WgradP p;
+  WgradP p{};
   int PIX;
   const int rc = wgrad_geometry(d, p, PIX);
   if (rc != TBG_OK) return rc;
@@ -1459,7 +1547,7 @@ extern "C" int tbg_conv2d_wgrad_bf16(const tbg_wgrad_desc *d, const float *S, co
                                      const float *s_scale, const float *l_scale, const float *addw, const float *addq,
                                      float gamma, float *workspace, long long workspace_bytes, void *stream) {
   if (!d || !S || !L || !dW || !workspace || ((addw == nullptr) != (addq == nullptr))) return TBG_EINVAL;
-  WgradP p;
+  WgradP p{};
   int PIX;
   int rc = wgrad_geometry(d, p, PIX, true);
   if (rc != TBG_OK) return rc;
@@ -1473,7 +1561,7 @@ extern "C" int tbg_conv2d_wgrad_bf16(const tbg_wgrad_desc *d, const float *S, co
 extern "C" int tbg_conv2d_wgrad_bf16_kernel_name(const tbg_wgrad_desc *d, char *buf, int n) {
   if (!buf || n < 1) return TBG_EINVAL;
   buf[0] = 0;
-  WgradP p;
+  WgradP p{};
   int PIX;
   const int rc = wgrad_geometry(d, p, PIX, true);
   if (rc != TBG_OK) return rc;
@@ -1485,7 +1573,7 @@ extern "C" int tbg_conv2d_wgrad_bf16_kernel_name(const tbg_wgrad_desc *d, char *
 extern "C" int tbg_conv2d_wgrad_kernel_name(const tbg_wgrad_desc *d, char *buf, int n) {
   if (!buf || n < 1) return TBG_EINVAL;
   buf[0] = 0;
-  WgradP p;
+  WgradP p{};
   int PIX;
   const int rc = wgrad_geometry(d, p, PIX);
   if (rc != TBG_OK) return rc;

@@ -1012,7 +1012,10 @@ def b_like(dout):
 
 
 def dense_bias_act(x, w, b, coef, lrmul=1.0, lrelu=False, offset=0.0):
-    fn = _DenseBiasAct if x.shape[1] <= DENSE_SMALL_K else _DenseBiasActGemm
+    # measured per layer in graph replay (tools/bench_dense.py, profiles/r02_dense_forms.txt): the one-launch kernels halve
+    # the lrelu layers (mapping network: 47 -> 24 us forward + backward); the linear style affines are a single library
+    # launch forward already (4.7 us) and a wash backward, so they keep the library form
+    fn = _DenseBiasAct if (lrelu and x.shape[1] <= DENSE_SMALL_K) else _DenseBiasActGemm
     return fn.apply(x, w, b, float(coef), float(lrmul), bool(lrelu), float(offset))
 
 
