@@ -113,6 +113,30 @@ def test_conv_bf16_three_passes_vs_rounded_oracle(dev, case):
         assert l2_err(ops._fwd_launch(xd, wd, geom), y64) < 1e-2
 
 
+@pytest.mark.parametrize("dims", [(3, 40, 72, 5, 36), (2, 64, 64, 8, 32), (1, 130, 70, 2, 128)], ids=["ragged", "one-tile", "3x2 tiles"])
+def test_wgrad_bf16_vector_staging(dev, dims):
+    """the float4-staged bf16 filter-gradient instance, with both scale vectors (rounded AFTER scaling, as the kernel
+    does) and the fused additive term, against the rounded-operand float64 reference."""
+    from textboxgan_amd import ops, native as N
+    B, C, M, H, W = dims
+    x, dy = rnd(B, C, H, W, seed=40), rnd(B, M, H, W, seed=41)
+    xs, ds = rnd(B, C, seed=42).abs() + 0.5, rnd(B, M, seed=43).abs() + 0.5
+    addw, addq = rnd(3, 3, C, M, seed=44), rnd(C, M, seed=45)
+    f32 = lambda t: t.float().double()  # the kernel multiplies in fp32 before rounding to bf16
+    xr = bf((f32(x) * f32(xs)[:, :, None, None]).float().double())
+    dyr = bf((f32(dy) * f32(ds)[:, :, None, None]).float().double())
+    w = torch.zeros(3, 3, C, M, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xr, w.permute(3, 2, 0, 1), padding=1), w, dyr)
+    ref = 0.7 * ref + 0.3 * f32(addw) * f32(addq)[None, None]
+    f = lambda t: t.float().to(dev).contiguous()
+    g = ops._Geom((1, 1), (1, 1), 3, 3, (H, W), (H, W))
+    desc = N.WgradDesc(B, M, C, H, W, H, W, 3, 3, 1, 1, 1, 1, C * M, M, 1, 0.7)
+    assert N.wgrad_kernel_name(desc, True) == "conv_wgrad_bf16_kernel<2, 2, 9, 64, 1, true>"
+    with ops.compute_dtype("bf16"):
+        dw = ops._bwd_weight_launch(f(x), f(dy), g, C, M, alpha=0.7, x_scale=f(xs), dy_scale=f(ds), add=(f(addw), f(addq), 0.3))
+    assert rel_err(dw, ref) < 5e-5
+
+
 TBF_CASES = [
     (2, 16, 32, 4, 16, (2, 2), "up 4x16"),
     (2, 128, 128, 16, 64, (2, 2), "up 16x64 128ch"),

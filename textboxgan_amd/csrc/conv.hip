@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -844,6 +845,101 @@ struct WgradP {
   int logTW, logTHs, NSEG, IHs, IWs, IWp, HALFW, lplane, ppc, NJ, nBG, tilesU, tilesV, nchunks, ksplit;
 };
 
+// ---- float4 staging of one 32 x 2 pixel chunk of a stride-1 3x3 filter gradient (NSEG == 1, Ws % 4 == Wl % 4 == 0, px == 1):
+// the S tile and the interior of the 4 x 34 L halo tile are read as float4 (4 + 8 loads per lane instead of 16 + 48 scalars),
+// the two halo columns as scalars, in two rounds of loads issued together -- the scalar form needed six dependent round
+// trips per chunk and cost a quarter of the fp32 kernel (tools/exp_wgrad_split.py: 801 us -> 594 us without staging).
+// BF: round to bf16 (RNE) on the way into LDS.  Tile pitches are compile-time constants (immediate LDS offsets).
+template <bool BF> struct WgVec {
+  static constexpr int SP = BF ? 72 : 68;       // S channel pitch (elements)
+  static constexpr int IWP = BF ? 40 : 34;      // L halo row pitch
+  static constexpr int LPLANE = BF ? 168 : 137;  // L channel pitch
+};
+
+template <bool BF>
+__device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void *Lsv, int b, int u0, int v0, int cs0, int cl0,
+                                                int tid) {
+  typedef typename std::conditional<BF, __bf16, float>::type T;
+  constexpr int SP = WgVec<BF>::SP, g_IWp = WgVec<BF>::IWP, g_lplane = WgVec<BF>::LPLANE;
+  T *Ss = reinterpret_cast<T *>(Ssv), *Ls = reinterpret_cast<T *>(Lsv);
+  const int HWs = p.Hs * p.Ws, HWl = p.Hl * p.Wl;
+  {
+      // scale factors: always loaded (from a valid address), selected afterwards -- no branch around any load
+      const bool hs = p.s_scale != nullptr, hl = p.l_scale != nullptr;
+      const float *ssp = hs ? p.s_scale : p.S, *lsp = hl ? p.l_scale : p.L;
+      // Every address is ONE per-lane base plus a wave-uniform multiple of the channel pitch (lane e = tid + 256 i keeps its
+      // position inside the tile and moves 8 / 16 / 32 channels per step): few live registers next to the 144 accumulators.
+      const int l_ch = tid >> 5, l_row = (tid >> 3) & 3, l_qx = tid & 7;
+      const int l_iy = u0 - p.py + l_row, l_ix = v0 + 4 * l_qx;
+      const bool l_in = l_iy >= 0 && l_iy < p.Hl && l_ix < p.Wl;
+      const unsigned l_g0 = (unsigned)((b * p.CL + cl0 + l_ch) * HWl + l_iy * p.Wl + l_ix);
+      T *l_d0 = Ls + l_ch * g_lplane + l_row * g_IWp + 1 + 4 * l_qx;
+      // two rounds of ~40 staging registers each (the accumulators leave no room for all 56 values at once)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float4 lv[4];
+        float lsc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // L interior: 64 channels x 4 halo rows x 8 quads, half of the channels per round
+          const int ci = 8 * (4 * hf + i);
+          const bool ok = l_in && cl0 + l_ch + ci < p.CL;
+          // branch-free: clamp the address, always load, select 0 (an `ok ? load : 0` is compiled to one branch per load)
+          lv[i] = *reinterpret_cast<const float4 *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl) : 0u));
+          const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
+          lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+        }
+        if (hf == 0) {
+          float4 sv[4];
+          float ssc[4];
+          const int s_ch = tid >> 4, s_pq = (tid & 15) * 4;
+          const int s_u = u0 + (s_pq >> 5), s_v = v0 + (s_pq & 31);
+          const bool s_in = s_u < p.Hs && s_v < p.Ws;
+          const unsigned s_g0 = (unsigned)((b * p.CS + cs0 + s_ch) * HWs + s_u * p.Ws + s_v);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {  // S: 64 channels x 16 quads
+            const bool ok = s_in && cs0 + s_ch + 16 * i < p.CS;
+            sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(16 * i * HWs) : 0u));
+            const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 16 * i) : 0u];
+            ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float4 v = sv[i];
+            v.x *= ssc[i]; v.y *= ssc[i]; v.z *= ssc[i]; v.w *= ssc[i];
+            if constexpr (BF) {
+              typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+              *reinterpret_cast<bf16x4_t *>(Ss + (s_ch + 16 * i) * SP + s_pq) = bf16x4_t{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+            } else {
+              *reinterpret_cast<float4 *>(Ss + (s_ch + 16 * i) * SP + s_pq) = v;
+            }
+          }
+        } else {
+          float ev[2], esc[2];
+          const int e_ch = tid >> 3, e_row = (tid >> 1) & 3, e_side = tid & 1;
+          const int e_iy = u0 - p.py + e_row, e_ix = e_side ? v0 + 32 : v0 - 1;
+          const bool e_in = e_iy >= 0 && e_iy < p.Hl && e_ix >= 0 && e_ix < p.Wl;
+          const unsigned e_g0 = (unsigned)((b * p.CL + cl0 + e_ch) * HWl + e_iy * p.Wl + e_ix);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {  // L halo columns: 64 channels x 4 rows x {left, right}
+            const bool ok = e_in && cl0 + e_ch + 32 * i < p.CL;
+            ev[i] = p.L[ok ? e_g0 + (unsigned)(32 * i * HWl) : 0u];
+            const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch + 32 * i) : 0u];
+            esc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            Ls[(e_ch + 32 * i) * g_lplane + e_row * g_IWp + (e_side ? 33 : 0)] = (T)(ev[i] * esc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          T *dst = l_d0 + 8 * (4 * hf + i) * g_lplane;
+          dst[0] = (T)(lv[i].x * lsc[i]); dst[1] = (T)(lv[i].y * lsc[i]); dst[2] = (T)(lv[i].z * lsc[i]); dst[3] = (T)(lv[i].w * lsc[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the second round's loads behind the first round's LDS writes (registers)
+      }
+  }
+}
+
 template <int WGS, int WGL, int NT, int PIX, bool GRP, bool VEC = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   constexpr int BS = WGS * 32, BL = WGL * 32, SP = PIX + 4;  // 16-byte aligned S rows; 68 words = conflict-free b128
@@ -855,7 +951,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   float *Ls = smem + BS * SP;  // [BL][lplane]
 
   // tile geometry: compile-time constants on the VEC path (immediate LDS offsets, no address registers)
-  const int g_IWp = VEC ? 34 : p.IWp, g_lplane = VEC ? 137 : p.lplane, g_logTW = VEC ? 5 : p.logTW;
+  const int g_IWp = VEC ? WgVec<false>::IWP : p.IWp, g_lplane = VEC ? WgVec<false>::LPLANE : p.lplane, g_logTW = VEC ? 5 : p.logTW;
   const int g_logTHs = VEC ? 1 : p.logTHs, g_IHs = VEC ? 4 : p.IHs, g_sy = VEC ? 1 : p.sy, g_sx = VEC ? 1 : p.sx;
   const int g_HALFW = p.HALFW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -910,80 +1006,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     const int u0 = tu << g_logTHs, v0 = tv << g_logTW;
     __syncthreads();
     if constexpr (VEC) {
-      // 32 x 2 pixel tiles of stride-1 3x3 layers whose rows are whole 16-byte units (Ws, Wl % 4 == 0): the S tile and the
-      // interior of the L halo tile are read as float4 (4 + 8 loads per lane instead of 16 + 48), the two halo columns as
-      // scalars, in two rounds of loads issued together -- the scalar form needed six dependent
-      // round trips per chunk and cost a quarter of the kernel (tools/exp_wgrad_split.py: 801 us -> 594 us without staging).
-      static_assert(!VEC || (NT == 9 && PIX == 64 && BS == 64 && BL == 64), "VEC staging: 3x3, 64-pixel chunks, 64x64 tiles");
-      const int b = bg;  // NSEG == 1
-      // scale factors: always loaded (from a valid address), selected afterwards -- no branch around any load
-      const bool hs = p.s_scale != nullptr, hl = p.l_scale != nullptr;
-      const float *ssp = hs ? p.s_scale : p.S, *lsp = hl ? p.l_scale : p.L;
-      // Every address is ONE per-lane base plus a wave-uniform multiple of the channel pitch (lane e = tid + 256 i keeps its
-      // position inside the tile and moves 8 / 16 / 32 channels per step): few live registers next to the 144 accumulators.
-      const int l_ch = tid >> 5, l_row = (tid >> 3) & 3, l_qx = tid & 7;
-      const int l_iy = u0 - p.py + l_row, l_ix = v0 + 4 * l_qx;
-      const bool l_in = l_iy >= 0 && l_iy < p.Hl && l_ix < p.Wl;
-      const unsigned l_g0 = (unsigned)((b * p.CL + cl0 + l_ch) * HWl + l_iy * p.Wl + l_ix);
-      float *l_d0 = Ls + l_ch * g_lplane + l_row * g_IWp + 1 + 4 * l_qx;
-      // two rounds of ~40 staging registers each (the accumulators leave no room for all 56 values at once)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        float4 lv[4];
-        float lsc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // L interior: 64 channels x 4 halo rows x 8 quads, half of the channels per round
-          const int ci = 8 * (4 * hf + i);
-          const bool ok = l_in && cl0 + l_ch + ci < p.CL;
-          // branch-free: clamp the address, always load, select 0 (an `ok ? load : 0` is compiled to one branch per load)
-          lv[i] = *reinterpret_cast<const float4 *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl) : 0u));
-          const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
-          lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
-        }
-        if (hf == 0) {
-          float4 sv[4];
-          float ssc[4];
-          const int s_ch = tid >> 4, s_pq = (tid & 15) * 4;
-          const int s_u = u0 + (s_pq >> 5), s_v = v0 + (s_pq & 31);
-          const bool s_in = s_u < p.Hs && s_v < p.Ws;
-          const unsigned s_g0 = (unsigned)((b * p.CS + cs0 + s_ch) * HWs + s_u * p.Ws + s_v);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {  // S: 64 channels x 16 quads
-            const bool ok = s_in && cs0 + s_ch + 16 * i < p.CS;
-            sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(16 * i * HWs) : 0u));
-            const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 16 * i) : 0u];
-            ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float4 v = sv[i];
-            v.x *= ssc[i]; v.y *= ssc[i]; v.z *= ssc[i]; v.w *= ssc[i];
-            *reinterpret_cast<float4 *>(Ss + (s_ch + 16 * i) * SP + s_pq) = v;
-          }
-        } else {
-          float ev[2], esc[2];
-          const int e_ch = tid >> 3, e_row = (tid >> 1) & 3, e_side = tid & 1;
-          const int e_iy = u0 - p.py + e_row, e_ix = e_side ? v0 + 32 : v0 - 1;
-          const bool e_in = e_iy >= 0 && e_iy < p.Hl && e_ix >= 0 && e_ix < p.Wl;
-          const unsigned e_g0 = (unsigned)((b * p.CL + cl0 + e_ch) * HWl + e_iy * p.Wl + e_ix);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {  // L halo columns: 64 channels x 4 rows x {left, right}
-            const bool ok = e_in && cl0 + e_ch + 32 * i < p.CL;
-            ev[i] = p.L[ok ? e_g0 + (unsigned)(32 * i * HWl) : 0u];
-            const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch + 32 * i) : 0u];
-            esc[i] = !ok ? 0.f : (hl ? sc : 1.f);
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            Ls[(e_ch + 32 * i) * g_lplane + e_row * g_IWp + (e_side ? 33 : 0)] = ev[i] * esc[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float *dst = l_d0 + 8 * (4 * hf + i) * g_lplane;
-          dst[0] = lv[i].x * lsc[i]; dst[1] = lv[i].y * lsc[i]; dst[2] = lv[i].z * lsc[i]; dst[3] = lv[i].w * lsc[i];
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the second round's loads behind the first round's LDS writes (registers)
-      }
+      static_assert(!VEC || (NT == 9 && PIX == 64 && BS == 64 && BL == 64 && SP == WgVec<false>::SP), "VEC staging: 3x3, 64-pixel chunks, 64x64 tiles");
+      wgrad_stage_vec<false>(p, Ss, Ls, bg, u0, v0, cs0, cl0, tid);
     } else {
     // Branch-free staging (same lesson as conv_fprop_kernel): clamp the address, always load, select 0 -- the loads
     // of a batch (and their scale factors) are then in flight together instead of one round trip per `if` block.
@@ -1120,7 +1144,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
 // Row pitches are multiples of 8 pixels; channel pitches are ODD multiples of 16 bytes (conflict-free b128 across lanes).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int WGS, int WGL, int NT, int PIX, int SX>
+template <int WGS, int WGL, int NT, int PIX, int SX, bool VEC = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p) {
   constexpr int BS = WGS * 32, BL = WGL * 32, SPB = PIX + 8;  // S row pitch (bf16 elements): 2*SPB bytes = odd * 16
   constexpr int KHn = (NT == 9) ? 3 : 1;
@@ -1140,7 +1164,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p)
   for (int j = 0; j < NJC; ++j) {
     d_pos[j] = -1; d_loff[j] = 0;
     const int e = lane + 64 * j;
-    if (j < p.NJ && e < p.ppc) {
+    if (!VEC && j < p.NJ && e < p.ppc) {
       const int per = p.IHs * p.IWs;
       const int seg = e / per;
       const int rem = e - seg * per;
@@ -1172,6 +1196,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p)
     const int bg = t2 / p.tilesU;
     const int u0 = tu << p.logTHs, v0 = tv << p.logTW;
     __syncthreads();
+    if constexpr (VEC) {
+      static_assert(!VEC || (NT == 9 && PIX == 64 && SX == 1 && BS == 64 && BL == 64 && SPB == WgVec<true>::SP), "VEC staging");
+      wgrad_stage_vec<true>(p, Ss, Ls, bg, u0, v0, cs0, cl0, tid);
+    } else {
     {  // S tile (branch-free, as in the fp32 kernel)
       const int b = bg * p.NSEG + sseg, u = u0 + sr, v = v0 + sq;
       const bool ok = b < p.B && u < p.Hs && v < p.Ws;
@@ -1237,6 +1265,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p)
               Ls[ch * p.lplane + d_loff[j]] = (__bf16)((g[j] >= 0 && cl0 + ch < p.CL) ? lv[u][j] : 0.f);
         }
       }
+    }
     }
     __syncthreads();
     const __bf16 *Sp = Ss + (ws * 32 + (lane & 31)) * SPB + 8 * half;
@@ -1409,17 +1438,26 @@ static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes, const N
   return TBG_OK;
 }
 
-template <int WGS, int WGL, int NT, int PIX, int SX>
+static bool wgrad_vec_ok(const WgradP &p, bool bf) {  // geometry of wgrad_stage_vec
+  return p.logTW == 5 && p.logTHs == 1 && p.NSEG == 1 && p.sx == 1 && p.sy == 1 && (p.Ws & 3) == 0 && (p.Wl & 3) == 0 &&
+         p.px == 1 && p.IWp == (bf ? WgVec<true>::IWP : WgVec<false>::IWP) &&
+         p.lplane == (bf ? WgVec<true>::LPLANE : WgVec<false>::LPLANE) && (((uintptr_t)p.S | (uintptr_t)p.L) & 15) == 0;
+}
+
+template <int WGS, int WGL, int NT, int PIX, int SX, bool VEC = false>
 static int launch_wgrad_bf16(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
   constexpr int BS = WGS * 32, BL = WGL * 32;
+  if constexpr (!VEC && NT == 9 && PIX == 64 && SX == 1 && WGS == 2 && WGL == 2) {
+    if (wgrad_vec_ok(p, true)) return launch_wgrad_bf16<WGS, WGL, NT, PIX, SX, true>(p, st, ws_bytes, name);
+  }
   if (name) {
-    snprintf(name->buf, name->n, "conv_wgrad_bf16_kernel<%d, %d, %d, %d, %d>", WGS, WGL, NT, PIX, SX);
+    snprintf(name->buf, name->n, "conv_wgrad_bf16_kernel<%d, %d, %d, %d, %d, %s>", WGS, WGL, NT, PIX, SX, VEC ? "true" : "false");
     return TBG_OK;
   }
   const size_t lds = ((size_t)BS * (PIX + 8) + (size_t)BL * p.lplane) * 2;
   if (p.NJ > ((NT == 1 && PIX == 64) ? 1 : WG_MAXNJ)) return TBG_EUNSUPPORTED;
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
-  auto kern = conv_wgrad_bf16_kernel<WGS, WGL, NT, PIX, SX>;
+  auto kern = conv_wgrad_bf16_kernel<WGS, WGL, NT, PIX, SX, VEC>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TBG_EHIP;
@@ -1441,9 +1479,7 @@ template <int WGS, int WGL, int NT, int PIX>
 static int launch_wgrad(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
   if constexpr (NT == 9 && PIX == 64 && WGS == 2 && WGL == 2) {
     // 32 x 2 pixel tiles of a stride-1 layer with 16-byte-aligned rows: float4 staging
-    if (p.logTW == 5 && p.logTHs == 1 && p.NSEG == 1 && p.sx == 1 && p.sy == 1 && (p.Ws & 3) == 0 && (p.Wl & 3) == 0 &&
-        p.px == 1 && (((uintptr_t)p.S | (uintptr_t)p.L) & 15) == 0)
-      return launch_wgrad_impl<WGS, WGL, NT, PIX, true, true>(p, st, ws_bytes, name);
+    if (wgrad_vec_ok(p, false)) return launch_wgrad_impl<WGS, WGL, NT, PIX, true, true>(p, st, ws_bytes, name);
   }
   if (p.logTW >= 2) return launch_wgrad_impl<WGS, WGL, NT, PIX, true>(p, st, ws_bytes, name);
   return launch_wgrad_impl<WGS, WGL, NT, PIX, false>(p, st, ws_bytes, name);

@@ -6,12 +6,9 @@ import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "textboxgan_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "scratch")
-VARIANTS = {
-    "nostage": [("    __syncthreads();\n    // Branch-free staging (same lesson as conv_fprop_kernel)",
-                 "    __syncthreads();\n    if (chunk == (int)blockIdx.z)\n    // Branch-free staging (same lesson as conv_fprop_kernel)"),
-                ("    {  // S tile\n      const int b = bg * p.NSEG + sseg, u = u0 + sr, v = v0 + sq;",
-                 "    {{  // S tile\n      const int b = bg * p.NSEG + sseg, u = u0 + sr, v = v0 + sq;"),
-                ("    __syncthreads();\n    if constexpr (GRP) {\n      // (tile rows of >= 4 pixels)", "    }\n    __syncthreads();\n    if constexpr (GRP) {\n      // (tile rows of >= 4 pixels)")],
+VARIANTS = {  # (the float4-staged instance: the shapes below all take it)
+    "nostage": [("      wgrad_stage_vec<false>(p, Ss, Ls, bg, u0, v0, cs0, cl0, tid);",
+                 "      if (chunk == (int)blockIdx.z) wgrad_stage_vec<false>(p, Ss, Ls, bg, u0, v0, cs0, cl0, tid);")],
     "nomfma": [("      for (int gp = 0; gp < PIX / 8; ++gp) {\n        const int pp = 8 * gp + 4 * half;",
                 "      for (int gp = 0; gp < 1; ++gp) {\n        const int pp = 8 * gp + 4 * half;")],
 }
