@@ -131,7 +131,7 @@ def test_wgrad_bf16_vector_staging(dev, dims):
     f = lambda t: t.float().to(dev).contiguous()
     g = ops._Geom((1, 1), (1, 1), 3, 3, (H, W), (H, W))
     desc = N.WgradDesc(B, M, C, H, W, H, W, 3, 3, 1, 1, 1, 1, C * M, M, 1, 0.7)
-    assert N.wgrad_kernel_name(desc, True) == "conv_wgrad_bf16_kernel<2, 2, 9, 64, 1, true>"
+    assert N.wgrad_kernel_name(desc, True) == "conv_wgrad_bf16_kernel<2, 2, 9, 64, 1, 1>"
     with ops.compute_dtype("bf16"):
         dw = ops._bwd_weight_launch(f(x), f(dy), g, C, M, alpha=0.7, x_scale=f(xs), dy_scale=f(ds), add=(f(addw), f(addq), 0.3))
     assert rel_err(dw, ref) < 5e-5

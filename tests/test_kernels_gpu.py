@@ -360,12 +360,46 @@ def test_conv2d_wgrad_vector_staging(dev, case):
     f = lambda t: t.float().to(dev).contiguous()
     g = ops._Geom((1, 1), (1, 1), 3, 3, (H, W), (H, W))
     desc = N.WgradDesc(B, M, C, H, W, H, W, 3, 3, 1, 1, 1, 1, C * M, M, 1, 0.7)
-    assert N.wgrad_kernel_name(desc).endswith("true, true>"), N.wgrad_kernel_name(desc)
+    assert N.wgrad_kernel_name(desc) == "conv_wgrad_kernel<2, 2, 9, 64, true, 1>", N.wgrad_kernel_name(desc)
     dw = ops._bwd_weight_launch(f(x), f(dy), g, C, M, alpha=0.7, x_scale=f(xs), dy_scale=f(ds), add=(f(addw), f(addq), 0.3))
     assert rel_err(dw, ref) < 3e-5
     dw_plain = ops._bwd_weight_launch(f(x), f(dy), g, C, M, alpha=1.0)
     (ref_plain,) = torch.autograd.grad(F.conv2d(x, w.permute(3, 2, 0, 1), padding=1), w, dy)
     assert rel_err(dw_plain, ref_plain) < 3e-5
+
+
+WGV2_CASES = [
+    (2, 40, 72, 11, 65, "odd map 11x65 -> 5x32, partial channel tiles"),
+    (3, 64, 64, 9, 130, "9x130 -> 4x64 (two tiles per row, Wl = 2 Ws + 2)"),
+    (1, 130, 70, 5, 129, "5x129 -> 2x64, three / two channel tiles"),
+]
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", WGV2_CASES, ids=[c[-1] for c in WGV2_CASES])
+def test_conv2d_wgrad_vector_staging_stride2(dev, case, bf16):
+    """the float4-staged stride-2 VALID filter-gradient instances (fp32 and bf16): scales, additive term, ragged channels."""
+    from textboxgan_amd import ops, native as N
+    B, C, M, H, W, _ = case
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    x, dy = rnd(B, C, H, W, seed=50), rnd(B, M, Ho, Wo, seed=51)
+    xs, ds = rnd(B, C, seed=52).abs() + 0.5, rnd(B, M, seed=53).abs() + 0.5
+    addw, addq = rnd(3, 3, C, M, seed=54), rnd(C, M, seed=55)
+    rd = (lambda t: t.float().bfloat16().double()) if bf16 else (lambda t: t)
+    f32 = lambda t: t.float().double()
+    xr = rd((f32(x) * f32(xs)[:, :, None, None]).float().double())
+    dyr = rd((f32(dy) * f32(ds)[:, :, None, None]).float().double())
+    w = torch.zeros(3, 3, C, M, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xr, w.permute(3, 2, 0, 1), stride=2), w, dyr)
+    ref = 0.7 * ref + 0.3 * f32(addw) * f32(addq)[None, None]
+    f = lambda t: t.float().to(dev).contiguous()
+    g = ops._Geom((2, 2), (0, 0), 3, 3, (H, W), (Ho, Wo))
+    desc = N.WgradDesc(B, M, C, Ho, Wo, H, W, 3, 3, 2, 2, 0, 0, C * M, M, 1, 0.7)
+    want = "conv_wgrad_bf16_kernel<2, 2, 9, 32, 2, 2>" if bf16 else "conv_wgrad_kernel<2, 2, 9, 32, true, 2>"
+    assert N.wgrad_kernel_name(desc, bf16) == want, N.wgrad_kernel_name(desc, bf16)
+    with ops.compute_dtype("bf16" if bf16 else "f32"):
+        dw = ops._bwd_weight_launch(f(x), f(dy), g, C, M, alpha=0.7, x_scale=f(xs), dy_scale=f(ds), add=(f(addw), f(addq), 0.3))
+    assert rel_err(dw, ref) < 5e-5
 
 
 def test_conv_random_shapes_all_three_passes(dev):

@@ -847,8 +847,8 @@ struct WgradP {
 
 // ---- float4 staging of one 32 x 2 pixel chunk of a stride-1 3x3 filter gradient (NSEG == 1, Ws % 4 == Wl % 4 == 0, px == 1):
 // the S tile and the interior of the 4 x 34 L halo tile are read as float4 (4 + 8 loads per lane instead of 16 + 48 scalars),
-// the two halo columns as scalars, in two rounds of loads issued together -- the scalar form needed six dependent round
-// trips per chunk and cost a quarter of the fp32 kernel (tools/exp_wgrad_split.py: 801 us -> 594 us without staging).
+// the two halo columns as scalars, all issued together (the compiler merges the two source-level rounds: 241 VGPRs, no
+// spill) -- the scalar form needed six dependent round trips per chunk and cost a quarter of the fp32 kernel (tools/exp_wgrad_split.py: 801 us -> 594 us without staging).
 // BF: round to bf16 (RNE) on the way into LDS.  Tile pitches are compile-time constants (immediate LDS offsets).
 template <bool BF> struct WgVec {
   static constexpr int SP = BF ? 72 : 68;       // S channel pitch (elements)
@@ -874,7 +874,6 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
       const bool l_in = l_iy >= 0 && l_iy < p.Hl && l_ix < p.Wl;
       const unsigned l_g0 = (unsigned)((b * p.CL + cl0 + l_ch) * HWl + l_iy * p.Wl + l_ix);
       T *l_d0 = Ls + l_ch * g_lplane + l_row * g_IWp + 1 + 4 * l_qx;
-      // two rounds of ~40 staging registers each (the accumulators leave no room for all 56 values at once)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         float4 lv[4];
@@ -935,12 +934,89 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
           T *dst = l_d0 + 8 * (4 * hf + i) * g_lplane;
           dst[0] = (T)(lv[i].x * lsc[i]); dst[1] = (T)(lv[i].y * lsc[i]); dst[2] = (T)(lv[i].z * lsc[i]); dst[3] = (T)(lv[i].w * lsc[i]);
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the second round's loads behind the first round's LDS writes (registers)
       }
   }
 }
 
-template <int WGS, int WGL, int NT, int PIX, bool GRP, bool VEC = false>
+// ---- the same for one 32 x 1 pixel chunk of a stride-2 VALID 3x3 filter gradient (the discriminator's downsampling
+// layers: L = the FIR-padded map, Wl = 2 Ws + 1 or + 2, so L rows are NOT 16-byte aligned -- the float4 loads are
+// dword-aligned ones, which global memory accepts).  Per channel 3 halo rows of 65 columns = 16 quads + 1 scalar, stored
+// de-interleaved (even | odd columns) as the compute loop expects.  Requires Ws % 32 == 0 (every tile column in range).
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+template <bool BF> struct WgVec2 {
+  static constexpr int SP = BF ? 40 : 36;
+  static constexpr int HALFW = BF ? 40 : 33;
+  static constexpr int IWP = 2 * HALFW;
+  static constexpr int LPLANE = BF ? 248 : 199;
+};
+
+template <bool BF>
+__device__ __forceinline__ void wgrad_stage_vec_s2(const WgradP &p, void *Ssv, void *Lsv, int b, int u0, int v0, int cs0,
+                                                   int cl0, int tid) {
+  typedef typename std::conditional<BF, __bf16, float>::type T;
+  constexpr int SP = WgVec2<BF>::SP, HALFW = WgVec2<BF>::HALFW, IWP = WgVec2<BF>::IWP, LPLANE = WgVec2<BF>::LPLANE;
+  T *Ss = reinterpret_cast<T *>(Ssv), *Ls = reinterpret_cast<T *>(Lsv);
+  const int HWs = p.Hs * p.Ws, HWl = p.Hl * p.Wl;
+  const bool hs = p.s_scale != nullptr, hl = p.l_scale != nullptr;
+  const float *ssp = hs ? p.s_scale : p.S, *lsp = hl ? p.l_scale : p.L;
+  const int l_ch = tid >> 4, l_qx = tid & 15;
+  const int iy0 = 2 * u0 - p.py;
+  const unsigned l_g0 = (unsigned)((b * p.CL + cl0 + l_ch) * HWl + max(iy0, 0) * p.Wl + 2 * v0 + 4 * l_qx);
+  T *l_d0 = Ls + l_ch * LPLANE + 2 * l_qx;
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    f32x4u lv[6];
+    float lsc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {  // L interior: 3 rows x 64 channels x 16 quads; step i -> row i / 4, channels + 16 (i % 4)
+      const int ii = 6 * hf + i, row = ii >> 2, ci = 16 * (ii & 3);
+      const bool ok = iy0 + row >= 0 && iy0 + row < p.Hl && cl0 + l_ch + ci < p.CL;
+      lv[i] = *reinterpret_cast<const f32x4u *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl + (row + min(iy0, 0)) * p.Wl) : 0u));
+      const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
+      lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+    }
+    if (hf == 0) {
+      float4 sv[2];
+      float ssc[2];
+      const int s_ch = tid >> 3, s_pq = (tid & 7) * 4;
+      const bool s_in = u0 < p.Hs && v0 + s_pq < p.Ws;
+      const unsigned s_g0 = (unsigned)((b * p.CS + cs0 + s_ch) * HWs + u0 * p.Ws + v0 + s_pq);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {  // S: 64 channels x 8 quads
+        const bool ok = s_in && cs0 + s_ch + 32 * i < p.CS;
+        sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(32 * i * HWs) : 0u));
+        const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 32 * i) : 0u];
+        ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float4 v = sv[i];
+        v.x *= ssc[i]; v.y *= ssc[i]; v.z *= ssc[i]; v.w *= ssc[i];
+        if constexpr (BF) {
+          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<bf16x4_t *>(Ss + (s_ch + 32 * i) * SP + s_pq) = bf16x4_t{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        } else {
+          *reinterpret_cast<float4 *>(Ss + (s_ch + 32 * i) * SP + s_pq) = v;
+        }
+      }
+    } else if (tid < 192) {  // the 65th column of each halo row (even part, place 32): 64 channels x 3 rows
+      const int e_ch = tid & 63, e_row = tid >> 6;
+      const bool ok = iy0 + e_row >= 0 && iy0 + e_row < p.Hl && cl0 + e_ch < p.CL && 2 * v0 + 64 < p.Wl;
+      const float ev = p.L[ok ? (unsigned)((b * p.CL + cl0 + e_ch) * HWl + (iy0 + e_row) * p.Wl + 2 * v0 + 64) : 0u];
+      const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch) : 0u];
+      Ls[e_ch * LPLANE + e_row * IWP + 32] = (T)(!ok ? 0.f : ev * (hl ? sc : 1.f));
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int ii = 6 * hf + i, row = ii >> 2, ci = 16 * (ii & 3);
+      T *dst = l_d0 + ci * LPLANE + row * IWP;
+      dst[0] = (T)(lv[i][0] * lsc[i]); dst[1] = (T)(lv[i][2] * lsc[i]);
+      dst[HALFW] = (T)(lv[i][1] * lsc[i]); dst[HALFW + 1] = (T)(lv[i][3] * lsc[i]);
+    }
+  }
+}
+
+template <int WGS, int WGL, int NT, int PIX, bool GRP, int VEC = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   constexpr int BS = WGS * 32, BL = WGL * 32, SP = PIX + 4;  // 16-byte aligned S rows; 68 words = conflict-free b128
   constexpr int KWt = (NT == 9) ? 3 : 1;
@@ -950,10 +1026,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   float *Ss = smem;            // [BS][SP]
   float *Ls = smem + BS * SP;  // [BL][lplane]
 
-  // tile geometry: compile-time constants on the VEC path (immediate LDS offsets, no address registers)
-  const int g_IWp = VEC ? WgVec<false>::IWP : p.IWp, g_lplane = VEC ? WgVec<false>::LPLANE : p.lplane, g_logTW = VEC ? 5 : p.logTW;
-  const int g_logTHs = VEC ? 1 : p.logTHs, g_IHs = VEC ? 4 : p.IHs, g_sy = VEC ? 1 : p.sy, g_sx = VEC ? 1 : p.sx;
-  const int g_HALFW = p.HALFW;
+  // tile geometry: compile-time constants on the float4-staged paths (immediate LDS offsets, no address registers)
+  const int g_IWp = VEC == 1 ? WgVec<false>::IWP : VEC == 2 ? WgVec2<false>::IWP : p.IWp;
+  const int g_lplane = VEC == 1 ? WgVec<false>::LPLANE : VEC == 2 ? WgVec2<false>::LPLANE : p.lplane;
+  const int g_logTW = VEC ? 5 : p.logTW, g_logTHs = VEC == 1 ? 1 : VEC == 2 ? 0 : p.logTHs;
+  const int g_IHs = VEC == 1 ? 4 : VEC == 2 ? 3 : p.IHs, g_sy = VEC ? VEC : p.sy, g_sx = VEC ? VEC : p.sx;
+  const int g_HALFW = VEC == 2 ? WgVec2<false>::HALFW : p.HALFW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ws = wave / WGL, wl = wave - ws * WGL;
   const int cs0 = blockIdx.x * BS, cl0 = blockIdx.y * BL;
@@ -1005,9 +1083,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     const int bg = t2 / p.tilesU;
     const int u0 = tu << g_logTHs, v0 = tv << g_logTW;
     __syncthreads();
-    if constexpr (VEC) {
-      static_assert(!VEC || (NT == 9 && PIX == 64 && BS == 64 && BL == 64 && SP == WgVec<false>::SP), "VEC staging: 3x3, 64-pixel chunks, 64x64 tiles");
+    if constexpr (VEC == 1) {
+      static_assert(VEC != 1 || (NT == 9 && PIX == 64 && BS == 64 && BL == 64 && SP == WgVec<false>::SP), "VEC staging: 3x3, 64-pixel chunks, 64x64 tiles");
       wgrad_stage_vec<false>(p, Ss, Ls, bg, u0, v0, cs0, cl0, tid);
+    } else if constexpr (VEC == 2) {
+      static_assert(VEC != 2 || (NT == 9 && PIX == 32 && BS == 64 && BL == 64 && SP == WgVec2<false>::SP), "stride-2 VEC staging");
+      wgrad_stage_vec_s2<false>(p, Ss, Ls, bg, u0, v0, cs0, cl0, tid);
     } else {
     // Branch-free staging (same lesson as conv_fprop_kernel): clamp the address, always load, select 0 -- the loads
     // of a batch (and their scale factors) are then in flight together instead of one round trip per `if` block.
@@ -1144,7 +1225,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
 // Row pitches are multiples of 8 pixels; channel pitches are ODD multiples of 16 bytes (conflict-free b128 across lanes).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int WGS, int WGL, int NT, int PIX, int SX, bool VEC = false>
+template <int WGS, int WGL, int NT, int PIX, int SX, int VEC = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p) {
   constexpr int BS = WGS * 32, BL = WGL * 32, SPB = PIX + 8;  // S row pitch (bf16 elements): 2*SPB bytes = odd * 16
   constexpr int KHn = (NT == 9) ? 3 : 1;
@@ -1196,9 +1277,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p)
     const int bg = t2 / p.tilesU;
     const int u0 = tu << p.logTHs, v0 = tv << p.logTW;
     __syncthreads();
-    if constexpr (VEC) {
-      static_assert(!VEC || (NT == 9 && PIX == 64 && SX == 1 && BS == 64 && BL == 64 && SPB == WgVec<true>::SP), "VEC staging");
+    if constexpr (VEC == 1) {
+      static_assert(VEC != 1 || (NT == 9 && PIX == 64 && SX == 1 && BS == 64 && BL == 64 && SPB == WgVec<true>::SP), "VEC staging");
       wgrad_stage_vec<true>(p, Ss, Ls, bg, u0, v0, cs0, cl0, tid);
+    } else if constexpr (VEC == 2) {
+      static_assert(VEC != 2 || (NT == 9 && PIX == 32 && SX == 2 && BS == 64 && BL == 64 && SPB == WgVec2<true>::SP), "stride-2 VEC staging");
+      wgrad_stage_vec_s2<true>(p, Ss, Ls, bg, u0, v0, cs0, cl0, tid);
     } else {
     {  // S tile (branch-free, as in the fp32 kernel)
       const int b = bg * p.NSEG + sseg, u = u0 + sr, v = v0 + sq;
@@ -1409,12 +1493,11 @@ static int wgrad_ksplit(int tiles, int nchunks) {
   return ksplit;
 }
 
-template <int WGS, int WGL, int NT, int PIX, bool GRP, bool VEC = false>
+template <int WGS, int WGL, int NT, int PIX, bool GRP, int VEC = 0>
 static int launch_wgrad_impl(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
   constexpr int BS = WGS * 32, BL = WGL * 32;
   if (name) {
-    snprintf(name->buf, name->n, "conv_wgrad_kernel<%d, %d, %d, %d, %s, %s>", WGS, WGL, NT, PIX, GRP ? "true" : "false",
-             VEC ? "true" : "false");
+    snprintf(name->buf, name->n, "conv_wgrad_kernel<%d, %d, %d, %d, %s, %d>", WGS, WGL, NT, PIX, GRP ? "true" : "false", VEC);
     return TBG_OK;
   }
   const size_t lds = ((size_t)BS * (PIX + 4) + (size_t)BL * p.lplane) * sizeof(float);
@@ -1443,15 +1526,24 @@ static bool wgrad_vec_ok(const WgradP &p, bool bf) {  // geometry of wgrad_stage
          p.px == 1 && p.IWp == (bf ? WgVec<true>::IWP : WgVec<false>::IWP) &&
          p.lplane == (bf ? WgVec<true>::LPLANE : WgVec<false>::LPLANE) && (((uintptr_t)p.S | (uintptr_t)p.L) & 15) == 0;
 }
+static bool wgrad_vec2_ok(const WgradP &p, bool bf) {  // geometry of wgrad_stage_vec_s2
+  return p.logTW == 5 && p.logTHs == 0 && p.NSEG == 1 && p.sx == 2 && p.sy == 2 && (p.Ws & 31) == 0 && p.px == 0 &&
+         2 * p.Ws < p.Wl && p.IWp == (bf ? WgVec2<true>::IWP : WgVec2<false>::IWP) &&
+         p.HALFW == (bf ? WgVec2<true>::HALFW : WgVec2<false>::HALFW) &&
+         p.lplane == (bf ? WgVec2<true>::LPLANE : WgVec2<false>::LPLANE) && ((uintptr_t)p.S & 15) == 0;
+}
 
-template <int WGS, int WGL, int NT, int PIX, int SX, bool VEC = false>
+template <int WGS, int WGL, int NT, int PIX, int SX, int VEC = 0>
 static int launch_wgrad_bf16(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
   constexpr int BS = WGS * 32, BL = WGL * 32;
   if constexpr (!VEC && NT == 9 && PIX == 64 && SX == 1 && WGS == 2 && WGL == 2) {
-    if (wgrad_vec_ok(p, true)) return launch_wgrad_bf16<WGS, WGL, NT, PIX, SX, true>(p, st, ws_bytes, name);
+    if (wgrad_vec_ok(p, true)) return launch_wgrad_bf16<WGS, WGL, NT, PIX, SX, 1>(p, st, ws_bytes, name);
+  }
+  if constexpr (!VEC && NT == 9 && PIX == 32 && SX == 2 && WGS == 2 && WGL == 2) {
+    if (wgrad_vec2_ok(p, true)) return launch_wgrad_bf16<WGS, WGL, NT, PIX, SX, 2>(p, st, ws_bytes, name);
   }
   if (name) {
-    snprintf(name->buf, name->n, "conv_wgrad_bf16_kernel<%d, %d, %d, %d, %d, %s>", WGS, WGL, NT, PIX, SX, VEC ? "true" : "false");
+    snprintf(name->buf, name->n, "conv_wgrad_bf16_kernel<%d, %d, %d, %d, %d, %d>", WGS, WGL, NT, PIX, SX, VEC);
     return TBG_OK;
   }
   const size_t lds = ((size_t)BS * (PIX + 8) + (size_t)BL * p.lplane) * 2;
@@ -1479,7 +1571,10 @@ template <int WGS, int WGL, int NT, int PIX>
 static int launch_wgrad(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
   if constexpr (NT == 9 && PIX == 64 && WGS == 2 && WGL == 2) {
     // 32 x 2 pixel tiles of a stride-1 layer with 16-byte-aligned rows: float4 staging
-    if (wgrad_vec_ok(p, false)) return launch_wgrad_impl<WGS, WGL, NT, PIX, true, true>(p, st, ws_bytes, name);
+    if (wgrad_vec_ok(p, false)) return launch_wgrad_impl<WGS, WGL, NT, PIX, true, 1>(p, st, ws_bytes, name);
+  }
+  if constexpr (NT == 9 && PIX == 32 && WGS == 2 && WGL == 2) {
+    if (wgrad_vec2_ok(p, false)) return launch_wgrad_impl<WGS, WGL, NT, PIX, true, 2>(p, st, ws_bytes, name);
   }
   if (p.logTW >= 2) return launch_wgrad_impl<WGS, WGL, NT, PIX, true>(p, st, ws_bytes, name);
   return launch_wgrad_impl<WGS, WGL, NT, PIX, false>(p, st, ws_bytes, name);
