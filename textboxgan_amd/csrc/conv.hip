@@ -934,6 +934,8 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
           T *dst = l_d0 + 8 * (4 * hf + i) * g_lplane;
           dst[0] = (T)(lv[i].x * lsc[i]); dst[1] = (T)(lv[i].y * lsc[i]); dst[2] = (T)(lv[i].z * lsc[i]); dst[3] = (T)(lv[i].w * lsc[i]);
         }
+        // bf16: keep the two rounds apart (measured: 347 vs 234 TFLOP/s on the 64x256 layer); fp32: the compiler merges them
+        if constexpr (BF) __builtin_amdgcn_sched_barrier(0);
       }
   }
 }
@@ -1013,6 +1015,7 @@ __device__ __forceinline__ void wgrad_stage_vec_s2(const WgradP &p, void *Ssv, v
       dst[0] = (T)(lv[i][0] * lsc[i]); dst[1] = (T)(lv[i][2] * lsc[i]);
       dst[HALFW] = (T)(lv[i][1] * lsc[i]); dst[HALFW + 1] = (T)(lv[i][3] * lsc[i]);
     }
+    if constexpr (BF) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
