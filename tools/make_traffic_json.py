@@ -7,12 +7,12 @@ kern = {}
 for line in open(src):
     if line.startswith("#") or line.startswith("kernel") or not line.strip():
         continue
-    name, rest = line[:66].strip(), line[66:].split()
-    if len(rest) < 7:
+    parts = line.rstrip().rsplit(None, 7)  # name (may contain spaces) + 7 numeric columns
+    if len(parts) < 8:
         continue
-    calls, avg, tot, mb, gbs, frac, busy = rest[:7]
+    name, (calls, avg, tot, mb, gbs, frac, busy) = parts[0].strip(), parts[1:]
     name = re.sub(r"^void ", "", name)
-    name = re.sub(r"\((ConvP|WgradP)\)?$", "", name).strip()
+    name = re.sub(r"\(.*$", "", name).strip()  # drop the argument list (possibly cut by the column width)
     if "conv_" not in name or mb == "nan":
         continue
     kern[name] = {"launches": int(calls), "avg_us": float(avg), "hbm_bytes_per_launch": int(float(mb) * 1e6),

@@ -33,7 +33,7 @@ print("#          -- python bench.py --roofline-only --steps 2 --warmup 1      (
 print("# hbm_MB/launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB / 1024  (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half of wide coalesced reads;")
 print("#                 uncalibrated for narrow accesses -> read GB/s as an upper estimate); GB/s = hbm bytes / average kernel duration; roof 8000 GB/s (6300 achievable)")
 print("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs): share of SIMD cycles with the fp32 MFMA pipe busy")
-print(f"{'kernel':66s} {'calls':>6s} {'avg_us':>8s} {'tot_ms':>8s} {'hbm_MB':>8s} {'GB/s':>7s} {'of8TB/s':>7s} {'mfma_busy':>9s}")
+print(f"{'kernel':80s} {'calls':>6s} {'avg_us':>8s} {'tot_ms':>8s} {'hbm_MB':>8s} {'GB/s':>7s} {'of8TB/s':>7s} {'mfma_busy':>9s}")
 rows = sorted(dur.items(), key=lambda kv: -kv[1][2])
 for k, (calls, avg, tot) in rows[:40]:
     kk = k
@@ -42,6 +42,6 @@ for k, (calls, avg, tot) in rows[:40]:
     gbs = mb * 1e6 / (avg * 1e-6) / 1e9 if mb == mb else float("nan")
     mf, gui = per(kk, "SQ_VALU_MFMA_BUSY_CYCLES"), per(kk, "GRBM_GUI_ACTIVE")
     busy = mf / (gui * 128) if (mf == mf and gui == gui and gui > 0 and mf > 0) else float("nan")
-    print(f"{k[:66]:66s} {calls:6d} {avg:8.1f} {tot:8.2f} {mb:8.2f} {gbs:7.0f} {gbs/8000 if gbs==gbs else float('nan'):7.3f} {busy:9.3f}")
+    print(f"{k[:80]:80s} {calls:6d} {avg:8.1f} {tot:8.2f} {mb:8.2f} {gbs:7.0f} {gbs/8000 if gbs==gbs else float('nan'):7.3f} {busy:9.3f}")
 PY
 head -40 $R/gpurun_out/${TAG}_pmc_report.txt | cut -c1-150
