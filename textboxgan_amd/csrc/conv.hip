@@ -617,7 +617,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   // form's 128x128 tiles at 3 waves/SIMD beat the merged form's 64x128 tiles at 2 waves/SIMD everywhere (76 vs 68).
   // variant 5 forces the merged form, variant 4 the per-class form.
   const bool merged = d->transposed && d->sy == 2 && d->sx == 2 && d->KH == 3 && d->KW == 3 && plain_epi && variant != 4 &&
-                      d->M > 32 && (variant == 5 || (bf && (long long)d->B * d->Hin * d->Win >= 16384));
+                      d->M > 32 && (variant == 5 || variant == 6 || (bf && (long long)d->B * d->Hin * d->Win >= 16384));
   int maxUg = 0, maxVg = 0, maxKH = 0, maxKW = 0, maxtaps = 0;
   if (!d->transposed) {
     p.sy = d->sy; p.sx = d->sx; p.osy = 1; p.osx = 1; p.nclass = 1;
@@ -716,6 +716,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   hipStream_t st = tbg_stream(stream);
   if (merged) {
     if (bf) return launch_fprop<2, 2, 1, 2, 16, MAXTAPS, 0, 2, true, true>(p, st, maxtaps, maxTilesN, name);
+    if (variant == 6) return launch_fprop<2, 2, 1, 2, 16, MAXTAPS, 0, 2, false, true>(p, st, maxtaps, maxTilesN, name);
     return launch_fprop<2, 2, 1, 2, 8, MAXTAPS, 0, 2, false, true>(p, st, maxtaps, maxTilesN, name);
   }
   if (bf) {  // bf16-in MFMA: chunks of 16 channels (32 for the few-tap classes), the same four tile shapes

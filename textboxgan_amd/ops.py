@@ -220,7 +220,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     if allow_split:
         tiles = _conv_tiles(M, _npix) * (stride[0] * stride[1] if transposed else 1)  # one launch covers all classes
         if (transposed and tuple(stride) == (2, 2) and KH == 3 and KW == 3 and M > 32 and FORCE_VARIANT != 4 and
-                (FORCE_VARIANT == 5 or (bf16 and B * Hin * Win >= 16384))):  # mirrors the library's choice (conv.hip)
+                (FORCE_VARIANT in (5, 6) or (bf16 and B * Hin * Win >= 16384))):  # mirrors the library's choice (conv.hip)
             tiles = math.ceil(M / 64) * math.ceil(_npix / 128)  # merged-class kernel: 64 x 128 tiles over input positions
         if tiles < 256 and nchunks >= 8:  # tools/bench_ksplit.py: ~300 blocks is the sweet spot (slab traffic ~ ksplit)
             target = max(1, min(nchunks // 4, math.ceil(288 / tiles)))
