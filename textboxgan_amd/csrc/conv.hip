@@ -800,7 +800,7 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
 
 extern "C" int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                                       const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant < 0 || variant > 5) return TBG_EINVAL;
+  if (variant < 0 || variant > 6) return TBG_EINVAL;
   return conv2d_impl(d, x, w, y, in_scale, epi, stream, nullptr, false, variant);
 }
 
