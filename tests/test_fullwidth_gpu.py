@@ -166,7 +166,8 @@ def _conv_cases_for_coverage():
         (4, 512, 512, 4, 16, 3, (1, 1), (1, 1), False),    # 64x64 tile <2,2,1,1,8,9,0,3>, split-K
         (2, 16, 32, 16, 64, 3, (1, 1), (1, 1), False),     # BM = 32 <1,4,1,2,8,9,0,3>
         (2, 40, 64, 16, 64, 3, (1, 1), (1, 1), False),     # M <= 64, few tiles: 64x64
-        (2, 64, 128, 67, 259, 3, (2, 2), (0, 0), False),   # strided
+        (2, 64, 128, 67, 259, 3, (2, 2), (0, 0), False),   # strided (ragged 33x129 output: scalar-staged filter gradient)
+        (2, 64, 128, 65, 257, 3, (2, 2), (0, 0), False),   # strided, 32x128 output: float4-staged filter gradient <2,2,9,32,true,2>
         (2, 128, 128, 16, 64, 3, (2, 2), (0, 0), True),    # stride-2 transposed, parity classes <2,2,2,2,16,4,0,3>
         (2, 128, 128, 16, 64, 3, (1, 2), (0, 0), True),    # stride (1,2) transposed: parity classes <2,2,2,2,16,4,0,3>
         (6, 32, 64, 32, 128, 3, (1, 2), (0, 0), True),     # the same on the 64 x 256 tile <1,4,2,2,16,4,0,3>

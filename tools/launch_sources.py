@@ -1,6 +1,6 @@
 """Where do the small launches of one training step come from?  One eager step under torch.profiler; every device kernel is
 attributed to the autograd node that launched it (backward) or to the innermost textboxgan_amd source line (forward).
-usage (GPU box): python tools/launch_sources.py [f32|bf16] [batch] [ocr|noocr]"""
+usage (GPU box): python tools/launch_sources.py [f32|bf16] [batch] [ocr|noocr] [plain|pl|r1]"""
 import sys; sys.path.insert(0, '.')
 import collections
 import torch
@@ -18,7 +18,8 @@ from textboxgan_amd.aster import AsterInferer
 kw = dict(aster_ocr=AsterInferer(model=_TinyOCR(cfg.max_char_number))) if NOOCR else {}
 st = build_trainer_state(cfg, dev, seed=0, compute_dtype=DTYPE, **kw); bench_init_(st)
 b = synthetic_batch(cfg, dev, 1234); ts = st["training_step"]
-args = (b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False, 1e-4)
+REG = sys.argv[4] if len(sys.argv) > 4 else "plain"
+args = (b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], REG == "r1", REG == "pl", 1e-4)
 for _ in range(2): ts.dist_train_step(*args)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
@@ -48,7 +49,7 @@ for e in prof.events():
         rec[0] += 1; rec[1] += k.duration; rec[2][k.name.replace("void ", "").replace("at::native::", "")[:90]] += 1
         n_k += 1
 tot = sum(r[1] for r in by_src.values())
-print(f"{n_k} launches, {tot/1e3:.2f} ms of kernel time in one eager step ({DTYPE}, B={BATCH}{', no OCR' if NOOCR else ''})")
+print(f"{n_k} launches, {tot/1e3:.2f} ms of kernel time in one eager step ({DTYPE}, B={BATCH}{', no OCR' if NOOCR else ''}, {REG})")
 print("--- by launch count")
 for src, (n, us, names) in sorted(by_src.items(), key=lambda kv: -kv[1][0])[:70]:
     print(f"{n:5d} launches {us/1e3:7.3f} ms avg {us/n:6.1f} us  {src[:70]}")
