@@ -195,6 +195,48 @@ def test_discriminator_matches_oracle(dev, mode):
         assert l2_err(a, b) < 5e-4 and rel_err(a, b) < 5e-2, n
 
 
+def test_discriminator_joint_pass_matches_two_oracle_calls(dev):
+    """D over [fake; real] with parts=2 (the d-step's single pass) == the oracle's two separate calls: scores, the
+    d-pass gradients (sum over both halves, image gradient pruned) and -- in the G-loss pass's first-half mode -- the
+    gradient w.r.t. the fake images with the filter gradients pruned.  Also with the staged (cuts) form."""
+    from textboxgan_amd import ops
+    from textboxgan_amd.models import Discriminator
+    cfg = small_config(4)
+    P = to64(M.init_discriminator(cfg, seed=3, bench_init=True))
+    for v in P.values():
+        v.requires_grad_(True)
+    names = list(P.keys())
+    fake, real = rnd(4, 3, 64, 256, seed=31).requires_grad_(True), rnd(4, 3, 64, 256, seed=32)
+    sf, sr = M.discriminator(P, cfg, fake), M.discriminator(P, cfg, real)
+    gf, gr = rnd(4, 1, seed=33), rnd(4, 1, seed=34)
+    (dfake_ref,) = torch.autograd.grad(sf, fake, gf, retain_graph=True)                     # G-loss pass
+    dpar_ref = torch.autograd.grad([sf, sr], [P[n] for n in names], [gf, gr])              # D-loss pass
+    D = _load(Discriminator(cfg), P, dev)
+    pd = dict(D.named_parameters())
+    f = lambda t: t.detach().float().to(dev)
+    for cuts in (None, [1, 3]):
+        faked = f(fake).requires_grad_(True)
+        both = torch.cat([faked, f(real)], dim=0)
+        out = D(both, parts=2, cuts=cuts)
+        scores, taps = out if cuts is not None else (out, None)
+        assert rel_err(scores[:4], sf) < 1e-4 and rel_err(scores[4:], sr) < 1e-4
+        ops.FLAGS.skip_d_wgrad, ops.FLAGS.d_first_half = True, 4
+        try:
+            (dfake,) = torch.autograd.grad(scores[:4], faked, f(gf), retain_graph=True)
+        finally:
+            ops.FLAGS.skip_d_wgrad, ops.FLAGS.d_first_half = False, 0
+        assert l2_err(dfake, dfake_ref) < 5e-4, "d/dfake in first-half mode"
+        ops.FLAGS.skip_image_grad = True
+        try:
+            gd = torch.autograd.grad(scores, [pd[n] for n in names], torch.cat([f(gf), f(gr)], dim=0))
+        finally:
+            ops.FLAGS.skip_image_grad = False
+        for n, a, b in zip(names, gd, dpar_ref):
+            assert l2_err(a, b) < 5e-4 and rel_err(a, b) < 5e-2, (cuts, n)
+        if cuts is not None:
+            assert len(taps) == 2 and all(t.shape[0] == 8 for t in taps)
+
+
 @pytest.mark.parametrize("mode", ["fused", "composable"])
 @pytest.mark.parametrize("training", [True, False])
 def test_generator_matches_oracle(dev, mode, training):

@@ -338,10 +338,11 @@ class DiscriminatorBlock(nn.Module):
         k = ops.fir_kernel(x.device, 1.0)
         rs = 1.0 / math.sqrt(2.0)
         # skip: blur + strided 1x1 conv == (blur evaluated only at the strided sites) + 1x1 conv
-        xd = ops.upfirdn2d(x, k, down=(2, sh), pad=(1, 2, 1, 2))
+        role = "d" if mode == "fused" else None  # (ops.FLAGS: which backward work a pass may skip)
+        xd = ops.upfirdn2d(x, k, down=(2, sh), pad=(1, 2, 1, 2), role=role)
         if mode == "fused":
             t = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1), role="d")
-            tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3))  # conv_downsample_2d, upfirdn_2d_v2.py:106-113
+            tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3), role="d")  # conv_downsample_2d, upfirdn_2d_v2.py:106-113
             u = ops.conv_bias_act_fused(tb, self.conv_1.w, self.apply_bias_act_1.b, stride=(sh, 2), role="d")
             return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=rs, role="d")
         t = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w * _coef(self.conv_0.w.shape), (1, 1), (1, 1)))
@@ -372,13 +373,14 @@ class DiscriminatorLastBlock(nn.Module):
         self.dense_1 = Dense(n_f0 * hw[0] * hw[1], n_f1)
         self.apply_bias_act_1 = BiasAct(n_f1, 1.0, "lrelu")
 
-    def forward(self, x, mode="fused"):
+    def forward(self, x, mode="fused", parts=1):
         if mode == "fused":  # one launch each: statistics layer, conv + bias + lrelu, dense + bias + lrelu
-            x = ops.minibatch_std_fused(x, 4)
+            x = ops.minibatch_std_fused(x, 4, parts, role="d")
             x = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1), role="d")
             return ops.dense_bias_act(x.reshape(x.shape[0], -1), self.dense_1.w, self.apply_bias_act_1.b,
                                       _coef(self.dense_1.w.shape, self.dense_1.gain, self.dense_1.lrmul),
                                       self.apply_bias_act_1.lrmul, lrelu=True)
+        assert parts == 1
         x = minibatch_std(x, 4).contiguous()
         x = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w * _coef(self.conv_0.w.shape), (1, 1), (1, 1)))
         return self.apply_bias_act_1(self.dense_1(x))
@@ -397,8 +399,10 @@ class Discriminator(nn.Module):
         self.last_dense = Dense(fm[-1], 1)
         self.last_bias = BiasAct(1, 1.0, "linear")
 
-    def forward(self, images, mode="fused", cuts=None):
-        """cuts: block indices k -- the activation ENTERING blocks[k] is returned too (``(scores, [h_k...])``), so that a
+    def forward(self, images, mode="fused", cuts=None, parts=1):
+        """parts: the batch is ``parts`` independent batches laid end to end (the d-step's [fake; real]): the minibatch
+        statistics stay inside each part, every other layer is per-sample (fused mode only).
+        cuts: block indices k -- the activation ENTERING blocks[k] is returned too (``(scores, [h_k...])``), so that a
         caller can run the backward pass in stages (deep layers first) and exchange each stage's gradients while the next
         stage still computes (training_step.py: bucketed data-parallel all-reduce)."""
         x = self.initial_fromrgb(images.contiguous(), mode)
@@ -407,7 +411,7 @@ class Discriminator(nn.Module):
             if cuts is not None and i in cuts:
                 taps.append(x)
             x = block(x, mode)
-        x = self.last_block(x, mode)
+        x = self.last_block(x, mode, parts)
         if mode == "fused":
             scores = ops.dense_bias_act(x, self.last_dense.w, self.last_bias.b,
                                         _coef(self.last_dense.w.shape, self.last_dense.gain, self.last_dense.lrmul),

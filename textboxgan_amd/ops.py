@@ -34,6 +34,11 @@ class _Flags:
     tag is never pruned, whatever its shape or owner."""
     skip_d_wgrad = False     # G-loss pass only needs dL/d(image) through the discriminator  (role "d" / "d_image")
     skip_image_grad = False  # D-loss pass does not need dL/d(image)                          (role "d_image")
+    # The d-step runs the discriminator ONCE over [fake; real] (2B samples).  In the G-loss pass only the first B samples
+    # carry a gradient (the score gradient of the real half is structurally zero): nodes with a "d" role then run their
+    # backward kernels on the leading d_first_half samples only and leave the rest of the returned tensor unwritten --
+    # nothing reads it (the concatenation's backward hands the generator the first half).  0 = off.
+    d_first_half = 0
 
 
 FLAGS = _Flags()
@@ -161,14 +166,16 @@ def _sep_factors(k: torch.Tensor):
 # raw launches
 # ----------------------------------------------------------------------------------------
 def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0),
-                  in_scale: Optional[torch.Tensor] = None, epi: Optional[N.Epilogue] = None) -> torch.Tensor:
+                  in_scale: Optional[torch.Tensor] = None, epi: Optional[N.Epilogue] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x NCHW (treated as [B*C, H, W, 1], upfirdn_2d_v2.py:166-183); up/down = (x, y);
-    pad = (x0, x1, y0, y1)."""
+    pad = (x0, x1, y0, y1).  out: a contiguous [B, C, outH, outW] tensor to write (e.g. a leading-batch view)."""
     B, Cc, H, W = x.shape
     kH, kW = k.shape
     outW = (W * up[0] + pad[0] + pad[1] - kW + down[0]) // down[0]
     outH = (H * up[1] + pad[2] + pad[3] - kH + down[1]) // down[1]
-    y = torch.empty((B, Cc, outH, outW), device=x.device, dtype=torch.float32)
+    y = torch.empty((B, Cc, outH, outW), device=x.device, dtype=torch.float32) if out is None else out
+    assert tuple(y.shape) == (B, Cc, outH, outW)
     sep = _sep_factors(k)
     if sep is not None:  # the model's filters: separable passes
         _nb = 4.0 * (x.numel() + y.numel() + (B * outH * outW if epi is not None and epi.noise else 0))
@@ -197,7 +204,7 @@ def _conv_tiles(M, npix):
 
 def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_hw: Tuple[int, int], stride=(1, 1),
                pad=(0, 0), transposed=False, flip=False, in_scale=None, epi: Optional[N.Epilogue] = None,
-               ldw: Optional[int] = None, allow_split=True, dot=None) -> torch.Tensor:
+               ldw: Optional[int] = None, allow_split=True, dot=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """w: a PackedFilter (pack_filter), or a tensor in GEMM layout [KH*KW, C, ldw] (any view with that memory layout,
     e.g. the HWIO parameter) which is packed here.
     dot = (aux, out): out[b,m] = sum_p (alpha*acc)[b,m,p] * aux[b,m,p]  (fused when K is not split)."""
@@ -256,14 +263,14 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
             slabs, nslab = tmp, 1
         else:
             nslab = ksplit
-        y = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
+        y = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32) if out is None else out
         N.check(N.lib().tbg_slab_epilogue_f32(N.ptr(slabs), N.ptr(y), B, M, Hout * Wout, nslab, C.byref(e1), N.stream()),
                 "tbg_slab_epilogue")
         return y
     if dot is not None:
         epi = N.Epilogue.from_buffer_copy(epi)
         epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(dot[1])
-    y = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
+    y = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32) if out is None else out
     N.check(PROFILE.launch(_kname, _flops, lambda: _conv(
         C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream()), _what, _bytes), _what)
     return y
@@ -469,10 +476,10 @@ def bias_act_fwd_raw(x, epi: N.Epilogue):
     return y
 
 
-def rgb_project_raw(x, w2d, O, scale, bias, skip, alpha, bias_mul=1.0):
+def rgb_project_raw(x, w2d, O, scale, bias, skip, alpha, bias_mul=1.0, out=None):
     """y[b,o,p] = alpha * sum_c x[b,c,p] w2d[c,o] scale[b,c] + bias[o] + skip[b,o,p]   (O <= 4; w2d rows of ldw = O)."""
     B, Cc, H, W = x.shape
-    y = torch.empty((B, O, H, W), device=x.device, dtype=torch.float32)
+    y = torch.empty((B, O, H, W), device=x.device, dtype=torch.float32) if out is None else out
     N.check(N.lib().tbg_rgb_project_f32(N.ptr(x), N.ptr(w2d), N.ptr(scale), N.ptr(bias), N.ptr(skip), N.ptr(y), B, Cc, O,
                                         O, H * W, alpha, bias_mul, N.stream()), "tbg_rgb_project")
     return y
@@ -547,11 +554,19 @@ def _flipped_fir(k: torch.Tensor) -> torch.Tensor:
     return torch.flip(k, (0, 1)).contiguous()
 
 
+def _half(role, B):
+    """leading samples a "d"-role node has to differentiate in this pass (FLAGS.d_first_half), or 0 = the whole batch."""
+    h = FLAGS.d_first_half
+    return h if (h and role in ("d", "d_image") and h < B) else 0
+
+
 class _UpFirDn2D(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, k, up, down, pad):
+    def forward(ctx, x, k, up, down, pad, role=None):
         ctx.save_for_backward(k)
         ctx.geom = (x.shape[2], x.shape[3], up, down, pad)
+        ctx.role = role
+        ctx.xshape = tuple(x.shape)
         return upfirdn2d_raw(x.contiguous(), k, up, down, pad)
 
     @staticmethod
@@ -564,12 +579,17 @@ class _UpFirDn2D(torch.autograd.Function):
         # upfirdn_2d_v2.py:204-209
         gpad = (kW - pad[0] - 1, inW * up[0] - outW * down[0] + pad[0] - up[0] + 1,
                 kH - pad[2] - 1, inH * up[1] - outH * down[1] + pad[2] - up[1] + 1)
-        return _UpFirDn2D.apply(dy, _flipped_fir(k), down, up, gpad), None, None, None, None
+        h = _half(ctx.role, dy.shape[0])
+        if h:  # first-order pass over the leading samples only; the rest of dx is never read
+            dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
+            upfirdn2d_raw(dy.contiguous()[:h], _flipped_fir(k), down, up, gpad, out=dx[:h])
+            return dx, None, None, None, None, None
+        return _UpFirDn2D.apply(dy, _flipped_fir(k), down, up, gpad), None, None, None, None, None
 
 
-def upfirdn2d(x, k, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0)):
-    """The reference op on NCHW input; differentiable to any order."""
-    return _UpFirDn2D.apply(x, k, tuple(up), tuple(down), tuple(pad))
+def upfirdn2d(x, k, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0), role=None):
+    """The reference op on NCHW input; differentiable to any order.  role: see FLAGS ("d": a discriminator layer)."""
+    return _UpFirDn2D.apply(x, k, tuple(up), tuple(down), tuple(pad), role)
 
 
 class _Geom:
@@ -585,18 +605,18 @@ def _fwd_launch(x, w, g: _Geom, alpha=1.0):
     return conv2d_raw(x, pack_filter(w, False, False), O, g.KH, g.KW, g.yhw, g.stride, g.pad, epi=N.epilogue(alpha=alpha))
 
 
-def _bwd_data_launch(dy, w, g: _Geom, alpha=1.0, in_scale=None, epi=None, dot=None):
+def _bwd_data_launch(dy, w, g: _Geom, alpha=1.0, in_scale=None, epi=None, dot=None, out=None):
     """dx[i,Y,X] = sum dy[o,oy,ox] w[kh,kw,i,o] over oy*s - p + kh = Y."""
     I = w.shape[2]
     epi = epi if epi is not None else N.epilogue(alpha=alpha)
     if g.stride == (1, 1):
         wt = pack_filter(w, transpose=True, flip=True)
         return conv2d_raw(dy, wt, I, g.KH, g.KW, g.xhw, (1, 1), (g.KH - 1 - g.pad[0], g.KW - 1 - g.pad[1]),
-                          in_scale=in_scale, epi=epi, dot=dot)
+                          in_scale=in_scale, epi=epi, dot=dot, out=out)
     assert g.pad == (0, 0), "strided convolutions on this path are VALID"
     wt = pack_filter(w, transpose=True, flip=False)
     return conv2d_raw(dy, wt, I, g.KH, g.KW, g.xhw, g.stride, (0, 0), transposed=True, in_scale=in_scale, epi=epi,
-                      dot=dot)
+                      dot=dot, out=out)
 
 
 def _bwd_weight_launch(x, dy, g: _Geom, I, O, alpha=1.0, x_scale=None, dy_scale=None, add=None):
@@ -823,11 +843,20 @@ class _ConvBiasActFused(torch.autograd.Function):
         stride, pad, act, res_scale, coef, has_res, yhw = ctx.cfgv
         KH, KW, I, O = w.shape
         dout = dout.contiguous()
+        h = _half(ctx.role, dout.shape[0])
+        if h:  # G-loss pass over [fake; real]: only the leading h samples carry a gradient (FLAGS.d_first_half)
+            assert FLAGS.skip_d_wgrad, "the first-half mode belongs to the pass that skips the discriminator's filter gradients"
+            dout_f, x_f, out_f = dout, x, out
+            dout, x, out = dout[:h], x[:h], (out[:h] if out is not None else None)
         dres = None
         if act == ACT_LRELU:
             assert not has_res
             _, dpre, pdb, _, _ = bias_act_bwd_raw(dout, out, _lrelu_epi(bias=b), want_db=b is not None)
             db = pdb.sum(dim=(0, 2)) if b is not None else None
+        elif has_res and h:  # the residual branch continues into another "d" node: full-size tensor, leading part written
+            dres = torch.empty_like(dout_f)
+            dpre = torch.mul(dout, res_scale, out=dres[:h])
+            db = dpre.sum(dim=(0, 2, 3)) if b is not None else None
         else:
             dpre = dout * res_scale if has_res else dout
             dres = dpre if has_res else None
@@ -837,10 +866,15 @@ class _ConvBiasActFused(torch.autograd.Function):
         thin = KH == 1 and KW == 1 and I <= 4 and stride == (1, 1)  # fromRGB: streaming kernels, not MFMA tiles
         prune_w = FLAGS.skip_d_wgrad and ctx.role in ("d", "d_image")
         if ctx.needs_input_grad[0] and not (FLAGS.skip_image_grad and ctx.role == "d_image"):
+            dx_out = None
+            if h:
+                dx = torch.empty_like(x_f)
+                dx_out = dx[:h]
             if thin:  # d(image)[b,c,p] = coef * sum_o w[c,o] dpre[b,o,p]
-                dx = rgb_project_raw(dpre, w.reshape(I, O).t().contiguous(), I, None, None, None, coef)
+                r = rgb_project_raw(dpre, w.reshape(I, O).t().contiguous(), I, None, None, None, coef, out=dx_out)
             else:
-                dx = _bwd_data_launch(dpre, w, g, alpha=coef)
+                r = _bwd_data_launch(dpre, w, g, alpha=coef, out=dx_out)
+            dx = dx if h else r
         dw = None
         if not prune_w:
             if thin:  # G[b,o,c] = sum_p dpre[b,o,p] x[b,c,p]
@@ -902,31 +936,44 @@ def demod_coefs(s, w):
 
 class _MinibatchStd(torch.autograd.Function):
     """mini_batch_std.py:10-35 as one launch forward and one backward (first order: the R1 pass, which needs the second-
-    order term, keeps the torch composition in models.minibatch_std)."""
+    order term, keeps the torch composition in models.minibatch_std).  parts > 1: the batch is that many independent
+    batches laid end to end (the d-step's [fake; real]) -- the statistics groups never mix them, exactly as in the
+    reference's separate discriminator calls."""
 
     @staticmethod
-    def forward(ctx, x, group):
+    def forward(ctx, x, group, parts, role):
         x = x.contiguous()
         B, Cc, H, W = x.shape
+        assert B % parts == 0
+        n = B // parts
         y = torch.empty((B, Cc + 1, H, W), device=x.device, dtype=torch.float32)
-        N.check(N.lib().tbg_minibatch_std_fwd_f32(N.ptr(x), N.ptr(y), B, Cc, H * W, group, N.stream()), "tbg_minibatch_std_fwd")
+        for i in range(parts):
+            N.check(N.lib().tbg_minibatch_std_fwd_f32(N.ptr(x[i * n:(i + 1) * n]), N.ptr(y[i * n:(i + 1) * n]), n, Cc, H * W,
+                                                      group, N.stream()), "tbg_minibatch_std_fwd")
         ctx.save_for_backward(x)
-        ctx.group = group
+        ctx.cfgv = (group, parts, role)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
+        group, parts, role = ctx.cfgv
         B, Cc, H, W = x.shape
+        n = B // parts
+        dy = dy.contiguous()
         dx = torch.empty_like(x)
-        N.check(N.lib().tbg_minibatch_std_bwd_f32(N.ptr(x), N.ptr(dy.contiguous()), N.ptr(dx), B, Cc, H * W, ctx.group,
-                                                  N.stream()), "tbg_minibatch_std_bwd")
-        return dx, None
+        h = _half(role, B)
+        assert h in (0, n), "first-half mode: the leading part is the differentiated one"
+        for i in range(1 if h else parts):
+            N.check(N.lib().tbg_minibatch_std_bwd_f32(N.ptr(x[i * n:(i + 1) * n]), N.ptr(dy[i * n:(i + 1) * n]),
+                                                      N.ptr(dx[i * n:(i + 1) * n]), n, Cc, H * W, group, N.stream()),
+                    "tbg_minibatch_std_bwd")
+        return dx, None, None, None
 
 
-def minibatch_std_fused(x, group=4):
-    return _MinibatchStd.apply(x, int(group))
+def minibatch_std_fused(x, group=4, parts=1, role=None):
+    return _MinibatchStd.apply(x, int(group), int(parts), role)
 
 
 # ----------------------------------------------------------------------------------------

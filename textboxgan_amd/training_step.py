@@ -331,8 +331,20 @@ class TrainingStep:
 
         staged = bool(self.d_cuts) and not do_r1_reg  # R1 steps (1 in 16) keep the single exchange: their D graph is second order
         cuts = sorted(self.d_cuts) if staged else None
-        if staged:
-            fake_scores, fake_taps = D(fake_images, cuts=cuts)
+        # Plain steps: ONE discriminator pass over [fake; real] (discriminator.py is per-sample except the minibatch
+        # statistics, which stay inside each half: parts=2) -- the same arithmetic as the reference's two calls
+        # (training_step.py:165-173) in half the launches and with twice the pixels per tile on the small maps.  The
+        # G-loss pass differentiates the fake half only (ops.FLAGS.d_first_half).  R1 steps keep two calls: the real
+        # half needs the second-order graph.
+        joint = not do_r1_reg
+        nb = fake_images.shape[0]
+        if joint:
+            both = torch.cat([fake_images, real_images], dim=0)
+            if staged:
+                scores, d_taps = D(both, cuts=cuts, parts=2)
+            else:
+                scores = D(both, parts=2)
+            fake_scores, real_scores = scores[:nb], scores[nb:]
         else:
             fake_scores = D(fake_images)
         g_loss = generator_loss(fake_scores, self.batch_size)
@@ -341,11 +353,7 @@ class TrainingStep:
 
         if do_r1_reg:
             real_scores, r1_penalty = self._r1_reg(real_images)
-        elif staged:
-            real_scores, real_taps = D(real_images, cuts=cuts)
-            r1_penalty = zero
         else:
-            real_scores = D(real_images)
             r1_penalty = zero
         d_loss = discriminator_loss(fake_scores, real_scores, self.batch_size)
         reg_d_loss = d_loss + r1_penalty
@@ -356,10 +364,12 @@ class TrainingStep:
 
         # --- three backward passes at the pre-update weights (training_step.py:194-213)
         ops.FLAGS.skip_d_wgrad = True
+        ops.FLAGS.d_first_half = nb if joint else 0
         try:
             grads = torch.autograd.grad(reg_g_loss, self.g_params, retain_graph=True, allow_unused=True)
         finally:
             ops.FLAGS.skip_d_wgrad = False
+            ops.FLAGS.d_first_half = 0
         write_grads(self.g_views, grads)
         if handles is not None:
             handles.append(self._all_reduce_async(self.g_grad))
@@ -399,7 +409,7 @@ class TrainingStep:
                 for si, (params, views, (b0, b1)) in enumerate(self.d_stages):
                     last = si == len(self.d_stages) - 1
                     k = len(cuts) - 1 - si  # taps feeding this stage sit at cuts[k] (none for the last stage)
-                    taps = [] if last else [fake_taps[k], real_taps[k]]
+                    taps = [] if last else [d_taps[k]]
                     grads = torch.autograd.grad(outs, list(params) + taps, grad_outputs=gouts, retain_graph=not last,
                                                 allow_unused=True)
                     write_grads(views, grads[:len(params)])
