@@ -1049,13 +1049,23 @@ class _DenseBiasActGemm(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.addmm(w, x.t(), dout, beta=0.0, alpha=alpha)
         if ctx.needs_input_grad[2]:
-            ones = dout.new_ones(dout.shape[0])
-            db = torch.addmv(b_like(dout), dout.t(), ones, beta=0.0, alpha=beta)
+            db = torch.addmv(b_like(dout), dout.t(), _ones(dout.device, dout.shape[0]), beta=0.0, alpha=beta)
         return dx, dw, db, None, None, None, None
 
 
 def b_like(dout):
     return dout.new_empty(dout.shape[1])
+
+
+_ONES = {}
+
+
+def _ones(device, n):
+    """constant ones vector (the bias gradient as a GEMV), one per (device, length) for the life of the process."""
+    key = (device, n)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, device=device, dtype=torch.float32)
+    return _ONES[key]
 
 
 def dense_bias_act(x, w, b, coef, lrmul=1.0, lrelu=False, offset=0.0):
