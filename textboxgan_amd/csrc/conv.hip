@@ -785,10 +785,12 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
   if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
   if (BM == 64) return launch_fprop<1, 4, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
-  // Largest launches (>= 1.5 waves of the 1024 block slots that 4 blocks/CU give): CK=4 chunks need 22 KB of LDS and
-  // 109 registers -> 4 waves/SIMD and a grid that fills whole rounds: 98 -> 104 TFLOP/s on 64x256 128->128
-  // (tools/bench_conv.py).  Smaller launches lose (more barriers per FLOP), so they keep CK=8 at 3 waves/SIMD.
-  if (maxtaps == 9 && p.NJ <= 3 && (long long)maxTilesN * ceil_div(p.M, BM) * p.nclass >= 1536 && p.ksplit == 1)
+  // Launches of more blocks than the 768 slots that 3 blocks/CU give: CK=4 chunks need 22 KB of LDS and 109 registers
+  // -> 4 waves/SIMD, 1024 slots.  98 -> 104 TFLOP/s on 64x256 128->128 (2048 tiles); and a 1024-tile launch (the joint
+  // discriminator pass's 32x128 layers at 2B = 32) is ONE full round instead of 768 + 256: 93 -> 126 TFLOP/s
+  // (tools/bench_variants_conv.py 32, profiles/r02_conv_variants_f32_b32.txt).  Launches that fit one round of the
+  // 3-blocks/CU instance lose with CK=4 (more barriers per FLOP: 116 vs 124 at 512 tiles) and keep CK=8.
+  if (maxtaps == 9 && p.NJ <= 3 && (long long)maxTilesN * ceil_div(p.M, BM) * p.nclass > 768 && p.ksplit == 1)
     return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 0, 4>(p, st, maxtaps, maxTilesN, name);
   return launch_fprop<2, 2, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
 }
