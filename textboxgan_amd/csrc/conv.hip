@@ -781,7 +781,13 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   }
   // Software-pipelined variant (double-buffered LDS, one barrier per chunk).  Measured (tools/bench_conv.py): +12% on
   // the 64x256 tile (76 -> 86 TFLOP/s), neutral on 128x128, -5..10% on the small-spatial 64x64 tile -> 64x256 only.
-  if (p.NJ <= 3 && BM == 64 && BN == 256) return launch_fprop<1, 4, 2, 2, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
+  if (p.NJ <= 3 && BM == 64 && BN == 256) {
+    // more tiles than the 768 slots of 3 blocks/CU (64x256 64->64 at B = 16: 1024 tiles): the same pipelined instance
+    // compiled for 4 blocks/CU fills whole rounds
+    if (variant != 1 && (long long)maxTilesN * ceil_div(p.M, BM) * p.nclass > 768 && p.ksplit == 1)
+      return launch_fprop<1, 4, 2, 2, 4, MAXTAPS, 3, 4>(p, st, maxtaps, maxTilesN, name);
+    return launch_fprop<1, 4, 2, 2, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
+  }
   if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
   if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
   if (BM == 64) return launch_fprop<1, 4, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
