@@ -161,7 +161,7 @@ def _conv_cases_for_coverage():
     descriptors select every conv_fprop / conv_wgrad instantiation the full-size step uses."""
     return [
         (2, 64, 64, 64, 256, 3, (1, 1), (1, 1), False),    # 64x256 tile, software-pipelined <1,4,2,2,4,9,3,3>
-        (8, 64, 64, 64, 256, 3, (1, 1), (1, 1), False),    # the same beyond 768 tiles: 4 blocks/CU <1,4,2,2,4,9,3,4>
+        (13, 64, 64, 64, 256, 3, (1, 1), (1, 1), False),   # the same beyond 768 tiles (832): 4 blocks/CU <1,4,2,2,4,9,3,4>
         (6, 24, 256, 64, 256, 3, (1, 1), (1, 1), False),   # >= 1536 tiles: 4 waves/SIMD <2,2,2,2,4,9,0,4>
         (2, 128, 128, 16, 64, 3, (1, 1), (1, 1), False),   # <2,2,2,2,8,9,0,3>
         (4, 512, 512, 4, 16, 3, (1, 1), (1, 1), False),    # 64x64 tile <2,2,1,1,8,9,0,3>, split-K
