@@ -25,7 +25,9 @@ def wall(fn, n=5):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
-s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+PRIO = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(priority=PRIO)
+print("side stream priority", PRIO, "(range", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "?", ")")
 def graph_of(fn, stream):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(stream):
