@@ -324,6 +324,24 @@ int tbg_dense_bwd_f32(const float *x, const float *w, const float *out, const fl
                       float *db, int R, int K, int N, float alpha, float beta, int lrelu, float offset,
                       void *stream);
 
+/* Several LINEAR dense layers that share the row count R, the reduction length K and alpha / beta / offset, in one launch
+ * per direction -- the generator's per-layer style affines (modulated_conv2d.py:52-56: s = dense(w_latent) + b + 1, one
+ * per modulated conv; synthesis_block.py:120-156 hands layer l row l of the [B, L, K] latent tensor).
+ *   forward:  out_i[r,n] = alpha * sum_k x_i[r*ldx + k] w_i[k,n] + beta * b_i[n] + offset        (b_i may be NULL)
+ *   backward: dx_i[r*ldx + k] = alpha sum_n dout_i[r,n] w_i[k,n];  dw_i = alpha x_i^T dout_i;  db_i = beta sum_r dout_i
+ * x_i / dx_i rows have pitch ldx >= K floats (slices of one [R, L, K] tensor: x_i = base + i*K, ldx = L*K), w_i is [K, N_i]
+ * row-major, out_i / dout_i are [R, N_i] contiguous; any of dx / dw / db may be NULL.  `items` is a HOST array of
+ * n <= TBG_DENSE_MAX_ITEMS entries (copied into the kernel arguments: no device table, graph-capturable). K <= 768. */
+#define TBG_DENSE_MAX_ITEMS 24
+typedef struct tbg_dense_item {
+  const float *x, *w, *b, *dout;
+  float *out, *dx, *dw, *db;
+  int N, ldx;
+} tbg_dense_item;
+int tbg_dense_multi_fwd_f32(const tbg_dense_item *items, int n, int R, int K, float alpha, float beta, float offset,
+                            void *stream);
+int tbg_dense_multi_bwd_f32(const tbg_dense_item *items, int n, int R, int K, float alpha, float beta, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimiser / EMA (multi-tensor over one flat buffer).
  * Keras Adam (reference train.py:58-75 -> ResourceApplyAdam): m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2;

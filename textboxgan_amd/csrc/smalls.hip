@@ -243,7 +243,7 @@ extern "C" int tbg_minibatch_std_bwd_f32(const float *x, const float *dy, float 
 struct DenseP {
   const float *x, *w, *b, *out_in, *dout;
   float *out, *dx, *dw, *db;
-  int R, K, N, lrelu, nb_dw;
+  int R, K, N, lrelu, nb_dw, ldx;  // ldx: row pitch of x and dx (floats)
   float alpha, beta, offset;
 };
 
@@ -251,13 +251,13 @@ struct DenseP {
 #define DN_KT 64   // k per thread and pass (all their filter loads are issued before the first use: one latency round)
 
 // block = 64 output columns x 4 k-quarters, DN_RT rows; dynamic LDS: xs[DN_RT][K + 4] + red[3][DN_RT][64]
-__global__ __launch_bounds__(256) void dense_fwd_kernel(const DenseP p) {
+__device__ __forceinline__ void dense_fwd_body(const DenseP &p, const int bx, const int by) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int KP = ((p.K + 4 * DN_KT - 1) / (4 * DN_KT)) * (4 * DN_KT) + 4;  // whole (zero-filled) passes: no k guards on the reads
   float *xs = dsm;                    // [DN_RT][KP]
   float *red = dsm + DN_RT * KP;      // [3][DN_RT][64]
   const int tid = threadIdx.x, nl = tid & 63, kq = tid >> 6;
-  const int n = blockIdx.x * 64 + nl, r0 = blockIdx.y * DN_RT;
+  const int n = bx * 64 + nl, r0 = by * DN_RT;
   const int nc = min(n, p.N - 1);
   float acc[DN_RT];
 #pragma unroll
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const DenseP p) {
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + 256 * u;
       const int r = e / KP, kk = e - r * KP;
-      v[u] = (e < DN_RT * KP && r0 + r < p.R && kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + kk] : 0.f;
+      v[u] = (e < DN_RT * KP && r0 + r < p.R && kk < p.K) ? p.x[(size_t)(r0 + r) * p.ldx + kk] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const DenseP p) {
 // blocks [nb_dw, ..): 16 filter rows k (4 per wave) x DN_RT rows of dx: a wave reads its filter rows coalesced along n (all loads
 // issued before the gm tile is staged), accumulates per-lane partial sums for the DN_RT rows and folds them across the wave.
 #define DN_NMAX 512  // columns a dx block keeps in registers per filter row (8 per lane); wider layers loop
-__global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
+__device__ __forceinline__ void dense_bwd_body(const DenseP &p, const int bx) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int tid = threadIdx.x, l = tid & 63, q = tid >> 6;
   const int ntn = (p.N + 63) / 64;
@@ -349,10 +349,10 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
         if (e0 + 256 * u < total) dst[e0 + 256 * u] = (p.lrelu && o[u] - p.offset <= 0.f) ? 0.2f * g[u] : g[u];
     }
   };
-  if ((int)blockIdx.x < p.nb_dw) {
+  if (bx < p.nb_dw) {
     float *gs = dsm;             // [32][64]
     float *xt = dsm + 32 * 64;   // [32][16]
-    const int tn = blockIdx.x % ntn, tk = blockIdx.x / ntn;
+    const int tn = bx % ntn, tk = bx / ntn;
     const int n = tn * 64 + l, k0 = tk * 16 + q * 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb = 0.f;
     for (int r0 = 0; r0 < p.R; r0 += 32) {
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int e = tid + 256 * u, r = e >> 4, kk = e & 15;
-        xv[u] = (r0 + r < p.R && tk * 16 + kk < p.K) ? p.x[(size_t)(r0 + r) * p.K + tk * 16 + kk] : 0.f;
+        xv[u] = (r0 + r < p.R && tk * 16 + kk < p.K) ? p.x[(size_t)(r0 + r) * p.ldx + tk * 16 + kk] : 0.f;
       }
       stage_gm(gs, r0, 32, tn * 64, 64);
       xt[tid] = xv[0]; xt[tid + 256] = xv[1];
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
     }
     return;
   }
-  const int bi = blockIdx.x - p.nb_dw;
+  const int bi = bx - p.nb_dw;
   const int ntk = (p.K + 15) / 16;
   const int tk = bi % ntk, tr = bi / ntk;
   const int r0 = tr * DN_RT;
@@ -430,8 +430,27 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) {
       const float s = wave_sum(acc[kr][r]);
       if (l == r) mine = s;
     }
-    if (k < p.K && l < DN_RT && r0 + l < p.R) p.dx[(size_t)(r0 + l) * p.K + k] = p.alpha * mine;
+    if (k < p.K && l < DN_RT && r0 + l < p.R) p.dx[(size_t)(r0 + l) * p.ldx + k] = p.alpha * mine;
   }
+}
+
+__global__ __launch_bounds__(256) void dense_fwd_kernel(const DenseP p) { dense_fwd_body(p, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void dense_bwd_kernel(const DenseP p) { dense_bwd_body(p, blockIdx.x); }
+
+// several layers that share R, K and the scalars in ONE launch (grid.z = layer): the generator's 16 style affines
+// s_l = style[:, l, :] @ W_l * coef + b_l + 1 (modulated_conv2d.py:52-56) read rows of one [R, L, K] tensor (ldx = L K) and
+// their backward writes d(style) in place, slot by slot.
+struct DenseMultiP { DenseP g[TBG_DENSE_MAX_ITEMS]; };
+__global__ __launch_bounds__(256) void dense_multi_fwd_kernel(const DenseMultiP mp) {
+  const DenseP &p = mp.g[blockIdx.z];
+  if ((int)blockIdx.x * 64 >= p.N) return;
+  dense_fwd_body(p, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void dense_multi_bwd_kernel(const DenseMultiP mp, const int nb_dx_of) {
+  const DenseP &p = mp.g[blockIdx.z];
+  const int nb_dx = p.dx ? ((p.K + 15) / 16) * ((p.R + DN_RT - 1) / DN_RT) : 0;
+  if ((int)blockIdx.x >= p.nb_dw + nb_dx) return;
+  dense_bwd_body(p, blockIdx.x);
 }
 
 extern "C" int tbg_dense_fwd_f32(const float *x, const float *w, const float *b, float *out, int R, int K, int N,
@@ -439,7 +458,7 @@ extern "C" int tbg_dense_fwd_f32(const float *x, const float *w, const float *b,
   if (!x || !w || !out || R < 1 || K < 1 || N < 1) return TBG_EINVAL;
   DenseP p = {};
   p.x = x; p.w = w; p.b = b; p.out = out; p.R = R; p.K = K; p.N = N; p.lrelu = lrelu; p.alpha = alpha; p.beta = beta;
-  p.offset = offset;
+  p.offset = offset; p.ldx = K;
   if (K > 768) return TBG_ERANGE;  // x rows are staged whole in LDS (<= 64 KB); large-K layers are GEMMs, not this kernel's job
   const size_t KP = (size_t)((K + 4 * DN_KT - 1) / (4 * DN_KT)) * (4 * DN_KT) + 4;
   const size_t lds = ((size_t)DN_RT * KP + 3 * DN_RT * 64) * sizeof(float);
@@ -454,7 +473,7 @@ extern "C" int tbg_dense_bwd_f32(const float *x, const float *w, const float *ou
   if (!x || !w || !dout || R < 1 || K < 1 || N < 1 || (lrelu && !out) || (!dx && !dw && !db)) return TBG_EINVAL;
   DenseP p = {};
   p.x = x; p.w = w; p.out_in = out; p.dout = dout; p.dx = dx; p.dw = dw; p.db = db; p.R = R; p.K = K; p.N = N;
-  p.lrelu = lrelu; p.alpha = alpha; p.beta = beta; p.offset = offset;
+  p.lrelu = lrelu; p.alpha = alpha; p.beta = beta; p.offset = offset; p.ldx = K;
   const int ntn = (N + 63) / 64;
   p.nb_dw = dw ? ntn * ((K + 15) / 16) : (db ? ntn : 0);  // db alone: the k-tile-0 row of blocks
   const int nb_dx = dx ? ((K + 15) / 16) * ((R + DN_RT - 1) / DN_RT) : 0;
@@ -462,6 +481,53 @@ extern "C" int tbg_dense_bwd_f32(const float *x, const float *w, const float *ou
   const size_t lds_dx = (size_t)DN_RT * nsp * sizeof(float), lds_dw = (size_t)(32 * 64 + 32 * 16) * sizeof(float);
   hipLaunchKernelGGL(dense_bwd_kernel, dim3(p.nb_dw + nb_dx), dim3(256), lds_dx > lds_dw ? lds_dx : lds_dw,
                      tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_dense_multi_fwd_f32(const tbg_dense_item *items, int n, int R, int K, float alpha, float beta,
+                                       float offset, void *stream) {
+  if (!items || n < 1 || n > TBG_DENSE_MAX_ITEMS || R < 1 || K < 1) return TBG_EINVAL;
+  if (K > 768) return TBG_ERANGE;
+  DenseMultiP mp = {};
+  int maxN = 0;
+  for (int i = 0; i < n; ++i) {
+    const tbg_dense_item &it = items[i];
+    if (!it.x || !it.w || !it.out || it.N < 1 || it.ldx < K) return TBG_EINVAL;
+    DenseP &p = mp.g[i];
+    p.x = it.x; p.w = it.w; p.b = it.b; p.out = it.out; p.R = R; p.K = K; p.N = it.N; p.lrelu = 0; p.alpha = alpha;
+    p.beta = beta; p.offset = offset; p.ldx = it.ldx;
+    if (it.N > maxN) maxN = it.N;
+  }
+  const size_t KP = (size_t)((K + 4 * DN_KT - 1) / (4 * DN_KT)) * (4 * DN_KT) + 4;
+  const size_t lds = ((size_t)DN_RT * KP + 3 * DN_RT * 64) * sizeof(float);
+  hipLaunchKernelGGL(dense_multi_fwd_kernel, dim3((maxN + 63) / 64, (R + DN_RT - 1) / DN_RT, n), dim3(256), lds,
+                     tbg_stream(stream), mp);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_dense_multi_bwd_f32(const tbg_dense_item *items, int n, int R, int K, float alpha, float beta,
+                                       void *stream) {
+  if (!items || n < 1 || n > TBG_DENSE_MAX_ITEMS || R < 1 || K < 1) return TBG_EINVAL;
+  DenseMultiP mp = {};
+  int maxB = 0, maxN = 0;
+  for (int i = 0; i < n; ++i) {
+    const tbg_dense_item &it = items[i];
+    if (!it.x || !it.w || !it.dout || it.N < 1 || it.ldx < K || (!it.dx && !it.dw && !it.db)) return TBG_EINVAL;
+    DenseP &p = mp.g[i];
+    p.x = it.x; p.w = it.w; p.dout = it.dout; p.dx = it.dx; p.dw = it.dw; p.db = it.db; p.R = R; p.K = K; p.N = it.N;
+    p.lrelu = 0; p.alpha = alpha; p.beta = beta; p.offset = 0.f; p.ldx = it.ldx;
+    const int ntn = (it.N + 63) / 64;
+    p.nb_dw = it.dw ? ntn * ((K + 15) / 16) : (it.db ? ntn : 0);
+    const int nb = p.nb_dw + (it.dx ? ((K + 15) / 16) * ((R + DN_RT - 1) / DN_RT) : 0);
+    if (nb > maxB) maxB = nb;
+    if (it.N > maxN) maxN = it.N;
+  }
+  const int nsp = ((maxN < DN_NMAX ? maxN : DN_NMAX) + 63) & ~63;
+  const size_t lds_dx = (size_t)DN_RT * nsp * sizeof(float), lds_dw = (size_t)(32 * 64 + 32 * 16) * sizeof(float);
+  hipLaunchKernelGGL(dense_multi_bwd_kernel, dim3(maxB, 1, n), dim3(256), lds_dx > lds_dw ? lds_dx : lds_dw,
+                     tbg_stream(stream), mp, 0);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }

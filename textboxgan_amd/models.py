@@ -203,8 +203,9 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2D(cfg, in_ch, 3, 1, up=False, demodulate=False)
         self.apply_bias = BiasAct(3, 1.0, "linear")
 
-    def forward(self, x, style, skip=None, mode="fused"):
-        s = self.conv.style(style, mode)
+    def forward(self, x, style, skip=None, mode="fused", s=None):
+        """s: the precomputed style affine of this layer (fused mode: ops.style_affines does all layers in one launch)."""
+        s = self.conv.style(style, mode) if s is None else s
         if mode == "fused":
             return ops.torgb_fused(x, self.conv.w, s, self.apply_bias.b, skip)
         y = self.apply_bias(self.conv.conv_composable(x, s, None))
@@ -223,10 +224,10 @@ class SynthesisBlock(nn.Module):
         self.apply_noise_1 = Noise()
         self.apply_bias_act_1 = BiasAct(fmaps, 1.0, "lrelu")
 
-    def forward(self, x, w0, w1, noise0, noise1, mode="fused"):
-        for conv, nz, ba, style, noise in ((self.conv_0, self.apply_noise_0, self.apply_bias_act_0, w0, noise0),
-                                           (self.conv_1, self.apply_noise_1, self.apply_bias_act_1, w1, noise1)):
-            s = conv.style(style, mode)
+    def forward(self, x, w0, w1, noise0, noise1, mode="fused", s0=None, s1=None):
+        for conv, nz, ba, style, noise, s in ((self.conv_0, self.apply_noise_0, self.apply_bias_act_0, w0, noise0, s0),
+                                              (self.conv_1, self.apply_noise_1, self.apply_bias_act_1, w1, noise1, s1)):
+            s = conv.style(style, mode) if s is None else s
             if mode == "fused":
                 fn = ops.modconv_up_fused if conv.up else ops.modconv_fused
                 x = fn(x, conv.w, s, noise, nz.noise_strength, ba.b)
@@ -261,11 +262,18 @@ class Synthesis(nn.Module):
         k_up = ops.fir_kernel(x.device, 4.0)
         ws = style.unbind(dim=1)  # one node: its backward is ONE stack of the per-layer latent gradients (16 selects
         # would each zero-fill a [B, n, 512] tensor and be summed pairwise by the autograd engine)
-        y = self.initial_torgb(x, ws[0], None, mode)
+        ss = [None] * style.shape[1]
+        if mode == "fused":  # all style affines in one launch (and one for their backward)
+            convs = [self.initial_torgb.conv] + [c for b, t in zip(self.synth_blocks, self.torgbs)
+                                                  for c in (b.conv_0, b.conv_1, t.conv)]
+            assert len(convs) == style.shape[1]
+            ss = ops.style_affines(style, [c.mod_dense.w for c in convs], [c.mod_bias.b for c in convs],
+                                   _coef(convs[0].mod_dense.w.shape))
+        y = self.initial_torgb(x, ws[0], None, mode, s=ss[0])
         for i, (block, torgb) in enumerate(zip(self.synth_blocks, self.torgbs)):
-            x = block(x, ws[3 * i], ws[3 * i + 1], noises[2 * i], noises[2 * i + 1], mode)
+            x = block(x, ws[3 * i], ws[3 * i + 1], noises[2 * i], noises[2 * i + 1], mode, s0=ss[3 * i], s1=ss[3 * i + 1])
             y = ops.upfirdn2d(y, k_up, up=(2, 2), pad=(2, 1, 2, 1))  # upsample_2d, :152
-            y = torgb(x, ws[3 * i + 2], y, mode)
+            y = torgb(x, ws[3 * i + 2], y, mode, s=ss[3 * i + 2])
         return y
 
 

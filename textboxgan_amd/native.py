@@ -21,7 +21,7 @@ SQRT2 = 1.4142135623730951
 
 EXPORTS = [
     "tbg_version", "tbg_strerror", "tbg_crc32c", "tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_upfirdn2d_sep_f32", "tbg_conv2d_f32",
-    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_conv2d_kernel_name", "tbg_conv2d_f32_variant", "tbg_conv2d_bf16_variant", "tbg_conv2d_wgrad_kernel_name", "tbg_weight_pack_bf16_bytes", "tbg_weight_pack_bf16", "tbg_weight_pack_multi", "tbg_modconv_bwd_smalls_f32", "tbg_torgb_bwd_smalls_f32", "tbg_minibatch_std_fwd_f32", "tbg_minibatch_std_bwd_f32", "tbg_dense_fwd_f32", "tbg_dense_bwd_f32", "tbg_conv2d_bf16", "tbg_conv2d_bf16_kernel_name", "tbg_conv2d_wgrad_bf16", "tbg_conv2d_wgrad_bf16_kernel_name", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_attn_ctx_fwd_f32", "tbg_attn_ctx_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
+    "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_conv2d_kernel_name", "tbg_conv2d_f32_variant", "tbg_conv2d_bf16_variant", "tbg_conv2d_wgrad_kernel_name", "tbg_weight_pack_bf16_bytes", "tbg_weight_pack_bf16", "tbg_weight_pack_multi", "tbg_modconv_bwd_smalls_f32", "tbg_torgb_bwd_smalls_f32", "tbg_minibatch_std_fwd_f32", "tbg_minibatch_std_bwd_f32", "tbg_dense_fwd_f32", "tbg_dense_bwd_f32", "tbg_dense_multi_fwd_f32", "tbg_dense_multi_bwd_f32", "tbg_conv2d_bf16", "tbg_conv2d_bf16_kernel_name", "tbg_conv2d_wgrad_bf16", "tbg_conv2d_wgrad_bf16_kernel_name", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_attn_ctx_fwd_f32", "tbg_attn_ctx_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
     "tbg_bias_act_bwd_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -39,6 +39,14 @@ class Epilogue(C.Structure):
 class PackItem(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("T", C.c_int), ("I", C.c_int), ("O", C.c_int),
                 ("transpose", C.c_int), ("flip", C.c_int), ("bf16", C.c_int)]
+
+
+class DenseItem(C.Structure):  # tbg_dense_item
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("dout", C.c_void_p), ("out", C.c_void_p),
+                ("dx", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("N", C.c_int), ("ldx", C.c_int)]
+
+
+DENSE_MAX_ITEMS = 24
 
 
 class ConvDesc(C.Structure):
@@ -97,6 +105,8 @@ def lib():
         l.tbg_minibatch_std_bwd_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
         l.tbg_dense_fwd_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, cf, cf, ci, cf, vp]
         l.tbg_dense_bwd_f32.argtypes = [vp] * 7 + [ci, ci, ci, cf, cf, ci, cf, vp]
+        l.tbg_dense_multi_fwd_f32.argtypes = [C.POINTER(DenseItem), ci, ci, ci, cf, cf, cf, vp]
+        l.tbg_dense_multi_bwd_f32.argtypes = [C.POINTER(DenseItem), ci, ci, ci, cf, cf, vp]
         l.tbg_weight_pack_bf16_bytes.argtypes = [ci, ci, ci, ci]
         l.tbg_weight_pack_bf16_bytes.restype = C.c_longlong
         l.tbg_conv2d_wgrad_kernel_name.argtypes = [C.POINTER(WgradDesc), C.c_char_p, ci]

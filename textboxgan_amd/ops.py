@@ -1057,6 +1057,65 @@ def b_like(dout):
     return dout.new_empty(dout.shape[1])
 
 
+class _StyleAffines(torch.autograd.Function):
+    """s_l = coef * style[:, l, :] @ W_l + b_l + 1 for every modulated layer l of the synthesis network at once
+    (modulated_conv2d.py:52-56, 74-76; synthesis_block.py:120-156 hands layer l row l of the broadcast latents): one
+    launch forward, one backward (tbg_dense_multi_*), instead of 2 and 3-4 library launches per layer.  d(style) is written
+    slot by slot into ONE [B, L, K] tensor."""
+
+    @staticmethod
+    def forward(ctx, style, coef, *wb):
+        style = style.contiguous()
+        B, L, K = style.shape
+        ws, bs = wb[:L], wb[L:]
+        assert len(ws) == L and len(bs) == L and L <= N.DENSE_MAX_ITEMS
+        outs = [torch.empty((B, w.shape[1]), device=style.device, dtype=torch.float32) for w in ws]
+        items = (N.DenseItem * L)()
+        sp = N.ptr(style)
+        for l, (w, b, o) in enumerate(zip(ws, bs, outs)):
+            items[l] = N.DenseItem(x=sp + 4 * l * K, w=N.ptr(w), b=N.ptr(b), out=N.ptr(o), N=w.shape[1], ldx=L * K)
+        N.check(N.lib().tbg_dense_multi_fwd_f32(items, L, B, K, coef, 1.0, 1.0, N.stream()), "tbg_dense_multi_fwd")
+        ctx.save_for_backward(style, *ws)
+        ctx.coef = coef
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *douts):
+        style, *ws = ctx.saved_tensors
+        B, L, K = style.shape
+        need_x = ctx.needs_input_grad[0]
+        dstyle = torch.empty_like(style) if need_x else None
+        dws = [torch.empty_like(w) if ctx.needs_input_grad[2 + l] else None for l, w in enumerate(ws)]
+        dbs = [torch.empty(w.shape[1], device=w.device, dtype=torch.float32) if ctx.needs_input_grad[2 + L + l] else None
+               for l, w in enumerate(ws)]
+        items = (N.DenseItem * L)()
+        sp, dsp = N.ptr(style), N.ptr(dstyle)
+        keep, n = [], 0
+        for l, w in enumerate(ws):
+            d = douts[l]
+            if d is None:  # an unused style (never on the training path): its slot of d(style) is zero
+                if need_x:
+                    dstyle[:, l].zero_()
+                if dws[l] is not None: dws[l].zero_()
+                if dbs[l] is not None: dbs[l].zero_()
+                continue
+            d = d.contiguous(); keep.append(d)
+            if not (need_x or dws[l] is not None or dbs[l] is not None):
+                continue
+            items[n] = N.DenseItem(x=sp + 4 * l * K, w=N.ptr(w), dout=N.ptr(d), dx=(dsp + 4 * l * K) if need_x else None,
+                                   dw=N.ptr(dws[l]), db=N.ptr(dbs[l]), N=w.shape[1], ldx=L * K)
+            n += 1
+        if n:
+            N.check(N.lib().tbg_dense_multi_bwd_f32(items, n, B, K, ctx.coef, 1.0, N.stream()), "tbg_dense_multi_bwd")
+        return (dstyle, None, *dws, *dbs)
+
+
+def style_affines(style, ws, bs, coef):
+    """style [B, L, K]; ws[l] [K, I_l], bs[l] [I_l]  ->  tuple of L tensors [B, I_l] = coef * style[:, l] @ ws[l] + bs[l] + 1."""
+    return _StyleAffines.apply(style, float(coef), *ws, *bs)
+
+
 _ONES = {}
 
 
