@@ -107,24 +107,25 @@ def test_dense_bias_act(dev, dims):
         assert rel_err(only_db, grads[2]) < 1e-5
 
 
-@pytest.mark.parametrize("dims", [(5, 100, (3, 70, 130)), (16, 512, (512, 512, 256, 128, 64, 3)), (33, 64, (65,))],
-                         ids=["ragged", "synthesis-like", "rows33"])
+@pytest.mark.parametrize("dims", [(5, 100, (3, 70, 130), None), (16, 512, (512, 512, 256, 128, 64, 3), (0, 0, 1, 2, 3, 5)),
+                                  (33, 64, (65,), None)], ids=["ragged", "synthesis-like (shared and unused rows)", "rows33"])
 def test_style_affines_one_launch(dev, dims):
     """all style affines of the synthesis network in one launch each way (tbg_dense_multi_*) vs the float64 definition
     s_l = coef * style[:, l] @ W_l + b_l + 1: outputs, d(style) (written slot by slot), dW_l, db_l; and with frozen weights."""
     from textboxgan_amd import ops
-    R_, K, Ns = dims
+    R_, K, Ns, rows = dims
     L = len(Ns)
-    style = rnd(R_, L, K, seed=61).requires_grad_(True)
+    rows = tuple(range(L)) if rows is None else rows
+    style = rnd(R_, max(rows) + 1, K, seed=61).requires_grad_(True)
     ws = [rnd(K, n, seed=62 + i).requires_grad_(True) for i, n in enumerate(Ns)]
     bs = [rnd(n, seed=82 + i).requires_grad_(True) for i, n in enumerate(Ns)]
     coef = 1.0 / math.sqrt(K)
-    refs = [coef * style[:, l] @ ws[l] + bs[l] + 1.0 for l in range(L)]
+    refs = [coef * style[:, rows[l]] @ ws[l] + bs[l] + 1.0 for l in range(L)]
     douts = [rnd(R_, n, seed=92 + i) for i, n in enumerate(Ns)]
     gref = torch.autograd.grad(refs, [style] + ws + bs, douts)
     f = lambda t: t.detach().float().to(dev).contiguous().requires_grad_(True)
     sd, wd, bd = f(style), [f(w) for w in ws], [f(b) for b in bs]
-    outs = ops.style_affines(sd, wd, bd, coef)
+    outs = ops.style_affines(sd, wd, bd, coef, rows)
     for o, r in zip(outs, refs):
         assert rel_err(o, r) < 1e-5
     gd = torch.autograd.grad(outs, [sd] + wd + bd, [d.float().to(dev) for d in douts], retain_graph=True)

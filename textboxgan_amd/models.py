@@ -262,18 +262,22 @@ class Synthesis(nn.Module):
         k_up = ops.fir_kernel(x.device, 4.0)
         ws = style.unbind(dim=1)  # one node: its backward is ONE stack of the per-layer latent gradients (16 selects
         # would each zero-fill a [B, n, 512] tensor and be summed pairwise by the autograd engine)
-        ss = [None] * style.shape[1]
+        nb = len(self.synth_blocks)
+        s_tr, s_c0, s_c1 = [None] * (nb + 1), [None] * nb, [None] * nb
         if mode == "fused":  # all style affines in one launch (and one for their backward)
             convs = [self.initial_torgb.conv] + [c for b, t in zip(self.synth_blocks, self.torgbs)
                                                   for c in (b.conv_0, b.conv_1, t.conv)]
-            assert len(convs) == style.shape[1]
+            rows = [0] + [r for i in range(nb) for r in (3 * i, 3 * i + 1, 3 * i + 2)]  # the latent row each layer reads
             ss = ops.style_affines(style, [c.mod_dense.w for c in convs], [c.mod_bias.b for c in convs],
-                                   _coef(convs[0].mod_dense.w.shape))
-        y = self.initial_torgb(x, ws[0], None, mode, s=ss[0])
+                                   _coef(convs[0].mod_dense.w.shape), rows)
+            s_tr[0] = ss[0]
+            for i in range(nb):
+                s_c0[i], s_c1[i], s_tr[i + 1] = ss[1 + 3 * i], ss[2 + 3 * i], ss[3 + 3 * i]
+        y = self.initial_torgb(x, ws[0], None, mode, s=s_tr[0])
         for i, (block, torgb) in enumerate(zip(self.synth_blocks, self.torgbs)):
-            x = block(x, ws[3 * i], ws[3 * i + 1], noises[2 * i], noises[2 * i + 1], mode, s0=ss[3 * i], s1=ss[3 * i + 1])
+            x = block(x, ws[3 * i], ws[3 * i + 1], noises[2 * i], noises[2 * i + 1], mode, s0=s_c0[i], s1=s_c1[i])
             y = ops.upfirdn2d(y, k_up, up=(2, 2), pad=(2, 1, 2, 1))  # upsample_2d, :152
-            y = torgb(x, ws[3 * i + 2], y, mode, s=ss[3 * i + 2])
+            y = torgb(x, ws[3 * i + 2], y, mode, s=s_tr[i + 1])
         return y
 
 

@@ -1058,62 +1058,81 @@ def b_like(dout):
 
 
 class _StyleAffines(torch.autograd.Function):
-    """s_l = coef * style[:, l, :] @ W_l + b_l + 1 for every modulated layer l of the synthesis network at once
-    (modulated_conv2d.py:52-56, 74-76; synthesis_block.py:120-156 hands layer l row l of the broadcast latents): one
-    launch forward, one backward (tbg_dense_multi_*), instead of 2 and 3-4 library launches per layer.  d(style) is written
-    slot by slot into ONE [B, L, K] tensor."""
+    """s_l = coef * style[:, rows[l], :] @ W_l + b_l + 1 for every modulated layer l of the synthesis network at once
+    (modulated_conv2d.py:52-56, 74-76; synthesis_block.py:120-156: layer l reads row rows[l] of the broadcast latents -- the
+    first toRGB and the first conv share row 0): one launch forward, one backward (tbg_dense_multi_*), instead of 2 and
+    3-4 library launches per layer.  d(style) is written row by row into ONE [B, n_rows, K] tensor (a row used by two
+    layers: the second contribution goes through a [B, K] scratch and one add)."""
 
     @staticmethod
-    def forward(ctx, style, coef, *wb):
+    def forward(ctx, style, coef, rows, *wb):
         style = style.contiguous()
-        B, L, K = style.shape
+        B, NR, K = style.shape
+        L = len(rows)
         ws, bs = wb[:L], wb[L:]
-        assert len(ws) == L and len(bs) == L and L <= N.DENSE_MAX_ITEMS
+        assert len(ws) == L and len(bs) == L and L <= N.DENSE_MAX_ITEMS and max(rows) < NR
         outs = [torch.empty((B, w.shape[1]), device=style.device, dtype=torch.float32) for w in ws]
         items = (N.DenseItem * L)()
         sp = N.ptr(style)
         for l, (w, b, o) in enumerate(zip(ws, bs, outs)):
-            items[l] = N.DenseItem(x=sp + 4 * l * K, w=N.ptr(w), b=N.ptr(b), out=N.ptr(o), N=w.shape[1], ldx=L * K)
+            items[l] = N.DenseItem(x=sp + 4 * rows[l] * K, w=N.ptr(w), b=N.ptr(b), out=N.ptr(o), N=w.shape[1], ldx=NR * K)
         N.check(N.lib().tbg_dense_multi_fwd_f32(items, L, B, K, coef, 1.0, 1.0, N.stream()), "tbg_dense_multi_fwd")
         ctx.save_for_backward(style, *ws)
-        ctx.coef = coef
+        ctx.cfgv = (coef, rows)
         return tuple(outs)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *douts):
         style, *ws = ctx.saved_tensors
-        B, L, K = style.shape
+        coef, rows = ctx.cfgv
+        B, NR, K = style.shape
+        L = len(rows)
         need_x = ctx.needs_input_grad[0]
         dstyle = torch.empty_like(style) if need_x else None
-        dws = [torch.empty_like(w) if ctx.needs_input_grad[2 + l] else None for l, w in enumerate(ws)]
-        dbs = [torch.empty(w.shape[1], device=w.device, dtype=torch.float32) if ctx.needs_input_grad[2 + L + l] else None
+        dws = [torch.empty_like(w) if ctx.needs_input_grad[3 + l] else None for l, w in enumerate(ws)]
+        dbs = [torch.empty(w.shape[1], device=w.device, dtype=torch.float32) if ctx.needs_input_grad[3 + L + l] else None
                for l, w in enumerate(ws)]
         items = (N.DenseItem * L)()
         sp, dsp = N.ptr(style), N.ptr(dstyle)
-        keep, n = [], 0
+        keep, n, written, extra = [], 0, set(), []
         for l, w in enumerate(ws):
             d = douts[l]
-            if d is None:  # an unused style (never on the training path): its slot of d(style) is zero
-                if need_x:
-                    dstyle[:, l].zero_()
+            if d is None:  # an unused style (never on the training path)
                 if dws[l] is not None: dws[l].zero_()
                 if dbs[l] is not None: dbs[l].zero_()
                 continue
             d = d.contiguous(); keep.append(d)
             if not (need_x or dws[l] is not None or dbs[l] is not None):
                 continue
-            items[n] = N.DenseItem(x=sp + 4 * l * K, w=N.ptr(w), dout=N.ptr(d), dx=(dsp + 4 * l * K) if need_x else None,
-                                   dw=N.ptr(dws[l]), db=N.ptr(dbs[l]), N=w.shape[1], ldx=L * K)
+            xp, dxp, ldx = sp + 4 * rows[l] * K, None, NR * K
+            if need_x and rows[l] not in written:
+                dxp = dsp + 4 * rows[l] * K
+                written.add(rows[l])
+            elif need_x:  # second layer on the same latent row: x and dx share one row pitch in the kernel, so both go dense
+                xrow = style[:, rows[l]].contiguous()
+                scratch = torch.empty((B, K), device=style.device, dtype=torch.float32)
+                keep.append(xrow); extra.append((rows[l], scratch))
+                xp, dxp, ldx = N.ptr(xrow), N.ptr(scratch), K
+            items[n] = N.DenseItem(x=xp, w=N.ptr(w), dout=N.ptr(d), dx=dxp, dw=N.ptr(dws[l]), db=N.ptr(dbs[l]),
+                                   N=w.shape[1], ldx=ldx)
             n += 1
         if n:
-            N.check(N.lib().tbg_dense_multi_bwd_f32(items, n, B, K, ctx.coef, 1.0, N.stream()), "tbg_dense_multi_bwd")
-        return (dstyle, None, *dws, *dbs)
+            N.check(N.lib().tbg_dense_multi_bwd_f32(items, n, B, K, coef, 1.0, N.stream()), "tbg_dense_multi_bwd")
+        if need_x:
+            for r in range(NR):
+                if r not in written:
+                    dstyle[:, r].zero_()
+            for r, scratch in extra:
+                dstyle[:, r] += scratch
+        return (dstyle, None, None, *dws, *dbs)
 
 
-def style_affines(style, ws, bs, coef):
-    """style [B, L, K]; ws[l] [K, I_l], bs[l] [I_l]  ->  tuple of L tensors [B, I_l] = coef * style[:, l] @ ws[l] + bs[l] + 1."""
-    return _StyleAffines.apply(style, float(coef), *ws, *bs)
+def style_affines(style, ws, bs, coef, rows=None):
+    """style [B, NR, K]; ws[l] [K, I_l], bs[l] [I_l]; rows[l] = the latent row layer l reads (default l)
+    ->  tuple of L tensors [B, I_l] = coef * style[:, rows[l]] @ ws[l] + bs[l] + 1."""
+    rows = tuple(range(len(ws))) if rows is None else tuple(int(r) for r in rows)
+    return _StyleAffines.apply(style, float(coef), rows, *ws, *bs)
 
 
 _ONES = {}
