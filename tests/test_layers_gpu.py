@@ -122,7 +122,7 @@ def test_style_affines_one_launch(dev, dims):
     coef = 1.0 / math.sqrt(K)
     refs = [coef * style[:, rows[l]] @ ws[l] + bs[l] + 1.0 for l in range(L)]
     douts = [rnd(R_, n, seed=92 + i) for i, n in enumerate(Ns)]
-    gref = torch.autograd.grad(refs, [style] + ws + bs, douts)
+    gref = torch.autograd.grad(refs, [style] + ws + bs, douts, retain_graph=True)
     f = lambda t: t.detach().float().to(dev).contiguous().requires_grad_(True)
     sd, wd, bd = f(style), [f(w) for w in ws], [f(b) for b in bs]
     outs = ops.style_affines(sd, wd, bd, coef, rows)
