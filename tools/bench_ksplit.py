@@ -10,8 +10,10 @@ shapes = [  # C, M, Hin, Win, Hout, Wout, stride
     (512, 256, 4, 16, 9, 33, (2, 2)), (512, 512, 2, 8, 5, 17, (2, 2)),
     # non-transposed small layers (3x3 s1)
     (512, 512, 4, 16, 4, 16, None), (512, 512, 2, 8, 2, 8, None), (256, 256, 8, 32, 8, 32, None), (512, 512, 4, 8, 4, 8, None),
+    # mid layers whose tile count is at or below one block per CU
+    (256, 256, 16, 64, 16, 64, None), (128, 128, 16, 64, 16, 64, None), (128, 128, 32, 128, 32, 128, None),
 ]
-B = 16
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 for C, M, Hin, Win, Hout, Wout, st in shapes:
     x = torch.randn(B, C, Hin, Win, device=dev); w = ops.pack_filter(torch.randn(9, C, M, device=dev), False, False)
     row = []
