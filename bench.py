@@ -189,6 +189,11 @@ def roofline_record(recs, dtype="f32"):
             "gflop_per_launch": round(r["flops"] / r["n"] / 1e9, 3),
             "all_kernels": {k: {"n": v["n"], "ms": round(v["ms"], 3),
                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in convs.items()},
+            # every MFMA launch of the pass together (forward, data- and filter-gradient instantiations): FLOP-weighted
+            "all_conv_kernels": (lambda fl, ms: {"achieved": round(fl / (ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                                                 "frac": round(fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                                                 "ms": round(ms, 3), "launches": sum(v["n"] for v in convs.values())})(
+                sum(v["flops"] for v in convs.values()), sum(v["ms"] for v in convs.values())),
             "hbm_bound_kernels": hbm}
 
 
