@@ -23,7 +23,7 @@ L = [("64x256 128->128", 128, 128, 64, 256, (1, 1)), ("32x128 128->128", 128, 12
      ("64x256 64->64", 64, 64, 64, 256, (1, 1)), ("32x128 256->128 (dgrad shape)", 256, 128, 32, 128, (1, 1)),
      ("down 66x258 64->128", 64, 128, 66, 258, (2, 2)), ("down 34x130 128->128", 128, 128, 34, 130, (2, 2)),
      ("down 18x66 128->256", 128, 256, 18, 66, (2, 2)), ("down 10x34 256->256 (w only)", 256, 256, 8, 34, (1, 2))]
-names = {0: "auto", 1: "tile128x256", 2: "ck32"} if BF16 else {0: "auto", 1: "pipelined", 2: "plain", 3: "occ4"}
+names = {0: "auto", 7: "scalar-halo", 1: "tile128x256", 2: "ck32"} if BF16 else {0: "auto", 7: "scalar-halo", 1: "pipelined", 2: "plain", 3: "occ4"}
 print(f"B={B}  TFLOP/s per variant (ksplit as the heuristic picks it)")
 for name, C, M, H, W, stride in L:
     x = torch.randn(B, C, H, W, device=dev)
@@ -32,7 +32,7 @@ for name, C, M, H, W, stride in L:
     ohw = ((H + 2 * pad[0] - 3) // stride[0] + 1, (W + 2 * pad[1] - 3) // stride[1] + 1)
     flops = 2.0 * B * C * M * 9 * ohw[0] * ohw[1]
     row = f"{name:34s}"
-    for v in sorted(names):
+    for v in names:
         ops.FORCE_VARIANT = v
         try:
             t = timeit(lambda: ops.conv2d_raw(x, wp, M, 3, 3, ohw, stride, pad))
