@@ -336,53 +336,6 @@ def test_conv2d_wgrad(dev, case):
     assert rel_err(dw, dw_ref) < 3e-5
 
 
-XV_CASES = [
-    (4, 128, 128, 16, 64, "two tile columns, four tile rows"),
-    (3, 100, 130, 12, 36, "ragged channels, a partial 32-wide tile column (W = 36)"),
-    (2, 20, 200, 6, 128, "C < one bf16 unit pair, partial tile rows (H = 6)"),
-]
-
-
-@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
-@pytest.mark.parametrize("case", XV_CASES, ids=[c[-1] for c in XV_CASES])
-def test_conv2d_vector_halo_staging(dev, case, bf16):
-    """the float4-halo-staged forward instance (3x3 stride-1 SAME, 32 x 4 pixel tiles, rows of whole 16-byte units), fp32 and
-    bf16: forward with modulation + the full epilogue, and the data gradient (same instance, transposed filter), against
-    float64 references on (for bf16) pre-rounded operands; and that it IS that instance / the scalar one under variant 7."""
-    from textboxgan_amd import native as N, ops
-    B, C, M, H, W, _ = case
-    x, w = rnd(B, C, H, W, seed=70), rnd(3, 3, C, M, seed=71) / math.sqrt(9 * C)
-    sc, dm, bias = rnd(B, C, seed=72).abs() + 0.5, rnd(B, M, seed=73).abs() + 0.5, rnd(M, seed=74)
-    rd = (lambda t: t.float().bfloat16().double()) if bf16 else (lambda t: t)
-    xs = rd((x.float().double() * sc.float().double()[:, :, None, None]).float().double())
-    ref = F.conv2d(xs, rd(w).permute(3, 2, 0, 1), padding=1) * dm[:, :, None, None] * 0.7 + bias[None, :, None, None]
-    ref = F.leaky_relu(ref, 0.2) * math.sqrt(2.0)
-    f = lambda t: t.float().to(dev).contiguous()
-    d = N.ConvDesc(B, C, M, H, W, H, W, 3, 3, 1, 1, 1, 1, 0, 0, M, 1)
-    name = N.conv_kernel_name(d, True, bf16)
-    assert name.endswith("false, true>") and name.startswith("conv_fprop_kernel<2, 2, 2, 2,"), name
-    dmd, bd, scd = f(dm), f(bias), f(sc)
-    epi = N.epilogue(alpha=0.7, out_scale=dmd, bias=bd, act=N.ACT_LRELU, slope=0.2, gain=math.sqrt(2.0))
-    with ops.compute_dtype("bf16" if bf16 else "f32"):
-        pf = ops.pack_filter(f(w).reshape(9, C, M), False, False)
-        y = ops.conv2d_raw(f(x), pf, M, 3, 3, (H, W), (1, 1), (1, 1), in_scale=scd, epi=epi, allow_split=False)
-        ops.FORCE_VARIANT = 7
-        try:
-            y_scalar = ops.conv2d_raw(f(x), pf, M, 3, 3, (H, W), (1, 1), (1, 1), in_scale=scd, epi=epi, allow_split=False)
-        finally:
-            ops.FORCE_VARIANT = 0
-    assert rel_err(y, ref) < 3e-5
-    assert rel_err(y_scalar, ref) < 3e-5
-    # data gradient: dy (M channels) -> dx (C channels)
-    dy = rnd(B, M, H, W, seed=75)
-    xr = x.clone().requires_grad_(True)
-    (gx,) = torch.autograd.grad(F.conv2d(xr, rd(w).permute(3, 2, 0, 1), padding=1), xr, rd(dy))
-    g = ops._Geom((1, 1), (1, 1), 3, 3, (H, W), (H, W))
-    with ops.compute_dtype("bf16" if bf16 else "f32"):
-        dx = ops._bwd_data_launch(f(dy), f(w), g)
-    assert rel_err(dx, gx) < 3e-5
-
-
 WGV_CASES = [
     (3, 40, 72, 5, 36, "ragged: odd rows, a partial 32-wide tile, partial channel tiles"),
     (2, 64, 64, 8, 32, "exactly one tile per row"),

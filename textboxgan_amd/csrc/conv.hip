@@ -82,8 +82,7 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // accumulates into class (kh&1, kw&1) -- 4 x (WTM x WTN) accumulator tiles -- reading x[u - (kh==2), v - (kw==2)].  Same MFMA
 // count as a 3x3 stride-1 convolution on the input grid and no per-class re-staging (the class-per-block form staged the
 // halo four times and ran 1/2/2/4-tap K loops).  Store-only epilogue (alpha * acc; split-K slabs allowed).
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF, int OCC = 3, bool BF = false, bool TM = false,
-          bool XV = false>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF, int OCC = 3, bool BF = false, bool TM = false>
 __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   constexpr int BM = WGM * WTM * 32;
   constexpr int NC = TM ? 4 : 1;            // accumulator sets (output-parity classes of the merged transposed form)
@@ -96,7 +95,6 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   static_assert(BF ? (CK % 16 == 0 && PF == 0) : (CK == 4 || CK % 8 == 0),
                 "chunk = one quad (half-waves split it) or whole unit pairs (half-wave h reads unit 2o+h)");
   static_assert(!PF || CK <= 8, "the pipelined variant prefetches one load batch");
-  static_assert(!XV || (PF == 0 && !TM && G4 == 2 && WGN * WTN * 32 == 128), "vector halo staging: 128-pixel tiles, two units per chunk");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -248,71 +246,6 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
       }
     }
   };
-  // XV: float4 halo staging for 3x3 stride-1 SAME layers on 32 x 4 pixel tiles whose rows are whole 16-byte units
-  // (Win % 4 == 0; one image per tile).  The 6 x 34 halo tile is 6 x 8 interior quads + 6 x 2 edge columns; a task is one
-  // (quad | edge position) x one 16-byte channel unit: lanes 0..95 read KP float4 (4 positions x KP channels), transpose in
-  // registers and write 4 units; lanes 96..119 read KP scalars and write 1 unit.  960 load instructions per block and chunk
-  // instead of 3264, and for the 16-channel bf16 chunks ONE round trip instead of two.
-  constexpr int XNL = BF ? 8 : 4;  // loads per task = channels per unit
-  float4 xq[XV ? XNL : 1];
-  auto xv_load = [&](int c0) {
-    const int t = tid;
-    const bool interior = t < 96;
-    const int tt = interior ? t : t - 96;
-    const int unit = interior ? tt / 48 : tt / 12;
-    const int rem = interior ? tt - unit * 48 : tt - unit * 12;
-    const int row = interior ? rem >> 3 : rem >> 1;
-    const int ixl = interior ? 1 + 4 * (rem & 7) : ((rem & 1) ? 33 : 0);
-    const int b = bg, iy = u0 - ci.py + row, ix = v0 - ci.px + ixl;
-    const bool okpos = t < 120 && b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-    const unsigned base = okpos ? (unsigned)(((b * p.C) * p.Hin + iy) * p.Win + ix) : 0u;
-#pragma unroll
-    for (int cc = 0; cc < XNL; ++cc) {
-      const int ch = min(c0 + unit * XNL + cc, p.C - 1);
-      const float *src = p.x + (base + (unsigned)(ch * HWin));
-      if (interior) xq[cc] = *reinterpret_cast<const float4 *>(src);  // (t >= 120 or padding: element 0.., discarded)
-      else xq[cc].x = *src;
-    }
-  };
-  auto xv_store = [&](int c0, float *Xbuf) {
-    const int t = tid;
-    if (t >= 120) return;
-    const bool interior = t < 96;
-    const int tt = interior ? t : t - 96;
-    const int unit = interior ? tt / 48 : tt / 12;
-    const int rem = interior ? tt - unit * 48 : tt - unit * 12;
-    const int row = interior ? rem >> 3 : rem >> 1;
-    const int ixl = interior ? 1 + 4 * (rem & 7) : ((rem & 1) ? 33 : 0);
-    const int iy = u0 - ci.py + row, ix = v0 - ci.px + ixl;
-    const bool okpos = bg < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-    float sc[XNL];
-    bool okc[XNL];  // padding / channel tail: selected to 0 (never multiplied: the clamped load may hold anything)
-#pragma unroll
-    for (int cc = 0; cc < XNL; ++cc) {
-      const int ch = c0 + unit * XNL + cc;
-      okc[cc] = okpos && ch < p.C;
-      sc[cc] = p.in_scale ? Ss[min(ch, p.C - 1)] : 1.f;
-    }
-    const int pos = row * p.IWp + ixl;
-    const int npos = interior ? 4 : 1;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (e < npos) {
-        float v[XNL];
-#pragma unroll
-        for (int cc = 0; cc < XNL; ++cc)
-          v[cc] = okc[cc] ? (e == 0 ? xq[cc].x : e == 1 ? xq[cc].y : e == 2 ? xq[cc].z : xq[cc].w) * sc[cc] : 0.f;
-        if constexpr (BF) {
-          float v8[8];
-#pragma unroll
-          for (int cc = 0; cc < 8; ++cc) v8[cc] = v[cc < XNL ? cc : 0];
-          reinterpret_cast<bf16x8 *>(Xbuf)[unit * p.planeStride + pos + e] = pack_bf16x8(v8);
-        } else {
-          reinterpret_cast<f32x4 *>(Xbuf)[unit * p.planeStride + pos + e] = f32x4{v[0], v[1], v[2], v[3]};
-        }
-      }
-    }
-  };
   auto mfma_taps = [&](const float *Abuf, const float *Xbuf) {
     const char *Ab = reinterpret_cast<const char *>(Abuf) + abytes;
     const char *Xb = reinterpret_cast<const char *>(Xbuf);
@@ -454,15 +387,6 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     for (int kc = kbeg; kc < kend; ++kc) {
       const int c0 = kc * CK;
       if (kc > kbeg) __syncthreads();
-      if constexpr (XV) {
-        xv_load(c0);
-        issue_filter_dma(kc, As);
-        xv_store(c0, Xs);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        mfma_taps(As, Xs);
-        continue;
-      }
       // halo batch 0 first: its round trip hides under the issue phase of the filter DMA below
       float xv0[CB];
       load_halo(c0, 0, xv0);
@@ -627,8 +551,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
 // name-only mode (name != NULL): write the instantiation the descriptor selects (rocprofv3 spelling) and launch nothing
 struct NameOut { char *buf; int n; };
 
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false, bool TM = false,
-          bool XV = false>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false, bool TM = false>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, const NameOut *name) {
   constexpr int BM = WGM * WTM * 32;
   constexpr int G4 = (CK + (BF ? 7 : 3)) / (BF ? 8 : 4);
@@ -642,11 +565,11 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   if (maxtaps > MT) return TBG_EUNSUPPORTED;
   if (name) {
-    snprintf(name->buf, name->n, "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s>", WGM, WGN, WTM, WTN, CK, MT, PF,
-             OCC, BF ? "true" : "false", TM ? "true" : "false", XV ? "true" : "false");
+    snprintf(name->buf, name->n, "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC,
+             BF ? "true" : "false", TM ? "true" : "false");
     return TBG_OK;
   }
-  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF, OCC, BF, TM, XV>;
+  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF, OCC, BF, TM>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TBG_EHIP;
@@ -791,11 +714,6 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   p.ksplit = d->ksplit;
   p.slab = (long long)d->B * d->M * d->Hout * d->Wout;
   hipStream_t st = tbg_stream(stream);
-  // float4 halo staging (XV): 3x3 stride-1 SAME on 32 x 4 pixel tiles, one image per tile, rows of whole 16-byte units.
-  // variant 7 forces the scalar staging (measurement aid).
-  const bool xv_ok = !d->transposed && d->KH == 3 && d->KW == 3 && p.sy == 1 && p.sx == 1 && d->py == 1 && d->px == 1 &&
-                     (d->Win & 3) == 0 && p.logTW == 5 && p.logTHs == 2 && p.NSEG == 1 && p.IHs == 6 && p.IWs == 34 &&
-                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 && BM == 128 && BN == 128 && variant == 0;
   if (merged) {
     if (bf) return launch_fprop<2, 2, 1, 2, 16, MAXTAPS, 0, 2, true, true>(p, st, maxtaps, maxTilesN, name);
     if (variant == 6) return launch_fprop<2, 2, 1, 2, 16, MAXTAPS, 0, 2, false, true>(p, st, maxtaps, maxTilesN, name);
@@ -824,7 +742,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     }
     if (variant == 2 && BM == 128 && BN == 128 && maxtaps > 4)  // 32-channel chunks: half the barriers
       return launch_fprop<2, 2, 2, 2, 32, MAXTAPS, 0, 2, true>(p, st, maxtaps, maxTilesN, name);
-    if (variant != 0 && variant != 4 && variant != 5 && variant != 7) return TBG_EUNSUPPORTED;
+    if (variant != 0 && variant != 4 && variant != 5) return TBG_EUNSUPPORTED;
     if (maxtaps > 1 && maxtaps <= 4) {
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
@@ -834,7 +752,6 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, MAXTAPS, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
     if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 16, MAXTAPS, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
     if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, MAXTAPS, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
-    if (xv_ok) return launch_fprop<2, 2, 2, 2, 16, MAXTAPS, 0, 3, true, false, true>(p, st, maxtaps, maxTilesN, name);
     return launch_fprop<2, 2, 2, 2, 16, MAXTAPS, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
   }
   // few-tap launches (the parity classes of a stride-2 transposed 3x3: 1/2/2/4 taps): a deeper channel chunk keeps
@@ -845,7 +762,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
     return launch_fprop<2, 2, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
   }
-  if (variant != 0 && variant != 4 && variant != 5 && variant != 7) {  // explicit instantiation choice (tbg_conv2d_f32_variant: tuning / test aid, stateless)
+  if (variant != 0 && variant != 4 && variant != 5) {  // explicit instantiation choice (tbg_conv2d_f32_variant: tuning / test aid, stateless)
     if (variant == 1 && p.NJ <= 3) {  // software-pipelined
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
@@ -881,7 +798,6 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   // 3-blocks/CU instance lose with CK=4 (more barriers per FLOP: 116 vs 124 at 512 tiles) and keep CK=8.
   if (maxtaps == 9 && p.NJ <= 3 && (long long)maxTilesN * ceil_div(p.M, BM) * p.nclass > 768 && p.ksplit == 1)
     return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 0, 4>(p, st, maxtaps, maxTilesN, name);
-  if (xv_ok) return launch_fprop<2, 2, 2, 2, 8, MAXTAPS, 0, 3, false, false, true>(p, st, maxtaps, maxTilesN, name);
   return launch_fprop<2, 2, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
 }
 
@@ -892,13 +808,13 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
 
 extern "C" int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                                       const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant < 0 || variant > 7) return TBG_EINVAL;
+  if (variant < 0 || variant > 6) return TBG_EINVAL;
   return conv2d_impl(d, x, w, y, in_scale, epi, stream, nullptr, false, variant);
 }
 
 extern "C" int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                                        const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant < 0 || variant == 3 || variant == 6 || variant > 7) return TBG_EINVAL;
+  if (variant < 0 || variant == 3 || variant > 5) return TBG_EINVAL;
   return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, true, variant);
 }
 
@@ -979,7 +895,6 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
           lv[i] = *reinterpret_cast<const float4 *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl) : 0u));
           const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
           lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
-          if (!ok) lv[i] = float4{0.f, 0.f, 0.f, 0.f};  // select, not 0 * x: the clamped load may hold Inf / NaN
         }
         if (hf == 0) {
           float4 sv[4];
@@ -994,7 +909,6 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
             sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(16 * i * HWs) : 0u));
             const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 16 * i) : 0u];
             ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
-            if (!ok) sv[i] = float4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -1019,7 +933,6 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
             ev[i] = p.L[ok ? e_g0 + (unsigned)(32 * i * HWl) : 0u];
             const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch + 32 * i) : 0u];
             esc[i] = !ok ? 0.f : (hl ? sc : 1.f);
-            if (!ok) ev[i] = 0.f;
           }
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -1072,7 +985,6 @@ __device__ __forceinline__ void wgrad_stage_vec_s2(const WgradP &p, void *Ssv, v
       lv[i] = *reinterpret_cast<const f32x4u *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl + (row + min(iy0, 0)) * p.Wl) : 0u));
       const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
       lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
-      if (!ok) lv[i] = f32x4u{0.f, 0.f, 0.f, 0.f};
     }
     if (hf == 0) {
       float4 sv[2];
@@ -1086,7 +998,6 @@ __device__ __forceinline__ void wgrad_stage_vec_s2(const WgradP &p, void *Ssv, v
         sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(32 * i * HWs) : 0u));
         const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 32 * i) : 0u];
         ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
-        if (!ok) sv[i] = float4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
