@@ -366,6 +366,12 @@ def test_conv2d_wgrad_vector_staging(dev, case):
     dw_plain = ops._bwd_weight_launch(f(x), f(dy), g, C, M, alpha=1.0)
     (ref_plain,) = torch.autograd.grad(F.conv2d(x, w.permute(3, 2, 0, 1), padding=1), w, dy)
     assert rel_err(dw_plain, ref_plain) < 3e-5
+    # padding is SELECTED to zero, not multiplied: the branch-free loads of out-of-range positions read element 0 of the
+    # tensor, and an Inf sitting there must stay inside its own output channel
+    dyi = f(dy).clone()
+    dyi[0, 0, 0, 0] = float("inf")
+    dwi = ops._bwd_weight_launch(f(x), dyi, g, C, M, alpha=1.0)
+    assert bool(torch.isfinite(dwi[..., 1:]).all()) and rel_err(dwi[..., 1:], ref_plain[..., 1:]) < 3e-5
 
 
 WGV2_CASES = [

@@ -895,6 +895,7 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
           lv[i] = *reinterpret_cast<const float4 *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl) : 0u));
           const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
           lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+          if (!ok) lv[i] = float4{0.f, 0.f, 0.f, 0.f};  // select, not 0 * x: the clamped load may hold Inf / NaN
         }
         if (hf == 0) {
           float4 sv[4];
@@ -909,6 +910,7 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
             sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(16 * i * HWs) : 0u));
             const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 16 * i) : 0u];
             ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
+            if (!ok) sv[i] = float4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -933,6 +935,7 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
             ev[i] = p.L[ok ? e_g0 + (unsigned)(32 * i * HWl) : 0u];
             const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch + 32 * i) : 0u];
             esc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+            if (!ok) ev[i] = 0.f;
           }
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -985,6 +988,7 @@ __device__ __forceinline__ void wgrad_stage_vec_s2(const WgradP &p, void *Ssv, v
       lv[i] = *reinterpret_cast<const f32x4u *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl + (row + min(iy0, 0)) * p.Wl) : 0u));
       const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
       lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+      if (!ok) lv[i] = f32x4u{0.f, 0.f, 0.f, 0.f};
     }
     if (hf == 0) {
       float4 sv[2];
@@ -998,6 +1002,7 @@ __device__ __forceinline__ void wgrad_stage_vec_s2(const WgradP &p, void *Ssv, v
         sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(32 * i * HWs) : 0u));
         const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 32 * i) : 0u];
         ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
+        if (!ok) sv[i] = float4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
