@@ -387,6 +387,26 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     for (int kc = kbeg; kc < kend; ++kc) {
       const int c0 = kc * CK;
       if (kc > kbeg) __syncthreads();
+      if constexpr (BF && CK == 2 * CB) {
+        // 16-channel bf16 chunks: BOTH 8-channel load batches of a position are issued before the first store (one HBM round
+        // trip per chunk instead of two -- the bf16 MFMA phase is too short to hide the second)
+        float xa[CB], xb[CB];
+        load_halo(c0, 0, xa);
+        load_halo(c0 + CB, 0, xb);
+        issue_filter_dma(kc, As);
+#pragma unroll
+        for (int j = 0; j < NJC; ++j) {
+          if (j < p.NJ) {  // uniform
+            if (j > 0) { load_halo(c0, j, xa); load_halo(c0 + CB, j, xb); }
+            store_halo(c0, 0, j, xa, Xs);
+            store_halo(c0 + CB, CB / KP, j, xb, Xs);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        mfma_taps(As, Xs);
+        continue;
+      }
       // halo batch 0 first: its round trip hides under the issue phase of the filter DMA below
       float xv0[CB];
       load_halo(c0, 0, xv0);
@@ -859,6 +879,15 @@ struct WgradP {
 // the two halo columns as scalars, all issued together (the compiler merges the two source-level rounds: 241 VGPRs, no
 // spill) -- the scalar form needed six dependent round trips per chunk and cost a quarter of the fp32 kernel (tools/exp_wgrad_split.py: 801 us -> 594 us without staging).
 // BF: round to bf16 (RNE) on the way into LDS.  Tile pitches are compile-time constants (immediate LDS offsets).
+// v_mul_legacy_f32: x * 0 = 0 for EVERY x (Inf and NaN included), IEEE otherwise.  The branch-free staging loads of padding /
+// out-of-range positions read a clamped (valid) address whose content is unrelated data; their scale factor is 0, and this
+// multiply keeps an Inf sitting there from becoming a NaN in the tile -- at no instruction cost.
+__device__ __forceinline__ float zmul(float a, float b) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <bool BF> struct WgVec {
   static constexpr int SP = BF ? 72 : 68;       // S channel pitch (elements)
   static constexpr int IWP = BF ? 40 : 34;      // L halo row pitch
@@ -894,8 +923,7 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
           // branch-free: clamp the address, always load, select 0 (an `ok ? load : 0` is compiled to one branch per load)
           lv[i] = *reinterpret_cast<const float4 *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl) : 0u));
           const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
-          lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
-          if (!ok) lv[i] = float4{0.f, 0.f, 0.f, 0.f};  // select, not 0 * x: the clamped load may hold Inf / NaN
+          lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);  // padding: scale 0, applied with v_mul_legacy (0 * Inf = 0, see zmul)
         }
         if (hf == 0) {
           float4 sv[4];
@@ -910,12 +938,11 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
             sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(16 * i * HWs) : 0u));
             const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 16 * i) : 0u];
             ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
-            if (!ok) sv[i] = float4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float4 v = sv[i];
-            v.x *= ssc[i]; v.y *= ssc[i]; v.z *= ssc[i]; v.w *= ssc[i];
+            v.x = zmul(v.x, ssc[i]); v.y = zmul(v.y, ssc[i]); v.z = zmul(v.z, ssc[i]); v.w = zmul(v.w, ssc[i]);
             if constexpr (BF) {
               typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
               *reinterpret_cast<bf16x4_t *>(Ss + (s_ch + 16 * i) * SP + s_pq) = bf16x4_t{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
@@ -935,16 +962,15 @@ __device__ __forceinline__ void wgrad_stage_vec(const WgradP &p, void *Ssv, void
             ev[i] = p.L[ok ? e_g0 + (unsigned)(32 * i * HWl) : 0u];
             const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch + 32 * i) : 0u];
             esc[i] = !ok ? 0.f : (hl ? sc : 1.f);
-            if (!ok) ev[i] = 0.f;
           }
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            Ls[(e_ch + 32 * i) * g_lplane + e_row * g_IWp + (e_side ? 33 : 0)] = (T)(ev[i] * esc[i]);
+            Ls[(e_ch + 32 * i) * g_lplane + e_row * g_IWp + (e_side ? 33 : 0)] = (T)zmul(ev[i], esc[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           T *dst = l_d0 + 8 * (4 * hf + i) * g_lplane;
-          dst[0] = (T)(lv[i].x * lsc[i]); dst[1] = (T)(lv[i].y * lsc[i]); dst[2] = (T)(lv[i].z * lsc[i]); dst[3] = (T)(lv[i].w * lsc[i]);
+          dst[0] = (T)zmul(lv[i].x, lsc[i]); dst[1] = (T)zmul(lv[i].y, lsc[i]); dst[2] = (T)zmul(lv[i].z, lsc[i]); dst[3] = (T)zmul(lv[i].w, lsc[i]);
         }
         // bf16: keep the two rounds apart (measured: 347 vs 234 TFLOP/s on the 64x256 layer); fp32: the compiler merges them
         if constexpr (BF) __builtin_amdgcn_sched_barrier(0);
@@ -988,7 +1014,6 @@ __device__ __forceinline__ void wgrad_stage_vec_s2(const WgradP &p, void *Ssv, v
       lv[i] = *reinterpret_cast<const f32x4u *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl + (row + min(iy0, 0)) * p.Wl) : 0u));
       const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
       lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
-      if (!ok) lv[i] = f32x4u{0.f, 0.f, 0.f, 0.f};
     }
     if (hf == 0) {
       float4 sv[2];
@@ -1002,12 +1027,11 @@ __device__ __forceinline__ void wgrad_stage_vec_s2(const WgradP &p, void *Ssv, v
         sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(32 * i * HWs) : 0u));
         const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 32 * i) : 0u];
         ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
-        if (!ok) sv[i] = float4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         float4 v = sv[i];
-        v.x *= ssc[i]; v.y *= ssc[i]; v.z *= ssc[i]; v.w *= ssc[i];
+        v.x = zmul(v.x, ssc[i]); v.y = zmul(v.y, ssc[i]); v.z = zmul(v.z, ssc[i]); v.w = zmul(v.w, ssc[i]);
         if constexpr (BF) {
           typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
           *reinterpret_cast<bf16x4_t *>(Ss + (s_ch + 32 * i) * SP + s_pq) = bf16x4_t{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
@@ -1026,8 +1050,8 @@ __device__ __forceinline__ void wgrad_stage_vec_s2(const WgradP &p, void *Ssv, v
     for (int i = 0; i < 6; ++i) {
       const int ii = 6 * hf + i, row = ii >> 2, ci = 16 * (ii & 3);
       T *dst = l_d0 + ci * LPLANE + row * IWP;
-      dst[0] = (T)(lv[i][0] * lsc[i]); dst[1] = (T)(lv[i][2] * lsc[i]);
-      dst[HALFW] = (T)(lv[i][1] * lsc[i]); dst[HALFW + 1] = (T)(lv[i][3] * lsc[i]);
+      dst[0] = (T)zmul(lv[i][0], lsc[i]); dst[1] = (T)zmul(lv[i][2], lsc[i]);
+      dst[HALFW] = (T)zmul(lv[i][1], lsc[i]); dst[HALFW + 1] = (T)zmul(lv[i][3], lsc[i]);
     }
     if constexpr (BF) __builtin_amdgcn_sched_barrier(0);
   }
