@@ -881,12 +881,19 @@ struct WgradP {
 // BF: round to bf16 (RNE) on the way into LDS.  Tile pitches are compile-time constants (immediate LDS offsets).
 // v_mul_legacy_f32: x * 0 = 0 for EVERY x (Inf and NaN included), IEEE otherwise.  The branch-free staging loads of padding /
 // out-of-range positions read a clamped (valid) address whose content is unrelated data; their scale factor is 0, and this
-// multiply keeps an Inf sitting there from becoming a NaN in the tile -- at no instruction cost.
-__device__ __forceinline__ float zmul(float a, float b) {
+// multiply keeps an Inf sitting there from becoming a NaN in the tile -- at no instruction cost (bf16 kernels; fp32: a select).
+__device__ __forceinline__ float zmul_legacy(float a, float b) {
   float r;
   asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// measured: the bf16 kernels (staging bound) gain from the one-instruction form (wgrad 3x3 stride-1 287 -> 338 TFLOP/s vs the
+// select form); the fp32 kernel prefers a select the scheduler can move (247 vs 254 us on the 64x256 layer)
+template <bool BF> __device__ __forceinline__ float zmul_t(float a, float b) {
+  if constexpr (BF) return zmul_legacy(a, b);
+  else return b != 0.f ? a * b : 0.f;
+}
+#define zmul zmul_t<BF>
 
 template <bool BF> struct WgVec {
   static constexpr int SP = BF ? 72 : 68;       // S channel pitch (elements)
@@ -1056,6 +1063,8 @@ __device__ __forceinline__ void wgrad_stage_vec_s2(const WgradP &p, void *Ssv, v
     if constexpr (BF) __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+#undef zmul
 
 template <int WGS, int WGL, int NT, int PIX, bool GRP, int VEC = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
