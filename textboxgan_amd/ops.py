@@ -39,6 +39,10 @@ class _Flags:
     # backward kernels on the leading d_first_half samples only and leave the rest of the returned tensor unwritten --
     # nothing reads it (the concatenation's backward hands the generator the first half).  0 = off.
     d_first_half = 0
+    # The regularisers' inner gradient (d(image . noise)/d(latents) for path length, d(scores)/d(image) for R1) reaches no
+    # filter: custom Functions are not pruned by autograd.grad(inputs=...), so without this flag every composable conv of
+    # that pass would also launch its filter gradient and throw it away.
+    no_filter_grads = False
 
 
 FLAGS = _Flags()
@@ -636,7 +640,7 @@ class _Conv2d(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = _Conv2dBwdData.apply(dy, w, ctx.g) if ctx.needs_input_grad[0] else None
-        dw = _Conv2dBwdWeight.apply(x, dy, ctx.g) if ctx.needs_input_grad[1] else None
+        dw = _Conv2dBwdWeight.apply(x, dy, ctx.g) if (ctx.needs_input_grad[1] and not FLAGS.no_filter_grads) else None
         return dx, dw, None
 
 
@@ -651,7 +655,7 @@ class _Conv2dBwdData(torch.autograd.Function):
     def backward(ctx, gdx):
         dy, w = ctx.saved_tensors
         g_dy = _Conv2d.apply(gdx, w, ctx.g) if ctx.needs_input_grad[0] else None
-        g_w = _Conv2dBwdWeight.apply(gdx, dy, ctx.g) if ctx.needs_input_grad[1] else None
+        g_w = _Conv2dBwdWeight.apply(gdx, dy, ctx.g) if (ctx.needs_input_grad[1] and not FLAGS.no_filter_grads) else None
         return g_dy, g_w, None
 
 

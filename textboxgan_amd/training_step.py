@@ -447,7 +447,11 @@ class TrainingStep:
         img, style = self.generator((input_words[:pl_mb], pl_z), batch_size=pl_mb, ret_style=True, training=False,
                                     rand=rand, noises_key="pl_noises", mode="composable")
         noise = rand["pl_noise"] if "pl_noise" in rand else torch.randn_like(img)
-        (g,) = torch.autograd.grad((img * (noise * self.pl_noise_scaler)).sum(), style, create_graph=True)
+        ops.FLAGS.no_filter_grads = True  # this inner gradient ends at the latents
+        try:
+            (g,) = torch.autograd.grad((img * (noise * self.pl_noise_scaler)).sum(), style, create_graph=True)
+        finally:
+            ops.FLAGS.no_filter_grads = False
         lengths = g.square().sum(dim=2).mean(dim=1).sqrt()
         with torch.no_grad():  # assigned BEFORE use, read back as a constant (:336-342)
             self.pl_mean.copy_(self.pl_mean + self.pl_decay * (lengths.mean() - self.pl_mean))
@@ -458,7 +462,11 @@ class TrainingStep:
         """training_step.py:349-373."""
         real = real_images.detach().clone().requires_grad_(True)
         real_scores = self.discriminator(real, mode="composable")
-        (g,) = torch.autograd.grad(real_scores.sum(), real, create_graph=True)
+        ops.FLAGS.no_filter_grads = True  # this inner gradient ends at the image
+        try:
+            (g,) = torch.autograd.grad(real_scores.sum(), real, create_graph=True)
+        finally:
+            ops.FLAGS.no_filter_grads = False
         pen = g.square().sum(dim=(1, 2, 3)) * (0.5 * self.r1_gamma) * self.d_reg_interval
         return real_scores, pen.sum() / self.batch_size
 
