@@ -702,6 +702,22 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     TW = pow2ceil(maxVg) < twmax ? pow2ceil(maxVg) : (twmax < BN ? twmax : BN);
     const int TR = BN / TW;
     THs = pow2ceil(maxUg) < TR ? pow2ceil(maxUg) : TR;
+    if (d->transposed && !merged && attempt == 0 && variant != 4) {
+      // Output-parity class grids are (H + 1) x (W + 1): 33 rows in tiles of 8 are 40 (+21 %), 17 in tiles of 4 are 20.  Lower
+      // tiles (several images per tile instead) pad less but re-load the halo row(s) more often: pick the tile height with the
+      // smallest padded-rows x halo-overhead product.  variant 8 / 9 force one / two halvings (measurement aid).
+      int best = THs;
+      if (variant == 8 || variant == 9) {
+        for (int k = 0; k < variant - 7 && best > 1; ++k) best >>= 1;
+      } else {
+        double bestc = 1e30;
+        for (int t = THs; t >= 1; t >>= 1) {
+          const double c = (double)ceil_div(maxUg, t) * t * (1.0 + 0.25 * (maxKH - 1) / t);
+          if (c < bestc * 0.999) { bestc = c; best = t; }
+        }
+      }
+      THs = best;
+    }
     p.logTW = ilog2(TW); p.logTHs = ilog2(THs); p.NSEG = TR / THs;
     p.IHs = (THs - 1) * p.sy + maxKH;
     p.IWs = (TW - 1) * p.sx + maxKW;
@@ -782,7 +798,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
     if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
     return launch_fprop<2, 2, 2, 2, 16, 4>(p, st, maxtaps, maxTilesN, name);
   }
-  if (variant != 0 && variant != 4 && variant != 5) {  // explicit instantiation choice (tbg_conv2d_f32_variant: tuning / test aid, stateless)
+  if (variant != 0 && variant != 4 && variant != 5 && variant < 8) {  // explicit instantiation choice (tbg_conv2d_f32_variant: tuning / test aid, stateless)
     if (variant == 1 && p.NJ <= 3) {  // software-pipelined
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 8, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 4, MAXTAPS, 3>(p, st, maxtaps, maxTilesN, name);
@@ -828,7 +844,7 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
 
 extern "C" int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                                       const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant < 0 || variant > 6) return TBG_EINVAL;
+  if (variant < 0 || variant == 7 || variant > 9) return TBG_EINVAL;
   return conv2d_impl(d, x, w, y, in_scale, epi, stream, nullptr, false, variant);
 }
 

@@ -17,13 +17,13 @@ L = [("G up 32x128 128->128", 128, 128, 32, 128), ("G up 16x64 256->128", 256, 1
      ("D dgrad 32x128 128->64", 128, 64, 32, 128), ("D dgrad 16x64 128->128", 128, 128, 16, 64), ("D dgrad 8x32 256->128", 256, 128, 8, 32),
      ("D dgrad 4x16 256->256", 256, 256, 4, 16)]
 for B, bf in ((16, False), (32, True)):
-    print(f"--- B={B} {'bf16' if bf else 'fp32'}: TFLOP/s merged (variant 5) | [fp32 only: merged with 16-channel chunks (variant 6)] | per-class (variant 4)")
+    print(f"--- B={B} {'bf16' if bf else 'fp32'}: TFLOP/s auto | per-class, full-height tiles (variant 4) | [fp32: tile height / 2 (8) | / 4 (9)] | merged (5)")
     for name, C, M, H, W in L:
         x = torch.randn(B, C, H, W, device=dev)
         wp = ops.pack_filter(torch.randn(3, 3, C, M, device=dev), False, False, bf16=bf)
         flops = 2.0 * B * C * M * 9 * H * W
         row = f"{name:28s}"
-        for v in ((5, 6, 4) if not bf else (5, 4)):
+        for v in ((0, 4, 8, 9, 5) if not bf else (0, 4, 5)):
             ops.FORCE_VARIANT = v
             t = timeit(lambda: ops.conv2d_raw(x, wp, M, 3, 3, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, flip=True))
             row += f" {flops / t / 1e9:7.1f}"
