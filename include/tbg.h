@@ -142,7 +142,8 @@ int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, 
  * variant 0 = the library's choice, 1 = software-pipelined (double-buffered LDS), 2 = plain 8-channel chunks,
  * 3 = 4-channel chunks at 4 waves/SIMD (128x128 tile only), 4 / 5 = stride-2 transposed 3x3 as one block per output-parity
  * class / as the merged-class kernel (all four classes from one staged halo tile), 6 = the merged-class kernel with
- * 16-channel chunks (fp32 only).  TBG_EUNSUPPORTED if the descriptor cannot take it. */
+ * 16-channel chunks (fp32 only), 8 / 9 = the per-class form with the tile height halved once / twice (variant 4 keeps the
+ * full-height tiles; 0 picks the height by padded rows x halo overhead).  TBG_EUNSUPPORTED if the descriptor cannot take it. */
 int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                            const float *in_scale, const tbg_epilogue *epi, int variant, void *stream);
 
