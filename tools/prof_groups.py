@@ -9,7 +9,10 @@ def family(n):
     if "upfirdn" in n: return "tbg upfirdn2d"
     if "bias_act" in n: return "tbg bias_act"
     if "rgb_" in n: return "tbg rgb"
-    if "weight_transpose" in n or "demod" in n or "wsq" in n or "adam" in n or "ema_" in n: return "tbg misc (transpose/demod/adam/ema)"
+    if "slab_epilogue" in n: return "tbg split-K epilogue"
+    if "lstm_step" in n or "attn_ctx" in n: return "tbg OCR recurrent (lstm_step / attn_ctx)"
+    if "dense_" in n or "smalls" in n or "mbstd" in n: return "tbg small-tensor kernels (dense / tails / mbstd)"
+    if "weight_pack" in n or "weight_transpose" in n or "demod" in n or "wsq" in n or "adam" in n or "ema_" in n: return "tbg misc (pack/demod/adam/ema)"
     if n.startswith("Cijk") or "gemm" in n.lower(): return "rocBLAS/hipBLASLt GEMM"
     if "LSTM" in n or "miopen" in n.lower() or "MIOpen" in n or "Im2d" in n or "Col2Im" in n or "batched_transpose" in n or "SubTensor" in n or "naive_conv" in n or "ck::" in n: return "MIOpen (LSTM etc.)"
     if "FillFunctor" in n: return "torch fill"

@@ -11,4 +11,6 @@ cd /tmp && export TMPDIR=/tmp
 (cd $R && python tools/prof_summary.py /tmp/prof_${TAG}_bench 45 > $R/gpurun_out/${TAG}_bench_kernel_stats.txt)
 (cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_roof -o r -- python bench.py --roofline-only --steps 4 --warmup 2 > $R/gpurun_out/${TAG}_roofline.json 2> /tmp/prof_${TAG}_roof.log)
 (cd $R && python tools/prof_summary.py /tmp/prof_${TAG}_roof 30 > $R/gpurun_out/${TAG}_roofline_kernel_stats.txt)
+# the same pass by kernel family, per step (6 eager non-regularised steps: 2 warm-up + 4)
+(cd $R && python tools/prof_groups.py /tmp/prof_${TAG}_roof 6 > $R/gpurun_out/${TAG}_roofline_groups.txt)
 head -8 $R/gpurun_out/${TAG}_roofline_kernel_stats.txt | cut -c1-170
