@@ -178,18 +178,18 @@ class ModulatedConv2D(nn.Module):
             return None
         if mode == "fused":
             return ops.demod_coefs(s, self.w)
-        wsq = (self.w * _coef(self.w.shape)).square().sum(dim=(0, 1))
+        wsq = self.w.square().sum(dim=(0, 1)) * (_coef(self.w.shape) ** 2)  # (coef w)^2 summed over the taps
         return torch.rsqrt(s.square() @ wsq + 1e-8)
 
     def conv_composable(self, x, s, d):
         """any-order path: x*s -> conv / up-conv+FIR -> *d   (the reference's CPU branch :94-96,:119-121)."""
-        wc = self.w * _coef(self.w.shape)
+        coef = _coef(self.w.shape)  # rides along as the primitives' alpha: no elementwise pass over the filter
         xs = x * s[:, :, None, None]
         if self.up:
-            y = ops.conv_transpose2d_s2(xs, torch.flip(wc, (0, 1)))
+            y = ops.conv_transpose2d_s2(xs, torch.flip(self.w, (0, 1)), alpha=coef)
             y = ops.upfirdn2d(y, ops.fir_kernel(x.device, 4.0), pad=(1, 1, 1, 1))
         else:
-            y = ops.conv2d(xs, wc, (1, 1), (self.k // 2, self.k // 2))
+            y = ops.conv2d(xs, self.w, (1, 1), (self.k // 2, self.k // 2), alpha=coef)
         if d is not None:
             y = y * d[:, :, None, None]
         return y
@@ -330,7 +330,7 @@ class FromRGB(nn.Module):
     def forward(self, x, mode="fused"):
         if mode == "fused":
             return ops.conv_bias_act_fused(x, self.conv.w, self.apply_bias_act.b, role="d_image")
-        return self.apply_bias_act(ops.conv2d(x, self.conv.w * _coef(self.conv.w.shape)))
+        return self.apply_bias_act(ops.conv2d(x, self.conv.w, alpha=_coef(self.conv.w.shape)))
 
 
 class DiscriminatorBlock(nn.Module):
@@ -357,10 +357,10 @@ class DiscriminatorBlock(nn.Module):
             tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3), role="d")  # conv_downsample_2d, upfirdn_2d_v2.py:106-113
             u = ops.conv_bias_act_fused(tb, self.conv_1.w, self.apply_bias_act_1.b, stride=(sh, 2), role="d")
             return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=rs, role="d")
-        t = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w * _coef(self.conv_0.w.shape), (1, 1), (1, 1)))
+        t = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w, (1, 1), (1, 1), alpha=_coef(self.conv_0.w.shape)))
         tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3))
-        u = self.apply_bias_act_1(ops.conv2d(tb, self.conv_1.w * _coef(self.conv_1.w.shape), (sh, 2)))
-        skip = ops.conv2d(xd, self.conv_skip.w * _coef(self.conv_skip.w.shape))
+        u = self.apply_bias_act_1(ops.conv2d(tb, self.conv_1.w, (sh, 2), alpha=_coef(self.conv_1.w.shape)))
+        skip = ops.conv2d(xd, self.conv_skip.w, alpha=_coef(self.conv_skip.w.shape))
         return (u + skip) * rs
 
 
@@ -394,7 +394,7 @@ class DiscriminatorLastBlock(nn.Module):
                                       self.apply_bias_act_1.lrmul, lrelu=True)
         assert parts == 1
         x = minibatch_std(x, 4).contiguous()
-        x = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w * _coef(self.conv_0.w.shape), (1, 1), (1, 1)))
+        x = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w, (1, 1), (1, 1), alpha=_coef(self.conv_0.w.shape)))
         return self.apply_bias_act_1(self.dense_1(x))
 
 

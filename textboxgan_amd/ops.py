@@ -630,69 +630,75 @@ def _bwd_weight_launch(x, dy, g: _Geom, I, O, alpha=1.0, x_scale=None, dy_scale=
 
 
 class _Conv2d(torch.autograd.Function):
+    """y = alpha * conv(x, w).  The three primitives (forward, data gradient, filter gradient) are each other's derivatives,
+    so the family is closed under differentiation to any order; the scalar alpha (the equalised-LR coefficient) rides along
+    instead of being a separate elementwise pass over the filter in every order of derivative."""
+
     @staticmethod
-    def forward(ctx, x, w, g):
+    def forward(ctx, x, w, g, alpha=1.0):
         ctx.save_for_backward(x, w)
-        ctx.g = g
-        return _fwd_launch(x.contiguous(), w.contiguous(), g)
+        ctx.g, ctx.alpha = g, alpha
+        return _fwd_launch(x.contiguous(), w.contiguous(), g, alpha)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dx = _Conv2dBwdData.apply(dy, w, ctx.g) if ctx.needs_input_grad[0] else None
-        dw = _Conv2dBwdWeight.apply(x, dy, ctx.g) if (ctx.needs_input_grad[1] and not FLAGS.no_filter_grads) else None
-        return dx, dw, None
+        dx = _Conv2dBwdData.apply(dy, w, ctx.g, ctx.alpha) if ctx.needs_input_grad[0] else None
+        dw = (_Conv2dBwdWeight.apply(x, dy, ctx.g, ctx.alpha)
+              if (ctx.needs_input_grad[1] and not FLAGS.no_filter_grads) else None)
+        return dx, dw, None, None
 
 
 class _Conv2dBwdData(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dy, w, g):
+    def forward(ctx, dy, w, g, alpha=1.0):
         ctx.save_for_backward(dy, w)
-        ctx.g = g
-        return _bwd_data_launch(dy.contiguous(), w.contiguous(), g)
+        ctx.g, ctx.alpha = g, alpha
+        return _bwd_data_launch(dy.contiguous(), w.contiguous(), g, alpha)
 
     @staticmethod
     def backward(ctx, gdx):
         dy, w = ctx.saved_tensors
-        g_dy = _Conv2d.apply(gdx, w, ctx.g) if ctx.needs_input_grad[0] else None
-        g_w = _Conv2dBwdWeight.apply(gdx, dy, ctx.g) if (ctx.needs_input_grad[1] and not FLAGS.no_filter_grads) else None
-        return g_dy, g_w, None
+        g_dy = _Conv2d.apply(gdx, w, ctx.g, ctx.alpha) if ctx.needs_input_grad[0] else None
+        g_w = (_Conv2dBwdWeight.apply(gdx, dy, ctx.g, ctx.alpha)
+               if (ctx.needs_input_grad[1] and not FLAGS.no_filter_grads) else None)
+        return g_dy, g_w, None, None
 
 
 class _Conv2dBwdWeight(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, dy, g):
+    def forward(ctx, x, dy, g, alpha=1.0):
         ctx.save_for_backward(x, dy)
-        ctx.g = g
-        return _bwd_weight_launch(x.contiguous(), dy.contiguous(), g, x.shape[1], dy.shape[1])
+        ctx.g, ctx.alpha = g, alpha
+        return _bwd_weight_launch(x.contiguous(), dy.contiguous(), g, x.shape[1], dy.shape[1], alpha)
 
     @staticmethod
     def backward(ctx, gw):
         x, dy = ctx.saved_tensors
         gw = gw.contiguous()
-        g_x = _Conv2dBwdData.apply(dy, gw, ctx.g) if ctx.needs_input_grad[0] else None
-        g_dy = _Conv2d.apply(x, gw, ctx.g) if ctx.needs_input_grad[1] else None
-        return g_x, g_dy, None
+        g_x = _Conv2dBwdData.apply(dy, gw, ctx.g, ctx.alpha) if ctx.needs_input_grad[0] else None
+        g_dy = _Conv2d.apply(x, gw, ctx.g, ctx.alpha) if ctx.needs_input_grad[1] else None
+        return g_x, g_dy, None, None
 
 
-def conv2d(x, w, stride=(1, 1), pad=(0, 0)):
-    """y[b,o] = sum x[b,i, oy*s-p+kh, ox*s-p+kw] w[kh,kw,i,o]  (HWIO filter)."""
+def conv2d(x, w, stride=(1, 1), pad=(0, 0), alpha=1.0):
+    """y[b,o] = alpha * sum x[b,i, oy*s-p+kh, ox*s-p+kw] w[kh,kw,i,o]  (HWIO filter)."""
     KH, KW = w.shape[0], w.shape[1]
     H, W = x.shape[2], x.shape[3]
     yhw = ((H + 2 * pad[0] - KH) // stride[0] + 1, (W + 2 * pad[1] - KW) // stride[1] + 1)
     if stride != (1, 1):
         assert pad == (0, 0)
-    return _Conv2d.apply(x, w, _Geom(tuple(stride), tuple(pad), KH, KW, (H, W), yhw))
+    return _Conv2d.apply(x, w, _Geom(tuple(stride), tuple(pad), KH, KW, (H, W), yhw), float(alpha))
 
 
-def conv_transpose2d_s2(x, wt):
-    """y[b,o,2a+kh,2b'+kw] += x[b,i,a,b'] wt[kh,kw,i,o]: the data gradient of a stride-2 VALID conv whose
+def conv_transpose2d_s2(x, wt, alpha=1.0):
+    """y[b,o,2a+kh,2b'+kw] += alpha * x[b,i,a,b'] wt[kh,kw,i,o]: the data gradient of a stride-2 VALID conv whose
     'input channels' are o -- expressed with the same primitive so it stays differentiable."""
     KH, KW = wt.shape[0], wt.shape[1]
     H, W = x.shape[2], x.shape[3]
     yhw = ((H - 1) * 2 + KH, (W - 1) * 2 + KW)
     g = _Geom((2, 2), (0, 0), KH, KW, yhw, (H, W))
-    return _Conv2dBwdData.apply(x, wt.transpose(2, 3).contiguous(), g)
+    return _Conv2dBwdData.apply(x, wt.transpose(2, 3).contiguous(), g, float(alpha))
 
 
 # ----------------------------------------------------------------------------------------
