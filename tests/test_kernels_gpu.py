@@ -560,7 +560,7 @@ def test_demod_coefs(dev):
 def test_modconv_bwd_smalls(dev):
     """tbg_modconv_bwd_smalls_f32 == the torch composition it replaces (modulated_conv2d.py:78-82), float64."""
     from textboxgan_amd import ops
-    for B, I, O, nch in ((16, 512, 512, 1), (5, 24, 40, 3), (32, 128, 128, 4)):
+    for B, I, O, nch in ((16, 512, 512, 1), (5, 24, 40, 3), (32, 128, 128, 4), (16, 128, 130, 16), (7, 30, 1030, 2)):
         pdb, pdn, pdy = rnd(B, O, nch, seed=90), rnd(B, O, nch, seed=91), rnd(B, O, nch, seed=92)
         d, s = rnd(B, O, seed=93).abs() + 0.5, rnd(B, I, seed=94) + 1.0
         wsq, ds_conv = rnd(I, O, seed=95).abs(), rnd(B, I, seed=96)

@@ -26,15 +26,25 @@ __global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP
   if ((int)blockIdx.x >= nI) {  // ---- bias / noise-strength gradients: blocks nI .. nI + ceil(O/256) - 1
     __shared__ float red[4];
     const int o = ((int)blockIdx.x - nI) * 256 + tid;
-    if (o < p.O) {
-      float a = 0.f;
-      for (int b = 0; b < p.B; ++b)
-        for (int c = 0; c < p.nch; ++c) a += p.pdb[((size_t)b * p.O + o) * p.nch + c];
-      p.db[o] = a;
+    if (o < p.O) {  // four samples per trip: independent load chains (a single chain was one round trip per element)
+      float a4[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < p.B; b += 4)
+        for (int c = 0; c < p.nch; ++c) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (b + u < p.B) a4[u] += p.pdb[((size_t)(b + u) * p.O + o) * p.nch + c];
+        }
+      p.db[o] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
     if ((int)blockIdx.x == nI && p.pdn) {
-      float a = 0.f;
-      for (int i = tid; i < p.B * p.O * p.nch; i += 256) a += p.pdn[i];
+      float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int n = p.B * p.O * p.nch;
+      for (int i = tid; i < n; i += 256 * 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i + 256 * u < n) a8[u] += p.pdn[i + 256 * u];
+      }
+      float a = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
       a = wave_sum(a);
       if ((tid & 63) == 0) red[tid >> 6] = a;
       __syncthreads();
@@ -47,15 +57,38 @@ __global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP
   float *s2 = wq + MS_IT * p.O;           // [B][MS_IT]
   float *part = s2 + p.B * MS_IT;         // [B][MS_IT][4] partial dots
   const int i0 = blockIdx.x * MS_IT;
-  for (int e = tid; e < p.B * p.O; e += 256) {
-    float a = 0.f;
-    for (int c = 0; c < p.nch; ++c) a += p.pdy[(size_t)e * p.nch + c];
-    const float dv = p.d[e];
-    t[e] = a * dv * dv;
+  {  // t[b,o]: four (b,o) entries per trip, their partial-sum loads in flight together (the one-entry-per-trip loop was a
+     // chain of B*O/256 dependent round trips -- most of this kernel's 29 us)
+    const int BO = p.B * p.O;
+    for (int e0 = tid; e0 < BO; e0 += 256 * 4) {
+      float a4[4] = {0.f, 0.f, 0.f, 0.f}, dv[4];
+      int ee[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ee[u] = min(e0 + 256 * u, BO - 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dv[u] = p.d[ee[u]];
+      for (int c = 0; c < p.nch; ++c) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a4[u] += p.pdy[(size_t)ee[u] * p.nch + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e0 + 256 * u < BO) t[e0 + 256 * u] = a4[u] * dv[u] * dv[u];
+    }
   }
-  for (int e = tid; e < MS_IT * p.O; e += 256) {
-    const int ii = e / p.O, o = e - ii * p.O;
-    wq[e] = (i0 + ii < p.I) ? p.wsq[(size_t)(i0 + ii) * p.O + o] : 0.f;
+  for (int e0 = tid; e0 < MS_IT * p.O; e0 += 256 * 8) {  // 8 loads in flight per lane
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = min(e0 + 256 * u, MS_IT * p.O - 1);
+      const int ii = e / p.O, o = e - ii * p.O;
+      v[u] = p.wsq[(size_t)min(i0 + ii, p.I - 1) * p.O + o];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u;
+      if (e < MS_IT * p.O) wq[e] = (i0 + e / p.O < p.I) ? v[u] : 0.f;
+    }
   }
   for (int e = tid; e < p.B * MS_IT; e += 256) {
     const int b = e / MS_IT, ii = e - b * MS_IT;
