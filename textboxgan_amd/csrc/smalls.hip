@@ -303,8 +303,28 @@ __device__ __forceinline__ void dense_fwd_body(const DenseP &p, const int bx, co
     const int k = kq * DN_KT + j;
     wv[j] = (k < p.K) ? p.w[(size_t)k * p.N + nc] : 0.f;
   }
-  // x rows: batches of 8 loads per lane in flight (a load-store-load-store loop is one HBM round trip per element)
-  for (int e0 = tid; e0 < DN_RT * KP; e0 += 256 * 8) {
+  // x rows.  Rows of whole 16-byte units: float4 loads, 8 per lane in flight (ONE round for K <= 512); the tail of the padded
+  // row (k >= K) is zero-filled by the scalar loop below
+  const bool xvec = (p.K & 3) == 0 && (p.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0;
+  if (xvec) {
+    const int KQ = KP >> 2;  // quads per padded row (KP % 4 == 0)
+    for (int e0 = tid; e0 < DN_RT * KQ; e0 += 256 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u;
+        const int r = e / KQ, kk = (e - r * KQ) * 4;
+        const bool ok = e < DN_RT * KQ && r0 + r < p.R && kk < p.K;
+        v[u] = *reinterpret_cast<const float4 *>(p.x + (ok ? (size_t)(r0 + r) * p.ldx + kk : 0));
+        if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + 256 * u < DN_RT * KQ) *reinterpret_cast<float4 *>(xs + (size_t)(e0 + 256 * u) * 4) = v[u];
+    }
+  }
+  // scalar form: batches of 8 loads per lane in flight (a load-store-load-store loop is one HBM round trip per element)
+  for (int e0 = tid; !xvec && e0 < DN_RT * KP; e0 += 256 * 8) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
