@@ -165,28 +165,31 @@ def roofline_record(recs, dtype="f32"):
     convs = {k: v for k, v in recs.items() if k.startswith("conv_")}
     name, r = max(((k, v) for k, v in convs.items() if "fprop" in k), key=lambda kv: kv[1]["ms"])
     achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+    # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 --pmc passes over
+    # `bench.py --roofline-only` (tools/pmc_report.sh, tools/make_traffic_json.py), matched by kernel instantiation; null if
+    # none is committed
+    traffic, traffic_src, mfma_busy = None, None, None
+    try:
+        tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "latest_traffic.json")))
+        if name in tj["kernels"]:
+            traffic = tj["kernels"][name]["hbm_bytes_per_launch"]
+            traffic_src = tj["kernels"][name].get("source", tj["source"])
+            mfma_busy = tj["kernels"][name].get("mfma_busy")
+    except (OSError, ValueError, KeyError):
+        pass
     if dtype == "bf16":
         # bf16-in MFMA with fp32 tensors in HBM: the dominant 3x3 convolutions sit below the bf16 ridge (SURVEY 8(d):
         # ~288 FLOP/B of fp32 traffic vs a ridge of 2500/8 = 312), so the bounding roof is HBM; both fractions are reported.
         tbs = r["bytes"] / (r["ms"] * 1e-3) / 1e12
         return {"bound": "hbm", "kernel": name, "achieved": round(tbs * 1e3, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
-                "frac": round(tbs / HBM_PEAK_TBS, 4), "traffic": None, "algorithmic_bytes": round(r["bytes"] / r["n"]),
+                "frac": round(tbs / HBM_PEAK_TBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "mfma_busy_pmc": mfma_busy, "algorithmic_bytes": round(r["bytes"] / r["n"]),
                 "launches": r["n"], "avg_launch_us": round(1e3 * r["ms"] / r["n"], 2),
                 "gflop_per_launch": round(r["flops"] / r["n"] / 1e9, 3), "achieved_tflops": round(achieved, 2),
                 "mfma_peak_tflops": BF16_MFMA_PEAK_TFLOPS, "frac_of_mfma_peak": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
                 "all_kernels": {k: {"n": v["n"], "ms": round(v["ms"], 3),
                                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                     "tb_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e12, 3)} for k, v in convs.items()}}
-    # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 --pmc passes over
-    # `bench.py --roofline-only` (tools/pmc_traffic.sh), matched by kernel instantiation; null if none is committed
-    traffic, traffic_src, mfma_busy = None, None, None
-    try:
-        tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "latest_traffic.json")))
-        if name in tj["kernels"]:
-            traffic, traffic_src = tj["kernels"][name]["hbm_bytes_per_launch"], tj["source"]
-            mfma_busy = tj["kernels"][name].get("mfma_busy")
-    except (OSError, ValueError, KeyError):
-        pass
     hbm = {}
     for k, v in recs.items():
         if not k.startswith("conv_") and v["bytes"] > 0 and v["ms"] > 0:

@@ -1,6 +1,7 @@
 """profiles/<tag>_pmc_report.txt (tools/pmc_report.sh) -> profiles/latest_traffic.json, the file bench.py reads
 roofline.traffic / mfma_busy_pmc from (PMC counters cannot be read from inside the process).
-usage: python tools/make_traffic_json.py profiles/r02_pmc_report.txt"""
+usage: python tools/make_traffic_json.py profiles/<tag>_pmc_report.txt [profiles/<tag>_bf16_pmc_conv.txt]
+(the optional second file: the bf16 pass, `name launches N hbm_MB X mfma_busy Y` lines)"""
 import json, re, sys
 src = sys.argv[1]
 kern = {}
@@ -17,6 +18,12 @@ for line in open(src):
         continue
     kern[name] = {"launches": int(calls), "avg_us": float(avg), "hbm_bytes_per_launch": int(float(mb) * 1e6),
                   "hbm_GBps": float(gbs), "mfma_busy": None if busy == "nan" else float(busy)}
+if len(sys.argv) > 2:  # bf16 instantiations (separate PMC passes over `bench.py --dtype bf16 --roofline-only`)
+    for line in open(sys.argv[2]):
+        m = re.match(r"(?:void )?(.*?)\((?:ConvP|WgradP)\)\s+launches\s+(\d+) hbm_MB\s+([\d.]+) mfma_busy\s+([\d.naN]+)", line)
+        if m:
+            kern[m.group(1).strip()] = {"launches": int(m.group(2)), "hbm_bytes_per_launch": int(float(m.group(3)) * 1e6),
+                                        "mfma_busy": None if m.group(4) == "nan" else float(m.group(4)), "source": sys.argv[2]}
 json.dump({"source": src, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE "
            "(separate passes) -- python bench.py --roofline-only --steps 2 --warmup 1",
            "correction": "(2 x FETCH_SIZE + WRITE_SIZE) KiB -> bytes, MI355X_MICROARCH.md HBM section", "kernels": kern},
