@@ -213,8 +213,30 @@ int tbg_conv2d_wgrad_bf16(const tbg_wgrad_desc *d, const float *S, const float *
                           long long workspace_bytes, void *stream);
 int tbg_conv2d_wgrad_bf16_kernel_name(const tbg_wgrad_desc *d, char *buf, int n);
 
+/* ------------------------------------------------------------------------------------------
+ * "f32x3" forms: fp32 results from the bf16 matrix pipe by exact operand splitting.  Every fp32 operand is written as
+ * the sum of three bf16 terms hi + mid + lo (3 x 8 significand bits = fp32's 24); products of bf16 values are exact in
+ * fp32, and the six largest of the nine partial products (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) are accumulated
+ * in fp32 by v_mfma_f32_32x32x16_bf16 -- the dropped terms are <= 2^-24 relative, i.e. the result carries fp32-grade
+ * error (measured against float64 it is slightly BETTER than the k-ordered fmaf chain of v_mfma_f32_32x32x2_f32) at 96
+ * instead of 256 matrix cycles per 8 channels.  Same tensors (fp32 in HBM), descriptors, epilogues, split-K slabs and error
+ * codes as tbg_conv2d_f32; the filter is packed by tbg_weight_pack_x3 as three bf16 planes Wp[3][T][ceil(C/8)][M][8]
+ * (tbg_weight_pack_x3_bytes bytes), the activations are split while they are staged into LDS.  Non-finite operands give
+ * NaN where fp32 arithmetic would give Inf (Inf - Inf in the split).
+ * ---------------------------------------------------------------------------------------- */
+long long tbg_weight_pack_x3_bytes(int T, int I, int O, int transpose);
+int tbg_weight_pack_x3(const float *src, void *dst, int T, int I, int O, int transpose, int flip, void *stream);
+int tbg_conv2d_x3(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,
+                  const tbg_epilogue *epi, void *stream);
+int tbg_conv2d_x3_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
+/* explicit form of the stride-2 transposed 3x3 launches (tuning / test aid): 0 = library's choice, 4 / 5 = class-per-block /
+ * merged-class. */
+int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,
+                          const tbg_epilogue *epi, int variant, void *stream);
+
 /* Multi-tensor filter packing: items_dev is a DEVICE array of n_items descriptors; item k is packed exactly as
- * tbg_weight_pack_f32 (bf16 = 0) / tbg_weight_pack_bf16 (bf16 = 1) would pack (src, dst, T, I, O, transpose, flip).
+ * tbg_weight_pack_f32 (bf16 = 0) / tbg_weight_pack_bf16 (bf16 = 1) / tbg_weight_pack_x3 (bf16 = 2) would pack
+ * (src, dst, T, I, O, transpose, flip).
  * One launch for all filters of a model (the training step refreshes its packed filters once per step). */
 typedef struct tbg_pack_item {
   const float *src; /* HWIO parameter [T][I][O] */

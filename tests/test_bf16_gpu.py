@@ -333,7 +333,7 @@ def test_merged_class_transposed_kernel(dev, case, bf16):
     if bf16 and B * H * W >= 16384:  # the library picks the merged form by itself here
         from textboxgan_amd import native as N
         d = N.ConvDesc(B, Cc, Mo, H, W, 2 * H + 1, 2 * W + 1, 3, 3, 2, 2, 0, 0, 1, 0, Mo, 1)
-        assert N.conv_kernel_name(d, True, True).endswith("true, true>")
+        assert N.conv_kernel_name(d, True, True).endswith("true, true, false>")
         with ops.compute_dtype("bf16"):
             y3 = ops.conv2d_raw(f(x), f(w), Mo, 3, 3, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, in_scale=f(s))
         assert rel_err(y3, ref) < 3e-5

@@ -520,7 +520,7 @@ class AsterLikeOCRHip(AsterLikeOCR):
         from . import ops
         if not x.is_cuda:
             raise RuntimeError("AsterLikeOCRHip runs on the GPU only (use AsterLikeOCR for the CPU definition)")
-        key = (id(blk), ops.is_bf16())  # the packed filters are dtype specific
+        key = (id(blk), ops.compute_mode())  # the packed filters are dtype specific
         if key not in self._cache:
             with torch.no_grad():
                 w, b = blk.folded()

@@ -41,6 +41,20 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const float (&v)[8]) {
   return r;
 }
 
+// fp32 -> three bf16 terms hi + mid + lo (8 + 8 + 8 significand bits: exact for every fp32 value whose low terms stay
+// in the normal range).  Products of two bf16 values are exact in fp32, so the six largest partial products of
+// (a_hi + a_mid + a_lo)(b_hi + b_mid + b_lo) reproduce a * b to ~2^-24 relative -- the "f32x3" arithmetic of the X3 kernels.
+__device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 bh = (__bf16)v[i];
+    const float r1 = v[i] - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    const float r2 = r1 - (float)bm;
+    h[i] = bh; m[i] = bm; l[i] = (__bf16)r2;
+  }
+}
+
 #define MAXCLS 4
 #define MAXTAPS 9
 #define MAXNJ 6
@@ -64,6 +78,7 @@ struct ConvP {
   int nclass, ksplit, nchunks, cps;
   long long slab;  // elements per split-K slab (= B*M*Hout*Wout)
   int a_floats, ck_rt;
+  int wplane;  // X3: floats between two planes (hi | mid | lo) of the packed filter
   ClassInfo cls[MAXCLS];
   EpiK e;
 };
@@ -82,26 +97,35 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // accumulates into class (kh&1, kw&1) -- 4 x (WTM x WTN) accumulator tiles -- reading x[u - (kh==2), v - (kw==2)].  Same MFMA
 // count as a 3x3 stride-1 convolution on the input grid and no per-class re-staging (the class-per-block form staged the
 // halo four times and ran 1/2/2/4-tap K loops).  Store-only epilogue (alpha * acc; split-K slabs allowed).
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF, int OCC = 3, bool BF = false, bool TM = false>
+// X3 = true (implies BF): "f32x3" -- fp32 operands split into three bf16 terms each (split3_bf16x8) and contracted on the bf16
+// pipe: per 8-channel unit THREE v_mfma_f32_32x32x16_bf16 whose two K halves carry different term pairs
+//     half-wave 0 / 1:   A (hi | mid) x B hi,   A (hi | mid) x B mid,   A (hi | lo) x B (lo | hi)
+// = the six largest of the nine partial products (hh, mh, hm, mm, hl, lh; the dropped ones are <= 2^-24 relative), fp32
+// accumulate: fp32-grade results at 3 bf16 MFMAs per 8 channels = 96 matrix cycles instead of 256 for v_mfma_f32_32x32x2_f32.
+// LDS holds three planes of the filter slice (packed hi | mid | lo by tbg_weight_pack_x3, DMA'd) and three of the halo tile
+// (split while staging); 2 A reads + 3 B reads per sub-tile row / column feed the three MFMAs.
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF, int OCC = 3, bool BF = false, bool TM = false, bool X3 = false>
 __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   constexpr int BM = WGM * WTM * 32;
   constexpr int NC = TM ? 4 : 1;            // accumulator sets (output-parity classes of the merged transposed form)
   static_assert(!TM || (PF == 0 && CK >= 8 && MT == 9), "merged transposed form: 9 taps, plain K loop");
+  static_assert(!X3 || BF, "the split-operand form runs on the bf16 pipe");
   constexpr int KP = BF ? 8 : 4;            // channels per 16-byte unit
+  constexpr int NP = X3 ? 3 : 1;            // operand planes in LDS
   constexpr int G4 = (CK + KP - 1) / KP;    // units (fp32: channel quads, bf16: octets) per chunk
   constexpr int CB = CK < 8 ? CK : 8;       // channels per halo load batch
   constexpr int NB = PF ? 2 : 1;            // LDS buffers (PF > 0: software-pipelined K loop)
   constexpr int NJC = PF ? PF : MAXNJ;      // halo positions per thread this instance can hold
-  static_assert(BF ? (CK % 16 == 0 && PF == 0) : (CK == 4 || CK % 8 == 0),
-                "chunk = one quad (half-waves split it) or whole unit pairs (half-wave h reads unit 2o+h)");
+  static_assert(X3 ? (CK % 8 == 0 && PF == 0) : BF ? (CK % 16 == 0 && PF == 0) : (CK == 4 || CK % 8 == 0),
+                "chunk = one quad (half-waves split it) or whole unit pairs (half-wave h reads unit 2o+h); X3: whole units");
   static_assert(!PF || CK <= 8, "the pipelined variant prefetches one load batch");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *As = smem;                                    // [NB][tap][quad][BM][4]
-  float *Xs = smem + NB * p.a_floats;                  // [NB][quad][halo position][4]
-  float *Ss = Xs + NB * G4 * 4 * p.planeStride;        // [NSEG][C] style modulation of this block's images
-  const int xbuf_floats = G4 * 4 * p.planeStride;
+  float *As = smem;                                    // [NB][plane][tap][quad][BM][4]
+  float *Xs = smem + NB * NP * p.a_floats;             // [NB][plane][quad][halo position][4]
+  float *Ss = Xs + NB * NP * G4 * 4 * p.planeStride;   // [NSEG][C] style modulation of this block's images
+  const int xbuf_floats = G4 * 4 * p.planeStride;      // one plane of one X buffer
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -161,15 +185,16 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     const int q = n & TWm, rr = n >> p.logTW;
     const int seg = rr >> p.logTHs, r = rr & THm;
     const int pos = (seg * p.IHs + r * p.sy) * p.IWp + q;
-    bbytes[j] = CK == 4 ? pos * 16 + half * 8 : (half * p.planeStride + pos) * 16;
+    bbytes[j] = X3 ? pos * 16 : CK == 4 ? pos * 16 + half * 8 : (half * p.planeStride + pos) * 16;
   }
   int tofft;  // lane t holds the LDS shift of tap t: fetched with v_readlane in the tap loop (no memory, no SALU chain)
   {
     const int khp = lane / ci.KWc, kwp = lane - khp * ci.KWc;
     tofft = (khp * p.IWp + (p.sx == 2 ? (kwp & 1) * p.HALFW + (kwp >> 1) : kwp)) * 16;
   }
-  const int abytes = CK == 4 ? (wm * (WTM * 32) + (lane & 31)) * 16 + half * 8
-                             : (half * BM + wm * (WTM * 32) + (lane & 31)) * 16;
+  const int abytes = X3 ? (wm * (WTM * 32) + (lane & 31)) * 16
+                      : CK == 4 ? (wm * (WTM * 32) + (lane & 31)) * 16 + half * 8
+                                : (half * BM + wm * (WTM * 32) + (lane & 31)) * 16;
 
   f32x16 acc[NC][WTM][WTN];
 #pragma unroll
@@ -214,9 +239,12 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
       const int gq = uu / BM, mm = uu - gq * BM;
       if (t < ntaps) {
         const float *src = p.w + tapbase[it] + (min(kc * G4 + gq, C4 - 1) * p.ldw + min(m0 + mm, p.ldw - 1)) * 4;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(Abuf + (size_t)(256 * it + (wave << 6)) * 4),
-                                         16, 0, 0);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)pl * p.wplane),
+                                           (__attribute__((address_space(3))) void *)(Abuf + pl * p.a_floats +
+                                                                                      (size_t)(256 * it + (wave << 6)) * 4),
+                                           16, 0, 0);
       }
     }
   };
@@ -237,7 +265,13 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
       }
 #pragma unroll
       for (int cc = 0; cc < CB; ++cc) xv[cc] = (lane_ok && (c0 + cc) < p.C) ? xv[cc] : 0.f;
-      if constexpr (BF) {  // 8 channels of a position = one 16-byte unit of bf16
+      if constexpr (X3) {  // hi | mid | lo planes of the 8-channel unit
+        bf16x8 h8, m8, l8;
+        split3_bf16x8(xv, h8, m8, l8);
+        bf16x8 *X8 = reinterpret_cast<bf16x8 *>(Xbuf) + qb * p.planeStride + loff[j];
+        const int pstride = xbuf_floats / 4;  // 16-byte units per plane
+        X8[0] = h8; X8[pstride] = m8; X8[2 * pstride] = l8;
+      } else if constexpr (BF) {  // 8 channels of a position = one 16-byte unit of bf16
         reinterpret_cast<bf16x8 *>(Xbuf)[qb * p.planeStride + loff[j]] = pack_bf16x8(xv);
       } else {
         f32x4 *X4 = reinterpret_cast<f32x4 *>(Xbuf);
@@ -245,6 +279,37 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
         if constexpr (CB == 8) X4[(qb + 1) * p.planeStride + loff[j]] = f32x4{xv[4], xv[5], xv[6], xv[7]};
       }
     }
+  };
+  // X3: byte offsets of the operand planes this lane reads (half-wave h supplies K half h of each MFMA)
+  const int a_pl = p.a_floats * 4, x_pl = xbuf_floats * 4;
+  const int aX = half * a_pl, aY = 2 * half * a_pl;  // A: (hi | mid) and (hi | lo)
+  const int bZ = 2 * (1 - half) * x_pl;              // B of the third product pair: (lo | hi)
+  auto x3_unit = [&](f32x16 (&ac)[WTM][WTN], const char *Au, const char *Xu) {
+    bf16x8 ax[WTM], ay[WTM], b0[WTN], b1[WTN], b2[WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+      ax[i] = *reinterpret_cast<const bf16x8 *>(Au + aX + i * 32 * 16);
+      ay[i] = *reinterpret_cast<const bf16x8 *>(Au + aY + i * 32 * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      b0[j] = *reinterpret_cast<const bf16x8 *>(Xu + bbytes[j]);
+      b1[j] = *reinterpret_cast<const bf16x8 *>(Xu + x_pl + bbytes[j]);
+      b2[j] = *reinterpret_cast<const bf16x8 *>(Xu + bZ + bbytes[j]);
+    }
+    // smallest terms first: hi*lo + lo*hi, then hi*mid + mid*mid, then hi*hi + mid*hi
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay[i], b2[j], ac[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[i], b1[j], ac[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[i], b0[j], ac[i][j], 0, 0, 0);
   };
   auto mfma_taps = [&](const float *Abuf, const float *Xbuf) {
     const char *Ab = reinterpret_cast<const char *>(Abuf) + abytes;
@@ -258,6 +323,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
           const int t = kh * 3 + kw;
           const int c = (kh & 1) * 2 + (kw & 1);
           const int toffb = (kh == 2 ? 0 : rowb) + (kw == 2 ? 0 : 16);  // x[u - (kh==2), v - (kw==2)] inside the halo tile
+          if constexpr (X3) {
+#pragma unroll
+            for (int u = 0; u < CK / 8; ++u)
+              x3_unit(acc[c], Ab + ((t * G4 + u) * BM) * 16, Xb + toffb + u * p.planeStride * 16);
+          } else
 #pragma unroll
           for (int o = 0; o < CK / (2 * KP); ++o) {
             if constexpr (BF) {
@@ -295,7 +365,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     }
     for (int t = 0; t < ntaps; ++t) {
       const int toffb = __builtin_amdgcn_readlane(tofft, t);  // tap shift in bytes (lane t of the table)
-      if constexpr (BF) {
+      if constexpr (X3) {
+#pragma unroll
+        for (int u = 0; u < CK / 8; ++u)
+          x3_unit(acc[0], Ab + ((t * G4 + u) * BM) * 16, Xb + toffb + u * p.planeStride * 16);
+      } else if constexpr (BF) {
 #pragma unroll
         for (int o = 0; o < CK / 16; ++o) {  // half-wave h holds k = 8h .. 8h+7 = the 8 channels of unit 2o+h
           bf16x8 a[WTM], b[WTN];
@@ -571,7 +645,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
 // name-only mode (name != NULL): write the instantiation the descriptor selects (rocprofv3 spelling) and launch nothing
 struct NameOut { char *buf; int n; };
 
-template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false, bool TM = false>
+template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false, bool TM = false, bool X3 = false>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, const NameOut *name) {
   constexpr int BM = WGM * WTM * 32;
   constexpr int G4 = (CK + (BF ? 7 : 3)) / (BF ? 8 : 4);
@@ -580,16 +654,16 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
   p.ck_rt = CK;
   p.nchunks = ceil_div(p.C, CK);
   p.cps = ceil_div(p.nchunks, p.ksplit);  // splits past the last chunk run no K loop and store zeros: every slab is fully written
-  const size_t lds = ((size_t)(PF ? 2 : 1) * ((size_t)p.a_floats + (size_t)G4 * 4 * p.planeStride) +
+  const size_t lds = ((size_t)(PF ? 2 : 1) * (X3 ? 3 : 1) * ((size_t)p.a_floats + (size_t)G4 * 4 * p.planeStride) +
                       (p.in_scale ? (size_t)p.NSEG * p.C : 0)) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   if (maxtaps > MT) return TBG_EUNSUPPORTED;
   if (name) {
-    snprintf(name->buf, name->n, "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s>", WGM, WGN, WTM, WTN, CK, MT, PF, OCC,
-             BF ? "true" : "false", TM ? "true" : "false");
+    snprintf(name->buf, name->n, "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s>", WGM, WGN, WTM, WTN, CK, MT, PF,
+             OCC, BF ? "true" : "false", TM ? "true" : "false", X3 ? "true" : "false");
     return TBG_OK;
   }
-  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF, OCC, BF, TM>;
+  auto kern = conv_fprop_kernel<WGM, WGN, WTM, WTN, CK, MT, PF, OCC, BF, TM, X3>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return TBG_EHIP;
@@ -601,8 +675,10 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
 }
 
 
+// mode: 0 = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = bf16 operands, 2 = f32x3 (three bf16 terms per fp32 operand)
 static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, float *y, const float *in_scale,
-                       const tbg_epilogue *epi, void *stream, const NameOut *name, bool bf = false, int variant = 0) {
+                       const tbg_epilogue *epi, void *stream, const NameOut *name, int mode = 0, int variant = 0) {
+  const bool bf = mode == 1, x3 = mode == 2;
   if (!d || !epi_valid(epi)) return TBG_EINVAL;
   if (!name && (!x || !w || !y)) return TBG_EINVAL;
   if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1 || d->Hout < 1 || d->Wout < 1) return TBG_EINVAL;
@@ -628,6 +704,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   p.ldw = d->ldw;
   p.e = make_epi(epi);
   const int T = d->KH * d->KW;
+  p.wplane = T * ((d->C + 7) / 8) * d->ldw * 4;
   // merged form of the stride-2 transposed 3x3 convolution (see the TM template parameter): store-only epilogues
   const bool plain_epi = !epi || (!epi->out_scale && !epi->bias && !epi->noise && !epi->residual && !epi->dot_aux &&
                                   epi->act == TBG_ACT_LINEAR && epi->gain == 1.f);
@@ -637,7 +714,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   // form's 128x128 tiles at 3 waves/SIMD beat the merged form's 64x128 tiles at 2 waves/SIMD everywhere (76 vs 68).
   // variant 5 forces the merged form, variant 4 the per-class form.
   const bool merged = d->transposed && d->sy == 2 && d->sx == 2 && d->KH == 3 && d->KW == 3 && plain_epi && variant != 4 &&
-                      d->M > 32 && (variant == 5 || variant == 6 || (bf && (long long)d->B * d->Hin * d->Win >= 16384));
+                      d->M > 32 && (variant == 5 || variant == 6 || ((bf || x3) && (long long)d->B * d->Hin * d->Win >= 16384));
   int maxUg = 0, maxVg = 0, maxKH = 0, maxKW = 0, maxtaps = 0;
   if (!d->transposed) {
     p.sy = d->sy; p.sx = d->sx; p.osy = 1; p.osx = 1; p.nclass = 1;
@@ -750,6 +827,20 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   p.ksplit = d->ksplit;
   p.slab = (long long)d->B * d->M * d->Hout * d->Wout;
   hipStream_t st = tbg_stream(stream);
+  if (x3) {  // f32x3: the tile shapes of the fp32 path, 8-channel chunks (16 for the few-tap classes), 2 blocks/CU
+    if (merged) return launch_fprop<2, 2, 1, 2, 8, MAXTAPS, 0, 2, true, true, true>(p, st, maxtaps, maxTilesN, name);
+    if (variant != 0 && variant != 4 && variant != 5) return TBG_EUNSUPPORTED;
+    if (maxtaps > 1 && maxtaps <= 4) {
+      if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
+      if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
+      if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
+      return launch_fprop<2, 2, 2, 2, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
+    }
+    if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, MAXTAPS, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
+    if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 8, MAXTAPS, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
+    if (BM == 64) return launch_fprop<1, 4, 2, 2, 8, MAXTAPS, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
+    return launch_fprop<2, 2, 2, 2, 8, MAXTAPS, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
+  }
   if (merged) {
     if (bf) return launch_fprop<2, 2, 1, 2, 16, MAXTAPS, 0, 2, true, true>(p, st, maxtaps, maxTilesN, name);
     if (variant == 6) return launch_fprop<2, 2, 1, 2, 16, MAXTAPS, 0, 2, false, true>(p, st, maxtaps, maxTilesN, name);
@@ -851,28 +942,43 @@ extern "C" int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, co
 extern "C" int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                                        const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
   if (variant < 0 || variant == 3 || variant > 5) return TBG_EINVAL;
-  return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, true, variant);
+  return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, 1, variant);
 }
 
 extern "C" int tbg_conv2d_bf16(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,
                                const tbg_epilogue *epi, void *stream) {
-  return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, true);
+  return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, 1);
 }
 
-static int conv_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n, bool bf) {
+extern "C" int tbg_conv2d_x3(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,
+                             const tbg_epilogue *epi, void *stream) {
+  return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, 2);
+}
+
+extern "C" int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
+                                     const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
+  if (variant != 0 && variant != 4 && variant != 5) return TBG_EINVAL;
+  return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, 2, variant);
+}
+
+static int conv_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n, int mode) {
   if (!buf || n < 1) return TBG_EINVAL;
   buf[0] = 0;
   NameOut no{buf, n};
   static const float dummy = 0.f;  // name-only mode never dereferences; in_scale only sizes the LDS request
-  return conv2d_impl(d, nullptr, nullptr, nullptr, has_in_scale ? &dummy : nullptr, nullptr, nullptr, &no, bf);
+  return conv2d_impl(d, nullptr, nullptr, nullptr, has_in_scale ? &dummy : nullptr, nullptr, nullptr, &no, mode);
 }
 
 extern "C" int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n) {
-  return conv_name(d, has_in_scale, buf, n, false);
+  return conv_name(d, has_in_scale, buf, n, 0);
 }
 
 extern "C" int tbg_conv2d_bf16_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n) {
-  return conv_name(d, has_in_scale, buf, n, true);
+  return conv_name(d, has_in_scale, buf, n, 1);
+}
+
+extern "C" int tbg_conv2d_x3_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n) {
+  return conv_name(d, has_in_scale, buf, n, 2);
 }
 
 // ============================================================================================

@@ -325,6 +325,57 @@ extern "C" int tbg_weight_pack_bf16(const float *src, void *dst, int T, int I, i
   return TBG_OK;
 }
 
+// f32x3 form of the packed filter (tbg_conv2d_x3): THREE bf16 planes Wp[plane][T][ceil(C/8)][M][8], plane 0 = hi = RNE(w),
+// plane 1 = mid = RNE(w - hi), plane 2 = lo = RNE(w - hi - mid): hi + mid + lo == w exactly (3 x 8 significand bits).
+__device__ __forceinline__ void tbg_split3(const float (&v)[8], tbg_bf16x8 &h, tbg_bf16x8 &m, tbg_bf16x8 &l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 bh = (__bf16)v[e];
+    const float r1 = v[e] - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    h[e] = bh; m[e] = bm; l[e] = (__bf16)(r1 - (float)bm);
+  }
+}
+
+__global__ __launch_bounds__(256) void weight_pack_x3_kernel(const float *__restrict__ src, tbg_bf16x8 *__restrict__ dst,
+                                                             int T, int I, int O, int transpose, int flip) {
+  const int t = blockIdx.z;
+  const int td = flip ? T - 1 - t : t;
+  const int C = transpose ? O : I, M = transpose ? I : O;
+  const int C8 = (C + 7) >> 3;
+  const int c8 = blockIdx.y;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * c8 + e;
+    const int i = transpose ? m : c, o = transpose ? c : m;
+    v[e] = (c < C) ? src[((size_t)t * I + i) * O + o] : 0.f;
+  }
+  tbg_bf16x8 h, mi, l;
+  tbg_split3(v, h, mi, l);
+  const size_t plane = (size_t)T * C8 * M, d = ((size_t)td * C8 + c8) * M + m;
+  dst[d] = h; dst[plane + d] = mi; dst[2 * plane + d] = l;
+}
+
+extern "C" long long tbg_weight_pack_x3_bytes(int T, int I, int O, int transpose) {
+  const long long b = tbg_weight_pack_bf16_bytes(T, I, O, transpose);
+  return b < 0 ? b : 3 * b;
+}
+
+extern "C" int tbg_weight_pack_x3(const float *src, void *dst, int T, int I, int O, int transpose, int flip,
+                                  void *stream) {
+  if (!src || !dst || T < 1 || I < 1 || O < 1) return TBG_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) != 0) return TBG_EINVAL;
+  const int C = transpose ? O : I, M = transpose ? I : O;
+  dim3 grid((M + 255) / 256, (C + 7) / 8, T);
+  hipLaunchKernelGGL(weight_pack_x3_kernel, grid, dim3(256), 0, tbg_stream(stream), src,
+                     reinterpret_cast<tbg_bf16x8 *>(dst), T, I, O, transpose, flip);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
 // Multi-tensor form: ONE launch packs every filter of a model (both orientations, either format) from a device table
 // -- the training step refreshes all its packed filters at the start of a step instead of ~140 small launches.
 __global__ __launch_bounds__(256) void weight_pack_multi_kernel(const tbg_pack_item *__restrict__ items) {
@@ -346,7 +397,12 @@ __global__ __launch_bounds__(256) void weight_pack_multi_kernel(const tbg_pack_i
       v[e] = (e < KP && c < C) ? it.src[((size_t)t * it.I + i) * it.O + o] : 0.f;
     }
     const size_t d = ((size_t)td * CU + cu) * M + m;
-    if (it.bf16) {
+    if (it.bf16 == 2) {  // f32x3: hi | mid | lo planes
+      tbg_bf16x8 h, mi, l;
+      tbg_split3(v, h, mi, l);
+      tbg_bf16x8 *dp = reinterpret_cast<tbg_bf16x8 *>(it.dst);
+      dp[d] = h; dp[(size_t)units + d] = mi; dp[2 * (size_t)units + d] = l;
+    } else if (it.bf16) {
       tbg_bf16x8 b;
 #pragma unroll
       for (int e = 0; e < 8; ++e) b[e] = (__bf16)v[e];

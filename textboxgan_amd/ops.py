@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from typing import NamedTuple, Optional, Tuple
 
 import numpy as np
@@ -32,49 +33,89 @@ class _Flags:
     gradients nobody consumes (torch gives custom Functions no per-call pruning info).  The flags act only on nodes that
     carry the matching ROLE tag (set by the discriminator's layers when they call conv_bias_act_fused): a node without a
     tag is never pruned, whatever its shape or owner."""
-    skip_d_wgrad = False     # G-loss pass only needs dL/d(image) through the discriminator  (role "d" / "d_image")
-    skip_image_grad = False  # D-loss pass does not need dL/d(image)                          (role "d_image")
-    # The d-step runs the discriminator ONCE over [fake; real] (2B samples).  In the G-loss pass only the first B samples
-    # carry a gradient (the score gradient of the real half is structurally zero): nodes with a "d" role then run their
-    # backward kernels on the leading d_first_half samples only and leave the rest of the returned tensor unwritten --
-    # nothing reads it (the concatenation's backward hands the generator the first half).  0 = off.
-    d_first_half = 0
-    # The regularisers' inner gradient (d(image . noise)/d(latents) for path length, d(scores)/d(image) for R1) reaches no
-    # filter: custom Functions are not pruned by autograd.grad(inputs=...), so without this flag every composable conv of
-    # that pass would also launch its filter gradient and throw it away.
-    no_filter_grads = False
+
+    def __init__(self):
+        self.skip_d_wgrad = False     # G-loss pass only needs dL/d(image) through the discriminator  (role "d" / "d_image")
+        self.skip_image_grad = False  # D-loss pass does not need dL/d(image)                          (role "d_image")
+        # The d-step runs the discriminator ONCE over [fake; real] (2B samples).  In the G-loss pass only the first B
+        # samples carry a gradient (the score gradient of the real half is structurally zero): nodes with a "d" role then
+        # run their backward kernels on the leading d_first_half samples only and leave the rest of the returned tensor
+        # unwritten -- nothing reads it (the concatenation's backward hands the generator the first half).  0 = off.
+        self.d_first_half = 0
+        # The regularisers' inner gradient (d(image . noise)/d(latents) for path length, d(scores)/d(image) for R1)
+        # reaches no filter: custom Functions are not pruned by autograd.grad(inputs=...), so without this flag every
+        # composable conv of that pass would also launch its filter gradient and throw it away.
+        self.no_filter_grads = False
+        # debug aid (ADVICE round 2): zero the never-read tail of the d_first_half gradient tensors instead of leaving it
+        # uninitialised, so anomaly mode / NaN checks see defined memory
+        self.zero_unread_tails = False
 
 
-FLAGS = _Flags()
+class _ThreadState(threading.local):
+    """Every piece of host-side mutable state of this module lives here, one copy per THREAD: two TrainingStep objects
+    driven from two threads (or a step and a validation pass) cannot see each other's pruning flags, arithmetic mode or
+    packed-filter scopes.  (torch runs a backward pass's Python callbacks on the thread that called autograd.grad /
+    backward for the device's default stream use here, so the flags set around a pass are the ones its nodes read.)"""
 
+    def __init__(self):
+        self.flags = _Flags()
+        self.compute = "f32"
+        self.pack_step = None    # live only inside filter_cache(): weights are constant within one step's passes
+        self.pack_store = None   # live only inside PackedStore.scope(): persistent packs of a training step
+
+
+_TLS = _ThreadState()
+
+
+class _FlagsProxy:
+    """``ops.FLAGS.x`` reads / writes the calling thread's flags."""
+
+    def __getattr__(self, name):
+        return getattr(_TLS.flags, name)
+
+    def __setattr__(self, name, value):
+        if not hasattr(_TLS.flags, name):
+            raise AttributeError(name)
+        setattr(_TLS.flags, name, value)
+
+
+FLAGS = _FlagsProxy()
 
 # ----------------------------------------------------------------------------------------
-# arithmetic type of the MFMA contractions: "f32" (v_mfma_f32_32x32x2_f32, exact) or "bf16" (bf16 operands rounded while
-# staging, fp32 accumulate: BASELINE configs[2]).  HBM tensors, epilogues, master weights and Adam stay fp32 either way.
+# arithmetic of the MFMA contractions:
+#   "f32"   v_mfma_f32_32x32x2_f32, exact fp32 products
+#   "bf16"  operands rounded to bf16 while staging, fp32 accumulate (BASELINE configs[2])
+#   "f32x3" fp32 operands split into three bf16 terms, six partial products on the bf16 pipe, fp32 accumulate: fp32-grade
+#           results (tbg.h "f32x3 forms")
+# HBM tensors, epilogues, master weights and Adam stay fp32 in every mode.
 # ----------------------------------------------------------------------------------------
-_COMPUTE_BF16 = False
+COMPUTE_MODES = ("f32", "bf16", "f32x3")
+FMT_F32, FMT_BF16, FMT_X3 = 0, 1, 2
+_FMT = {"f32": FMT_F32, "bf16": FMT_BF16, "f32x3": FMT_X3}
 
 
 class compute_dtype:
-    """``with ops.compute_dtype("bf16"): ...`` -- scope in which conv / filter-gradient launches use the bf16 entries."""
+    """``with ops.compute_dtype("bf16"): ...`` -- scope in which conv / filter-gradient launches use that arithmetic."""
 
     def __init__(self, dtype: str):
-        assert dtype in ("f32", "bf16"), dtype
-        self.bf16 = dtype == "bf16"
+        assert dtype in COMPUTE_MODES, dtype
+        self.mode = dtype
 
     def __enter__(self):
-        global _COMPUTE_BF16
-        self._prev, _COMPUTE_BF16 = _COMPUTE_BF16, self.bf16
+        self._prev, _TLS.compute = _TLS.compute, self.mode
         return self
 
     def __exit__(self, *exc):
-        global _COMPUTE_BF16
-        _COMPUTE_BF16 = self._prev
+        _TLS.compute = self._prev
         return False
 
 
+def compute_mode() -> str:
+    return _TLS.compute
+
+
 def is_bf16() -> bool:
-    return _COMPUTE_BF16
+    return _TLS.compute == "bf16"
 
 
 class _Profile:
@@ -218,14 +259,16 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         w = pack_filter(w.reshape(KH * KW, Cc, ldw), transpose=False, flip=False)
     assert w.C == Cc and w.M >= M and w.T == KH * KW, "packed filter does not match the convolution"
     ldw = w.M
-    bf16 = w.bf16
-    _conv = N.lib().tbg_conv2d_bf16 if bf16 else N.lib().tbg_conv2d_f32
+    fmt = w.fmt
+    bf16 = fmt != FMT_F32  # a 16-bit operand pipe (bf16 or f32x3): shares the merged-class rule of the library
+    _conv = (N.lib().tbg_conv2d_f32, N.lib().tbg_conv2d_bf16, N.lib().tbg_conv2d_x3)[fmt]
     if FORCE_VARIANT:
-        _v, _fn = FORCE_VARIANT, (N.lib().tbg_conv2d_bf16_variant if bf16 else N.lib().tbg_conv2d_f32_variant)
+        _v, _fn = FORCE_VARIANT, (N.lib().tbg_conv2d_f32_variant, N.lib().tbg_conv2d_bf16_variant,
+                                  N.lib().tbg_conv2d_x3_variant)[fmt]
         _conv = lambda d_, x_, w_, y_, s_, e_, st_: _fn(d_, x_, w_, y_, s_, e_, _v, st_)
     w = w.data
     Hout, Wout = out_hw
-    nchunks = math.ceil(Cc / (16 if bf16 else 8))
+    nchunks = math.ceil(Cc / (16 if fmt == FMT_BF16 else 8))
     ksplit = 1
     _npix = B * (math.ceil(Hout / stride[0]) * math.ceil(Wout / stride[1]) if transposed else Hout * Wout)
     if allow_split:
@@ -248,7 +291,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
              f"p={tuple(pad)} T={int(transposed)} ldw={ldw} ksplit={ksplit}]")
     _flops = 2.0 * B * M * Cc * KH * KW * (Hin * Win if transposed else Hout * Wout)
     _bytes = 4.0 * (B * Cc * Hin * Win + B * M * Hout * Wout * ksplit + KH * KW * Cc * M)  # x + y (slabs) + filter, once each
-    _kname = lambda: N.conv_kernel_name(d, in_scale is not None, bf16)
+    _kname = lambda: N.conv_kernel_name(d, in_scale is not None, fmt)
     if ksplit > 1:
         # split-K: every split stores alpha*acc into its own slab (no zero-fill, no atomics); one flat pass sums the
         # slabs and applies the real epilogue
@@ -300,9 +343,12 @@ def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, o
         raise N.TbgError("tbg_conv2d_wgrad: unsupported geometry")
     ws = _workspace(S.device, nbytes)
     _flops = 2.0 * B * CS * CL * Hs * Ws * KH * KW
-    bf16 = _COMPUTE_BF16
-    _kname = lambda: N.wgrad_kernel_name(d, bf16)
-    _wg = N.lib().tbg_conv2d_wgrad_bf16 if bf16 else N.lib().tbg_conv2d_wgrad_ex_f32
+    fmt = _FMT[_TLS.compute]
+    if fmt == FMT_X3 and not HAVE_WGRAD_X3:
+        fmt = FMT_F32
+    _kname = lambda: N.wgrad_kernel_name(d, fmt)
+    _wg = (N.lib().tbg_conv2d_wgrad_ex_f32, N.lib().tbg_conv2d_wgrad_bf16,
+           getattr(N.lib(), "tbg_conv2d_wgrad_x3", None))[fmt]
     addw, addq, gamma = add if add is not None else (None, None, 0.0)
     N.check(PROFILE.launch(_kname, _flops, lambda: _wg(
         C.byref(d), N.ptr(S), N.ptr(L), N.ptr(out) + 4 * out_offset, N.ptr(s_scale), N.ptr(l_scale),
@@ -312,6 +358,9 @@ def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, o
     return out
 
 
+HAVE_WGRAD_X3 = False  # set below once the library exports the f32x3 filter gradient
+
+
 class PackedFilter(NamedTuple):
     """Wp[T][ceil(C/4)][M][4] fp32 (tbg_weight_pack_f32) or Wp[T][ceil(C/8)][M][8] bf16 (tbg_weight_pack_bf16): the filter
     formats of tbg_conv2d_f32 / tbg_conv2d_bf16."""
@@ -319,11 +368,13 @@ class PackedFilter(NamedTuple):
     T: int
     C: int
     M: int
-    bf16: bool = False
+    fmt: int = FMT_F32  # FMT_F32 | FMT_BF16 | FMT_X3 (three bf16 planes, tbg_weight_pack_x3)
+
+    @property
+    def bf16(self) -> bool:
+        return self.fmt == FMT_BF16
 
 
-_PACK_STEP: Optional[dict] = None  # live only inside filter_cache(): weights are constant within one step's passes
-_PACK_STORE: Optional["PackedStore"] = None  # live only inside PackedStore.scope(): persistent packs of a training step
 
 
 class PackedStore:
@@ -349,13 +400,11 @@ class PackedStore:
 
         class _Scope:
             def __enter__(self_):
-                global _PACK_STORE
-                self_._outer, _PACK_STORE = _PACK_STORE, store
+                self_._outer, _TLS.pack_store = _TLS.pack_store, store
                 return store
 
             def __exit__(self_, *exc):
-                global _PACK_STORE
-                _PACK_STORE = self_._outer
+                _TLS.pack_store = self_._outer
                 store._fresh = False
                 # a step that discovered new filters (always an EAGER step: get() never registers during capture) rebuilds the
                 # device table here, outside any capture, so that refresh() never has to copy from the host inside one
@@ -382,10 +431,10 @@ class PackedStore:
             N.check(N.lib().tbg_weight_pack_multi(self._table.data_ptr(), self._n, N.stream()), "tbg_weight_pack_multi")
         self._fresh = True
 
-    def get(self, w, T, I, O, transpose, flip, bf16):
+    def get(self, w, T, I, O, transpose, flip, fmt):
         if not self._fresh:
             return None
-        key = (w.data_ptr(), T, I, O, bool(transpose), bool(flip), bool(bf16))
+        key = (w.data_ptr(), T, I, O, bool(transpose), bool(flip), int(fmt))
         hit = self.items.get(key)
         if hit is not None:
             # in the table since an earlier step -> refreshed this step (entries added after this step's refresh carry
@@ -393,8 +442,8 @@ class PackedStore:
             return hit[0]
         if torch.cuda.is_current_stream_capturing():
             return None  # never grow the table while a graph is being captured: the caller packs on demand
-        pf = _pack_now(w, T, I, O, transpose, flip, bf16)
-        self.items[key] = (pf, (w.data_ptr(), pf.data.data_ptr(), T, I, O, int(transpose), int(flip), int(bf16)))
+        pf = _pack_now(w, T, I, O, transpose, flip, fmt)
+        self.items[key] = (pf, (w.data_ptr(), pf.data.data_ptr(), T, I, O, int(transpose), int(flip), int(fmt)))
         return pf
 
 
@@ -403,44 +452,59 @@ class filter_cache:
     passes, see the same weights).  Nothing outlives the scope, so an optimiser update can never meet a stale pack."""
 
     def __enter__(self):
-        global _PACK_STEP
-        self._outer = _PACK_STEP
-        if _PACK_STEP is None:
-            _PACK_STEP = {}
+        self._outer = _TLS.pack_step
+        if _TLS.pack_step is None:
+            _TLS.pack_step = {}
         return self
 
     def __exit__(self, *exc):
-        global _PACK_STEP
-        _PACK_STEP = self._outer
+        _TLS.pack_step = self._outer
         return False
 
 
-def pack_filter(w: torch.Tensor, transpose: bool, flip: bool, bf16: Optional[bool] = None) -> PackedFilter:
+def _fmt_of(bf16) -> int:
+    """None: the current ops.compute_dtype; bool (legacy): bf16 / f32; str: a COMPUTE_MODES name; int: a FMT_* value."""
+    if bf16 is None:
+        return _FMT[_TLS.compute]
+    if isinstance(bf16, str):
+        return _FMT[bf16]
+    if isinstance(bf16, bool):
+        return FMT_BF16 if bf16 else FMT_F32
+    return int(bf16)
+
+
+def pack_filter(w: torch.Tensor, transpose: bool, flip: bool, bf16=None) -> PackedFilter:
     """HWIO [KH,KW,I,O] / [T,I,O] parameter -> PackedFilter.  transpose: C = O, M = I (data gradient).
-    bf16 = None: the current ops.compute_dtype."""
-    bf16 = _COMPUTE_BF16 if bf16 is None else bool(bf16)
+    bf16: the filter format (see _fmt_of; None = the current ops.compute_dtype)."""
+    fmt = _fmt_of(bf16)
     if w.dim() == 4:
         T, I, O = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
     else:
         T, I, O = w.shape
     cache = None
-    if _PACK_STEP is not None and w.is_leaf and w.requires_grad:  # live parameters only: the key is an address
-        cache = _PACK_STEP
-    key = (w.data_ptr(), T, I, O, bool(transpose), bool(flip), w._version, bf16)
+    if _TLS.pack_step is not None and w.is_leaf and w.requires_grad:  # live parameters only: the key is an address
+        cache = _TLS.pack_step
+    key = (w.data_ptr(), T, I, O, bool(transpose), bool(flip), w._version, fmt)
     if cache is not None and key in cache:
         return cache[key]
-    if cache is not None and _PACK_STORE is not None and w.is_contiguous():
-        pf = _PACK_STORE.get(w, T, I, O, transpose, flip, bf16)
+    if cache is not None and _TLS.pack_store is not None and w.is_contiguous():
+        pf = _TLS.pack_store.get(w, T, I, O, transpose, flip, fmt)
         if pf is not None:
             return pf
-    pf = _pack_now(w.contiguous(), T, I, O, transpose, flip, bf16)
+    pf = _pack_now(w.contiguous(), T, I, O, transpose, flip, fmt)
     if cache is not None:
         cache[key] = pf
     return pf
 
 
-def _pack_now(w, T, I, O, transpose, flip, bf16) -> PackedFilter:
-    if bf16:
+def _pack_now(w, T, I, O, transpose, flip, fmt) -> PackedFilter:
+    fmt = int(fmt)
+    if fmt == FMT_X3:
+        nb = N.lib().tbg_weight_pack_x3_bytes(T, I, O, int(transpose))
+        out = torch.empty(nb // 2, device=w.device, dtype=torch.bfloat16)
+        N.check(N.lib().tbg_weight_pack_x3(N.ptr(w), N.ptr(out), T, I, O, int(transpose), int(flip), N.stream()),
+                "tbg_weight_pack_x3")
+    elif fmt == FMT_BF16:
         nb = N.lib().tbg_weight_pack_bf16_bytes(T, I, O, int(transpose))
         out = torch.empty(nb // 2, device=w.device, dtype=torch.bfloat16)
         N.check(N.lib().tbg_weight_pack_bf16(N.ptr(w), N.ptr(out), T, I, O, int(transpose), int(flip), N.stream()),
@@ -450,7 +514,7 @@ def _pack_now(w, T, I, O, transpose, flip, bf16) -> PackedFilter:
         out = torch.empty(n, device=w.device, dtype=torch.float32)
         N.check(N.lib().tbg_weight_pack_f32(N.ptr(w), N.ptr(out), T, I, O, int(transpose), int(flip), N.stream()),
                 "tbg_weight_pack")
-    return PackedFilter(out, T, O if transpose else I, I if transpose else O, bf16)
+    return PackedFilter(out, T, O if transpose else I, I if transpose else O, fmt)
 
 
 def bias_act_bwd_raw(dout, out_act, epi: N.Epilogue, want_dx=False, want_dpre=True, want_db=True, want_dn=False,

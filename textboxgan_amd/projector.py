@@ -101,7 +101,7 @@ class LPIPS(nn.Module):
         if not x.is_cuda:  # no CPU path in the product (the CPU definition lives in oracle/ref_projector.py)
             raise RuntimeError("LPIPS runs its convolutions on the HIP kernels: device tensors only")
         from . import ops
-        key = (i, ops.is_bf16())
+        key = (i, ops.compute_mode())
         if key not in self._packs:
             self._packs[key] = ops.frozen_conv_packs(conv.kernel, (1, 1))
         return ops.frozen_conv(x, conv.kernel, conv.bias, (1, 1), (1, 1), True, None, self._packs[key])

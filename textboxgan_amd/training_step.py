@@ -73,7 +73,7 @@ class TrainingStep:
         self.use_graphs = use_graphs
         # "f32": exact fp32 MFMA contractions (BASELINE configs[1]).  "bf16": conv / filter-gradient operands rounded to
         # bf16 on their way into LDS, fp32 accumulate, fp32 master weights + Adam (BASELINE configs[2]).
-        assert compute_dtype in ("f32", "bf16")
+        assert compute_dtype in ops.COMPUTE_MODES
         self.compute_dtype = compute_dtype
         # OCR branch (forward + its own backward) on a second HIP stream.  Worth ~1% only (415 -> 418-420 text-boxes/s):
         # tools/graph_branch_test.py shows that on MI355X / ROCm 7.2 neither eager streams nor captured fork/join branches

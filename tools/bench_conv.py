@@ -4,6 +4,8 @@ import math, torch
 from textboxgan_amd import ops, native as N
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+ops._TLS.compute = sys.argv[2] if len(sys.argv) > 2 else "f32"  # f32 | bf16 | f32x3
+print("arithmetic:", ops.compute_mode())
 
 def timeit(fn, n=30):
     for _ in range(10): fn()  # clocks ramp from idle over the first launches: 5 timed calls under-reported by ~20%
