@@ -177,6 +177,29 @@ def roofline_record(recs, dtype="f32"):
             mfma_busy = tj["kernels"][name].get("mfma_busy")
     except (OSError, ValueError, KeyError):
         pass
+    if dtype == "f32x3":
+        # split-operand arithmetic on the bf16 pipe: 6 bf16 products per fp32 product -> the roof in fp32-equivalent FLOPs is
+        # the dense bf16 MFMA peak / 6
+        peak = BF16_MFMA_PEAK_TFLOPS / 6.0
+        return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "peak_note": "fp32-equivalent: 2500 TFLOP/s dense bf16 MFMA / 6 partial products (3xbf16 split operands)",
+                "frac_of_exact_f32_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_bytes": round(r["bytes"] / r["n"]),
+                "traffic_unit": "bytes/launch (HBM, PMC); algorithmic_bytes = input + output + filter once each, per launch",
+                "traffic_source": traffic_src, "mfma_busy_pmc": mfma_busy,
+                "launches": r["n"], "avg_launch_us": round(1e3 * r["ms"] / r["n"], 2),
+                "gflop_per_launch": round(r["flops"] / r["n"] / 1e9, 3),
+                "all_kernels": {k: {"n": v["n"], "ms": round(v["ms"], 3),
+                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in convs.items()},
+                "all_conv_kernels": (lambda fl, ms: {"achieved": round(fl / (ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                                                     "ms": round(ms, 3), "launches": sum(v["n"] for v in convs.values())})(
+                    sum(v["flops"] for v in convs.values()), sum(v["ms"] for v in convs.values())),
+                "hbm_bound_kernels": {k: {"n": v["n"], "ms": round(v["ms"], 3),
+                                          "algorithmic_mb_per_launch": round(v["bytes"] / v["n"] / 1e6, 3),
+                                          "achieved_tb_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e12, 3),
+                                          "frac_of_8tb_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e12 / HBM_PEAK_TBS, 3)}
+                                      for k, v in recs.items() if not k.startswith("conv_") and v["bytes"] > 0 and v["ms"] > 0}}
     if dtype == "bf16":
         # bf16-in MFMA with fp32 tensors in HBM: the dominant 3x3 convolutions sit below the bf16 ridge (SURVEY 8(d):
         # ~288 FLOP/B of fp32 traffic vs a ridge of 2500/8 = 312), so the bounding roof is HBM; both fractions are reported.
@@ -213,15 +236,192 @@ def roofline_record(recs, dtype="f32"):
             "hbm_bound_kernels": hbm}
 
 
+HEADLINE_ARITH = "f32x3"  # arithmetic of the default (BASELINE configs[1]) line; --dtype f32 gives the exact-fp32 MFMA line
+
+
+def graph_mode(ts):
+    """how the step actually ran: "single" (one HIP graph per step variant), "split" (per-gradient-set graphs with the
+    all-reduces between them), "two-phase" (gradient graph | blocking exchange | update graph) or "eager"."""
+    if not ts.use_graphs or not ts._graphs:
+        return "eager"
+    n = max(len(g[0]) for g in ts._graphs.values())
+    return "single" if n == 1 else "two-phase" if n == 2 else "split"
+
+
+def timed_loop(state, batch, steps, warmup, world):
+    """W untimed + K timed steps in the caller protocol's cadence, bracketed by barrier + synchronize; max over ranks."""
+    run_steps(state, batch, warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(state, batch, steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=batch["real_images"].device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def variant_step_ms(state, batch, reps=(6, 3, 3)):
+    """milliseconds of ONE step of each lazy-regularisation variant (SURVEY 8(d) Config 2: "non-reg step and the 16-step
+    average"): plain, +PL (every 8th step), +PL+R1 (every 16th).  Real optimisation steps, flags forced."""
+    ts = state["training_step"]
+    a = (batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"])
+    out = {}
+    for name, (r1, pl), n in (("plain", (False, False), reps[0]), ("pl", (False, True), reps[1]), ("pl_r1", (True, True), reps[2])):
+        ts.dist_train_step(*a, r1, pl, 1e-4)  # untimed
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ts.dist_train_step(*a, r1, pl, 1e-4)
+            state["g_clone"].set_as_moving_average_of(state["generator"])
+        torch.cuda.synchronize()
+        out[name] = round(1e3 * (time.perf_counter() - t0) / n, 3)
+    return out
+
+
+def cycle_value(step_ms, batch):
+    """text-boxes/s over one aligned 16-step cycle: 14 plain + 1 PL + 1 PL+R1 steps (config.py:86,93)."""
+    return round(batch * 16 / ((14 * step_ms["plain"] + step_ms["pl"] + step_ms["pl_r1"]) * 1e-3), 2)
+
+
+WORKLOAD_ARITH = {
+    "f32": "fp32, exact v_mfma_f32_32x32x2_f32 contractions",
+    "f32x3": "fp32 tensors; forward / data-gradient contractions as 3xbf16 split operands, 6 products, fp32 accumulate "
+             "(tbg_conv2d_x3: fp32-grade error, passes every fp32 parity test at the fp32 tolerances); filter gradients on "
+             "exact v_mfma_f32_32x32x2_f32",
+    "bf16": "bf16 MFMA operands / fp32 accumulate / fp32 master weights + Adam",
+}
+
+
+def build_state(cfg, device, dtype, graphs, tiny_ocr=False):
+    from textboxgan_amd.training_step import build_trainer_state
+    ocr = None
+    if tiny_ocr:
+        from textboxgan_amd.aster import AsterInferer
+        ocr = AsterInferer(model=_TinyOCR(cfg.max_char_number))
+    state = build_trainer_state(cfg, device, aster_ocr=ocr, seed=0, use_graphs=graphs, compute_dtype=dtype)  # identical replicas
+    bench_init_(state)
+    return state
+
+
+def roofline_pass(state, batch, dtype, steps=2):
+    """same step, eager, every instrumented launch bracketed by HIP events on its stream"""
+    from textboxgan_amd import ops
+    ts = state["training_step"]
+    was = ts.use_graphs
+    ts.use_graphs = False
+    ops.PROFILE.enable()
+    try:
+        for _ in range(steps):
+            ts.dist_train_step(batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"], False,
+                               False, 1e-4)
+        torch.cuda.synchronize()
+        recs = ops.PROFILE.collect()
+    finally:
+        ops.PROFILE.disable()
+        ts.use_graphs = was
+    return roofline_record(recs, dtype) if recs else None
+
+
+def sub_record(device, dtype, per_gpu_batch, steps, warmup, graphs, with_ocr_excluded=True, with_roofline=True):
+    """a complete single-GPU measurement of another configuration inside the same JSON line (configs[2], exact fp32)"""
+    from textboxgan_amd.config import Config
+    cfg = Config(batch_size_per_gpu=per_gpu_batch, num_replicas=1)
+    batch = synthetic_batch(cfg, device, 1234)
+    state = build_state(cfg, device, dtype, graphs)
+    a = (batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"])
+    if graphs:
+        state["training_step"].prepare_graphs(*a)
+    dt = timed_loop(state, batch, steps, warmup, 1)
+    rec = {"dtype": dtype, "per_gpu_batch": per_gpu_batch, "steps": steps, "warmup": warmup,
+           "value": round(per_gpu_batch * steps / dt, 2), "unit": "text-boxes/s", "ms_per_step": round(1e3 * dt / steps, 3),
+           "arithmetic": WORKLOAD_ARITH[dtype], "graph_mode": graph_mode(state["training_step"])}
+    rec["step_ms"] = variant_step_ms(state, batch)
+    rec["value_16step"] = cycle_value(rec["step_ms"], per_gpu_batch)
+    if with_roofline:
+        rec["roofline"] = roofline_pass(state, batch, dtype)
+    del state
+    torch.cuda.empty_cache()
+    if with_ocr_excluded:
+        st2 = build_state(cfg, device, dtype, graphs, tiny_ocr=True)
+        if graphs:
+            st2["training_step"].prepare_graphs(*a)
+        dt2 = timed_loop(st2, batch, steps, warmup, 1)
+        rec["ocr_excluded_value"] = round(per_gpu_batch * steps / dt2, 2)
+        rec["ocr_excluded_ms_per_step"] = round(1e3 * dt2 / steps, 3)
+        del st2
+        torch.cuda.empty_cache()
+    return rec
+
+
+def dist_record(state, batch, world, backend, steps=6):
+    """N > 1: what the first RCCL run needs on record: collective bandwidth of the three
+    gradient buffers alone, and the step time with / without the exchange -> how much of it the backward passes hide."""
+    ts = state["training_step"]
+    dev = batch["real_images"].device
+    bufs = [ts.g_grad, ts.o_grad, ts.d_grad]
+    nbytes = sum(b.numel() for b in bufs) * 4
+    for _ in range(2):
+        for b in bufs:
+            dist.all_reduce(b, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        for b in bufs:
+            dist.all_reduce(b, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    t_ar = (time.perf_counter() - t0) / 5
+    tt = torch.tensor([t_ar], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    t_ar = float(tt.item())
+    a = (batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"], False, False, 1e-4)
+
+    def plain_ms(n):
+        for _ in range(2):
+            ts.dist_train_step(*a)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ts.dist_train_step(*a)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / n], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return 1e3 * float(t.item())
+
+    with_x = plain_ms(steps)
+    ts.exchange.muted = True  # same launches, no gradient collectives (replicas drift apart: measurement only, last thing run)
+    try:
+        without_x = plain_ms(steps)
+    finally:
+        ts.exchange.muted = False
+    exposed = max(with_x - without_x, 0.0)
+    return {"world_size": dist.get_world_size(), "backend": backend, "graph_mode": graph_mode(ts),
+            "gradient_bytes_per_step": nbytes,
+            "allreduce_alone_ms": round(1e3 * t_ar, 3),
+            "bus_bw_GBps": round(2 * (world - 1) / world * nbytes / t_ar / 1e9, 1),
+            "bus_bw_convention": "2(N-1)/N * S / t over the three flat gradient buffers (39.96 + 34.75 + 62.38 MB)",
+            "plain_step_ms_with_exchange": round(with_x, 3), "plain_step_ms_without_exchange": round(without_x, 3),
+            "overlap_frac": round(1.0 - min(exposed / (1e3 * t_ar), 1.0), 3) if t_ar > 0 else None,
+            "capture_error": ts.capture_error}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (BASELINE configs[1]: 16; configs[2]: 32)")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="arithmetic of the MFMA contractions: f32 = BASELINE configs[1] (the headline); bf16 = configs[2] "
-                         "(bf16 operands, fp32 accumulate, fp32 master weights / Adam; default batch 32)")
+    ap.add_argument("--dtype", choices=("auto", "f32", "f32x3", "bf16"), default="auto",
+                    help="arithmetic of the MFMA contractions.  auto = the BASELINE configs[1] headline (fp32 tensors, "
+                         f"{HEADLINE_ARITH} contractions); f32 = exact fp32 MFMA; bf16 = configs[2] (default batch 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="SURVEY 8(d) protocol instead of the bounded sample: batch 16, 3 warm-up + 10 timed steps at all "
@@ -232,12 +432,18 @@ def main():
     ap.add_argument("--no-ocr-excluded", action="store_true",
                     help="skip the second timed loop that replaces the (guessed) OCR network by a trivial stand-in")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sub-records", action="store_true",
+                    help="skip the extra single-GPU measurements appended to the default line: configs2_bf16 (BASELINE "
+                         "configs[2]: bf16, batch 32) and exact_f32 (the same configs[1] step on exact fp32 MFMA)")
     ap.add_argument("--no-graphs", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the instrumented roofline pass (eager, non-regularised steps): the command the "
                          "profiles/*_roofline_kernel_stats.txt rocprofv3 summaries are taken with, so that rocprof's "
                          "per-kernel average covers the same launches as roofline.avg_launch_us")
     args = ap.parse_args()
+    headline = args.dtype == "auto"
+    if headline:
+        args.dtype = HEADLINE_ARITH
     if args.batch is None:
         args.batch = 32 if args.dtype == "bf16" else 16
 
@@ -246,6 +452,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("TBG_BENCH_SINGLE_DEVICE"):  # launcher smoke test on a 1-GPU box: all ranks share cuda:0
         local_rank = 0
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -260,23 +467,18 @@ def main():
 
     from textboxgan_amd import ops
     from textboxgan_amd.config import Config
-    from textboxgan_amd.training_step import build_trainer_state
 
     cfg = Config(batch_size_per_gpu=args.batch, num_replicas=world)
-    tiny = None
     if args.tiny_ocr:
-        from textboxgan_amd.aster import AsterInferer
-        tiny = AsterInferer(model=_TinyOCR(cfg.max_char_number))
         args.no_ocr_excluded = True
-    state = build_trainer_state(cfg, device, aster_ocr=tiny, seed=0, use_graphs=not args.no_graphs,  # identical replicas
-                                compute_dtype=args.dtype)
-    bench_init_(state)
+    graphs = not args.no_graphs
+    state = build_state(cfg, device, args.dtype, graphs, tiny_ocr=args.tiny_ocr)
     batch = synthetic_batch(cfg, device, 1234 + rank)
+    a4 = (batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"])
 
     if args.roofline_only:
-        args.no_graphs = True
         ts = state["training_step"]; ts.use_graphs = False
-        a = (batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"], False, False, 1e-4)
+        a = (*a4, False, False, 1e-4)
         for _ in range(args.warmup):
             ts.dist_train_step(*a)
         torch.cuda.synchronize()
@@ -286,78 +488,68 @@ def main():
         print(json.dumps({"roofline": roofline_record(ops.PROFILE.collect(), args.dtype), "steps": args.steps,
                           "warmup": args.warmup}), flush=True)
         return
-    if not args.no_graphs:  # untimed: warm up + capture the three step variants (6 real steps)
-        state["training_step"].prepare_graphs(batch["real_images"], batch["ocr_images"], batch["input_words"],
-                                              batch["ocr_labels"])
-    run_steps(state, batch, args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(state, batch, args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    if graphs:  # untimed: warm up + capture the three step variants (6 real steps)
+        state["training_step"].prepare_graphs(*a4)
+    dt = timed_loop(state, batch, args.steps, args.warmup, world)
+    ts = state["training_step"]
 
     out = None
     if rank == 0:
         value = args.batch * world * args.steps / dt
+        cfgname = "BASELINE configs[2]" if args.dtype == "bf16" else "BASELINE configs[1]"
         out = {
             "metric": "text-boxes/sec (G+D+OCR training_step)" + (" [OCR NETWORK EXCLUDED: --tiny-ocr]" if args.tiny_ocr else ""),
             "value": round(value, 2), "unit": "text-boxes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": (f"training_step G+D+OCR, bs={args.batch}/GPU, 64x256 boxes, max_char_number=8, " +
-                                    ("fp32 (BASELINE configs[1])" if args.dtype == "f32" else
-                                     "bf16 MFMA operands / fp32 accumulate / fp32 master weights + Adam (BASELINE configs[2])") +
+                                    f"{WORKLOAD_ARITH[args.dtype]} ({cfgname})" +
                                     "; PL every 8th / R1 every 16th step (config.py:81-94); "
                                     "g_clone EMA included; OCR = ASTER-shaped frozen net (synthetic weights)"),
+                       "arithmetic": args.dtype,
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "conv_gflop_per_image_nonreg_step": CONV_GFLOP_PER_IMAGE},
             "conv_tflops_vs_step_time": round(value * CONV_GFLOP_PER_IMAGE / 1e3 / world, 2),
+            "graph_mode": graph_mode(ts), "capture_error": ts.capture_error,
         }
+    if world == 1:
+        sm = variant_step_ms(state, batch)
+        out["step_ms"] = sm
+        out["value_16step"] = cycle_value(sm, args.batch)
+    else:
+        dr = dist_record(state, batch, world, backend)
+        if rank == 0:
+            out["dist"] = dr
 
     # ---- roofline pass: same step, every conv launch bracketed by HIP events on its stream
-    if rank == 0 and not args.no_roofline:
-        ops.PROFILE.enable()
-        ts = state["training_step"]
-        ts.use_graphs = False  # the instrumented pass brackets individual launches
-        for _ in range(2):
-            ts.dist_train_step(batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"],
-                               False, False, 1e-4) if world == 1 else None
-        torch.cuda.synchronize()
-        recs = ops.PROFILE.collect()
-        ops.PROFILE.disable()
-        if recs:
-            out["roofline"] = roofline_record(recs, args.dtype)
+    if rank == 0 and world == 1 and not args.no_roofline:
+        rl = roofline_pass(state, batch, args.dtype)
+        if rl:
+            out["roofline"] = rl
     if world > 1:
         dist.barrier()
     # ---- same loop with the OCR NETWORK excluded (the ASTER-shaped stand-in is a guess)
+    del state, ts
+    torch.cuda.empty_cache()
     if world == 1 and not args.no_ocr_excluded:
-        from textboxgan_amd.aster import AsterInferer
-        del state
-        torch.cuda.empty_cache()
-        st2 = build_trainer_state(cfg, device, aster_ocr=AsterInferer(model=_TinyOCR(cfg.max_char_number)), seed=0,
-                                  use_graphs=not args.no_graphs, compute_dtype=args.dtype)
-        bench_init_(st2)
-        if not args.no_graphs:
-            st2["training_step"].prepare_graphs(batch["real_images"], batch["ocr_images"], batch["input_words"],
-                                                batch["ocr_labels"])
-        run_steps(st2, batch, args.warmup)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_steps(st2, batch, args.steps)
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t0
+        st2 = build_state(cfg, device, args.dtype, graphs, tiny_ocr=True)
+        if graphs:
+            st2["training_step"].prepare_graphs(*a4)
+        dt2 = timed_loop(st2, batch, args.steps, args.warmup, 1)
         out["ocr_excluded_value"] = round(args.batch * args.steps / dt2, 2)
         out["ocr_excluded_ms_per_step"] = round(1e3 * dt2 / args.steps, 3)
+        del st2
+        torch.cuda.empty_cache()
+    # ---- the other single-GPU configurations, inside the same driver-run line
+    if world == 1 and headline and not args.no_sub_records and not args.tiny_ocr:
+        out["configs2_bf16"] = sub_record(device, "bf16", 32, 8, 2, graphs)
+        out["configs2_bf16"]["workload"] = ("BASELINE configs[2]: training_step + R1 + path-length regularisation, bs=32, bf16 "
+                                            "MFMA operands / fp32 accumulate / fp32 master weights + Adam, 1 MI355X; reg "
+                                            "cadence of config.py (PL/8, R1/16)")
+        if HEADLINE_ARITH != "f32":
+            out["exact_f32"] = sub_record(device, "f32", 16, 8, 2, graphs, with_ocr_excluded=False)
+            out["exact_f32"]["workload"] = "BASELINE configs[1] on exact fp32 MFMA (v_mfma_f32_32x32x2_f32) for every contraction"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if args.cpu_baseline_full:
             out["cpu_baseline"] = cpu_baseline(batch_size=16, warmup=3, steps=10)

@@ -102,6 +102,12 @@ int tbg_upfirdn2d_sep_f32(const float *x, const float *kx, const float *ky, floa
                           int padx0, int padx1, int pady0, int pady1, const float *in_scale, int M,
                           const tbg_epilogue *epi, void *stream);
 
+/* Kernel instantiation (rocprofv3 spelling) that the upfirdn2d entries select for a geometry (sep = 1: the separable
+ * entry): a pure function of its arguments.  Tests use it to prove that every instantiation a training step launches is
+ * compared with the oracle. */
+int tbg_upfirdn2d_kernel_name(int minor, int kH, int kW, int upx, int upy, int downx, int downy, int padx0,
+                              int pady0, int sep, char *buf, int n);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution as fp32-MFMA implicit GEMM (v_mfma_f32_32x32x2_f32).  One descriptor serves:
  *   transposed = 0 : y[b,m,oy,ox] = sum_{t=(kh,kw),c} x[b,c,oy*sy-py+kh,ox*sx-px+kw] * W[t'][c][m]

@@ -21,3 +21,20 @@ def dev():
 
     native.lib()  # fail loudly if the HIP library is missing
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def arith(request):
+    """arithmetic of the MFMA contractions for this test (ops.compute_dtype scope): "f32" unless parametrised."""
+    from textboxgan_amd import ops
+
+    mode = getattr(request, "param", "f32")
+    with ops.compute_dtype(mode):
+        yield mode
+
+
+def arith_modes(fn):
+    """run an fp32 parity test in BOTH fp32 arithmetics -- exact v_mfma_f32_32x32x2_f32 and "f32x3" (three bf16 terms per
+    operand on the bf16 pipe) -- at the SAME tolerance (the split path may carry the fp32
+    configuration only if every fp32 test passes at the unchanged fp32 tolerances)."""
+    return pytest.mark.usefixtures("arith")(pytest.mark.parametrize("arith", ["f32", "f32x3"], indirect=True)(fn))

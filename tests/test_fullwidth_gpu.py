@@ -16,6 +16,8 @@ import torch
 from oracle import ref_model as M, ref_ops as R
 from textboxgan_amd.config import Config
 
+from conftest import arith_modes
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -38,6 +40,7 @@ def full4():
     return cfg, M.make_batch(cfg), M.make_rand(cfg, seed=99)
 
 
+@arith_modes
 @pytest.mark.parametrize("training", [False, True], ids=["inference", "training"])
 def test_generator_full_width_rgb_within_1e3(dev, full4, training):
     """north_star: generator RGB output within 1e-3 max-abs of the reference on identical seeds (B = 4)."""
@@ -55,6 +58,7 @@ def test_generator_full_width_rgb_within_1e3(dev, full4, training):
     assert err <= 1e-3, f"max-abs {err} (|ref|max {float(ref.abs().max())})"
 
 
+@arith_modes
 def test_discriminator_full_width_forward_backward(dev, full4):
     """D forward + all parameter gradients + the image gradient at the real widths (B = 4)."""
     from textboxgan_amd.models import Discriminator
@@ -80,55 +84,152 @@ def test_discriminator_full_width_forward_backward(dev, full4):
         assert l2_err(a, e) < 2e-3, n
 
 
-@pytest.mark.parametrize("reg", [(False, False), (True, True)], ids=["plain", "r1+pl"])
-def test_training_step_full_width_matches_oracle(dev, full4, reg):
-    """one dist_train_step at the real Config (B = 4): 7 losses, the three gradient sets, post-Adam weights, pl_mean."""
-    from textboxgan_amd.aster import AsterLikeOCR
+# ----------------------------------------------------------------------------------------------------------------
+# one whole dist_train_step at the real Config against the CPU oracle, per arithmetic
+# ----------------------------------------------------------------------------------------------------------------
+# fp32 bars (unchanged since round 2; "f32x3" -- three bf16 terms per operand on the bf16 pipe -- must meet the SAME bars).
+_TOL_F32 = dict(loss=5e-4, g=5e-3, ocr=2e-2, ocr_scalar=6e-2, ocr_scalar_abs=2e-3, d=5e-3, flat_g=2e-3, flat_o=5e-3, flat_d=2e-3, pl_mean=2e-4,
+                adam=1e-3)
+# bf16 mode has no counterpart in the (fp32-only) reference; the bars are the mode-accuracy bars of tests/test_bf16_gpu.py's
+# docstring: unit round-off 2^-9 per operand through 12 + 7 layers and their backward -> losses 3e-2, gradient SETS 8e-2
+# relative L2; single tensors (few elements, sums with cancellation) 2.5e-1; the post-Adam comparison is dropped (with
+# beta1 = 0 a step is ~lr*sign(g): a sign flip of a near-zero gradient is not an error of the mode).
+_TOL_BF16 = dict(loss=3e-2, g=2.5e-1, ocr=None, ocr_scalar=5e-1, ocr_scalar_abs=5e-2, d=2.5e-1, flat_g=8e-2, flat_o=8e-2, flat_d=8e-2, pl_mean=3e-2,
+                 adam=None)
+STEP_TOL = {"f32": _TOL_F32, "f32x3": _TOL_F32, "bf16": _TOL_BF16}
+_ORACLE_STEPS, _PRODUCT_STEPS = {}, {}
+
+
+def _oracle_step(B, reg):
+    """the CPU oracle's step (losses, the three gradient sets, post-step state) for batch B: computed once per (B, reg) and
+    shared by every arithmetic that is compared with it."""
+    key = (B, reg)
+    if key not in _ORACLE_STEPS:
+        from textboxgan_amd.aster import AsterLikeOCR
+        cfg = Config(batch_size_per_gpu=B)
+        batch, rand = M.make_batch(cfg), M.make_rand(cfg, seed=99)
+        st = M.make_state(cfg, seed=0, bench_init=True)
+        init = {k: {n: v.clone() for n, v in st[k].items()} for k in ("G", "D")}
+        ocr_cpu = AsterLikeOCR(max_steps=cfg.max_char_number)
+        prev = torch.get_num_threads()
+        if B >= 16:  # the per-sample pieces over-subscribe oneDNN on a 256-thread host (44 s / step against ~13 s)
+            torch.set_num_threads(min(prev, 16))
+        try:
+            losses, grads = M.training_step(st, cfg, batch["real_images"], batch["ocr_images"], batch["input_words"],
+                                            batch["ocr_labels"], reg[0], reg[1], 1e-4, rand, ocr_cpu.serve, return_grads=True)
+        finally:
+            torch.set_num_threads(prev)
+        _ORACLE_STEPS[key] = (cfg, batch, rand, init, st, losses, grads)
+    return _ORACLE_STEPS[key]
+
+
+def _step_vs_oracle(dev, arith, B, reg, tol_override=None):
+    """run ONE product dist_train_step (arithmetic `arith`, per-GPU batch B, lazy-reg flags reg) on the oracle's weights and
+    injected randomness, compare 7 losses, the three gradient sets (per tensor and as flat buffers), pl_mean and the
+    post-Adam discriminator, and return the set of kernel instantiations the step launched (native.record_calls)."""
+    key = (str(dev), arith, B, reg)
+    if key in _PRODUCT_STEPS:
+        return _PRODUCT_STEPS[key]
+    from textboxgan_amd import native as N
     from textboxgan_amd.training_step import build_trainer_state
+    tol = dict(STEP_TOL[arith], **(tol_override or {}))
     do_r1, do_pl = reg
-    cfg, batch, rand = full4
-    st = M.make_state(cfg, seed=0, bench_init=True)
-    prod = build_trainer_state(cfg, dev, seed=0)
-    prod["generator"].load_state_dict({k: v.clone() for k, v in st["G"].items()})
-    prod["discriminator"].load_state_dict({k: v.clone() for k, v in st["D"].items()})
+    cfg, batch, rand, init, st, ref_losses, ref_grads = _oracle_step(B, reg)
+    prod = build_trainer_state(cfg, dev, seed=0, compute_dtype=arith)
+    prod["generator"].load_state_dict({k: v.clone() for k, v in init["G"].items()})
+    prod["discriminator"].load_state_dict({k: v.clone() for k, v in init["D"].items()})
+    prod["g_clone"].load_state_dict({k: v.clone() for k, v in init["G"].items()})  # model_loader.py:13-20: g_clone starts as G
     ts = prod["training_step"]
-    ocr_cpu = AsterLikeOCR(max_steps=cfg.max_char_number)
-    w = 1e-4
-    ref_losses, ref_grads = M.training_step(st, cfg, batch["real_images"], batch["ocr_images"], batch["input_words"],
-                                            batch["ocr_labels"], do_r1, do_pl, w, rand, ocr_cpu.serve, return_grads=True)
     b = {k: v.to(dev) for k, v in batch.items()}
-    losses = ts.dist_train_step(b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], do_r1, do_pl, w,
-                                rand=_todev(rand, dev))
-    torch.cuda.synchronize()
+    with N.record_calls() as log:
+        losses = ts.dist_train_step(b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], do_r1, do_pl, 1e-4,
+                                    rand=_todev(rand, dev))
+        torch.cuda.synchronize()
     flat = lambda t: [float(x) for x in t] if isinstance(t, tuple) else [float(t)]
     got = flat(losses[0]) + flat(losses[1]) + flat(losses[2])
     exp = flat(ref_losses[0]) + flat(ref_losses[1]) + flat(ref_losses[2])
     for name, a, e in zip(("reg_g", "g", "pl", "reg_d", "d", "r1", "ocr"), got, exp):
-        assert abs(a - e) <= 5e-4 * max(1.0, abs(e)), (name, a, e)
+        assert abs(a - e) <= tol["loss"] * max(1.0, abs(e)), (arith, name, a, e)
     gnames = [n for n in prod["generator"]._flat.names if n.startswith(("latent_encoder.", "synthesis."))]
     worst = max((l2_err(v, ref_grads["g"][n]), n) for n, v in zip(gnames, ts.g_views))
-    assert worst[0] < 5e-3, ("g", worst)
+    assert worst[0] < tol["g"], (arith, "g", worst)
     onames = [n for n in prod["generator"]._flat.names if n.startswith(("synthesis.", "word_encoder."))]
     # the OCR-weighted (1e-4) gradients are sums with heavy cancellation; a SCALAR parameter (noise_strength) is one such
     # sum, so its relative error is the conditioning of that sum (measured 2.4e-2 on synth_blocks.4.apply_noise_1)
-    worst = max((l2_err(v, ref_grads["ocr"][n]), n) for n, v in zip(onames, ts.o_views) if v.numel() > 1)
-    assert worst[0] < 2e-2, ("ocr", worst)
-    worst = max((l2_err(v, ref_grads["ocr"][n]), n) for n, v in zip(onames, ts.o_views) if v.numel() == 1)
-    assert worst[0] < 6e-2, ("ocr scalar", worst)
-    worst = max((l2_err(v, ref_grads["d"][n]), n) for n, v in zip(prod["discriminator"]._flat.names, ts.d_views))
-    assert worst[0] < 5e-3, ("d", worst)
-    # whole flat gradient buffers (what Adam / the all-reduce consume)
     cat = lambda names, d: torch.cat([d[n].reshape(-1) for n in names])
     catv = lambda views: torch.cat([v.reshape(-1) for v in views])  # (the flat buffers carry alignment padding)
-    assert l2_err(catv(ts.g_views), cat(gnames, ref_grads["g"])) < 2e-3
-    assert l2_err(catv(ts.o_views), cat(onames, ref_grads["ocr"])) < 5e-3
-    assert l2_err(catv(ts.d_views), cat(prod["discriminator"]._flat.names, ref_grads["d"])) < 2e-3
+    if tol["ocr"] is None:
+        # bf16: the OCR-weighted set cannot be compared element-wise.  The recogniser's image gradient is a chaotic function
+        # of the image for this random-weight stand-in (exact-fp32 kernel noise of 1e-7 already becomes 1.2e-3 on this set),
+        # and the bf16 generator's images differ from the oracle's by ~1e-2: measured relative L2 0.9-1.1 with the OCR
+        # network itself at fp32 grade.  What is asserted: the loss (above), finiteness and the set's magnitude.
+        a, e = catv(ts.o_views), cat(onames, ref_grads["ocr"])
+        assert torch.isfinite(a).all()
+        ratio = float(a.double().norm().cpu() / e.double().norm())
+        assert 0.5 < ratio < 2.0, (arith, "ocr set norm ratio", ratio)
+        onames = []
+    worst = max([(l2_err(v, ref_grads["ocr"][n]), n) for n, v in zip(onames, ts.o_views) if v.numel() > 1] or [(0.0, "-")])
+    assert worst[0] < (tol["ocr"] or 1.0), (arith, "ocr", worst)
+    # scalars: relative error, or -- for a scalar that is a small part of the set -- its absolute error against the SET's
+    # norm.  Measured (tools/diag_step_errors.py, profiles/r03_step_error_tables.txt): every tensor of this set carries an
+    # absolute error of 1e-4 .. 1.2e-3 of the set norm in both fp32 arithmetics; on a scalar holding 1.4 % of the norm that
+    # reads as 8e-2 relative, and the fp32 CPU oracle's own value of such a scalar moves by up to 1e-1 with its thread count.
+    o_norm = float(torch.sqrt(sum([ref_grads["ocr"][n].double().square().sum() for n in onames] or [torch.zeros(())])))
+    for n, v in zip(onames, ts.o_views):
+        if v.numel() == 1:
+            e = ref_grads["ocr"][n].double()
+            err = float((v.detach().double().cpu() - e).abs())
+            assert err <= tol["ocr_scalar"] * float(e.abs()) or err <= tol["ocr_scalar_abs"] * o_norm, (arith, "ocr scalar", n, err, float(e), o_norm)
+    worst = max((l2_err(v, ref_grads["d"][n]), n) for n, v in zip(prod["discriminator"]._flat.names, ts.d_views))
+    assert worst[0] < tol["d"], (arith, "d", worst)
+    # whole flat gradient buffers (what Adam / the all-reduce consume)
+    errs = dict(g=l2_err(catv(ts.g_views), cat(gnames, ref_grads["g"])),
+                o=l2_err(catv(ts.o_views), cat(onames, ref_grads["ocr"])) if onames else 0.0,
+                d=l2_err(catv(ts.d_views), cat(prod["discriminator"]._flat.names, ref_grads["d"])))
+    assert errs["g"] < tol["flat_g"] and errs["o"] < tol["flat_o"] and errs["d"] < tol["flat_d"], (arith, errs)
     if do_pl:
-        assert abs(float(prod["pl_mean"]) - float(st["pl_mean"])) <= 2e-4 * max(1.0, abs(float(st["pl_mean"])))
-    for n, v in prod["discriminator"].state_dict().items():
-        assert l2_err(v, st["D"][n]) < 1e-3, ("D after Adam", n)
+        assert abs(float(prod["pl_mean"]) - float(st["pl_mean"])) <= tol["pl_mean"] * max(1.0, abs(float(st["pl_mean"])))
+    if tol["adam"] is not None:
+        for n, v in prod["discriminator"].state_dict().items():
+            assert l2_err(v, st["D"][n]) < tol["adam"], (arith, "D after Adam", n)
+    # the caller's g_clone EMA (train.py:208, generator.py:48-59) against the oracle's
+    with N.record_calls() as log2:
+        prod["g_clone"].set_as_moving_average_of(prod["generator"])
+        torch.cuda.synchronize()
+    expect = {k: v.clone() for k, v in init["G"].items()}  # g_clone before the update (= G before the step)
+    M.ema_update(expect, {k: v.detach().cpu() for k, v in prod["generator"].state_dict().items()})  # the oracle's rule
+    for n, v in prod["g_clone"].state_dict().items():
+        d = float((v.detach().cpu().double() - expect[n].double()).abs().max())
+        assert d <= 1e-6 * max(1.0, float(expect[n].abs().max())), (arith, "g_clone after EMA", n, d)
+    log = set(log) | set(log2)
+    _PRODUCT_STEPS[key] = (frozenset(log), errs)
+    return _PRODUCT_STEPS[key]
 
 
+@arith_modes
+@pytest.mark.parametrize("reg", [(False, False), (True, True)], ids=["plain", "r1+pl"])
+def test_training_step_full_width_matches_oracle(dev, arith, reg):
+    """one dist_train_step at the real Config (B = 4): 7 losses, the three gradient sets, post-Adam weights, pl_mean --
+    in exact fp32 and in f32x3 arithmetic at the same (fp32) tolerances."""
+    _step_vs_oracle(dev, arith, 4, reg)
+
+
+@pytest.mark.parametrize("reg", [(False, False), (True, True)], ids=["plain", "r1+pl"])
+def test_training_step_full_width_matches_oracle_bf16(dev, reg):
+    """BASELINE configs[2] arithmetic (bf16 MFMA operands, fp32 accumulate) at the real widths against the fp32 CPU oracle:
+    losses, every gradient tensor, the three flat gradient sets, pl_mean -- at the bf16 mode-accuracy bars (_TOL_BF16).
+    Round 2 compared this mode with the product's own fp32 path only."""
+    _step_vs_oracle(dev, "bf16", 4, reg)
+
+
+@pytest.mark.parametrize("arith", ["f32x3", "f32"])
+def test_training_step_full_width_batch16_matches_oracle(dev, arith):
+    """the BENCHMARKED geometry: per-GPU batch 16 (joint [fake; real] discriminator pass over 32 samples, the tile
+    rounds and split-K choices of the B = 16 launches) -- one plain step against the CPU oracle at the fp32 tolerances."""
+    _step_vs_oracle(dev, arith, 16, (False, False))
+
+
+@arith_modes
 def test_hello_full_size_fixture(dev):
     """BASELINE configs[0] ("Hello", B = 1, generator forward) at the real widths against the committed float64-oracle
     fixture (tests/golden/hello_fullsize.npz, made by tests/golden/make_golden_fullsize.py)."""
@@ -180,64 +281,88 @@ def _conv_cases_for_coverage():
     ]
 
 
-def _run_conv_case(dev, case, seed):
-    """forward (+ data gradient + filter gradient for the non-transposed forms) vs float64 torch; returns the kernel
-    names these launches select."""
+def _run_conv_case(dev, case, seed, arith="f32"):
+    """forward (+ data gradient + filter gradient for the non-transposed forms) vs float64 torch, in arithmetic `arith`
+    (bf16: the float64 reference is evaluated on operands pre-rounded to bf16 exactly as the kernels round them, cf.
+    tests/test_bf16_gpu.py); returns the kernel instantiations these launches select."""
     import torch.nn.functional as F
     from textboxgan_amd import native as N, ops
     B, Cc, Mo, H, W, k, stride, pad, transposed = case
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, Cc, H, W, generator=g, dtype=torch.float64)
     w = torch.randn(k, k, Cc, Mo, generator=g, dtype=torch.float64) / math.sqrt(k * k * Cc)
+    q = (lambda t: t.float().bfloat16().double()) if arith == "bf16" else (lambda t: t.float().double())
     rel = lambda a, r: float((a.double().cpu() - r).abs().max() / (r.abs().max() + 1e-30))
-    names = set()
-    prof = ops.PROFILE
-    prof.enable()
-    try:
+    with N.record_calls() as log, ops.compute_dtype(arith):
         if transposed:
-            ref = F.conv_transpose2d(x, w.permute(2, 3, 0, 1), stride=stride)
+            ref = F.conv_transpose2d(q(x), q(w).permute(2, 3, 0, 1), stride=stride)
             y = ops.conv2d_raw(x.float().to(dev), w.float().to(dev), Mo, k, k, (ref.shape[2], ref.shape[3]), stride, (0, 0),
                                transposed=True)
-            assert rel(y, ref) < 3e-5, ("transposed", case)
+            assert rel(y, ref) < 3e-5, ("transposed", arith, case)
         else:
-            xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            xr, wr = q(x).requires_grad_(True), q(w).requires_grad_(True)
             ref = F.conv2d(xr, wr.permute(3, 2, 0, 1), stride=stride, padding=pad)
             dy = torch.randn(*ref.shape, generator=g, dtype=torch.float64)
-            gx, gw = torch.autograd.grad(ref, (xr, wr), dy)
+            gx, gw = torch.autograd.grad(ref, (xr, wr), q(dy))
+            if arith == "bf16" and dy.shape[3] <= 4:  # narrow rows keep the exact fp32 filter-gradient kernel
+                xe, we = x.float().double().requires_grad_(True), w.float().double().requires_grad_(True)
+                (gw,) = torch.autograd.grad(F.conv2d(xe, we.permute(3, 2, 0, 1), stride=stride, padding=pad), we,
+                                            dy.float().double())
             geom = ops._Geom(stride, pad, k, k, (H, W), (ref.shape[2], ref.shape[3]))
             xd, wd, dyd = x.float().to(dev), w.float().to(dev), dy.float().to(dev)
-            assert rel(ops._fwd_launch(xd, wd, geom), ref.detach()) < 3e-5, ("fwd", case)
-            assert rel(ops._bwd_data_launch(dyd, wd, geom), gx) < 3e-5, ("dgrad", case)
-            assert rel(ops._bwd_weight_launch(xd, dyd, geom, Cc, Mo), gw) < 5e-5, ("wgrad", case)
-    finally:
-        recs = prof.collect()
-        prof.disable()
-    names.update(k for k in recs if k.startswith("conv_"))
-    return names
+            assert rel(ops._fwd_launch(xd, wd, geom), ref.detach()) < 3e-5, ("fwd", arith, case)
+            assert rel(ops._bwd_data_launch(dyd, wd, geom), gx) < 3e-5, ("dgrad", arith, case)
+            assert rel(ops._bwd_weight_launch(xd, dyd, geom, Cc, Mo), gw) < 5e-5, ("wgrad", arith, case)
+    return set(log)
 
 
-def test_every_step_instantiation_is_oracle_compared(dev):
-    """run the BASELINE configs[1] step (B = 16, full widths, eager) with the launch recorder on, collect every
-    conv_fprop / conv_wgrad instantiation name (tbg_conv2d_kernel_name: a pure function of the descriptor), and require
-    each one to be selected by at least one of the float64-oracle-compared cases above (which are run here)."""
+_COVERED = {}
+
+
+def _covered(dev, arith):
+    """kernel instantiations launched by ORACLE-COMPARED work in arithmetic `arith`: the convolution cases above (float64
+    reference per launch) plus two whole full-width steps (plain and R1 + path length, B = 4) that are compared with the
+    CPU oracle on losses and every gradient -- they bring every non-convolution kernel family (FIR, RGB ends, bias/act,
+    dense, minibatch-std, split-K epilogue, modulated-conv tails, filter packing, Adam, the frozen OCR's LSTM / attention
+    kernels) at the real channel widths."""
+    if arith not in _COVERED:
+        cov = set()
+        for i, case in enumerate(_conv_cases_for_coverage()):
+            cov |= _run_conv_case(dev, case, 500 + i, arith)
+            if arith == "bf16":  # the frozen OCR branch of a bf16 step runs on the f32x3 kernels (training_step.py)
+                cov |= _run_conv_case(dev, case, 500 + i, "f32x3")
+        for reg in ((False, False), (True, True)):
+            cov |= set(_step_vs_oracle(dev, arith, 4, reg)[0])
+        _COVERED[arith] = cov
+    return _COVERED[arith]
+
+
+STEP_VARIANTS = [(a, b, r) for a, b in (("f32x3", 16), ("f32", 16), ("bf16", 32))
+                 for r in ((False, False), (False, True), (True, True))]
+
+
+@pytest.mark.parametrize("arith,B,reg", STEP_VARIANTS,
+                         ids=[f"{a}-B{b}-{'plain' if r == (False, False) else 'pl' if r == (False, True) else 'pl+r1'}"
+                              for a, b, r in STEP_VARIANTS])
+def test_every_step_instantiation_is_oracle_compared(dev, arith, B, reg):
+    """run each BENCHMARKED step variant -- {plain, +PL, +PL+R1} x {configs[1]: B = 16 in f32x3 (the headline arithmetic)
+    and exact fp32, configs[2]: B = 32 in bf16}, full widths, eager -- with the call recorder on, and require EVERY kernel
+    instantiation it launches (convolutions, filter gradients and FIR by their template instantiation, every other
+    family by its entry point) to be launched by oracle-compared work as well (_covered)."""
     from bench import bench_init_, synthetic_batch
-    from textboxgan_amd import ops
+    from textboxgan_amd import native as N
     from textboxgan_amd.training_step import build_trainer_state
-    covered = set()
-    for i, case in enumerate(_conv_cases_for_coverage()):
-        covered |= _run_conv_case(dev, case, 500 + i)
-    cfg = Config(batch_size_per_gpu=16)
-    st = build_trainer_state(cfg, dev, seed=0, use_graphs=False)
+    covered = _covered(dev, arith)
+    cfg = Config(batch_size_per_gpu=B)
+    st = build_trainer_state(cfg, dev, seed=0, use_graphs=False, compute_dtype=arith)
     bench_init_(st)
     batch = synthetic_batch(cfg, dev, 1234)
     ts = st["training_step"]
-    ops.PROFILE.enable()
-    try:
-        ts.dist_train_step(batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"], False, False,
+    with N.record_calls() as used:
+        ts.dist_train_step(batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"], reg[0], reg[1],
                            1e-4)
-        used = {k for k in ops.PROFILE.collect() if k.startswith("conv_")}
-    finally:
-        ops.PROFILE.disable()
-    assert used, "the recorder saw no convolution launches"
-    missing = sorted(used - covered)
-    assert not missing, f"instantiations launched by the step but never compared with the oracle: {missing}"
+        st["g_clone"].set_as_moving_average_of(st["generator"])
+        torch.cuda.synchronize()
+    assert any(k.startswith("conv_fprop") for k in used) and any(k.startswith("upfirdn2d") for k in used), sorted(used)
+    missing = sorted(set(used) - covered)
+    assert not missing, f"launched by the {arith} B={B} step but never compared with the oracle: {missing}"

@@ -200,3 +200,39 @@ def test_aster_wrapper_combine_forward_and_backward_matches_oracle_on_cpu():
     assert full.shape == (1, 8, C) and torch.equal(full[0, 2], row(1, 5.0)) and float(full[0, 3, 1]) == 1000.0
     with pytest.raises(ValueError):
         AsterInferer(model=plain, combine_forward_and_backward=True)
+
+
+def test_ops_host_state_is_lock_guarded():
+    """pruning flags, arithmetic mode and packed-filter scopes are process-wide (torch's autograd thread must see them) and
+    guarded by a re-entrant lock that a step holds across its passes: a second thread that wants
+    to run its own step waits for the first one's scope to end and then finds the state restored."""
+    import threading
+    import time
+
+    from textboxgan_amd import ops
+    seen = {}
+
+    def other():
+        with ops.STATE_LOCK:  # what TrainingStep._compute_grads does first
+            seen["flags"] = (ops.FLAGS.skip_d_wgrad, ops.FLAGS.d_first_half, ops.FLAGS.no_filter_grads)
+            seen["mode"] = ops.compute_mode()
+            seen["scopes"] = (ops._TLS.pack_step, ops._TLS.pack_store)
+            seen["t"] = time.monotonic()
+
+    with ops.STATE_LOCK, ops.STATE_LOCK:  # re-entrant: nested scopes of one thread
+        ops.FLAGS.skip_d_wgrad, ops.FLAGS.d_first_half, ops.FLAGS.no_filter_grads = True, 7, True
+        try:
+            with ops.compute_dtype("f32x3"), ops.filter_cache(), ops.PackedStore().scope():
+                t = threading.Thread(target=other)
+                t.start()
+                time.sleep(0.2)
+                assert "flags" not in seen, "the second thread must wait for the lock"
+                assert ops.compute_mode() == "f32x3"
+        finally:
+            ops.FLAGS.skip_d_wgrad, ops.FLAGS.d_first_half, ops.FLAGS.no_filter_grads = False, 0, False
+        released = time.monotonic()
+    t.join()
+    assert seen["t"] >= released
+    assert (seen["flags"], seen["mode"], seen["scopes"]) == ((False, 0, False), "f32", (None, None))
+    with __import__("pytest").raises(AttributeError):
+        ops.FLAGS.no_such_flag = 1

@@ -8,6 +8,8 @@ import torch.nn.functional as F
 
 from oracle import ref_ops as R
 
+from conftest import arith_modes
+
 pytestmark = pytest.mark.gpu
 
 
@@ -237,6 +239,7 @@ CONV_CASES = [
 ]
 
 
+@arith_modes
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[-1] for c in CONV_CASES])
 def test_conv2d_forward(dev, case):
     from textboxgan_amd import ops
@@ -248,6 +251,7 @@ def test_conv2d_forward(dev, case):
     assert rel_err(y, ref) < 2e-5
 
 
+@arith_modes
 def test_conv2d_flip(dev):
     from textboxgan_amd import ops
     x = rnd(2, 16, 8, 16, seed=12)
@@ -265,6 +269,7 @@ TCONV_CASES = [
 ]
 
 
+@arith_modes
 @pytest.mark.parametrize("case", TCONV_CASES, ids=[c[-1] for c in TCONV_CASES])
 def test_conv2d_transposed(dev, case):
     from textboxgan_amd import ops
@@ -282,6 +287,7 @@ def test_conv2d_transposed(dev, case):
     assert rel_err(y2, ref2) < 2e-5
 
 
+@arith_modes
 def test_conv2d_fused_epilogue(dev):
     from textboxgan_amd import ops, native as N
     B, C, M, H, W = 3, 32, 48, 8, 32
@@ -408,6 +414,7 @@ def test_conv2d_wgrad_vector_staging_stride2(dev, case, bf16):
     assert rel_err(dw, ref) < 5e-5
 
 
+@arith_modes
 def test_conv_random_shapes_all_three_passes(dev):
     """seeded sweep over awkward shapes (channels not multiples of 4 / 32, odd maps, 1- and 2-pixel maps, every stride
     the kernels accept): forward, data gradient and filter gradient against float64 autograd."""
@@ -440,6 +447,7 @@ def test_conv_random_shapes_all_three_passes(dev):
     assert n_split == 28
 
 
+@arith_modes
 def test_conv_primitives_double_backward(dev):
     """conv2d / bwd_data / bwd_weight close under differentiation (R1 and path-length need it)."""
     from textboxgan_amd import ops
@@ -463,6 +471,7 @@ def test_conv_primitives_double_backward(dev):
             assert rel_err(a, b) < 5e-5
 
 
+@arith_modes
 def test_conv_transpose_primitive(dev):
     from textboxgan_amd import ops
     x = rnd(2, 8, 5, 7, seed=44).requires_grad_(True)

@@ -8,6 +8,8 @@ import torch
 from oracle import ref_model as M, ref_ops as R
 from textboxgan_amd.config import small_config
 
+from conftest import arith_modes
+
 pytestmark = pytest.mark.gpu
 
 
@@ -36,6 +38,7 @@ def to64(P):
     return {k: v.double() for k, v in P.items()}
 
 
+@arith_modes
 @pytest.mark.parametrize("up", [False, True], ids=["conv_1", "conv_0_up"])
 @pytest.mark.parametrize("shape", [(3, 16, 24, 8, 32), (2, 128, 128, 16, 64), (16, 512, 512, 4, 16)],
                          ids=["small", "128ch", "512ch-splitk"])
@@ -204,6 +207,7 @@ def _load(module, P, dev):
     return module.to(dev)
 
 
+@arith_modes
 @pytest.mark.parametrize("mode", ["fused", "composable"])
 def test_discriminator_matches_oracle(dev, mode):
     from textboxgan_amd.models import Discriminator
@@ -227,6 +231,7 @@ def test_discriminator_matches_oracle(dev, mode):
         assert l2_err(a, b) < 5e-4 and rel_err(a, b) < 5e-2, n
 
 
+@arith_modes
 def test_discriminator_joint_pass_matches_two_oracle_calls(dev):
     """D over [fake; real] with parts=2 (the d-step's single pass) == the oracle's two separate calls: scores, the
     d-pass gradients (sum over both halves, image gradient pruned) and -- in the G-loss pass's first-half mode -- the
@@ -269,6 +274,7 @@ def test_discriminator_joint_pass_matches_two_oracle_calls(dev):
             assert len(taps) == 2 and all(t.shape[0] == 8 for t in taps)
 
 
+@arith_modes
 @pytest.mark.parametrize("mode", ["fused", "composable"])
 @pytest.mark.parametrize("training", [True, False])
 def test_generator_matches_oracle(dev, mode, training):
@@ -317,6 +323,7 @@ def test_generator_hello_known_answer_geometry(dev):
     assert u8.shape == (64, 160, 3) and u8.dtype == torch.uint8
 
 
+@arith_modes
 def test_ocr_hip_matches_torch_definition(dev):
     """AsterLikeOCRHip (convs on the MFMA kernel) == AsterLikeOCR (plain torch, CPU): logits and d/dimage."""
     from textboxgan_amd.aster import AsterInferer, AsterLikeOCRHip
@@ -335,6 +342,7 @@ def test_ocr_hip_matches_torch_definition(dev):
     assert rel_err(outs[1][1], outs[0][1]) < 5e-3
 
 
+@arith_modes
 @pytest.mark.parametrize("kind", ["up3x3", "conv3x3", "torgb1x1"])
 def test_modconv_composable_block_exact(dev, kind):
     """any-order path of one modulated conv (x*s -> HIP conv primitive(s) -> *d) vs the oracle: forward and
@@ -362,6 +370,7 @@ def test_modconv_composable_block_exact(dev, kind):
         assert rel_err(a, b) < 1e-5
 
 
+@arith_modes
 def test_hip_path_reproduces_committed_golden_fixtures(dev):
     """tests/golden/*.npz (float64 oracle outputs committed as data): upfirdn2d cases and the whole
     generator -> mask -> discriminator chain at the reduced-channel config on the HIP path."""

@@ -9,6 +9,8 @@ import torch
 from oracle import ref_model as M, ref_projector as RP
 from textboxgan_amd.config import Config, small_config
 
+from conftest import arith_modes
+
 pytestmark = pytest.mark.gpu
 
 
@@ -18,6 +20,7 @@ def l2_err(a, ref):
     return float((a - ref).norm() / (ref.norm() + 1e-30))
 
 
+@arith_modes
 def test_lpips_forward_and_image_gradient(dev):
     from textboxgan_amd.projector import LPIPS
     lp = LPIPS()
@@ -48,6 +51,7 @@ def _rand(cfg, steps, n_latent, seed):
                 noises=[[nrm(1, 1, h, w) for (h, w) in res for _ in range(2)] for _ in range(steps)])
 
 
+@arith_modes
 def test_projector_steps_match_oracle(dev):
     from textboxgan_amd.aster import AsterInferer, AsterLikeOCR, AsterLikeOCRHip
     from textboxgan_amd.models import Generator

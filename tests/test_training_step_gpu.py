@@ -7,6 +7,8 @@ import torch
 from oracle import ref_model as M
 from textboxgan_amd.config import small_config
 
+from conftest import arith_modes
+
 pytestmark = pytest.mark.gpu
 
 
@@ -29,6 +31,7 @@ def _todev(rand, dev):
             for k, v in rand.items()}
 
 
+@arith_modes
 @pytest.mark.parametrize("reg", [(False, False), (True, True)], ids=["plain", "r1+pl"])
 def test_training_step_matches_oracle(dev, reg):
     from textboxgan_amd.aster import AsterLikeOCR
@@ -125,3 +128,45 @@ def test_validation_step_and_chosen_words(dev):
     assert abs(float(loss) - float(ref)) <= 2e-4 * max(1.0, abs(float(ref)))
     outs = generate_chosen_words(prod["g_clone"], ["Hello", "GAN", "abcdefghij"], cfg)
     assert [o.shape for o in outs] == [(64, 160, 3), (64, 96, 3), (64, 256, 3)] and outs[0].dtype.name == "uint8"
+
+
+def test_short_batch_is_rejected(dev):
+    """the reference never feeds a short batch (drop_remainder=True, training_data_loader.py:93-97); z, noise and the loss
+    normalisation are sized by the configured batch, so a ragged final batch must raise instead of running with
+    mismatched style / image batches (it used to fall back to an eager step that corrupted gradients)."""
+    from textboxgan_amd.training_step import build_trainer_state
+    cfg = small_config(4)
+    for graphs in (False, True):
+        prod = build_trainer_state(cfg, dev, seed=1, use_graphs=graphs)
+        b = {k: v.to(dev) for k, v in M.make_batch(cfg).items()}
+        with pytest.raises(ValueError, match="samples per replica"):
+            prod["training_step"].dist_train_step(b["real_images"][:3], b["ocr_images"], b["input_words"][:3],
+                                                  b["ocr_labels"][:3], False, False, 1e-4)
+
+
+def test_unread_gradient_tails_are_never_read(dev):
+    """In the G-loss pass over the joint [fake; real] batch the discriminator's nodes differentiate the leading half only
+    and leave the rest of their gradient tensors unwritten (ops.FLAGS.d_first_half).  Run the same step with those tails
+    filled with NaN and with zeros (FLAGS.unread_tail_fill): every loss and gradient must be finite and equal (up to the
+    run-to-run noise of the fp32 atomics in the style-gradient reductions), i.e. nothing ever reads a tail."""
+    from textboxgan_amd import ops
+    from textboxgan_amd.training_step import build_trainer_state
+    cfg = small_config(4)
+    batch, rand = M.make_batch(cfg), M.make_rand(cfg, seed=5)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    outs = []
+    for fill in (float("nan"), 0.0):
+        prod = build_trainer_state(cfg, dev, seed=3)
+        ts = prod["training_step"]
+        ops.FLAGS.unread_tail_fill = fill
+        try:
+            losses = ts.dist_train_step(b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False,
+                                        1e-4, rand=_todev(rand, dev))
+        finally:
+            ops.FLAGS.unread_tail_fill = None
+        torch.cuda.synchronize()
+        outs.append((torch.stack([x.reshape(()) for x in losses[0] + losses[1]] + [losses[2].reshape(())]),
+                     ts.g_grad.clone(), ts.o_grad.clone(), ts.d_grad.clone()))
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.isfinite(a).all() and torch.isfinite(c).all()
+        assert l2_err(a, c) < 1e-5

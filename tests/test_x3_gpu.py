@@ -78,6 +78,7 @@ def test_conv_x3_matches_float64_at_fp32_tolerance(dev, ci):
                 (gx,) = torch.autograd.grad(F.conv2d(xr, w32.permute(3, 2, 0, 1), stride=stride, padding=pad), xr, dy.double())
                 dx = ops._bwd_data_launch(dy.to(dev), wd, geom)
                 errs[mode] = max(rel(y, ref), rel(dx, gx))
+    print(f"\nX3ERR {case}: f32 {errs['f32']:.3e}  f32x3 {errs['f32x3']:.3e}")
     assert errs["f32x3"] < 3e-5, (case, errs)
     assert errs["f32x3"] <= max(2.0 * errs["f32"], 1e-6), (case, errs)
 

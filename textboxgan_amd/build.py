@@ -10,6 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtbg_hip.so")
+HOST_LIB = os.path.join(HERE, "libtbg_host.so")
 SOURCES = ["elementwise.hip", "upfirdn.hip", "conv.hip", "rgb.hip", "lstm.hip", "smalls.hip", "host_util.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
 
@@ -28,13 +29,20 @@ def _digest() -> str:
 def build_native(force: bool = False, verbose: bool = True) -> str:
     stamp = LIB + ".sha256"
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+    if (not force and os.path.exists(LIB) and os.path.exists(HOST_LIB) and os.path.exists(stamp)
+            and open(stamp).read().strip() == dig):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, *FLAGS, "-shared", "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
     if verbose:
         print("[tbg build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    # the host-only helpers once more WITHOUT the HIP runtime (g++): the checkpoint checksum on CPU-only hosts
+    host_cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "c++",
+                os.path.join(CSRC, "host_util.hip"), "-o", HOST_LIB]
+    if verbose:
+        print("[tbg build]", " ".join(host_cmd), flush=True)
+    subprocess.check_call(host_cmd)
     with open(stamp, "w") as f:
         f.write(dig)
     return LIB

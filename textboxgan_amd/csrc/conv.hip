@@ -363,6 +363,55 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
         }
       return;
     }
+    if constexpr (X3 && WTM * WTN <= 4) {
+      // all MT taps present (every 3x3 launch): straight-line code over (tap, unit) steps with the operand reads of step
+      // i+1 issued before the MFMAs of step i (two register sets).  The rolled loop below exposed one LDS round trip per tap:
+      // 12 bf16 MFMAs (384 cycles) cover far less of it than the 16 fp32 ones (1024 cycles) of the exact kernel.
+      if (ntaps == MT) {
+        constexpr int NS = MT * (CK / 8);
+        bf16x8 ax[2][WTM], ay[2][WTM], b0[2][WTN], b1[2][WTN], b2[2][WTN];
+        auto ld = [&](int st, int buf) {
+          const int t = st / (CK / 8), u = st % (CK / 8);
+          const char *Au = Ab + ((t * G4 + u) * BM) * 16;
+          const char *Xu = Xb + __builtin_amdgcn_readlane(tofft, t) + u * p.planeStride * 16;
+#pragma unroll
+          for (int i = 0; i < WTM; ++i) {
+            ax[buf][i] = *reinterpret_cast<const bf16x8 *>(Au + aX + i * 32 * 16);
+            ay[buf][i] = *reinterpret_cast<const bf16x8 *>(Au + aY + i * 32 * 16);
+          }
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) {
+            b0[buf][j] = *reinterpret_cast<const bf16x8 *>(Xu + bbytes[j]);
+            b1[buf][j] = *reinterpret_cast<const bf16x8 *>(Xu + x_pl + bbytes[j]);
+            b2[buf][j] = *reinterpret_cast<const bf16x8 *>(Xu + bZ + bbytes[j]);
+          }
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          const int cb = st & 1;
+          if (st + 1 < NS) ld(st + 1, cb ^ 1);
+          __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of this step's MFMAs (the scheduler sinks them otherwise)
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+              acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay[cb][i], b2[cb][j], acc[0][i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+              acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[cb][i], b1[cb][j], acc[0][i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+              acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[cb][i], b0[cb][j], acc[0][i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+      }
+    }
     for (int t = 0; t < ntaps; ++t) {
       const int toffb = __builtin_amdgcn_readlane(tofft, t);  // tap shift in bytes (lane t of the table)
       if constexpr (X3) {
@@ -420,7 +469,54 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     }
   };
 
-  if constexpr (PF > 0) {
+  bool done = false;
+  if constexpr (X3) {
+    // f32x3 K loop with the halo tile of chunk k+1 PREFETCHED INTO REGISTERS while chunk k's MFMAs run (single LDS buffer: three
+    // operand planes leave no room for a second one at 2 blocks/CU).  Per chunk: barrier | split + store the prefetched tile
+    // | issue the filter DMA | issue the loads of the next tile | wait for the DMA only (counted vmcnt: the loads stay in
+    // flight) | barrier | MFMAs.  The HBM round trip of the halo no longer sits between two MFMA phases; what stays exposed
+    // is the filter DMA (L2-resident) and the store pass.
+    constexpr int NJX = 2, NBT = CK / CB;  // positions per thread this path holds; 8-channel load batches per position
+    if (p.NJ <= NJX) {
+      done = true;
+      float xr[NJX][NBT][CB];
+      auto loadx = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NJX; ++j)
+          if (j < p.NJ) {  // uniform
+#pragma unroll
+            for (int bt = 0; bt < NBT; ++bt) load_halo(c0 + bt * CB, j, xr[j][bt]);
+          }
+      };
+      if (kbeg < kend) loadx(kbeg * CK);
+      if (p.in_scale) __syncthreads();  // Ss visible
+      for (int kc = kbeg; kc < kend; ++kc) {
+        if (kc > kbeg) {  // every wave is done reading the previous chunk's tiles
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int j = 0; j < NJX; ++j)
+          if (j < p.NJ) {
+#pragma unroll
+            for (int bt = 0; bt < NBT; ++bt) store_halo(kc * CK + bt * CB, bt, j, xr[j][bt], Xs);
+          }
+        issue_filter_dma(kc, As);
+        if (kc + 1 < kend) {
+          loadx((kc + 1) * CK);
+          // the DMA pieces are older than the loads just issued: leave exactly those loads outstanding
+          if (p.NJ == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NBT * CB) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NBT * CB) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        mfma_taps(As, Xs);
+      }
+    }
+  }
+  if (done) {
+  } else if constexpr (PF > 0) {
     // Software-pipelined K loop, ONE barrier per chunk: the filter DMA and the halo loads of chunk k+1 are issued
     // before the MFMA work of chunk k (they land in the other LDS buffer / in registers while the matrix cores run),
     // so no memory round trip is exposed.  Measured need: without it the staging of co-resident blocks did NOT overlap
@@ -676,8 +772,20 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
 
 
 // mode: 0 = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = bf16 operands, 2 = f32x3 (three bf16 terms per fp32 operand)
+static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, float *y, const float *in_scale,
+                        const tbg_epilogue *epi, void *stream, const NameOut *name, int mode, int variant, bool force64);
+
 static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, float *y, const float *in_scale,
                        const tbg_epilogue *epi, void *stream, const NameOut *name, int mode = 0, int variant = 0) {
+  int rc = conv2d_tiled(d, x, w, y, in_scale, epi, stream, name, mode, variant, false);
+  // a tile whose halo does not fit LDS (three operand planes in f32x3; many small images per 256-pixel tile): the 64 x 64
+  // tile packs a quarter of the images.  launch_fprop refuses BEFORE launching anything, so the retry is clean.
+  if (rc == TBG_EUNSUPPORTED && variant == 0) rc = conv2d_tiled(d, x, w, y, in_scale, epi, stream, name, mode, variant, true);
+  return rc;
+}
+
+static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, float *y, const float *in_scale,
+                        const tbg_epilogue *epi, void *stream, const NameOut *name, int mode, int variant, bool force64) {
   const bool bf = mode == 1, x3 = mode == 2;
   if (!d || !epi_valid(epi)) return TBG_EINVAL;
   if (!name && (!x || !w || !y)) return TBG_EINVAL;
@@ -763,6 +871,7 @@ static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, f
   // tile configuration
   int BM, BN;
   if (merged) { BM = 64; BN = 128; }  // 4 classes x (1 x 2) MFMA tiles per wave = 128 accumulators
+  else if (force64) { BM = 64; BN = 64; }
   else {
     const long long npix = (long long)d->B * maxUg * maxVg;  // N of the (largest class) GEMM
     if (d->M <= 32) { BM = 32; BN = 256; }

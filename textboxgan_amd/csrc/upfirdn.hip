@@ -21,6 +21,8 @@
 //   * upfirdn2d_direct_kernel: everything else (any filter size, factors, minor): one lane per output, walks only the
 //     taps that land on an input sample.
 // Both fuse an optional per-plane input scale and the shared epilogue (demodulation scale, noise, bias, LeakyReLU).
+#include <stdio.h>
+
 #include "common.h"
 
 struct UpfirdnP {
@@ -360,4 +362,27 @@ extern "C" int tbg_upfirdn2d_sep_f32(const float *x, const float *kx, const floa
   if ((rc = upfirdn_epi(p, in_scale, M, epi)) != TBG_OK) return rc;
   p.kx = kx; p.ky = ky;
   return upfirdn_dispatch(p, tbg_stream(stream));
+}
+
+// Kernel instantiation (rocprofv3 spelling) the three entries above select: a pure function of the geometry (the same
+// conditions as upfirdn_dispatch).  sep: the separable entry (tbg_upfirdn2d_sep_f32).  Test / profiling aid, like
+// tbg_conv2d_kernel_name.
+extern "C" int tbg_upfirdn2d_kernel_name(int minor, int kH, int kW, int upx, int upy, int downx, int downy, int padx0,
+                                         int pady0, int sep, char *buf, int n) {
+  if (!buf || n < 1) return TBG_EINVAL;
+  buf[0] = 0;
+  if (minor < 1 || kH < 1 || kW < 1 || upx < 1 || upy < 1 || downx < 1 || downy < 1) return TBG_EINVAL;
+  if (minor == 1 && kW <= 4 && kH <= 4) {
+    const int rx = pmod(padx0, upx), ry = pmod(pady0, upy);
+    static const int tab[][6] = {{1, 1, 1, 1, 0, 0}, {2, 2, 1, 1, 0, 0}, {2, 2, 1, 1, 1, 0}, {2, 2, 1, 1, 0, 1}, {2, 2, 1, 1, 1, 1},
+                                 {1, 1, 2, 2, 0, 0}, {1, 1, 2, 1, 0, 0}, {2, 1, 1, 1, 0, 0}, {2, 1, 1, 1, 1, 0}};
+    for (const auto &t : tab)
+      if (upx == t[0] && upy == t[1] && downx == t[2] && downy == t[3] && rx == t[4] && ry == t[5]) {
+        snprintf(buf, n, "upfirdn2d_tile_kernel<%d, %d, %d, %d, %d, %d, %s>", t[0], t[1], t[2], t[3], t[4], t[5],
+                 sep ? "true" : "false");
+        return TBG_OK;
+      }
+  }
+  snprintf(buf, n, "upfirdn2d_direct_kernel");
+  return TBG_OK;
 }

@@ -21,13 +21,14 @@ class GradExchange:
         self.pg = process_group
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         self._pending: List = []
+        self.muted = False  # measurement aid (bench.py dist_record): skip the gradient collectives, keep every launch
 
     def world_size(self) -> int:
         return dist.get_world_size(self.pg) if self.active else 1
 
     def start(self, flat_grad: torch.Tensor):
         """Asynchronous SUM all-reduce of one flat gradient buffer; returns a handle (or None)."""
-        if not self.active:
+        if not self.active or self.muted:
             return None
         return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
@@ -37,7 +38,7 @@ class GradExchange:
             handle.wait()
 
     def reduce_now(self, bufs: Sequence[torch.Tensor]) -> None:
-        if self.active:
+        if self.active and not self.muted:
             for b in bufs:
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg)
 

@@ -22,7 +22,7 @@ SQRT2 = 1.4142135623730951
 EXPORTS = [
     "tbg_version", "tbg_strerror", "tbg_crc32c", "tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_upfirdn2d_sep_f32", "tbg_conv2d_f32",
     "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_conv2d_kernel_name", "tbg_conv2d_f32_variant", "tbg_conv2d_bf16_variant", "tbg_conv2d_wgrad_kernel_name", "tbg_weight_pack_bf16_bytes", "tbg_weight_pack_bf16", "tbg_weight_pack_multi", "tbg_modconv_bwd_smalls_f32", "tbg_torgb_bwd_smalls_f32", "tbg_minibatch_std_fwd_f32", "tbg_minibatch_std_bwd_f32", "tbg_dense_fwd_f32", "tbg_dense_bwd_f32", "tbg_dense_multi_fwd_f32", "tbg_dense_multi_bwd_f32", "tbg_conv2d_bf16", "tbg_conv2d_bf16_kernel_name", "tbg_conv2d_wgrad_bf16", "tbg_conv2d_wgrad_bf16_kernel_name", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_attn_ctx_fwd_f32", "tbg_attn_ctx_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
-    "tbg_weight_pack_x3_bytes", "tbg_weight_pack_x3", "tbg_conv2d_x3", "tbg_conv2d_x3_kernel_name", "tbg_conv2d_x3_variant",
+    "tbg_upfirdn2d_kernel_name", "tbg_weight_pack_x3_bytes", "tbg_weight_pack_x3", "tbg_conv2d_x3", "tbg_conv2d_x3_kernel_name", "tbg_conv2d_x3_variant",
     "tbg_bias_act_bwd_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -111,6 +111,7 @@ def lib():
         l.tbg_weight_pack_bf16_bytes.argtypes = [ci, ci, ci, ci]
         l.tbg_weight_pack_bf16_bytes.restype = C.c_longlong
         l.tbg_conv2d_wgrad_kernel_name.argtypes = [C.POINTER(WgradDesc), C.c_char_p, ci]
+        l.tbg_upfirdn2d_kernel_name.argtypes = [ci] * 10 + [C.c_char_p, ci]
         l.tbg_weight_pack_x3_bytes.argtypes = [ci, ci, ci, ci]
         l.tbg_weight_pack_x3_bytes.restype = C.c_longlong
         l.tbg_weight_pack_x3.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
@@ -125,8 +126,79 @@ def lib():
         l.tbg_adam_tf_f32.argtypes = [vp, vp, vp, vp, ll, cf, cf, cf, cf, vp, vp]
         l.tbg_ema_lerp_f32.argtypes = [vp, vp, ll, cf, vp]
         l.tbg_demod_coefs_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, cf, vp]
-        _lib = l
+        _lib = _LibProxy(l)
     return _lib
+
+
+# ----------------------------------------------------------------------------------------
+# call recorder (tests): which kernel instantiation every C-ABI call selects
+# ----------------------------------------------------------------------------------------
+CALL_LOG = None  # None = off; a set collects one key per distinct (entry, instantiation)
+
+
+class record_calls:
+    """``with native.record_calls() as log:`` -- log (a set) receives, for every compute entry called inside the scope, the
+    kernel instantiation it selects where the library can name it (convolutions, filter gradients, upfirdn2d: the
+    *_kernel_name entries, pure functions of the descriptor) and the entry name otherwise.  Test infrastructure: proves
+    that everything a training step launches is also launched by an oracle-compared case."""
+
+    def __enter__(self):
+        global CALL_LOG
+        self._prev, CALL_LOG = CALL_LOG, set()
+        return CALL_LOG
+
+    def __exit__(self, *exc):
+        global CALL_LOG
+        CALL_LOG = self._prev
+        return False
+
+
+_CONV_FMT = {"tbg_conv2d_f32": 0, "tbg_conv2d_f32_variant": 0, "tbg_conv2d_bf16": 1, "tbg_conv2d_bf16_variant": 1,
+             "tbg_conv2d_x3": 2, "tbg_conv2d_x3_variant": 2}
+_WGRAD_FMT = {"tbg_conv2d_wgrad_f32": 0, "tbg_conv2d_wgrad_ex_f32": 0, "tbg_conv2d_wgrad_bf16": 1, "tbg_conv2d_wgrad_x3": 2}
+
+
+def _call_key(name, a):
+    try:
+        if name in _CONV_FMT and not name.endswith("_variant"):
+            return conv_kernel_name(a[0]._obj, a[4] is not None, _CONV_FMT[name])
+        if name in _WGRAD_FMT:
+            return wgrad_kernel_name(a[0]._obj, _WGRAD_FMT[name])
+        if name in ("tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_upfirdn2d_sep_f32"):
+            if name == "tbg_upfirdn2d_f32":      # x k y major inH inW minor kH kW upx upy downx downy padx0 padx1 pady0 pady1
+                minor, g = a[6], a[7:17]
+            elif name == "tbg_upfirdn2d_ex_f32":  # x k y major inH inW kH kW upx upy downx downy padx0 padx1 pady0 pady1 ...
+                minor, g = 1, a[6:16]
+            else:                                # x kx ky y major inH inW kH kW upx upy downx downy padx0 padx1 pady0 pady1 ...
+                minor, g = 1, a[7:17]
+            kH, kW, upx, upy, dnx, dny, px0, _px1, py0, _py1 = g
+            buf = C.create_string_buffer(96)
+            _lib._l.tbg_upfirdn2d_kernel_name(minor, kH, kW, upx, upy, dnx, dny, px0, py0, int(name.endswith("sep_f32")), buf, 96)
+            return buf.value.decode()
+    except Exception as e:  # never let the recorder break a call
+        return f"{name} [unnamed: {type(e).__name__}]"
+    return name
+
+
+_NOT_COMPUTE = ("tbg_version", "tbg_strerror", "tbg_crc32c", "_kernel_name", "_bytes", "_floats", "_chunks")
+
+
+class _LibProxy:
+    """the ctypes library; while a record_calls scope is active every compute entry also logs what it launches"""
+
+    def __init__(self, l):
+        self._l = l
+
+    def __getattr__(self, name):
+        fn = getattr(self._l, name)
+        if CALL_LOG is None or not name.startswith("tbg_") or name.endswith(_NOT_COMPUTE) or name in _NOT_COMPUTE:
+            return fn
+
+        def rec(*a):
+            if CALL_LOG is not None:
+                CALL_LOG.add(_call_key(name, a))
+            return fn(*a)
+        return rec
 
 
 def check(rc: int, what: str):

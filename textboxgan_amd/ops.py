@@ -46,16 +46,18 @@ class _Flags:
         # reaches no filter: custom Functions are not pruned by autograd.grad(inputs=...), so without this flag every
         # composable conv of that pass would also launch its filter gradient and throw it away.
         self.no_filter_grads = False
-        # debug aid: zero the never-read tail of the d_first_half gradient tensors instead of leaving it
-        # uninitialised, so anomaly mode / NaN checks see defined memory
-        self.zero_unread_tails = False
+        # debug aid: fill value for the never-read tail of the d_first_half gradient tensors -- None leaves
+        # it uninitialised (production), 0.0 gives anomaly mode / NaN checks defined memory, NaN makes any read of it loud
+        self.unread_tail_fill = None
 
 
-class _ThreadState(threading.local):
-    """Every piece of host-side mutable state of this module lives here, one copy per THREAD: two TrainingStep objects
-    driven from two threads (or a step and a validation pass) cannot see each other's pruning flags, arithmetic mode or
-    packed-filter scopes.  (torch runs a backward pass's Python callbacks on the thread that called autograd.grad /
-    backward for the device's default stream use here, so the flags set around a pass are the ones its nodes read.)"""
+class _State:
+    """Every piece of host-side mutable state of this module: the pruning flags, the arithmetic mode and the packed-filter
+    scopes.  It is PROCESS-wide on purpose -- torch runs a backward pass's Python callbacks on its per-device autograd
+    thread, not on the thread that called autograd.grad, so thread-local storage would hide the flags from exactly the
+    nodes that read them -- and is guarded by STATE_LOCK instead: a scope that changes it (TrainingStep._compute_grads,
+    the projector, validation passes) holds the re-entrant lock from before its forward until after its last backward,
+    so two step objects driven from two threads take turns instead of corrupting each other."""
 
     def __init__(self):
         self.flags = _Flags()
@@ -64,11 +66,12 @@ class _ThreadState(threading.local):
         self.pack_store = None   # live only inside PackedStore.scope(): persistent packs of a training step
 
 
-_TLS = _ThreadState()
+_TLS = _State()
+STATE_LOCK = threading.RLock()
 
 
 class _FlagsProxy:
-    """``ops.FLAGS.x`` reads / writes the calling thread's flags."""
+    """``ops.FLAGS.x`` reads / writes the process-wide flags (hold STATE_LOCK around a pass that sets them)."""
 
     def __getattr__(self, name):
         return getattr(_TLS.flags, name)
@@ -628,6 +631,16 @@ def _half(role, B):
     return h if (h and role in ("d", "d_image") and h < B) else 0
 
 
+def _tail_empty(shape, device):
+    """gradient tensor of a d_first_half node whose trailing samples nobody reads: uninitialised, or filled with
+    FLAGS.unread_tail_fill (debug aid: a test runs a step with NaN tails and with zero tails and requires finite, equal
+    results, i.e. proves the tail is never read)."""
+    fill = FLAGS.unread_tail_fill
+    if fill is None:
+        return torch.empty(shape, device=device, dtype=torch.float32)
+    return torch.full(shape, float(fill), device=device, dtype=torch.float32)
+
+
 class _UpFirDn2D(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k, up, down, pad, role=None):
@@ -649,7 +662,7 @@ class _UpFirDn2D(torch.autograd.Function):
                 kH - pad[2] - 1, inH * up[1] - outH * down[1] + pad[2] - up[1] + 1)
         h = _half(ctx.role, dy.shape[0])
         if h:  # first-order pass over the leading samples only; the rest of dx is never read
-            dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
+            dx = _tail_empty(ctx.xshape, dy.device)
             upfirdn2d_raw(dy.contiguous()[:h], _flipped_fir(k), down, up, gpad, out=dx[:h])
             return dx, None, None, None, None, None
         return _UpFirDn2D.apply(dy, _flipped_fir(k), down, up, gpad), None, None, None, None, None
@@ -791,6 +804,7 @@ class _ModConvFused(torch.autograd.Function):
     def forward(ctx, x, w, s, noise, strength, b):
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
+        assert x.shape[0] == s.shape[0] and s.shape[1] == I, "one style row per sample (a short batch must not reach the fused layers)"
         x = x.contiguous(); s = s.contiguous()
         d, wsq = demod_coefs_raw(s, w.contiguous(), coef)
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=coef)
@@ -827,6 +841,7 @@ class _ModConvUpFused(torch.autograd.Function):
     def forward(ctx, x, w, s, noise, strength, b):
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
+        assert x.shape[0] == s.shape[0] and s.shape[1] == I, "one style row per sample (a short batch must not reach the fused layers)"
         x = x.contiguous(); s = s.contiguous()
         d, wsq = demod_coefs_raw(s, w.contiguous(), coef)
         H, W = x.shape[2], x.shape[3]
@@ -873,6 +888,7 @@ class _ToRGBFused(torch.autograd.Function):
     def forward(ctx, x, w, s, b, skip):
         _, _, I, O = w.shape
         coef = 1.0 / math.sqrt(I)
+        assert x.shape[0] == s.shape[0] and s.shape[1] == I, "one style row per sample"
         x = x.contiguous()
         y = rgb_project_raw(x, w, O, s, b, None if skip is None else skip.contiguous(), coef)
         ctx.save_for_backward(x, w, s)
@@ -928,7 +944,7 @@ class _ConvBiasActFused(torch.autograd.Function):
             _, dpre, pdb, _, _ = bias_act_bwd_raw(dout, out, _lrelu_epi(bias=b), want_db=b is not None)
             db = pdb.sum(dim=(0, 2)) if b is not None else None
         elif has_res and h:  # the residual branch continues into another "d" node: full-size tensor, leading part written
-            dres = torch.empty_like(dout_f)
+            dres = _tail_empty(dout_f.shape, dout_f.device)
             dpre = torch.mul(dout, res_scale, out=dres[:h])
             db = dpre.sum(dim=(0, 2, 3)) if b is not None else None
         else:
@@ -942,7 +958,7 @@ class _ConvBiasActFused(torch.autograd.Function):
         if ctx.needs_input_grad[0] and not (FLAGS.skip_image_grad and ctx.role == "d_image"):
             dx_out = None
             if h:
-                dx = torch.empty_like(x_f)
+                dx = _tail_empty(x_f.shape, x_f.device)
                 dx_out = dx[:h]
             if thin:  # d(image)[b,c,p] = coef * sum_o w[c,o] dpre[b,o,p]
                 r = rgb_project_raw(dpre, w.reshape(I, O).t().contiguous(), I, None, None, None, coef, out=dx_out)
@@ -1036,9 +1052,9 @@ class _MinibatchStd(torch.autograd.Function):
         B, Cc, H, W = x.shape
         n = B // parts
         dy = dy.contiguous()
-        dx = torch.empty_like(x)
         h = _half(role, B)
         assert h in (0, n), "first-half mode: the leading part is the differentiated one"
+        dx = _tail_empty(x.shape, x.device) if h else torch.empty_like(x)
         for i in range(1 if h else parts):
             N.check(N.lib().tbg_minibatch_std_bwd_f32(N.ptr(x[i * n:(i + 1) * n]), N.ptr(dy[i * n:(i + 1) * n]),
                                                       N.ptr(dx[i * n:(i + 1) * n]), n, Cc, H * W, group, N.stream()),

@@ -49,12 +49,16 @@ class FlatParams:
     def make_grad_buffer(self, begin: int, end: int):
         """Flat gradient buffer for [begin, end) + per-parameter views into it."""
         buf = torch.zeros(end - begin, device=self.flat.device, dtype=torch.float32)
-        views = [buf[o - begin: o - begin + p.numel()].view(p.shape)
-                 for p, o in zip(self.params, self.offsets) if begin <= o < end]
+        views = GradViews(buf[o - begin: o - begin + p.numel()].view(p.shape)
+                          for p, o in zip(self.params, self.offsets) if begin <= o < end)
         return buf, views
 
 
-_WG_CACHE: Dict[int, tuple] = {}
+class GradViews(list):
+    """Per-parameter views that tile one flat gradient buffer (FlatParams.make_grad_buffer).  Carries write_grads' copy
+    plan as an attribute, so the plan lives and dies with the list it describes -- no module-level cache keyed by id()
+    (an id can be recycled once its object is freed)."""
+    plan = None
 
 
 def write_grads(views: List[torch.Tensor], grads) -> None:
@@ -63,9 +67,8 @@ def write_grads(views: List[torch.Tensor], grads) -> None:
     parameter: ``_foreach_copy_`` lowered to ~320 separate D2D copies per step (profiles/r02_pmc_report.txt)."""
     if not views:
         return
-    key = id(views)
-    hit = _WG_CACHE.get(key)
-    if hit is None or hit[0] is not views:
+    hit = getattr(views, "plan", None)
+    if hit is None:
         base = views[0]._base if views[0]._base is not None else views[0]
         starts = [v.storage_offset() for v in views]
         ends = [o + v.numel() for o, v in zip(starts, views)]
@@ -74,8 +77,9 @@ def write_grads(views: List[torch.Tensor], grads) -> None:
         dev = views[0].device
         pads = {g: torch.zeros(g, device=dev) for g in set(gaps) if g > 0}
         zeros = {}
-        hit = (views, base.view(-1)[starts[0]:ends[-1]], gaps, pads, zeros)
-        _WG_CACHE[key] = hit
+        hit = (None, base.view(-1)[starts[0]:ends[-1]], gaps, pads, zeros)
+        if isinstance(views, GradViews):
+            views.plan = hit
     _, out, gaps, pads, zeros = hit
     pieces = []
     for i, (v, g) in enumerate(zip(views, grads)):

@@ -51,17 +51,20 @@ def _crc_table() -> np.ndarray:
 
 
 def _native_crc():
-    """tbg_crc32c of libtbg_hip.so (host code: SSE4.2 crc32 instruction) when the library is built; else None."""
-    try:
-        from . import native
-        if os.path.exists(native.LIB_PATH):
-            lib = native.lib()
-            fn = lib.tbg_crc32c
-            fn.restype = C.c_uint32
-            fn.argtypes = [C.c_void_p, C.c_longlong, C.c_uint32]
-            return fn
-    except Exception:  # library absent / not loadable: the pure-python path below is always available
-        pass
+    """tbg_crc32c (host code: SSE4.2 crc32 instruction).  Looked for first in libtbg_host.so -- the same source built with
+    g++ and NO HIP runtime dependency, so a CPU-only inference host loading a checkpoint gets the native checksum too
+     -- then in libtbg_hip.so; None if neither loads."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("libtbg_host.so", "libtbg_hip.so"):
+        path = os.path.join(here, name)
+        try:
+            if os.path.exists(path):
+                fn = C.CDLL(path).tbg_crc32c
+                fn.restype = C.c_uint32
+                fn.argtypes = [C.c_void_p, C.c_longlong, C.c_uint32]
+                return fn
+        except (OSError, AttributeError):  # not loadable here (e.g. no HIP runtime): try the next one
+            continue
     return None
 
 
@@ -81,6 +84,10 @@ def crc32c(data, crc: int = 0) -> int:
         _NATIVE = _native_crc()
     if _NATIVE is not None and data.size >= 64:
         return int(_NATIVE(data.ctypes.data, data.size, crc))
+    if data.size >= (1 << 20):
+        import warnings
+        warnings.warn("crc32c: native library not loadable, checksumming %d bytes in pure Python (slow): build "
+                      "textboxgan_amd/libtbg_host.so with `python -m textboxgan_amd.build`" % data.size)
     t = _crc_table()
     c = crc ^ 0xFFFFFFFF
     for b in data.tolist():

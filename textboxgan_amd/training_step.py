@@ -29,7 +29,7 @@ from . import ops
 from .config import Config, cfg as default_cfg
 from .dist_utils import GradExchange
 from .models import Discriminator, Generator, mask_text_box
-from .optim import AdamTF, flatten_generator, flatten_module, write_grads
+from .optim import AdamTF, GradViews, flatten_generator, flatten_module, write_grads
 
 
 def generator_loss(fake_scores, batch_size):
@@ -57,7 +57,7 @@ class TrainingStep:
     def __init__(self, generator: Generator, discriminator: Discriminator, aster_ocr, g_optimizer: AdamTF,
                  ocr_optimizer: AdamTF, d_optimizer: AdamTF, g_reg_interval: int, d_reg_interval: int,
                  pl_mean: torch.Tensor, cfg: Config = default_cfg, process_group=None, use_graphs: bool = False,
-                 compute_dtype: str = "f32"):
+                 compute_dtype: Optional[str] = "f32"):
         self.generator, self.discriminator, self.aster_ocr = generator, discriminator, aster_ocr
         self.g_optimizer, self.ocr_optimizer, self.d_optimizer = g_optimizer, ocr_optimizer, d_optimizer
         self.g_reg_interval, self.d_reg_interval = g_reg_interval, d_reg_interval
@@ -71,15 +71,17 @@ class TrainingStep:
         self.pl_noise_scaler = 1.0 / math.sqrt(float(cfg.image_width) * float(cfg.char_height))
         self.pg = process_group
         self.use_graphs = use_graphs
-        # "f32": exact fp32 MFMA contractions (BASELINE configs[1]).  "bf16": conv / filter-gradient operands rounded to
-        # bf16 on their way into LDS, fp32 accumulate, fp32 master weights + Adam (BASELINE configs[2]).
+        # "f32": exact fp32 MFMA contractions.  "f32x3": fp32 tensors, forward / data-gradient contractions as three bf16 terms
+        # per operand on the bf16 pipe (fp32-grade, tbg.h "f32x3 forms").  "bf16": conv / filter-gradient operands rounded to
+        # bf16 on their way into LDS, fp32 accumulate, fp32 master weights + Adam (BASELINE configs[2]).  None: the
+        # ops.compute_dtype scope in force when the step object is built.
+        if compute_dtype is None:
+            compute_dtype = ops.compute_mode()
         assert compute_dtype in ops.COMPUTE_MODES
         self.compute_dtype = compute_dtype
-        # OCR branch (forward + its own backward) on a second HIP stream.  Worth ~1% only (415 -> 418-420 text-boxes/s):
-        # tools/graph_branch_test.py shows that on MI355X / ROCm 7.2 neither eager streams nor captured fork/join branches
-        # overlap a chain of small kernels with a large kernel to any useful degree (7.67 vs 7.96 ms).
-        self.overlap_ocr = True
-        self._ocr_stream = None
+        # (Round 2 ran the frozen-OCR branch on a second HIP stream; profiles/r02_stream_concurrency.txt measured that
+        # the fork hides nothing on this stack -- 29.11 vs 29.20 ms/step -- so the branch is issued in line again.)
+        self.capture_error = None  # text of a failed HIP-graph capture (the step then runs eagerly): surfaced by bench.py
         self._graphs = {}
         self._packs = ops.PackedStore()
         self._warmed = set()
@@ -115,14 +117,31 @@ class TrainingStep:
         for lo in reversed([0] + bounds[:-1]):
             b0 = df.offsets[lo]
             b1 = df.offsets[hi] if hi < len(names) else df.total
-            stages.append((self.d_params[lo:hi], self.d_views[lo:hi], (b0, b1)))
+            stages.append((self.d_params[lo:hi], GradViews(self.d_views[lo:hi]), (b0, b1)))
             hi = lo
+        # the staged backward relies on the flat layout: stage slices are contiguous, deepest first, and tile d_grad
+        assert self.d_params == list(df.params) and len(self.d_views) == len(self.d_params)
+        assert stages[0][2][1] == df.total and stages[-1][2][0] == 0, "stage slices must cover the flat gradient buffer"
+        assert all(a[2][0] == b[2][1] for a, b in zip(stages, stages[1:])), "stage slices must be contiguous"
+        assert sum(len(st[0]) for st in stages) == len(self.d_params)
+        for c in self.d_cuts:  # everything from blocks[c] on (deeper blocks, last_block, last_dense, last_bias) is one suffix
+            i0 = first_index(f"blocks.{c}.")
+            assert not any(n.startswith(("initial_fromrgb.",) + tuple(f"blocks.{k}." for k in range(c))) for n in names[i0:]), \
+                "discriminator parameters are not ordered shallow -> deep"
         return stages
 
     # ------------------------------------------------------------------------------------
     def dist_train_step(self, real_images, ocr_images, input_words, ocr_labels, do_r1_reg: bool, do_pl_reg: bool,
                         ocr_loss_weight: float, rand: Optional[dict] = None):
-        """training_step.py:57-136.  Inputs are this rank's shard of the global batch."""
+        """training_step.py:57-136.  Inputs are this rank's shard of the global batch: exactly ``cfg.batch_size_per_gpu``
+        samples -- the reference's loaders use drop_remainder=True (training_data_loader.py:93-97), z / noise / loss
+        normalisation are sized by the configured batch, and a HIP graph is bound to its geometry, so a short batch is an
+        error here, not a silent broadcast."""
+        nb = self.batch_size_per_gpu
+        if real_images.shape[0] != nb or input_words.shape[0] != nb or ocr_labels.shape[0] != nb:
+            raise ValueError(f"dist_train_step expects {nb} samples per replica (drop_remainder=True semantics), got "
+                             f"real_images {tuple(real_images.shape)}, input_words {tuple(input_words.shape)}, "
+                             f"ocr_labels {tuple(ocr_labels.shape)}")
         if self.use_graphs and rand is None:
             gen_losses, disc_losses, ocr_loss = self._graphed_step(real_images, ocr_images, input_words, ocr_labels,
                                                                    bool(do_r1_reg), bool(do_pl_reg), ocr_loss_weight)
@@ -146,11 +165,6 @@ class TrainingStep:
             self._static = dict(real=real_images.clone(), ocr_img=ocr_images.clone(), words=input_words.clone(),
                                 labels=ocr_labels.clone(), w=torch.zeros((), device=real_images.device))
         st = self._static
-        for name, t in (("real", real_images), ("ocr_img", ocr_images), ("words", input_words), ("labels", ocr_labels)):
-            if tuple(t.shape) != tuple(st[name].shape):
-                # a captured graph is bound to its batch geometry: a ragged final batch must not broadcast silently
-                # into the static buffers -- run it eagerly instead
-                return self._train_step(real_images, ocr_images, input_words, ocr_labels, do_r1, do_pl, ocr_w, None)
         st["real"].copy_(real_images); st["ocr_img"].copy_(ocr_images); st["words"].copy_(input_words)
         st["labels"].copy_(ocr_labels); st["w"].fill_(ocr_w)
         key = (do_r1, do_pl)
@@ -170,6 +184,7 @@ class TrainingStep:
                     self._graphs[key] = self._capture_split(st, do_r1, do_pl)
                 except Exception as e:  # a failed capture must not take a multi-GPU job down: finish it eagerly
                     import sys
+                    self.capture_error = f"split capture {key}: {type(e).__name__}: {e}"
                     print(f"[tbg] HIP-graph capture failed ({type(e).__name__}: {e}); continuing WITHOUT graphs",
                           file=sys.stderr, flush=True)
                     torch.cuda.synchronize()
@@ -192,6 +207,7 @@ class TrainingStep:
                         self._apply_updates()
                 except Exception as e:
                     import sys
+                    self.capture_error = f"capture {key}: {type(e).__name__}: {e}"
                     print(f"[tbg] HIP-graph capture failed ({type(e).__name__}: {e}); continuing WITHOUT graphs",
                           file=sys.stderr, flush=True)
                     torch.cuda.synchronize()
@@ -296,7 +312,7 @@ class TrainingStep:
 
     def _compute_grads(self, *args, **kw):
         # packed filters are shared by the forward and the three backward passes
-        with ops.filter_cache(), ops.compute_dtype(self.compute_dtype), self._packs.scope():
+        with ops.STATE_LOCK, ops.filter_cache(), ops.compute_dtype(self.compute_dtype), self._packs.scope():
             self._packs.refresh()  # ONE launch re-packs every filter from the weights the last update left
             return self._compute_grads_impl(*args, **kw)
 
@@ -313,21 +329,16 @@ class TrainingStep:
         fake_images = G((input_words, z), training=True, rand=rand)
         fake_images = mask_text_box(fake_images, input_words, cfg.char_width)
 
-        main_stream = torch.cuda.current_stream()
-        if self.overlap_ocr:
-            # fork: the frozen OCR (and, through autograd's stream tracking, its backward) runs on a side stream
-            if self._ocr_stream is None:
-                self._ocr_stream = torch.cuda.Stream()
-            side = self._ocr_stream
-            side.wait_stream(main_stream)
-            with torch.cuda.stream(side):
-                fake_images.record_stream(side)
-                ocr_loss = self._get_ocr_loss(fake_images, ocr_labels, ocr_images)
-                ocr_loss_w = ocr_loss_weight * ocr_loss
-                # the OCR network's own backward (hundreds of small kernels) is issued HERE, from the side stream, so
-                # that it runs beside the discriminator passes and the g-pass backward of the main stream instead of
-                # in front of the generator's ocr-pass backward; only d(ocr_loss)/d(fake_images) crosses back
-                (dfake_ocr,) = torch.autograd.grad(ocr_loss_w, fake_images, retain_graph=False)
+        # frozen OCR branch and its own backward, issued in line (training_step.py:375-402): only d(ocr_loss)/d(fake_images)
+        # is kept for the generator's ocr-pass below
+        # The recogniser always runs at fp32 grade (north_star: OCR loss within 1e-4): measured on the full-width step, its
+        # image gradient amplifies operand rounding by ~1e4 (exact-fp32 kernels: 1.2e-3 relative L2 on the OCR gradient
+        # set), so bf16 operands (2^-9) leave nothing of it (relative L2 1.09 against the fp32 oracle).  In bf16 mode its
+        # convolutions therefore take the f32x3 kernels (the frozen filters are packed per arithmetic by their owner).
+        with ops.compute_dtype("f32x3" if self.compute_dtype == "bf16" else self.compute_dtype):
+            ocr_loss = self._get_ocr_loss(fake_images, ocr_labels, ocr_images)
+            ocr_loss_w = ocr_loss_weight * ocr_loss
+            (dfake_ocr,) = torch.autograd.grad(ocr_loss_w, fake_images, retain_graph=False)
 
         staged = bool(self.d_cuts) and not do_r1_reg  # R1 steps (1 in 16) keep the single exchange: their D graph is second order
         cuts = sorted(self.d_cuts) if staged else None
@@ -358,10 +369,6 @@ class TrainingStep:
         d_loss = discriminator_loss(fake_scores, real_scores, self.batch_size)
         reg_d_loss = d_loss + r1_penalty
 
-        if not self.overlap_ocr:
-            ocr_loss = self._get_ocr_loss(fake_images, ocr_labels, ocr_images)
-            ocr_loss_w = ocr_loss_weight * ocr_loss
-
         # --- three backward passes at the pre-update weights (training_step.py:194-213)
         ops.FLAGS.skip_d_wgrad = True
         ops.FLAGS.d_first_half = nb if joint else 0
@@ -373,21 +380,11 @@ class TrainingStep:
         write_grads(self.g_views, grads)
         if handles is not None:
             handles.append(self._all_reduce_async(self.g_grad))
-        ocr_joined = False
         if boundary is not None:
-            if self.overlap_ocr:  # a forked stream must rejoin the capturing stream before its graph ends
-                main_stream.wait_stream(self._ocr_stream)
-                ocr_joined = True
             boundary()
 
-        if self.overlap_ocr:
-            if not ocr_joined:
-                main_stream.wait_stream(self._ocr_stream)
-            dfake_ocr.record_stream(main_stream)
-            grads = torch.autograd.grad(fake_images, self.o_params, grad_outputs=dfake_ocr, retain_graph=True,
-                                        allow_unused=True)
-        else:
-            grads = torch.autograd.grad(ocr_loss_w, self.o_params, retain_graph=True, allow_unused=True)
+        grads = torch.autograd.grad(fake_images, self.o_params, grad_outputs=dfake_ocr, retain_graph=True,
+                                    allow_unused=True)
         write_grads(self.o_views, grads)
         if handles is not None:
             handles.append(self._all_reduce_async(self.o_grad))
@@ -422,8 +419,6 @@ class TrainingStep:
         finally:
             ops.FLAGS.skip_image_grad = False
 
-        if self.overlap_ocr and not ocr_joined:
-            main_stream.wait_stream(self._ocr_stream)  # join
         return ((reg_g_loss.detach(), g_loss.detach(), pl_penalty.detach()),
                 (reg_d_loss.detach(), d_loss.detach(), r1_penalty.detach()),
                 (ocr_loss_w / ocr_loss_weight).detach())
@@ -480,7 +475,7 @@ class TrainingStep:
 
 
 def build_trainer_state(cfg: Config, device, aster_ocr=None, seed: int = 0, process_group=None,
-                        use_graphs: bool = False, compute_dtype: str = "f32"):
+                        use_graphs: bool = False, compute_dtype: Optional[str] = None):
     """The wiring of reference train.py:25-108 / model_loader.py:13-20: models (g_clone starts as a
     copy of G), lazy-reg-rescaled optimiser settings, three Adam states, pl_mean, TrainingStep."""
     from .aster import AsterInferer

@@ -17,7 +17,7 @@ dev = torch.device('cuda:0')
 cfg = Config(batch_size_per_gpu=16)
 st = build_trainer_state(cfg, dev, seed=0, use_graphs=False); bench_init_(st)
 b = synthetic_batch(cfg, dev, 1234); ts = st["training_step"]
-ts.overlap_ocr = False
+
 args = (b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False, 1e-4)
 for _ in range(2): ts.dist_train_step(*args)
 torch.cuda.synchronize()
