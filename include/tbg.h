@@ -235,6 +235,15 @@ int tbg_weight_pack_x3(const float *src, void *dst, int T, int I, int O, int tra
 int tbg_conv2d_x3(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,
                   const tbg_epilogue *epi, void *stream);
 int tbg_conv2d_x3_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
+/* filter gradient in f32x3 arithmetic: the float4-staged geometries (stride-1 3x3 with 16-byte-aligned rows, stride-2 VALID
+ * 3x3 with Ws % 32 == 0 -- the layers that hold the FLOPs) run conv_wgrad_x3_kernel (both operands split into three bf16
+ * terms while staged, six products per tap, fp32 accumulate); every other geometry runs the exact fp32 kernel of
+ * tbg_conv2d_wgrad_ex_f32.  Arguments, workspace (tbg_conv2d_wgrad_workspace_bytes) and error codes as that entry. */
+int tbg_conv2d_wgrad_x3(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
+                        const float *s_scale, const float *l_scale, const float *addw,
+                        const float *addq, float gamma, float *workspace,
+                        long long workspace_bytes, void *stream);
+int tbg_conv2d_wgrad_x3_kernel_name(const tbg_wgrad_desc *d, char *buf, int n);
 /* explicit form of the stride-2 transposed 3x3 launches (tuning / test aid): 0 = library's choice, 4 / 5 = class-per-block /
  * merged-class. */
 int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,

@@ -108,3 +108,59 @@ def test_conv_x3_merged_transposed_vs_float64(dev):
                                               N.stream()), "x3 variant")
         err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
         assert err < 3e-5, (variant, err)
+
+
+def _rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64)
+
+
+def _rel(a, r):
+    return float((a.double().cpu() - r).abs().max() / (r.abs().max() + 1e-30))
+
+
+X3_WG1 = [(3, 40, 72, 5, 36), (2, 64, 64, 8, 32), (1, 130, 70, 2, 128), (2, 64, 64, 3, 100), (4, 128, 128, 16, 64)]
+X3_WG2 = [(2, 40, 72, 11, 65), (3, 64, 64, 9, 130), (1, 130, 70, 5, 129), (4, 64, 128, 33, 129)]
+
+
+@pytest.mark.parametrize("stride,case", [(1, c) for c in X3_WG1] + [(2, c) for c in X3_WG2],
+                         ids=[f"s1-{c}" for c in X3_WG1] + [f"s2-{c}" for c in X3_WG2])
+def test_wgrad_x3_matches_float64_at_fp32_tolerance(dev, stride, case):
+    """conv_wgrad_x3_kernel (both float4-staged geometries; ragged maps, partial channel tiles, several chunks per block) with
+    both per-(sample, channel) scale vectors and the fused additive term against float64 on the fp32 operands: the fp32
+    kernels' bar (3e-5 / 5e-5 for the strided form), and not worse than 2x the exact fp32 kernel."""
+    import torch.nn.functional as F
+    B, C, M, H, W = case
+    Ho, Wo = ((H - 3) // 2 + 1, (W - 3) // 2 + 1) if stride == 2 else (H, W)
+    x, dy = _rnd(B, C, H, W, seed=40), _rnd(B, M, Ho, Wo, seed=41)
+    xs, ds = _rnd(B, C, seed=42).abs() + 0.5, _rnd(B, M, seed=43).abs() + 0.5
+    addw, addq = _rnd(3, 3, C, M, seed=44), _rnd(C, M, seed=45)
+    f32 = lambda t: t.float().double()
+    xr = (f32(x) * f32(xs)[:, :, None, None]).float().double()      # the scaled operands as the kernels form them (fp32)
+    dyr = (f32(dy) * f32(ds)[:, :, None, None]).float().double()
+    w = torch.zeros(3, 3, C, M, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xr, w.permute(3, 2, 0, 1), stride=stride, padding=1 if stride == 1 else 0)
+    (ref,) = torch.autograd.grad(y, w, dyr)
+    ref = 0.7 * ref + 0.3 * f32(addw) * f32(addq)[None, None]
+    f = lambda t: t.float().to(dev).contiguous()
+    g = ops._Geom((stride, stride), (1, 1) if stride == 1 else (0, 0), 3, 3, (H, W), (Ho, Wo))
+    pad = 1 if stride == 1 else 0
+    desc = N.WgradDesc(B, M, C, Ho, Wo, H, W, 3, 3, stride, stride, pad, pad, C * M, M, 1, 0.7)
+    assert N.wgrad_kernel_name(desc, ops.FMT_X3) == f"conv_wgrad_x3_kernel<{stride}>"
+    errs = {}
+    for mode in ("f32", "f32x3"):
+        with ops.compute_dtype(mode):
+            dw = ops._bwd_weight_launch(f(x), f(dy), g, C, M, alpha=0.7, x_scale=f(xs), dy_scale=f(ds),
+                                        add=(f(addw), f(addq), 0.3))
+        errs[mode] = _rel(dw, ref)
+    print(f"\nX3WG s{stride} {case}: f32 {errs['f32']:.3e}  f32x3 {errs['f32x3']:.3e}")
+    assert errs["f32x3"] < (3e-5 if stride == 1 else 5e-5), errs
+    assert errs["f32x3"] <= max(2.0 * errs["f32"], 1e-6), errs
+
+
+def test_wgrad_x3_small_geometries_fall_back_to_exact_fp32(dev):
+    """narrow maps / 1x1 filters are not x3 geometries: the entry runs the exact fp32 kernel (and says so by name)."""
+    desc = N.WgradDesc(4, 512, 513, 4, 4, 4, 4, 3, 3, 1, 1, 1, 1, 513 * 512, 512, 1, 1.0)
+    assert N.wgrad_kernel_name(desc, ops.FMT_X3) == N.wgrad_kernel_name(desc, ops.FMT_F32)
+    desc = N.WgradDesc(2, 64, 3, 16, 64, 16, 64, 1, 1, 1, 1, 0, 0, 3 * 64, 64, 1, 1.0)
+    assert N.wgrad_kernel_name(desc, ops.FMT_X3) == N.wgrad_kernel_name(desc, ops.FMT_F32)

@@ -1678,6 +1678,287 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p)
     for (int r16 = 0; r16 < 16; ++r16) wsp[(t * 16 + r16) * 256 + tid] = acc[t][r16];
 }
 
+// ---- f32x3 filter gradient (tbg.h "f32x3 forms"): S and L split into three bf16 terms each while they are staged (three LDS
+// planes per operand), six partial products per tap on v_mfma_f32_32x32x16_bf16 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi;
+// smallest first), fp32 accumulate.  Same block / wave / accumulator structure and the same float4-staged tile geometries as
+// conv_wgrad_bf16_kernel's VEC forms (VEC = 1: stride-1 3x3, 32 x 2-pixel chunks; VEC = 2: stride-2 VALID 3x3, 32 x 1).  Three
+// planes of both tiles take 92 / 111 KB of LDS -> ONE block per CU (one wave per SIMD, up to 512 registers), so the overlap
+// that co-resident blocks give the other kernels is built into the wave instead: the global loads of chunk k+1 are issued into
+// registers before the MFMA phase of chunk k (54 MFMAs per 16 pixels and wave cover the round trip) and split + stored after it.
+template <int VEC> struct WgX3 {
+  static constexpr int PIX = VEC == 1 ? 64 : 32;
+  static constexpr int SPB = VEC == 1 ? WgVec<true>::SP : WgVec2<true>::SP;
+  static constexpr int IWP = VEC == 1 ? WgVec<true>::IWP : WgVec2<true>::IWP;
+  static constexpr int LPLANE = VEC == 1 ? WgVec<true>::LPLANE : WgVec2<true>::LPLANE;
+  static constexpr int HALFW = VEC == 1 ? 0 : WgVec2<true>::HALFW;
+  static constexpr int NL = VEC == 1 ? 8 : 12;  // float4 loads of the L interior per lane
+  static constexpr int NS = VEC == 1 ? 4 : 2;   // float4 loads of S per lane
+  static constexpr int NE = VEC == 1 ? 2 : 1;   // scalar halo-column loads per lane
+};
+
+template <int VEC> struct WgX3Regs {
+  f32x4u lv[WgX3<VEC>::NL];
+  float lsc[WgX3<VEC>::NL];
+  float4 sv[WgX3<VEC>::NS];
+  float ssc[WgX3<VEC>::NS];
+  float ev[WgX3<VEC>::NE], esc[WgX3<VEC>::NE];
+};
+
+__device__ __forceinline__ void split3_store(__bf16 *dst, int plane_stride, float v) {
+  const __bf16 bh = (__bf16)v;
+  const float r1 = v - (float)bh;
+  const __bf16 bm = (__bf16)r1;
+  dst[0] = bh; dst[plane_stride] = bm; dst[2 * plane_stride] = (__bf16)(r1 - (float)bm);
+}
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+// four / two consecutive places: one 8-byte / 4-byte store per plane
+__device__ __forceinline__ void split3_store4(__bf16 *dst, int plane_stride, float v0, float v1, float v2, float v3) {
+  const float v[4] = {v0, v1, v2, v3};
+  bf16x4v h, m, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 bh = (__bf16)v[e];
+    const float r1 = v[e] - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    h[e] = bh; m[e] = bm; l[e] = (__bf16)(r1 - (float)bm);
+  }
+  *reinterpret_cast<bf16x4v *>(dst) = h;
+  *reinterpret_cast<bf16x4v *>(dst + plane_stride) = m;
+  *reinterpret_cast<bf16x4v *>(dst + 2 * plane_stride) = l;
+}
+__device__ __forceinline__ void split3_store2(__bf16 *dst, int plane_stride, float v0, float v1) {
+  const float v[2] = {v0, v1};
+  bf16x2v h, m, l;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const __bf16 bh = (__bf16)v[e];
+    const float r1 = v[e] - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    h[e] = bh; m[e] = bm; l[e] = (__bf16)(r1 - (float)bm);
+  }
+  *reinterpret_cast<bf16x2v *>(dst) = h;
+  *reinterpret_cast<bf16x2v *>(dst + plane_stride) = m;
+  *reinterpret_cast<bf16x2v *>(dst + 2 * plane_stride) = l;
+}
+
+// issue every global load of one chunk (branch-free: clamped addresses, scale factor 0 for padding / out-of-range)
+template <int VEC>
+__device__ __forceinline__ void wgrad_x3_load(const WgradP &p, WgX3Regs<VEC> &r, int b, int u0, int v0, int cs0, int cl0, int tid) {
+  const int HWs = p.Hs * p.Ws, HWl = p.Hl * p.Wl;
+  const bool hs = p.s_scale != nullptr, hl = p.l_scale != nullptr;
+  const float *ssp = hs ? p.s_scale : p.S, *lsp = hl ? p.l_scale : p.L;
+  if constexpr (VEC == 1) {
+    // L halo tile, rows of 34 (x = v0 - 1 .. v0 + 32 at places 0 .. 33): each lane loads the FOUR PLACES 4q .. 4q + 3, i.e.
+    // x = v0 + 4q - 1 .. + 2 -- a dword-aligned float4 -- so that its three bf16 planes are 8-byte LDS stores (the x-aligned
+    // quads of the bf16 kernel land on odd places and cost four 2-byte stores each).  The very first quad of a row would
+    // start one float before the row (x = -1): it loads x = 0 .. 3 instead and is shifted right by one place in registers.
+    const int l_ch = tid >> 5, l_row = (tid >> 3) & 3, l_qx = tid & 7;
+    // The quad of the last column alone (x = Wl - 1, a ragged last tile) would run past the row: it loads x - 3 .. x and keeps
+    // its last element.  No lane reads outside the row it belongs to.
+    const int l_iy = u0 - p.py + l_row, l_ix = v0 + 4 * l_qx - 1;
+    const bool l_sh = l_ix < 0, l_last = l_ix == p.Wl - 1;
+    const bool l_in = l_iy >= 0 && l_iy < p.Hl && l_ix < p.Wl;
+    const unsigned l_g0 = (unsigned)((b * p.CL + cl0 + l_ch) * HWl + l_iy * p.Wl + l_ix + (l_sh ? 1 : l_last ? -3 : 0));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool ok = l_in && cl0 + l_ch + 8 * i < p.CL;
+      f32x4u v = *reinterpret_cast<const f32x4u *>(p.L + (ok ? l_g0 + (unsigned)(8 * i * HWl) : 0u));
+      if (l_sh) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }
+      if (l_last) { v[0] = v[3]; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+      r.lv[i] = v;
+      const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + 8 * i) : 0u];
+      r.lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+    }
+    const int s_ch = tid >> 4, s_pq = (tid & 15) * 4;
+    const int s_u = u0 + (s_pq >> 5), s_v = v0 + (s_pq & 31);
+    const bool s_in = s_u < p.Hs && s_v < p.Ws;
+    const unsigned s_g0 = (unsigned)((b * p.CS + cs0 + s_ch) * HWs + s_u * p.Ws + s_v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = s_in && cs0 + s_ch + 16 * i < p.CS;
+      r.sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(16 * i * HWs) : 0u));
+      const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 16 * i) : 0u];
+      r.ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
+    }
+    // the two places the quads leave: 32 and 33 (x = v0 + 31, v0 + 32)
+    const int e_ch = tid >> 3, e_row = (tid >> 1) & 3, e_side = tid & 1;
+    const int e_iy = u0 - p.py + e_row, e_ix = v0 + 31 + e_side;
+    const bool e_in = e_iy >= 0 && e_iy < p.Hl && e_ix < p.Wl;
+    const unsigned e_g0 = (unsigned)((b * p.CL + cl0 + e_ch) * HWl + e_iy * p.Wl + e_ix);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = e_in && cl0 + e_ch + 32 * i < p.CL;
+      r.ev[i] = p.L[ok ? e_g0 + (unsigned)(32 * i * HWl) : 0u];
+      const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch + 32 * i) : 0u];
+      r.esc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+    }
+  } else {
+    const int l_ch = tid >> 4, l_qx = tid & 15;
+    const int iy0 = 2 * u0 - p.py;
+    const unsigned l_g0 = (unsigned)((b * p.CL + cl0 + l_ch) * HWl + max(iy0, 0) * p.Wl + 2 * v0 + 4 * l_qx);
+#pragma unroll
+    for (int ii = 0; ii < 12; ++ii) {
+      const int row = ii >> 2, ci = 16 * (ii & 3);
+      const bool ok = iy0 + row >= 0 && iy0 + row < p.Hl && cl0 + l_ch + ci < p.CL;
+      r.lv[ii] = *reinterpret_cast<const f32x4u *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl + (row + min(iy0, 0)) * p.Wl) : 0u));
+      const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
+      r.lsc[ii] = !ok ? 0.f : (hl ? sc : 1.f);
+    }
+    const int s_ch = tid >> 3, s_pq = (tid & 7) * 4;
+    const bool s_in = u0 < p.Hs && v0 + s_pq < p.Ws;
+    const unsigned s_g0 = (unsigned)((b * p.CS + cs0 + s_ch) * HWs + u0 * p.Ws + v0 + s_pq);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = s_in && cs0 + s_ch + 32 * i < p.CS;
+      r.sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(32 * i * HWs) : 0u));
+      const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 32 * i) : 0u];
+      r.ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
+    }
+    {  // the 65th column of each halo row (even part, place 32): 64 channels x 3 rows, lanes 0..191
+      const int e_ch = tid & 63, e_row = min(tid >> 6, 2);
+      const bool ok = tid < 192 && iy0 + e_row >= 0 && iy0 + e_row < p.Hl && cl0 + e_ch < p.CL && 2 * v0 + 64 < p.Wl;
+      r.ev[0] = p.L[ok ? (unsigned)((b * p.CL + cl0 + e_ch) * HWl + (iy0 + e_row) * p.Wl + 2 * v0 + 64) : 0u];
+      const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch) : 0u];
+      r.esc[0] = !ok ? 0.f : (hl ? sc : 1.f);
+    }
+  }
+}
+
+// scale, split into hi | mid | lo and store the chunk's tiles (three planes each)
+template <int VEC>
+__device__ __forceinline__ void wgrad_x3_store(const WgX3Regs<VEC> &r, __bf16 *Ss, __bf16 *Ls, int tid) {
+  constexpr int SPB = WgX3<VEC>::SPB, IWP = WgX3<VEC>::IWP, LPLANE = WgX3<VEC>::LPLANE, HALFW = WgX3<VEC>::HALFW;
+  constexpr int SPL = 64 * SPB, LPL = 64 * LPLANE;  // plane strides (elements)
+  if constexpr (VEC == 1) {
+    const int l_ch = tid >> 5, l_row = (tid >> 3) & 3, l_qx = tid & 7;
+    __bf16 *l_d0 = Ls + l_ch * LPLANE + l_row * IWP + 4 * l_qx;  // places 4q .. 4q + 3: 8-byte aligned (IWP, LPLANE % 4 == 0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      split3_store4(l_d0 + 8 * i * LPLANE, LPL, zmul_legacy(r.lv[i][0], r.lsc[i]), zmul_legacy(r.lv[i][1], r.lsc[i]),
+                    zmul_legacy(r.lv[i][2], r.lsc[i]), zmul_legacy(r.lv[i][3], r.lsc[i]));
+    const int s_ch = tid >> 4, s_pq = (tid & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      split3_store4(Ss + (s_ch + 16 * i) * SPB + s_pq, SPL, zmul_legacy(r.sv[i].x, r.ssc[i]), zmul_legacy(r.sv[i].y, r.ssc[i]),
+                    zmul_legacy(r.sv[i].z, r.ssc[i]), zmul_legacy(r.sv[i].w, r.ssc[i]));
+    const int e_ch = tid >> 3, e_row = (tid >> 1) & 3, e_side = tid & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      split3_store(Ls + (e_ch + 32 * i) * LPLANE + e_row * IWP + 32 + e_side, LPL, zmul_legacy(r.ev[i], r.esc[i]));
+  } else {
+    const int l_ch = tid >> 4, l_qx = tid & 15;
+    __bf16 *l_d0 = Ls + l_ch * LPLANE + 2 * l_qx;
+#pragma unroll
+    for (int ii = 0; ii < 12; ++ii) {
+      const int row = ii >> 2, ci = 16 * (ii & 3);
+      __bf16 *dst = l_d0 + ci * LPLANE + row * IWP;  // even | odd columns, two places each: 4-byte stores
+      split3_store2(dst, LPL, zmul_legacy(r.lv[ii][0], r.lsc[ii]), zmul_legacy(r.lv[ii][2], r.lsc[ii]));
+      split3_store2(dst + HALFW, LPL, zmul_legacy(r.lv[ii][1], r.lsc[ii]), zmul_legacy(r.lv[ii][3], r.lsc[ii]));
+    }
+    const int s_ch = tid >> 3, s_pq = (tid & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      split3_store4(Ss + (s_ch + 32 * i) * SPB + s_pq, SPL, zmul_legacy(r.sv[i].x, r.ssc[i]), zmul_legacy(r.sv[i].y, r.ssc[i]),
+                    zmul_legacy(r.sv[i].z, r.ssc[i]), zmul_legacy(r.sv[i].w, r.ssc[i]));
+    if (tid < 192) split3_store(Ls + (tid & 63) * LPLANE + (tid >> 6) * IWP + 32, LPL, zmul_legacy(r.ev[0], r.esc[0]));
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(const WgradP p) {
+  constexpr int PIX = WgX3<VEC>::PIX, SPB = WgX3<VEC>::SPB, IWP = WgX3<VEC>::IWP, LPLANE = WgX3<VEC>::LPLANE;
+  constexpr int HALFW = WgX3<VEC>::HALFW, SX = VEC, NT = 9;
+  constexpr int SPL = 64 * SPB, LPL = 64 * LPLANE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16 *Ss = reinterpret_cast<__bf16 *>(smem);  // [3][64][SPB]
+  __bf16 *Ls = Ss + 3 * SPL;                       // [3][64][LPLANE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ws = wave >> 1, wl = wave & 1;
+  const int cs0 = blockIdx.x * 64, cl0 = blockIdx.y * 64;
+  const int half = lane >> 5;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto chunk_pos = [&](int chunk, int &bg, int &u0, int &v0) {
+    const int tv = chunk % p.tilesV;
+    const int t2 = chunk / p.tilesV;
+    const int tu = t2 % p.tilesU;
+    bg = t2 / p.tilesU;
+    u0 = tu << (VEC == 1 ? 1 : 0); v0 = tv << 5;
+  };
+  WgX3Regs<VEC> rg;
+  int chunk = blockIdx.z;
+  if (chunk < p.nchunks) {
+    int bg, u0, v0;
+    chunk_pos(chunk, bg, u0, v0);
+    wgrad_x3_load<VEC>(p, rg, bg, u0, v0, cs0, cl0, tid);
+  }
+  const __bf16 *Sp = Ss + (ws * 32 + (lane & 31)) * SPB + 8 * half;
+  const __bf16 *Lp = Ls + (wl * 32 + (lane & 31)) * LPLANE;
+  for (; chunk < p.nchunks; chunk += p.ksplit) {
+    __syncthreads();  // the previous chunk's MFMA phase is done with the tiles
+    wgrad_x3_store<VEC>(rg, Ss, Ls, tid);
+    __syncthreads();
+    if (chunk + p.ksplit < p.nchunks) {  // next chunk's loads: in flight under the MFMA phase below
+      int bg, u0, v0;
+      chunk_pos(chunk + p.ksplit, bg, u0, v0);
+      wgrad_x3_load<VEC>(p, rg, bg, u0, v0, cs0, cl0, tid);
+    }
+    // (a two-register-set version that issued group g+1's reads ahead of group g's MFMAs measured SLOWER -- 103 vs 140 TFLOP/s
+    // on the 64x256 layer: 256 VGPRs + 194 AGPRs with accumulator-file copies in the loop -- so the groups stay rolled and
+    // the compiler batches each group's 21 reads in front of its 54 MFMAs)
+#pragma unroll 1
+    for (int gp = 0; gp < PIX / 16; ++gp) {
+      const int pp = 16 * gp + 8 * half;  // first of this half-wave's 8 pixels (one 32-pixel tile row)
+      const __bf16 *Lg = Lp + (VEC == 1 ? (pp >> 5) * IWP : 0) + (pp & 31);
+      bf16x8 a[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8 *>(Sp + pl * SPL + 16 * gp);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        i32x4 b[3][3];  // [plane][kw]
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const __bf16 *row = Lg + pl * LPL + kh * IWP;
+          const i32x4 e = *reinterpret_cast<const i32x4 *>(row);
+          const int e4 = *reinterpret_cast<const int *>(row + 8);
+          i32x4 s1;
+          s1[0] = __builtin_amdgcn_alignbit(e[1], e[0], 16); s1[1] = __builtin_amdgcn_alignbit(e[2], e[1], 16);
+          s1[2] = __builtin_amdgcn_alignbit(e[3], e[2], 16); s1[3] = __builtin_amdgcn_alignbit(e4, e[3], 16);
+          b[pl][0] = e;
+          if constexpr (SX == 2) {  // kw = 0: even[0..7], kw = 1: odd[0..7], kw = 2: even[1..8]
+            b[pl][1] = *reinterpret_cast<const i32x4 *>(row + HALFW);
+            b[pl][2] = s1;
+          } else {                  // kw = 0, 1, 2: window[0..7], [1..8], [2..9]
+            b[pl][1] = s1;
+            b[pl][2][0] = e[1]; b[pl][2][1] = e[2]; b[pl][2][2] = e[3]; b[pl][2][3] = e4;
+          }
+        }
+        // six partial products per tap, smallest first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            acc[3 * kh + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], __builtin_bit_cast(bf16x8, b[PB[q]][kw]),
+                                                                       acc[3 * kh + kw], 0, 0, 0);
+      }
+    }
+  }
+
+  const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float *wsp = p.ws + blk * (size_t)(NT * 16 * 256);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r16 = 0; r16 < 16; ++r16) wsp[(t * 16 + r16) * 256 + tid] = acc[t][r16];
+}
+
 // few output tiles, many partials: one block per (tile, tap, accumulator register) -- 16x more blocks than the
 // transposing kernel below, scattered 4-byte stores
 template <int WGS, int WGL, int NT>
@@ -1968,6 +2249,70 @@ extern "C" int tbg_conv2d_wgrad_bf16(const tbg_wgrad_desc *d, const float *S, co
   const size_t wsb = workspace_bytes < 0 ? 0 : (size_t)workspace_bytes;
   if (p.logTW < 3) return wgrad_select(p, d->KH * d->KW, PIX, tbg_stream(stream), wsb, nullptr);
   return wgrad_bf16_select(p, d->KH * d->KW, PIX, d->sx, tbg_stream(stream), wsb, nullptr);
+}
+
+// f32x3 filter gradient: the float4-staged geometries (the large stride-1 and stride-2 3x3 layers, where the FLOPs are) take
+// conv_wgrad_x3_kernel; everything else keeps the exact fp32 kernel.  Workspace = tbg_conv2d_wgrad_workspace_bytes(d).
+template <int VEC>
+static int launch_wgrad_x3(WgradP &p, hipStream_t st, size_t ws_bytes, const NameOut *name) {
+  if (name) {
+    snprintf(name->buf, name->n, "conv_wgrad_x3_kernel<%d>", VEC);
+    return TBG_OK;
+  }
+  const size_t lds = (size_t)3 * 64 * (WgX3<VEC>::SPB + WgX3<VEC>::LPLANE) * 2;
+  auto kern = conv_wgrad_x3_kernel<VEC>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return TBG_EHIP;
+  const int tx = ceil_div(p.CS, 64), ty = ceil_div(p.CL, 64);
+  p.ksplit = wgrad_ksplit(tx * ty, p.nchunks);
+  if ((size_t)p.ksplit * tx * ty * 9 * 16 * 256 * sizeof(float) > ws_bytes) return TBG_EINVAL;
+  hipLaunchKernelGGL(kern, dim3(tx, ty, p.ksplit), dim3(256), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  if (tx * ty * 9 >= 256)
+    hipLaunchKernelGGL((conv_wgrad_reduce_kernel<2, 2, 9>), dim3(tx, ty, 9), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_reduce_wide_kernel<2, 2, 9>), dim3(tx, ty, 9 * 16), dim3(256), 0, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// 0: not an x3 geometry (caller falls back to the exact fp32 kernel); 1 / 2: the VEC form
+static int wgrad_x3_form(const tbg_wgrad_desc *d, WgradP &p, int &rc) {
+  int PIX;
+  rc = wgrad_geometry(d, p, PIX, true);
+  if (rc != TBG_OK) return 0;
+  if (d->KH != 3 || d->KW != 3) return 0;
+  if (PIX == 64 && wgrad_vec_ok(p, true)) return 1;
+  if (PIX == 32 && wgrad_vec2_ok(p, true)) return 2;
+  return 0;
+}
+
+extern "C" int tbg_conv2d_wgrad_x3(const tbg_wgrad_desc *d, const float *S, const float *L, float *dW,
+                                   const float *s_scale, const float *l_scale, const float *addw, const float *addq,
+                                   float gamma, float *workspace, long long workspace_bytes, void *stream) {
+  if (!d || !S || !L || !dW || !workspace || ((addw == nullptr) != (addq == nullptr))) return TBG_EINVAL;
+  WgradP p{};
+  int rc;
+  p.S = S; p.L = L;  // (the alignment test of the float4 forms reads the pointers)
+  const int form = wgrad_x3_form(d, p, rc);
+  if (rc != TBG_OK) return rc;
+  if (!form) return tbg_conv2d_wgrad_ex_f32(d, S, L, dW, s_scale, l_scale, addw, addq, gamma, workspace, workspace_bytes, stream);
+  p.s_scale = s_scale; p.l_scale = l_scale; p.dW = dW; p.ws = workspace;
+  p.addw = addw; p.addq = addq; p.gamma = gamma;
+  const size_t wsb = workspace_bytes < 0 ? 0 : (size_t)workspace_bytes;
+  return form == 1 ? launch_wgrad_x3<1>(p, tbg_stream(stream), wsb, nullptr) : launch_wgrad_x3<2>(p, tbg_stream(stream), wsb, nullptr);
+}
+
+extern "C" int tbg_conv2d_wgrad_x3_kernel_name(const tbg_wgrad_desc *d, char *buf, int n) {
+  if (!buf || n < 1) return TBG_EINVAL;
+  buf[0] = 0;
+  WgradP p{};
+  int rc;
+  const int form = wgrad_x3_form(d, p, rc);  // (name-only: the 16-byte pointer alignment the launch also requires is assumed)
+  if (rc != TBG_OK) return rc;
+  if (!form) return tbg_conv2d_wgrad_kernel_name(d, buf, n);
+  NameOut no{buf, n};
+  return form == 1 ? launch_wgrad_x3<1>(p, nullptr, 0, &no) : launch_wgrad_x3<2>(p, nullptr, 0, &no);
 }
 
 extern "C" int tbg_conv2d_wgrad_bf16_kernel_name(const tbg_wgrad_desc *d, char *buf, int n) {

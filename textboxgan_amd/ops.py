@@ -361,7 +361,7 @@ def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, o
     return out
 
 
-HAVE_WGRAD_X3 = False  # set below once the library exports the f32x3 filter gradient
+HAVE_WGRAD_X3 = True  # tbg_conv2d_wgrad_x3 (falls back to the exact fp32 kernel inside the library for the small geometries)
 
 
 class PackedFilter(NamedTuple):
