@@ -288,21 +288,28 @@ int tbg_attn_ctx_bwd_f32(const float *dctx, const float *a, const float *q, cons
 
 /* ------------------------------------------------------------------------------------------
  * Thin 1x1 convolutions at the RGB ends (one side has O <= 4 channels): HBM-bound streaming kernels.
- * project:      y[b,o,p] = alpha * sum_c x[b,c,p] * w[c*ldw+o] * (scale ? scale[b*C+c] : 1)
- *                          + (bias ? bias[o]*bias_mul : 0) + (skip ? skip[b,o,p] : 0)
+ * project:      y[b,o,p] = (alpha * sum_c x[b,c,p] * w[c*ldw+o] * (scale ? scale[b*C+c] : 1)
+ *                           + (bias ? bias[o]*bias_mul : 0) + (skip ? skip[b,o,p] : 0)) * m[b,p]
  *               = ToRGB.call (layers/to_rgb.py:28-33) incl. the `y = upsample(y) + torgb` add
- *               (synthesis_block.py:152-153); also the image gradient of FromRGB.
- * backproject:  dx[b,c,p] = alpha * (scale ? scale[b*C+c] : 1) * sum_o w[c*ldw+o] * dy[b,o,p]   (if dx)
- *               G[b,c,o] += sum_p x[b,c,p] * dy[b,o,p]                                    (if G; PRE-ZEROED)
+ *               (synthesis_block.py:152-153) and, on the last block, mask_text_box (utils/utils.py:11-45) as the
+ *               epilogue; also the image gradient of FromRGB.
+ * backproject:  dym[b,o,p] = dy[b,o,p] * m[b,p]   (written out if dym != NULL: the gradient of the skip image / bias)
+ *               dx[b,c,p] = alpha * (scale ? scale[b*C+c] : 1) * sum_o w[c*ldw+o] * dym[b,o,p]          (if dx)
+ *               G[b,c,k,o] = sum_{p in pixel chunk k} x[b,c,p] * dym[b,o,p]                               (if G)
  *               = data gradient of ToRGB plus the channel Gram from which d(weight) and d(style) follow;
- *               with dx = NULL the filter gradient of FromRGB (layers/from_rgb.py:26-29).
+ *               with dx = NULL the filter gradient of FromRGB (layers/from_rgb.py:26-29).  G holds
+ *               tbg_rgb_backproject_chunks(HW) partial sums per (b, c): plain stores, no atomics, no zero-fill --
+ *               deterministic; the caller adds them up.
+ * Column mask m (NULL = 1): m[b,p] = colmask[b*ceil(maskW/maskCW) + (p % maskW) / maskCW] -- one value per maskCW-wide
+ * column band of a row-major map of width maskW (HW % maskW == 0).
  * ---------------------------------------------------------------------------------------- */
 int tbg_rgb_project_f32(const float *x, const float *w, const float *scale, const float *bias,
                         const float *skip, float *y, int B, int C, int O, int ldw, int HW, float alpha,
-                        float bias_mul, void *stream);
+                        float bias_mul, const float *colmask, int maskW, int maskCW, void *stream);
+int tbg_rgb_backproject_chunks(int HW);
 int tbg_rgb_backproject_f32(const float *x, const float *dy, const float *w, const float *scale,
                             float *dx, float *G, int B, int C, int O, int ldw, int HW, float alpha,
-                            void *stream);
+                            const float *colmask, int maskW, int maskCW, float *dym, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * bias_act: stand-alone epilogue (x: [B,M,HW]) and its backward.

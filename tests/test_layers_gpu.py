@@ -69,19 +69,21 @@ def test_modconv_fused_fwd_bwd(dev, up, shape):
     outd = fn(xd, wd, s, nd, std, bd)  # demodulation inside the node
     assert rel_err(outd, out) < 3e-5
     gd = torch.autograd.grad(outd, (xd, wd, mwd, mbd, std, bd), f(dout))
+    # A pre-activation within rounding of zero can take the other LeakyReLU branch under a different (equally valid) fp32
+    # summation order.  Count such flips explicitly: with none, the gradients must agree element-wise; ONE flipped activation
+    # (b, o, y, x) moves a whole filter column of dw, the style gradient of its sample (hence ~half of dmod_w) and a patch of
+    # dx by up to ~2e-2 of max (measured: f32x3 on the 128-channel up layer, 1 flip of 1048576 activations: dw 973 elements in
+    # one column, dmod_w 1035 of 2560 elements <= 2.6e-3), so then the bar is relative L2.
+    flips = int(((outd.detach().cpu() > 0) != (out.detach() > 0)).sum())
+    assert flips <= 1e-5 * out.numel() + 1, flips
     for name, a, b in zip(("dx", "dw", "dmod_w", "dmod_b", "dstrength", "dbias"), gd, grads):
-        # strict on the bulk, tolerant of LeakyReLU branch flips: ONE pre-activation within rounding of zero can take the other
-        # branch under a different (equally valid) fp32 summation order, which changes dx by ~2e-2 of max at a handful of
-        # positions (seen with the merged-class transposed kernel: 445 of 262144 elements)
+        if flips:
+            d = a.detach().double().cpu() - b.detach().double()
+            assert float(d.norm() / (b.detach().double().norm() + 1e-30)) < 5e-3 and float(d.abs().max() / b.detach().abs().max()) < 5e-2, (name, flips)
+            continue
         err = (a.detach().double().cpu() - b.detach().double()).abs() / (b.detach().double().abs().max() + 1e-30)
         n_bad = int((err > 2e-4).sum())
-        if name == "dw":
-            # ONE flipped activation (b, o, y, x) moves the whole filter column dw[:, :, :, o] (9 * I elements): count flipped
-            # output channels instead of elements (seen in f32x3 arithmetic: 973 of 147456 elements, all in one column)
-            bad_cols = int((err > 2e-4).reshape(-1, err.shape[-1]).any(dim=0).sum())
-            assert bad_cols <= max(2, 0.02 * err.shape[-1]) and float(err.max()) < 5e-2, (name, bad_cols, n_bad, float(err.max()))
-            continue
-        assert n_bad <= 0.005 * err.numel() and float(err.max()) < 5e-2, (name, n_bad, float(err.max()))
+        assert n_bad == 0, (name, n_bad, float(err.max()))
 
 
 @pytest.mark.parametrize("dims", [(5, 24, 40), (32, 256, 256), (16, 256, 512), (64, 100, 130), (16, 512, 1), (33, 96, 65),
@@ -187,24 +189,38 @@ def test_frozen_attn_decoder(dev):
     assert rel_err(gd, g) < 1e-4
 
 
-def test_torgb_fused(dev):
+@pytest.mark.parametrize("dims,masked", [((3, 24, 8, 32), False), ((3, 24, 8, 32), True), ((4, 128, 64, 256), True),
+                                         ((2, 130, 6, 40), True), ((2, 512, 2, 8), False)],
+                         ids=["small", "small-masked", "last-block-masked", "ragged-masked", "first-block"])
+def test_torgb_fused(dev, dims, masked):
+    """ToRGB (+ skip add, + mask_text_box as the launch's epilogue on the last block) forward and all six gradients; the
+    128-channel 64x256 case is the step's last block (8 pixel chunks of the deterministic channel-Gram reduction)."""
     from textboxgan_amd import ops
-    B, I, H, W, sd = 3, 24, 8, 32, 16
+    B, I, H, W = dims
+    sd = 16
     x, style, skip = rnd(B, I, H, W, seed=11), rnd(B, sd, seed=12), rnd(B, 3, H, W, seed=13)
     w, mw, mb, b = rnd(1, 1, I, 3, seed=14), rnd(sd, I, seed=15), rnd(I, seed=16) * 0.1, rnd(3, seed=17)
+    cw = max(W // 8, 1)
+    words = torch.tensor([[1] * (1 + (i * 3) % 8) + [0] * (7 - (i * 3) % 8) for i in range(B)])
     leaves = [t.requires_grad_(True) for t in (x, w, mw, mb, b, skip)]
     y = R.t_modulated_conv2d(x, style, w, mw, mb, up=False, demodulate=False, fused=False)
     out = R.t_bias_act(y, b, "linear") + skip
+    if masked:
+        out = R.t_mask_text_box(out, words, cw)
     dout = rnd(*out.shape, seed=18)
     grads = torch.autograd.grad(out, leaves, dout)
     f = lambda t: t.detach().float().to(dev).contiguous().requires_grad_(True)
     xd, wd, mwd, mbd, bd, skd = [f(t) for t in (x, w, mw, mb, b, skip)]
     s = torch.addmm(mbd + 1.0, style.float().to(dev), mwd / math.sqrt(sd))
-    outd = ops.torgb_fused(xd, wd, s, bd, skd)
+    colmask = (words != 0).float().to(dev) if masked else None
+    outd = ops.torgb_fused(xd, wd, s, bd, skd, colmask, cw if masked else 0)
     assert rel_err(outd, out) < 3e-5
-    gd = torch.autograd.grad(outd, (xd, wd, mwd, mbd, bd, skd), dout.float().to(dev))
+    gd = torch.autograd.grad(outd, (xd, wd, mwd, mbd, bd, skd), dout.float().to(dev), retain_graph=True)
     for name, a, b_ in zip(("dx", "dw", "dmod_w", "dmod_b", "db", "dskip"), gd, grads):
         assert rel_err(a, b_) < 2e-4, name
+    # the channel Gram is reduced without atomics: two runs are bit-identical
+    gd2 = torch.autograd.grad(ops.torgb_fused(xd, wd, s, bd, skd, colmask, cw if masked else 0), (wd, mwd), dout.float().to(dev))
+    assert torch.equal(gd2[0], gd[1]) and torch.equal(gd2[1], gd[2])
 
 
 def _load(module, P, dev):

@@ -203,13 +203,17 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2D(cfg, in_ch, 3, 1, up=False, demodulate=False)
         self.apply_bias = BiasAct(3, 1.0, "linear")
 
-    def forward(self, x, style, skip=None, mode="fused", s=None):
-        """s: the precomputed style affine of this layer (fused mode: ops.style_affines does all layers in one launch)."""
+    def forward(self, x, style, skip=None, mode="fused", s=None, colmask=None, mask_cw=0):
+        """s: the precomputed style affine of this layer (fused mode: ops.style_affines does all layers in one launch).
+        colmask [B, W // mask_cw]: mask_text_box (utils/utils.py:11-45) applied by the same launch (last block only)."""
         s = self.conv.style(style, mode) if s is None else s
         if mode == "fused":
-            return ops.torgb_fused(x, self.conv.w, s, self.apply_bias.b, skip)
+            return ops.torgb_fused(x, self.conv.w, s, self.apply_bias.b, skip, colmask, mask_cw)
         y = self.apply_bias(self.conv.conv_composable(x, s, None))
-        return y if skip is None else skip + y
+        y = y if skip is None else skip + y
+        if colmask is not None:
+            y = y * colmask.repeat_interleave(mask_cw, dim=1)[:, None, None, :]
+        return y
 
 
 class SynthesisBlock(nn.Module):
@@ -255,7 +259,8 @@ class Synthesis(nn.Module):
     def noise_shapes(self, B):
         return [(B, 1, h, w) for (h, w) in self.resolutions[1:] for _ in range(2)]
 
-    def forward(self, x, style, noises: Optional[List[torch.Tensor]] = None, mode="fused"):
+    def forward(self, x, style, noises: Optional[List[torch.Tensor]] = None, mode="fused", colmask=None, mask_cw=0):
+        """colmask / mask_cw: the text-box mask of the final image, applied inside the last toRGB launch."""
         B = x.shape[0]
         if noises is None:  # fresh noise on every call, also at inference (noise.py:16-19)
             noises = [torch.randn(s, device=x.device) for s in self.noise_shapes(B)]
@@ -277,7 +282,8 @@ class Synthesis(nn.Module):
         for i, (block, torgb) in enumerate(zip(self.synth_blocks, self.torgbs)):
             x = block(x, ws[3 * i], ws[3 * i + 1], noises[2 * i], noises[2 * i + 1], mode, s0=s_c0[i], s1=s_c1[i])
             y = ops.upfirdn2d(y, k_up, up=(2, 2), pad=(2, 1, 2, 1))  # upsample_2d, :152
-            y = torgb(x, ws[3 * i + 2], y, mode, s=s_tr[i + 1])
+            last = i == nb - 1
+            y = torgb(x, ws[3 * i + 2], y, mode, s=s_tr[i + 1], colmask=colmask if last else None, mask_cw=mask_cw if last else 0)
         return y
 
 
@@ -293,14 +299,18 @@ class Generator(nn.Module):
         self.latent_encoder = LatentEncoder(cfg, self.n_style)
 
     def forward(self, inputs, batch_size=None, ret_style=False, truncation_psi=1.0, training=False,
-                rand: Optional[dict] = None, noises_key="noises", mode="fused"):
+                rand: Optional[dict] = None, noises_key="noises", mode="fused", mask_words=None):
+        """mask_words [B, max_char_number]: return mask_text_box(image, mask_words, char_width) -- the mask
+        (utils/utils.py:11-45) is then the epilogue of the last toRGB launch instead of a pass over the image."""
         words, z = inputs
         rand = rand or {}
+        colmask = None if mask_words is None else (mask_words != 0).to(torch.float32).contiguous()
         we = self.word_encoder(words, batch_size, training=training, dropout_mask=rand.get("dropout_mask"))
         style = self.latent_encoder(z, training=training, truncation_psi=truncation_psi, rand=rand)
         if ret_style:
             style = style.clone()
-        img = self.synthesis(we, style, rand.get(noises_key), mode)
+        img = self.synthesis(we, style, rand.get(noises_key), mode, colmask=colmask,
+                             mask_cw=self.cfg.char_width if colmask is not None else 0)
         return (img, style) if ret_style else img
 
     @torch.no_grad()

@@ -547,24 +547,34 @@ def bias_act_fwd_raw(x, epi: N.Epilogue):
     return y
 
 
-def rgb_project_raw(x, w2d, O, scale, bias, skip, alpha, bias_mul=1.0, out=None):
-    """y[b,o,p] = alpha * sum_c x[b,c,p] w2d[c,o] scale[b,c] + bias[o] + skip[b,o,p]   (O <= 4; w2d rows of ldw = O)."""
+def rgb_project_raw(x, w2d, O, scale, bias, skip, alpha, bias_mul=1.0, out=None, colmask=None, mask_cw=0):
+    """y[b,o,p] = (alpha * sum_c x[b,c,p] w2d[c,o] scale[b,c] + bias[o] + skip[b,o,p]) * m   (O <= 4; w2d rows of ldw = O).
+    colmask [B, W // mask_cw]: m = colmask[b, column // mask_cw] (mask_text_box as the epilogue)."""
     B, Cc, H, W = x.shape
     y = torch.empty((B, O, H, W), device=x.device, dtype=torch.float32) if out is None else out
-    N.check(N.lib().tbg_rgb_project_f32(N.ptr(x), N.ptr(w2d), N.ptr(scale), N.ptr(bias), N.ptr(skip), N.ptr(y), B, Cc, O,
-                                        O, H * W, alpha, bias_mul, N.stream()), "tbg_rgb_project")
+    _nb = 4.0 * (x.numel() + y.numel() * (2 if skip is not None else 1))
+    N.check(PROFILE.launch("rgb_project_kernel", 0.0, lambda: N.lib().tbg_rgb_project_f32(
+        N.ptr(x), N.ptr(w2d), N.ptr(scale), N.ptr(bias), N.ptr(skip), N.ptr(y), B, Cc, O, O, H * W, alpha, bias_mul,
+        N.ptr(colmask), W, int(mask_cw), N.stream()), nbytes=_nb), "tbg_rgb_project")
     return y
 
 
-def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True):
-    """dx[b,c,p] = alpha*scale[b,c]*sum_o w2d[c,o] dy[b,o,p];  G[b,c,o] = sum_p x[b,c,p] dy[b,o,p]."""
+def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True, colmask=None, mask_cw=0, want_dym=False):
+    """dym = dy * m;  dx[b,c,p] = alpha*scale[b,c]*sum_o w2d[c,o] dym[b,o,p];  G[b,c,o] = sum_p x[b,c,p] dym[b,o,p]
+    (the kernel writes one partial G per 2048-pixel chunk -- no atomics, deterministic -- summed here).
+    returns (dx, G) or (dx, G, dym)."""
     B, Cc, H, W = x.shape
     O = dy.shape[1]
     dx = torch.empty_like(x) if want_dx else None
-    G = torch.zeros((B, Cc, O), device=x.device, dtype=torch.float32) if want_G else None
-    N.check(N.lib().tbg_rgb_backproject_f32(N.ptr(x), N.ptr(dy), N.ptr(w2d), N.ptr(scale), N.ptr(dx), N.ptr(G), B, Cc, O,
-                                            O, H * W, alpha, N.stream()), "tbg_rgb_backproject")
-    return dx, G
+    nchunk = N.lib().tbg_rgb_backproject_chunks(H * W)
+    Gp = torch.empty((B, Cc, nchunk, O), device=x.device, dtype=torch.float32) if want_G else None
+    dym = torch.empty_like(dy) if want_dym else None
+    _nb = 4.0 * (x.numel() * (int(want_dx) + int(want_G)) + dy.numel())
+    N.check(PROFILE.launch("rgb_backproject_kernel", 0.0, lambda: N.lib().tbg_rgb_backproject_f32(
+        N.ptr(x), N.ptr(dy), N.ptr(w2d), N.ptr(scale), N.ptr(dx), N.ptr(Gp), B, Cc, O, O, H * W, alpha, N.ptr(colmask), W,
+        int(mask_cw), N.ptr(dym), N.stream()), nbytes=_nb), "tbg_rgb_backproject")
+    G = (Gp.sum(dim=2) if nchunk > 1 else Gp[:, :, 0]) if want_G else None
+    return (dx, G, dym) if want_dym else (dx, G)
 
 
 def modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv):
@@ -881,31 +891,36 @@ class _ModConvUpFused(torch.autograd.Function):
 
 
 class _ToRGBFused(torch.autograd.Function):
-    """y = coef*conv1x1(s*x, w) + b (+ skip).  to_rgb.py:28-33 (modconv without demod) and the
-    ``y = upsample(y) + torgb`` add of synthesis_block.py:152-153."""
+    """y = (coef*conv1x1(s*x, w) + b (+ skip)) * m.  to_rgb.py:28-33 (modconv without demod), the
+    ``y = upsample(y) + torgb`` add of synthesis_block.py:152-153 and -- on the last block of a training step --
+    mask_text_box (utils/utils.py:11-45: m = 1 on the columns of real characters, else 0) as the launch's epilogue; the
+    backward launch masks dy while it stages it."""
 
     @staticmethod
-    def forward(ctx, x, w, s, b, skip):
+    def forward(ctx, x, w, s, b, skip, colmask, mask_cw):
         _, _, I, O = w.shape
         coef = 1.0 / math.sqrt(I)
         assert x.shape[0] == s.shape[0] and s.shape[1] == I, "one style row per sample"
         x = x.contiguous()
-        y = rgb_project_raw(x, w, O, s, b, None if skip is None else skip.contiguous(), coef)
-        ctx.save_for_backward(x, w, s)
+        y = rgb_project_raw(x, w, O, s, b, None if skip is None else skip.contiguous(), coef, colmask=colmask, mask_cw=mask_cw)
+        ctx.save_for_backward(x, w, s, colmask)
         ctx.has_skip = skip is not None
-        ctx.coef = coef
+        ctx.coef, ctx.mask_cw = coef, mask_cw
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        x, w, s = ctx.saved_tensors
+        x, w, s, colmask = ctx.saved_tensors
         _, _, I, O = w.shape
         dy = dy.contiguous()
+        if colmask is not None:
+            dx, G, dy = rgb_backproject_raw(x, dy, w, s, ctx.coef, colmask=colmask, mask_cw=ctx.mask_cw, want_dym=True)
+        else:
+            dx, G = rgb_backproject_raw(x, dy, w, s, ctx.coef, want_dx=True, want_G=True)  # G[b,c,o] = sum_p x*dy
         db = dy.sum(dim=(0, 2, 3))
-        dx, G = rgb_backproject_raw(x, dy, w, s, ctx.coef, want_dx=True, want_G=True)  # G[b,c,o] = sum_p x*dy
-        ds, dw = torgb_bwd_smalls_raw(G, w.reshape(I, O), s, ctx.coef)
-        return dx, dw.reshape(w.shape), ds, db, (dy if ctx.has_skip else None)
+        ds, dw = torgb_bwd_smalls_raw(G.contiguous(), w.reshape(I, O), s, ctx.coef)
+        return dx, dw.reshape(w.shape), ds, db, (dy if ctx.has_skip else None), None, None
 
 
 class _ConvBiasActFused(torch.autograd.Function):
@@ -986,8 +1001,9 @@ def modconv_up_fused(x, w, s, noise, strength, b):
     return _ModConvUpFused.apply(x, w, s, noise, strength, b)
 
 
-def torgb_fused(x, w, s, b, skip=None):
-    return _ToRGBFused.apply(x, w, s, b, skip)
+def torgb_fused(x, w, s, b, skip=None, colmask=None, mask_cw=0):
+    """colmask [B, W // mask_cw] (float 0/1): multiply the output's column bands by it (mask_text_box fused in)."""
+    return _ToRGBFused.apply(x, w, s, b, skip, colmask, int(mask_cw))
 
 
 def conv_bias_act_fused(x, w, b, stride=(1, 1), pad=(0, 0), act=ACT_LRELU, residual=None, res_scale=1.0, role=None):

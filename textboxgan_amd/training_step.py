@@ -326,8 +326,8 @@ class TrainingStep:
         zero = torch.zeros((), device=dev)
         z = rand["z"] if "z" in rand else torch.randn(self.batch_size_per_gpu, cfg.z_dim, device=dev)
 
-        fake_images = G((input_words, z), training=True, rand=rand)
-        fake_images = mask_text_box(fake_images, input_words, cfg.char_width)
+        # generator forward; mask_text_box (training_step.py:160-163, utils/utils.py:11-45) is the last toRGB's epilogue
+        fake_images = G((input_words, z), training=True, rand=rand, mask_words=input_words)
 
         # frozen OCR branch and its own backward, issued in line (training_step.py:375-402): only d(ocr_loss)/d(fake_images)
         # is kept for the generator's ocr-pass below
