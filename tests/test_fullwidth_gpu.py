@@ -264,6 +264,7 @@ def _conv_cases_for_coverage():
         (2, 64, 64, 64, 256, 3, (1, 1), (1, 1), False),    # 64x256 tile, software-pipelined <1,4,2,2,4,9,3,3>
         (13, 64, 64, 64, 256, 3, (1, 1), (1, 1), False),   # the same beyond 768 tiles (832): 4 blocks/CU <1,4,2,2,4,9,3,4>
         (6, 24, 256, 64, 256, 3, (1, 1), (1, 1), False),   # >= 1536 tiles: 4 waves/SIMD <2,2,2,2,4,9,0,4>
+        (8, 16, 128, 64, 256, 3, (1, 1), (1, 1), False),   # >= 1024 tiles of 128x128: the f32x3 128x256 tile <2,2,2,4,8,9,0,2>
         (2, 128, 128, 16, 64, 3, (1, 1), (1, 1), False),   # <2,2,2,2,8,9,0,3>
         (4, 512, 512, 4, 16, 3, (1, 1), (1, 1), False),    # 64x64 tile <2,2,1,1,8,9,0,3>, split-K
         (2, 16, 32, 16, 64, 3, (1, 1), (1, 1), False),     # BM = 32 <1,4,1,2,8,9,0,3>

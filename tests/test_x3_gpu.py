@@ -46,7 +46,7 @@ def _cases():
     return _conv_cases_for_coverage()
 
 
-@pytest.mark.parametrize("ci", range(17))
+@pytest.mark.parametrize("ci", range(18))
 def test_conv_x3_matches_float64_at_fp32_tolerance(dev, ci):
     """every conv case of the fp32 coverage list (forward, data gradient; transposed classes; split-K; strided) in f32x3
     arithmetic: <= 3e-5 of the float64 result -- the fp32 kernels' bar -- and not worse than 2x the exact-fp32 kernel."""
@@ -86,7 +86,9 @@ def test_conv_x3_matches_float64_at_fp32_tolerance(dev, ci):
 def test_conv_x3_kernel_names_and_merged_form(dev):
     d = N.ConvDesc(16, 128, 128, 32, 128, 65, 257, 3, 3, 2, 2, 0, 0, 1, 1, 128, 1)
     assert N.conv_kernel_name(d, True, ops.FMT_X3).endswith("true, true, true>")
-    d = N.ConvDesc(16, 128, 128, 64, 256, 64, 256, 3, 3, 1, 1, 1, 1, 0, 0, 128, 1)
+    d = N.ConvDesc(16, 128, 128, 64, 256, 64, 256, 3, 3, 1, 1, 1, 1, 0, 0, 128, 1)  # 2048 tiles of 128 x 128 -> 128 x 256 tiles
+    assert N.conv_kernel_name(d, True, ops.FMT_X3) == "conv_fprop_kernel<2, 2, 2, 4, 8, 9, 0, 2, true, false, true>"
+    d = N.ConvDesc(16, 128, 128, 32, 128, 32, 128, 3, 3, 1, 1, 1, 1, 0, 0, 128, 1)
     assert N.conv_kernel_name(d, True, ops.FMT_X3) == "conv_fprop_kernel<2, 2, 2, 2, 8, 9, 0, 2, true, false, true>"
 
 

@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     // | issue the filter DMA | issue the loads of the next tile | wait for the DMA only (counted vmcnt: the loads stay in
     // flight) | barrier | MFMAs.  The HBM round trip of the halo no longer sits between two MFMA phases; what stays exposed
     // is the filter DMA (L2-resident) and the store pass.
-    constexpr int NJX = 2, NBT = CK / CB;  // positions per thread this path holds; 8-channel load batches per position
+    constexpr int NJX = CK == 8 ? 3 : 2, NBT = CK / CB;  // positions per thread this path holds (3: the 9 x 65 halo of a
+                                                         // stride-2 128-pixel tile); 8-channel load batches per position
     if (p.NJ <= NJX) {
       done = true;
       float xr[NJX][NBT][CB];
@@ -506,7 +507,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
           loadx((kc + 1) * CK);
           // the DMA pieces are older than the loads just issued: leave exactly those loads outstanding
           if (p.NJ == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NBT * CB) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NBT * CB) : "memory");
+          else if (p.NJ == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NBT * CB) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJX * NBT * CB) : "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
@@ -880,6 +882,12 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
       const long long tiles128 = (long long)ceil_div(d->M, 128) * ((npix + 127) / 128);
       if (tiles128 <= 16) { BM = 64; BN = 64; }  // tiny-spatial / wide-channel: more, smaller blocks
       else { BM = 128; BN = 128; }
+      // f32x3, launches of >= 1024 128x128 tiles (the 64x256 layers; the joint discriminator pass's 32x128 layers): a
+      // 128 x 256 tile halves the filter DMA per MFMA and the barrier count and still fills whole rounds of the 512 slots.
+      // variant 1 forces it, variant 2 forbids it (tbg_conv2d_x3_variant).
+      if (x3 && !d->transposed && d->sy == 1 && d->sx == 1 && T == 9 && BM == 128 && d->ksplit == 1 &&
+          (variant == 1 || (variant == 0 && tiles128 >= 1024)))
+        BN = 256;
     }
   }
   constexpr int twmax = 32;  // tile rows of at most 32 pixels (wider rows were measured slower: fewer rows per halo)
@@ -938,7 +946,8 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
   hipStream_t st = tbg_stream(stream);
   if (x3) {  // f32x3: the tile shapes of the fp32 path, 8-channel chunks (16 for the few-tap classes), 2 blocks/CU
     if (merged) return launch_fprop<2, 2, 1, 2, 8, MAXTAPS, 0, 2, true, true, true>(p, st, maxtaps, maxTilesN, name);
-    if (variant != 0 && variant != 4 && variant != 5) return TBG_EUNSUPPORTED;
+    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 5) return TBG_EUNSUPPORTED;
+    if (BM == 128 && BN == 256) return launch_fprop<2, 2, 2, 4, 8, MAXTAPS, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
     if (maxtaps > 1 && maxtaps <= 4) {
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
@@ -1066,7 +1075,7 @@ extern "C" int tbg_conv2d_x3(const tbg_conv_desc *d, const float *x, const void 
 
 extern "C" int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                                      const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant != 0 && variant != 4 && variant != 5) return TBG_EINVAL;
+  if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 5) return TBG_EINVAL;
   return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, 2, variant);
 }
 

@@ -6,6 +6,7 @@ from textboxgan_amd import ops
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 BF16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"
+X3 = len(sys.argv) > 2 and sys.argv[2] == "f32x3"
 
 def timeit(fn, n=30):
     for _ in range(10): fn()
@@ -24,10 +25,12 @@ L = [("64x256 128->128", 128, 128, 64, 256, (1, 1)), ("32x128 128->128", 128, 12
      ("down 66x258 64->128", 64, 128, 66, 258, (2, 2)), ("down 34x130 128->128", 128, 128, 34, 130, (2, 2)),
      ("down 18x66 128->256", 128, 256, 18, 66, (2, 2)), ("down 10x34 256->256 (w only)", 256, 256, 8, 34, (1, 2))]
 names = {0: "auto", 7: "scalar-halo", 1: "tile128x256", 2: "ck32"} if BF16 else {0: "auto", 7: "scalar-halo", 1: "pipelined", 2: "plain", 3: "occ4"}
+if X3:
+    names = {0: "auto", 1: "tile128x256", 2: "tile128x128"}
 print(f"B={B}  TFLOP/s per variant (ksplit as the heuristic picks it)")
 for name, C, M, H, W, stride in L:
     x = torch.randn(B, C, H, W, device=dev)
-    wp = ops.pack_filter(torch.randn(3, 3, C, M, device=dev), False, False, bf16=BF16)
+    wp = ops.pack_filter(torch.randn(3, 3, C, M, device=dev), False, False, bf16="f32x3" if X3 else BF16)
     pad = (1, 1) if stride == (1, 1) else (0, 0)
     ohw = ((H + 2 * pad[0] - 3) // stride[0] + 1, (W + 2 * pad[1] - 3) // stride[1] + 1)
     flops = 2.0 * B * C * M * 9 * ohw[0] * ohw[1]
