@@ -1711,6 +1711,11 @@ template <int VEC> struct WgX3Regs {
   float4 sv[WgX3<VEC>::NS];
   float ssc[WgX3<VEC>::NS];
   float ev[WgX3<VEC>::NE], esc[WgX3<VEC>::NE];
+  // validity bits of the loads above and the row-edge flags of the L quads.  wgrad_x3_load only ISSUES loads and sets these
+  // bits; every operation on a loaded value (scale select, the edge shifts) waits for wgrad_x3_store -- a select on a loaded
+  // register inside the load function made the compiler wait for the loads right there (vmcnt(18) .. vmcnt(0) in front of the
+  // MFMA phase), i.e. nothing was in flight under the MFMAs (tools/exp_wgx3_split.py: the loads cost 90-140 us of 530).
+  unsigned lok, sok, eok, edge;  // edge: bit 0 = first quad starts before the row, bit 1 = last column alone
 };
 
 __device__ __forceinline__ void split3_store(__bf16 *dst, int plane_stride, float v) {
@@ -1769,15 +1774,14 @@ __device__ __forceinline__ void wgrad_x3_load(const WgradP &p, WgX3Regs<VEC> &r,
     const bool l_sh = l_ix < 0, l_last = l_ix == p.Wl - 1;
     const bool l_in = l_iy >= 0 && l_iy < p.Hl && l_ix < p.Wl;
     const unsigned l_g0 = (unsigned)((b * p.CL + cl0 + l_ch) * HWl + l_iy * p.Wl + l_ix + (l_sh ? 1 : l_last ? -3 : 0));
+    r.edge = (l_sh ? 1u : 0u) | (l_last ? 2u : 0u);
+    r.lok = 0; r.sok = 0; r.eok = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const bool ok = l_in && cl0 + l_ch + 8 * i < p.CL;
-      f32x4u v = *reinterpret_cast<const f32x4u *>(p.L + (ok ? l_g0 + (unsigned)(8 * i * HWl) : 0u));
-      if (l_sh) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }
-      if (l_last) { v[0] = v[3]; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
-      r.lv[i] = v;
-      const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + 8 * i) : 0u];
-      r.lsc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+      r.lok |= ok ? (1u << i) : 0u;
+      r.lv[i] = *reinterpret_cast<const f32x4u *>(p.L + (ok ? l_g0 + (unsigned)(8 * i * HWl) : 0u));
+      r.lsc[i] = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + 8 * i) : 0u];
     }
     const int s_ch = tid >> 4, s_pq = (tid & 15) * 4;
     const int s_u = u0 + (s_pq >> 5), s_v = v0 + (s_pq & 31);
@@ -1786,9 +1790,9 @@ __device__ __forceinline__ void wgrad_x3_load(const WgradP &p, WgX3Regs<VEC> &r,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool ok = s_in && cs0 + s_ch + 16 * i < p.CS;
+      r.sok |= ok ? (1u << i) : 0u;
       r.sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(16 * i * HWs) : 0u));
-      const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 16 * i) : 0u];
-      r.ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
+      r.ssc[i] = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 16 * i) : 0u];
     }
     // the two places the quads leave: 32 and 33 (x = v0 + 31, v0 + 32)
     const int e_ch = tid >> 3, e_row = (tid >> 1) & 3, e_side = tid & 1;
@@ -1798,11 +1802,12 @@ __device__ __forceinline__ void wgrad_x3_load(const WgradP &p, WgX3Regs<VEC> &r,
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool ok = e_in && cl0 + e_ch + 32 * i < p.CL;
+      r.eok |= ok ? (1u << i) : 0u;
       r.ev[i] = p.L[ok ? e_g0 + (unsigned)(32 * i * HWl) : 0u];
-      const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch + 32 * i) : 0u];
-      r.esc[i] = !ok ? 0.f : (hl ? sc : 1.f);
+      r.esc[i] = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch + 32 * i) : 0u];
     }
   } else {
+    r.edge = 0; r.lok = 0; r.sok = 0; r.eok = 0;
     const int l_ch = tid >> 4, l_qx = tid & 15;
     const int iy0 = 2 * u0 - p.py;
     const unsigned l_g0 = (unsigned)((b * p.CL + cl0 + l_ch) * HWl + max(iy0, 0) * p.Wl + 2 * v0 + 4 * l_qx);
@@ -1810,9 +1815,9 @@ __device__ __forceinline__ void wgrad_x3_load(const WgradP &p, WgX3Regs<VEC> &r,
     for (int ii = 0; ii < 12; ++ii) {
       const int row = ii >> 2, ci = 16 * (ii & 3);
       const bool ok = iy0 + row >= 0 && iy0 + row < p.Hl && cl0 + l_ch + ci < p.CL;
+      r.lok |= ok ? (1u << ii) : 0u;
       r.lv[ii] = *reinterpret_cast<const f32x4u *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl + (row + min(iy0, 0)) * p.Wl) : 0u));
-      const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
-      r.lsc[ii] = !ok ? 0.f : (hl ? sc : 1.f);
+      r.lsc[ii] = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
     }
     const int s_ch = tid >> 3, s_pq = (tid & 7) * 4;
     const bool s_in = u0 < p.Hs && v0 + s_pq < p.Ws;
@@ -1820,25 +1825,42 @@ __device__ __forceinline__ void wgrad_x3_load(const WgradP &p, WgX3Regs<VEC> &r,
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool ok = s_in && cs0 + s_ch + 32 * i < p.CS;
+      r.sok |= ok ? (1u << i) : 0u;
       r.sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(32 * i * HWs) : 0u));
-      const float sc = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 32 * i) : 0u];
-      r.ssc[i] = !ok ? 0.f : (hs ? sc : 1.f);
+      r.ssc[i] = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 32 * i) : 0u];
     }
     {  // the 65th column of each halo row (even part, place 32): 64 channels x 3 rows, lanes 0..191
       const int e_ch = tid & 63, e_row = min(tid >> 6, 2);
       const bool ok = tid < 192 && iy0 + e_row >= 0 && iy0 + e_row < p.Hl && cl0 + e_ch < p.CL && 2 * v0 + 64 < p.Wl;
+      r.eok = ok ? 1u : 0u;
       r.ev[0] = p.L[ok ? (unsigned)((b * p.CL + cl0 + e_ch) * HWl + (iy0 + e_row) * p.Wl + 2 * v0 + 64) : 0u];
-      const float sc = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch) : 0u];
-      r.esc[0] = !ok ? 0.f : (hl ? sc : 1.f);
+      r.esc[0] = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch) : 0u];
     }
   }
 }
 
 // scale, split into hi | mid | lo and store the chunk's tiles (three planes each)
 template <int VEC>
-__device__ __forceinline__ void wgrad_x3_store(const WgX3Regs<VEC> &r, __bf16 *Ss, __bf16 *Ls, int tid) {
+__device__ __forceinline__ void wgrad_x3_store(const WgradP &p, WgX3Regs<VEC> &r, __bf16 *Ss, __bf16 *Ls, int tid) {
   constexpr int SPB = WgX3<VEC>::SPB, IWP = WgX3<VEC>::IWP, LPLANE = WgX3<VEC>::LPLANE, HALFW = WgX3<VEC>::HALFW;
   constexpr int SPL = 64 * SPB, LPL = 64 * LPLANE;  // plane strides (elements)
+  {  // first touch of the loaded values: scale factors (0 for padding / out of range) and the row-edge shifts
+    const bool hs = p.s_scale != nullptr, hl = p.l_scale != nullptr;
+#pragma unroll
+    for (int i = 0; i < WgX3<VEC>::NL; ++i) {
+      r.lsc[i] = !((r.lok >> i) & 1u) ? 0.f : (hl ? r.lsc[i] : 1.f);
+      if constexpr (VEC == 1) {
+        f32x4u v = r.lv[i];
+        if (r.edge & 1u) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }
+        if (r.edge & 2u) { v[0] = v[3]; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+        r.lv[i] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WgX3<VEC>::NS; ++i) r.ssc[i] = !((r.sok >> i) & 1u) ? 0.f : (hs ? r.ssc[i] : 1.f);
+#pragma unroll
+    for (int i = 0; i < WgX3<VEC>::NE; ++i) r.esc[i] = !((r.eok >> i) & 1u) ? 0.f : (hl ? r.esc[i] : 1.f);
+  }
   if constexpr (VEC == 1) {
     const int l_ch = tid >> 5, l_row = (tid >> 3) & 3, l_qx = tid & 7;
     __bf16 *l_d0 = Ls + l_ch * LPLANE + l_row * IWP + 4 * l_qx;  // places 4q .. 4q + 3: 8-byte aligned (IWP, LPLANE % 4 == 0)
@@ -1911,7 +1933,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(const WgradP p) {
   const __bf16 *Lp = Ls + (wl * 32 + (lane & 31)) * LPLANE;
   for (; chunk < p.nchunks; chunk += p.ksplit) {
     __syncthreads();  // the previous chunk's MFMA phase is done with the tiles
-    wgrad_x3_store<VEC>(rg, Ss, Ls, tid);
+    wgrad_x3_store<VEC>(p, rg, Ss, Ls, tid);
     __syncthreads();
     if (chunk + p.ksplit < p.nchunks) {  // next chunk's loads: in flight under the MFMA phase below
       int bg, u0, v0;

@@ -184,14 +184,14 @@ class ModulatedConv2D(nn.Module):
     def conv_composable(self, x, s, d):
         """any-order path: x*s -> conv / up-conv+FIR -> *d   (the reference's CPU branch :94-96,:119-121)."""
         coef = _coef(self.w.shape)  # rides along as the primitives' alpha: no elementwise pass over the filter
-        xs = x * s[:, :, None, None]
+        xs = ops.scale_ch(x, s) if x.is_cuda else x * s[:, :, None, None]
         if self.up:
             y = ops.conv_transpose2d_s2(xs, torch.flip(self.w, (0, 1)), alpha=coef)
             y = ops.upfirdn2d(y, ops.fir_kernel(x.device, 4.0), pad=(1, 1, 1, 1))
         else:
             y = ops.conv2d(xs, self.w, (1, 1), (self.k // 2, self.k // 2), alpha=coef)
         if d is not None:
-            y = y * d[:, :, None, None]
+            y = ops.scale_ch(y, d) if y.is_cuda else y * d[:, :, None, None]
         return y
 
 
@@ -235,8 +235,8 @@ class SynthesisBlock(nn.Module):
             if mode == "fused":
                 fn = ops.modconv_up_fused if conv.up else ops.modconv_fused
                 x = fn(x, conv.w, s, noise, nz.noise_strength, ba.b)
-            else:
-                x = ba(conv.conv_composable(x, s, conv.demod(s, mode)) + noise * nz.noise_strength)
+            else:  # any-order path: one launch for noise + bias + lrelu (ops.bias_act_c), gradients again primitives
+                x = ops.bias_act_c(conv.conv_composable(x, s, conv.demod(s, mode)), noise, nz.noise_strength, ba.b)
         return x
 
 
@@ -340,7 +340,7 @@ class FromRGB(nn.Module):
     def forward(self, x, mode="fused"):
         if mode == "fused":
             return ops.conv_bias_act_fused(x, self.conv.w, self.apply_bias_act.b, role="d_image")
-        return self.apply_bias_act(ops.conv2d(x, self.conv.w, alpha=_coef(self.conv.w.shape)))
+        return ops.bias_act_c(ops.conv2d(x, self.conv.w, alpha=_coef(self.conv.w.shape)), None, None, self.apply_bias_act.b)
 
 
 class DiscriminatorBlock(nn.Module):
@@ -367,9 +367,11 @@ class DiscriminatorBlock(nn.Module):
             tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3), role="d")  # conv_downsample_2d, upfirdn_2d_v2.py:106-113
             u = ops.conv_bias_act_fused(tb, self.conv_1.w, self.apply_bias_act_1.b, stride=(sh, 2), role="d")
             return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=rs, role="d")
-        t = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w, (1, 1), (1, 1), alpha=_coef(self.conv_0.w.shape)))
+        t = ops.bias_act_c(ops.conv2d(x, self.conv_0.w, (1, 1), (1, 1), alpha=_coef(self.conv_0.w.shape)), None, None,
+                           self.apply_bias_act_0.b)
         tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3))
-        u = self.apply_bias_act_1(ops.conv2d(tb, self.conv_1.w, (sh, 2), alpha=_coef(self.conv_1.w.shape)))
+        u = ops.bias_act_c(ops.conv2d(tb, self.conv_1.w, (sh, 2), alpha=_coef(self.conv_1.w.shape)), None, None,
+                           self.apply_bias_act_1.b)
         skip = ops.conv2d(xd, self.conv_skip.w, alpha=_coef(self.conv_skip.w.shape))
         return (u + skip) * rs
 
@@ -404,7 +406,8 @@ class DiscriminatorLastBlock(nn.Module):
                                       self.apply_bias_act_1.lrmul, lrelu=True)
         assert parts == 1
         x = minibatch_std(x, 4).contiguous()
-        x = self.apply_bias_act_0(ops.conv2d(x, self.conv_0.w, (1, 1), (1, 1), alpha=_coef(self.conv_0.w.shape)))
+        x = ops.bias_act_c(ops.conv2d(x, self.conv_0.w, (1, 1), (1, 1), alpha=_coef(self.conv_0.w.shape)), None, None,
+                           self.apply_bias_act_0.b)
         return self.apply_bias_act_1(self.dense_1(x))
 
 

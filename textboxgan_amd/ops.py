@@ -789,6 +789,96 @@ def conv_transpose2d_s2(x, wt, alpha=1.0):
 
 
 # ----------------------------------------------------------------------------------------
+# composable elementwise primitives (gradients of any order) for the regularised passes.  The path-length and R1 terms
+# differentiate THROUGH a gradient (training_step.py:300-373), so their networks cannot use the once-differentiable fused
+# layers; written with torch broadcasting ops, the per-layer chain x*s -> conv -> *d -> + noise*strength -> + b -> lrelu -> *sqrt2
+# and its first and second derivative cost ~540 elementwise launches per PL step (profiles/r02_e_launch_sources_pl_step.txt).
+# Every map in that chain is bilinear or piecewise linear, so three primitives closed under differentiation cover it, each
+# ONE launch of an existing kernel:
+#   scale_ch(x, s)[b,c,p] = x[b,c,p] s[b,c]        (tbg_bias_act_fwd_f32, out_scale)          d/dx = scale_ch(g, s), d/ds = dot_hw(g, x)
+#   dot_hw(a, b)[b,c]     = sum_p a b               (tbg_bias_act_bwd_f32's per-plane sums)    d/da = scale_ch(b, g), d/db = scale_ch(a, g)
+#   mask_mul(g, out)      = g * lrelu'(out) * gain  (tbg_bias_act_bwd_f32, dpre)               d/dg = mask_mul(., out); lrelu'' = 0
+# and bias_act_c = lrelu(y + noise*strength + b)*sqrt2 (one tbg_bias_act_fwd_f32 launch) whose backward is mask_mul + sums.
+# ----------------------------------------------------------------------------------------
+class _ScaleCh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        x, s = x.contiguous(), s.contiguous()
+        ctx.save_for_backward(x, s)
+        return bias_act_fwd_raw(x, N.epilogue(out_scale=s))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        dx = _ScaleCh.apply(g, s) if ctx.needs_input_grad[0] else None
+        ds = _DotHW.apply(g, x) if ctx.needs_input_grad[1] else None
+        return dx, ds
+
+
+class _DotHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        _, _, _, _, pdy = bias_act_bwd_raw(a, b, N.epilogue(), want_dpre=False, want_db=False, want_dyy=True)
+        return pdy.sum(dim=2) if pdy.shape[2] > 1 else pdy[:, :, 0]
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        da = _ScaleCh.apply(b, g) if ctx.needs_input_grad[0] else None
+        db = _ScaleCh.apply(a, g) if ctx.needs_input_grad[1] else None
+        return da, db
+
+
+class _MaskMul(torch.autograd.Function):
+    """g * (out > 0 ? 1 : 0.2) * sqrt2: the LeakyReLU derivative taken from the saved OUTPUT (sign(out) = sign(pre))."""
+
+    @staticmethod
+    def forward(ctx, g, out):
+        ctx.save_for_backward(out)
+        _, dpre, _, _, _ = bias_act_bwd_raw(g.contiguous(), out, _lrelu_epi(), want_dpre=True, want_db=False)
+        return dpre
+
+    @staticmethod
+    def backward(ctx, gg):
+        (out,) = ctx.saved_tensors
+        return (_MaskMul.apply(gg, out) if ctx.needs_input_grad[0] else None), None
+
+
+class _BiasActC(torch.autograd.Function):
+    """out = lrelu(y + noise*strength + b) * sqrt2   (noise.py:12-22 + bias_act.py:25-34), differentiable to any order."""
+
+    @staticmethod
+    def forward(ctx, y, noise, strength, b):
+        y = y.contiguous()
+        out = bias_act_fwd_raw(y, _lrelu_epi(bias=b, noise=noise, strength=strength))
+        ctx.save_for_backward(out, noise)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, noise = ctx.saved_tensors
+        dpre = _MaskMul.apply(dout, out)
+        dstrength = None
+        if noise is not None and ctx.needs_input_grad[2]:
+            dstrength = (dpre.sum(dim=1, keepdim=True) * noise).sum()
+        db = dpre.sum(dim=(0, 2, 3)) if ctx.needs_input_grad[3] else None
+        return (dpre if ctx.needs_input_grad[0] else None), None, dstrength, db
+
+
+def scale_ch(x, s):
+    """x [B,C,H,W] * s [B,C] (style modulation / demodulation of the composable path)."""
+    return _ScaleCh.apply(x, s)
+
+
+def bias_act_c(y, noise, strength, b):
+    """lrelu(y + noise*strength + b) * sqrt2 with gradients of any order (noise / strength may be None)."""
+    return _BiasActC.apply(y, noise, strength, b)
+
+
+# ----------------------------------------------------------------------------------------
 # fused first-order layers
 # ----------------------------------------------------------------------------------------
 def _lrelu_epi(**kw):
