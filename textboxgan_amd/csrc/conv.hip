@@ -1940,37 +1940,89 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(const WgradP p) {
       chunk_pos(chunk + p.ksplit, bg, u0, v0);
       wgrad_x3_load<VEC>(p, rg, bg, u0, v0, cs0, cl0, tid);
     }
-    // (a two-register-set version that issued group g+1's reads ahead of group g's MFMAs measured SLOWER -- 103 vs 140 TFLOP/s
-    // on the 64x256 layer: 256 VGPRs + 194 AGPRs with accumulator-file copies in the loop -- so the groups stay rolled and
-    // the compiler batches each group's 21 reads in front of its 54 MFMAs)
+    // MFMA phase as NG x 3 steps of (16-pixel group, filter row): the LDS reads of step i+1 are issued before the 18 MFMAs of
+    // step i (two small register sets, order pinned with sched_barrier).  With ONE wave per SIMD nothing else covers an LDS round
+    // trip: tools/exp_wgx3_split.py measured the phase at 400 us with its operand reads and 255 us without (64x256 layer) when
+    // the compiler batched a group's 21 reads in front of its 54 MFMAs.  (Double-buffering whole GROUPS instead cost 256 VGPRs
+    // + accumulator-file copies and ran slower: 103 vs 140 TFLOP/s.)
+    // The stride-2 form (two groups per chunk, a fourth read per plane) measured 6 % SLOWER this way (105 vs 114 TFLOP/s) and
+    // keeps the rolled loop below.
+    if constexpr (VEC == 1) {
+    constexpr int NG = PIX / 16, NST = NG * 3;
+    bf16x8 a[2][3];                   // [group parity][plane]
+    i32x4 we[2][3], wo[2][3];         // [step parity][plane]: the 8-pixel window (even columns when SX == 2) / the odd columns
+    int w4[2][3];                     // pixels 8, 9 of the window
+    auto ld = [&](int st, int bs) {
+      const int gp = st / 3, kh = st - 3 * gp;
+      const int pp = 16 * gp + 8 * half;  // first of this half-wave's 8 pixels (one 32-pixel tile row)
+      const __bf16 *Lg = Lp + (VEC == 1 ? (pp >> 5) * IWP : 0) + (pp & 31) + kh * IWP;
+      if (kh == 0) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          a[gp & 1][pl] = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(Sp + pl * SPL + 16 * gp, 16));
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {  // window starts are multiples of 8 pixels and every pitch a multiple of 8: 16-byte
+        const __bf16 *row = Lg + pl * LPL;  // aligned (said explicitly: unproven, the compiler split the reads into ds_read2_b32)
+        we[bs][pl] = *reinterpret_cast<const i32x4 *>(__builtin_assume_aligned(row, 16));
+        w4[bs][pl] = *reinterpret_cast<const int *>(row + 8);
+        if constexpr (SX == 2) wo[bs][pl] = *reinterpret_cast<const i32x4 *>(__builtin_assume_aligned(row + HALFW, 16));
+      }
+    };
+    ld(0, 0);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int bs = st & 1, gp = st / 3, kh = st - 3 * gp;
+      if (st + 1 < NST) ld(st + 1, bs ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      i32x4 b[3][3];  // [plane][kw]
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const i32x4 e = we[bs][pl];
+        const int e4 = w4[bs][pl];
+        i32x4 s1;
+        s1[0] = __builtin_amdgcn_alignbit(e[1], e[0], 16); s1[1] = __builtin_amdgcn_alignbit(e[2], e[1], 16);
+        s1[2] = __builtin_amdgcn_alignbit(e[3], e[2], 16); s1[3] = __builtin_amdgcn_alignbit(e4, e[3], 16);
+        b[pl][0] = e;
+        if constexpr (SX == 2) {  // kw = 0: even[0..7], kw = 1: odd[0..7], kw = 2: even[1..8]
+          b[pl][1] = wo[bs][pl];
+          b[pl][2] = s1;
+        } else {                  // kw = 0, 1, 2: window[0..7], [1..8], [2..9]
+          b[pl][1] = s1;
+          b[pl][2][0] = e[1]; b[pl][2][1] = e[2]; b[pl][2][2] = e[3]; b[pl][2][3] = e4;
+        }
+      }
+      // six partial products per tap, smallest first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          acc[3 * kh + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gp & 1][PA[q]], __builtin_bit_cast(bf16x8, b[PB[q]][kw]),
+                                                                     acc[3 * kh + kw], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    } else {
 #pragma unroll 1
     for (int gp = 0; gp < PIX / 16; ++gp) {
-      const int pp = 16 * gp + 8 * half;  // first of this half-wave's 8 pixels (one 32-pixel tile row)
-      const __bf16 *Lg = Lp + (VEC == 1 ? (pp >> 5) * IWP : 0) + (pp & 31);
+      const int pp = 16 * gp + 8 * half;
+      const __bf16 *Lg = Lp + (pp & 31);
       bf16x8 a[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8 *>(Sp + pl * SPL + 16 * gp);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
-        i32x4 b[3][3];  // [plane][kw]
+        i32x4 b[3][3];  // [plane][kw]: even[0..7], odd[0..7], even[1..8]
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
           const __bf16 *row = Lg + pl * LPL + kh * IWP;
           const i32x4 e = *reinterpret_cast<const i32x4 *>(row);
           const int e4 = *reinterpret_cast<const int *>(row + 8);
-          i32x4 s1;
-          s1[0] = __builtin_amdgcn_alignbit(e[1], e[0], 16); s1[1] = __builtin_amdgcn_alignbit(e[2], e[1], 16);
-          s1[2] = __builtin_amdgcn_alignbit(e[3], e[2], 16); s1[3] = __builtin_amdgcn_alignbit(e4, e[3], 16);
           b[pl][0] = e;
-          if constexpr (SX == 2) {  // kw = 0: even[0..7], kw = 1: odd[0..7], kw = 2: even[1..8]
-            b[pl][1] = *reinterpret_cast<const i32x4 *>(row + HALFW);
-            b[pl][2] = s1;
-          } else {                  // kw = 0, 1, 2: window[0..7], [1..8], [2..9]
-            b[pl][1] = s1;
-            b[pl][2][0] = e[1]; b[pl][2][1] = e[2]; b[pl][2][2] = e[3]; b[pl][2][3] = e4;
-          }
+          b[pl][1] = *reinterpret_cast<const i32x4 *>(row + HALFW);
+          b[pl][2][0] = __builtin_amdgcn_alignbit(e[1], e[0], 16); b[pl][2][1] = __builtin_amdgcn_alignbit(e[2], e[1], 16);
+          b[pl][2][2] = __builtin_amdgcn_alignbit(e[3], e[2], 16); b[pl][2][3] = __builtin_amdgcn_alignbit(e4, e[3], 16);
         }
-        // six partial products per tap, smallest first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
         constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
         for (int q = 0; q < 6; ++q)
@@ -1979,6 +2031,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(const WgradP p) {
             acc[3 * kh + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], __builtin_bit_cast(bf16x8, b[PB[q]][kw]),
                                                                        acc[3 * kh + kw], 0, 0, 0);
       }
+    }
     }
   }
 

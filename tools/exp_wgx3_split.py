@@ -6,13 +6,19 @@ import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "textboxgan_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "scratch")
-STORE = ("    wgrad_x3_store<VEC>(rg, Ss, Ls, tid);\n    __syncthreads();\n    if (chunk + p.ksplit < p.nchunks) {",
-         "    if (chunk == (int)blockIdx.z) wgrad_x3_store<VEC>(rg, Ss, Ls, tid);\n    __syncthreads();\n    if (chunk + p.ksplit < p.nchunks) {")
+STORE = ("    wgrad_x3_store<VEC>(p, rg, Ss, Ls, tid);\n    __syncthreads();\n    if (chunk + p.ksplit < p.nchunks) {",
+         "    if (chunk == (int)blockIdx.z) wgrad_x3_store<VEC>(p, rg, Ss, Ls, tid);\n    __syncthreads();\n    if (chunk + p.ksplit < p.nchunks) {")
 LOAD = ("      chunk_pos(chunk + p.ksplit, bg, u0, v0);\n      wgrad_x3_load<VEC>(p, rg, bg, u0, v0, cs0, cl0, tid);",
         "      chunk_pos(chunk + p.ksplit, bg, u0, v0);\n      if (chunk < 0) wgrad_x3_load<VEC>(p, rg, bg, u0, v0, cs0, cl0, tid);")
 MFMA = ("#pragma unroll 1\n    for (int gp = 0; gp < PIX / 16; ++gp) {\n      const int pp = 16 * gp + 8 * half;  // first of this half-wave's 8 pixels (one 32-pixel tile row)\n      const __bf16 *Lg = Lp + (VEC == 1",
         "#pragma unroll 1\n    for (int gp = 0; gp < (chunk == (int)blockIdx.z ? PIX / 16 : 0); ++gp) {\n      const int pp = 16 * gp + 8 * half;  // first of this half-wave's 8 pixels (one 32-pixel tile row)\n      const __bf16 *Lg = Lp + (VEC == 1")
+NOLDS = [("      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8 *>(Sp + pl * SPL + 16 * gp);",
+          "      for (int pl = 0; pl < 3; ++pl) { i32x4 t = {gp + pl, lane, chunk, pl}; a[pl] = __builtin_bit_cast(bf16x8, t); }"),
+         ("          const i32x4 e = *reinterpret_cast<const i32x4 *>(row);\n          const int e4 = *reinterpret_cast<const int *>(row + 8);",
+          "          const i32x4 e = {gp, kh + pl, lane, (int)(size_t)row};\n          const int e4 = chunk;")]
 VARIANTS = {"nostage": [STORE], "noload": [LOAD], "nomfma": [MFMA], "noboth": [STORE, LOAD]}
+if os.environ.get("WG_ABLATE") == "2":
+    VARIANTS = {"noboth": [STORE, LOAD], "noboth_nolds": [STORE, LOAD] + NOLDS}
 
 
 def build():
