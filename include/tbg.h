@@ -102,6 +102,12 @@ int tbg_upfirdn2d_sep_f32(const float *x, const float *kx, const float *ky, floa
                           int padx0, int padx1, int pady0, int pady1, const float *in_scale, int M,
                           const tbg_epilogue *epi, void *stream);
 
+/* The op's second registered type (upfirdn_2d.cu:323-324: `half`): x [major,inH,inW,minor], k [kH,kW] and y are IEEE fp16,
+ * the accumulation is fp32 (.cu:101,195), the result is rounded to fp16 once.  Same attributes, output size rule and error
+ * codes as tbg_upfirdn2d_f32. */
+int tbg_upfirdn2d_f16(const void *x, const void *k, void *y, int major, int inH, int inW, int minor, int kH, int kW,
+                      int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, void *stream);
+
 /* Kernel instantiation (rocprofv3 spelling) that the upfirdn2d entries select for a geometry (sep = 1: the separable
  * entry): a pure function of its arguments.  Tests use it to prove that every instantiation a training step launches is
  * compared with the oracle. */

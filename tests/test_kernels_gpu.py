@@ -61,6 +61,32 @@ def test_upfirdn2d_matches_oracle(dev, case):
 
 
 @pytest.mark.parametrize("case", UF_CASES, ids=[c[-1] for c in UF_CASES])
+def test_upfirdn2d_f16_matches_oracle(dev, case):
+    """the op's second registered type (upfirdn_2d.cu:323-324): fp16 tensors, fp32 accumulation (.cu:101,195), one rounding
+    of the result -- against the float64 oracle evaluated on the fp16-rounded operands: within half an fp16 ulp of it (+ the
+    fp32 accumulation error), i.e. 1e-3 of max; minor > 1 (the op's NHWC "minor" axis) included."""
+    import ctypes as C
+    from textboxgan_amd import native as N
+    major, H, W, up, down, pad, gain, _ = case
+    for minor in (1, 3):
+        x = rnd(major, H, W, minor, seed=1).half()
+        k = torch.from_numpy(R.setup_kernel([1, 3, 3, 1]).astype(np.float64) * gain)
+        k[0, 1] += 0.05
+        k = k.half()
+        ref = R.t_upfirdn2d(x.double(), k.double().numpy(), upx=up[0], upy=up[1], downx=down[0], downy=down[1],
+                            padx0=pad[0], padx1=pad[1], pady0=pad[2], pady1=pad[3])
+        xd, kd = x.to(dev).contiguous(), k.to(dev).contiguous()
+        y = torch.empty(tuple(ref.shape), device=dev, dtype=torch.float16)
+        N.check(N.lib().tbg_upfirdn2d_f16(N.ptr(xd), N.ptr(kd), N.ptr(y), major, H, W, minor, 4, 4, up[0], up[1], down[0], down[1],
+                                          pad[0], pad[1], pad[2], pad[3], N.stream()), "tbg_upfirdn2d_f16")
+        assert tuple(y.shape) == tuple(ref.shape)
+        assert rel_err(y, ref) < 1e-3
+    # argument checks as the fp32 entry (OP_REQUIRES list, upfirdn_2d.cu:241-256)
+    assert N.lib().tbg_upfirdn2d_f16(N.ptr(xd), N.ptr(kd), N.ptr(y), major, H, W, 0, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, N.stream()) != 0
+    assert N.lib().tbg_upfirdn2d_f16(N.ptr(xd), None, N.ptr(y), major, H, W, 1, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, N.stream()) != 0
+
+
+@pytest.mark.parametrize("case", UF_CASES, ids=[c[-1] for c in UF_CASES])
 @pytest.mark.parametrize("taps", [4, 3, 2], ids=["4tap", "3tap", "2tap"])
 def test_upfirdn2d_separable_matches_oracle(dev, case, taps):
     """tbg_upfirdn2d_sep_f32 (1-D factors; the path the model's [1,3,3,1] filters take) == the oracle applied to

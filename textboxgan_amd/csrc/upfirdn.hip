@@ -23,6 +23,8 @@
 // Both fuse an optional per-plane input scale and the shared epilogue (demodulation scale, noise, bias, LeakyReLU).
 #include <stdio.h>
 
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 struct UpfirdnP {
@@ -362,6 +364,57 @@ extern "C" int tbg_upfirdn2d_sep_f32(const float *x, const float *kx, const floa
   if ((rc = upfirdn_epi(p, in_scale, M, epi)) != TBG_OK) return rc;
   p.kx = kx; p.ky = ky;
   return upfirdn_dispatch(p, tbg_stream(stream));
+}
+
+// ---- 16-bit form: the reference op is registered for `float` AND `half` (REGISTER_KERNEL_BUILDER ... TypeConstraint<Eigen::half>,
+// upfirdn_2d.cu:323-324), both accumulating in fp32 (.cu:101,195: `float v = 0`).  x, k and y are IEEE half tensors, the
+// accumulator and the filter product are fp32, the result is rounded to half once (round-to-nearest-even) -- the op's own
+// numerics.  One lane per output element (the reference's "ref-like" form): nothing in the training step uses a 16-bit FIR
+// (activations stay fp32 in HBM), so this entry completes the boundary rather than a hot path.
+__global__ __launch_bounds__(256) void upfirdn2d_direct_f16_kernel(const __half *__restrict__ x, const __half *__restrict__ k,
+                                                                   __half *__restrict__ y, const UpfirdnP p) {
+  const long long total = (long long)p.major * p.outH * p.outW * p.minor;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    long long r = idx;
+    const int mi = (int)(r % p.minor); r /= p.minor;
+    const int ox = (int)(r % p.outW); r /= p.outW;
+    const int oy = (int)(r % p.outH);
+    const int major = (int)(r / p.outH);
+    const int By = oy * p.downy - p.pady0, Bx = ox * p.downx - p.padx0;
+    int jy0 = (-By) % p.upy; if (jy0 < 0) jy0 += p.upy;
+    int jx0 = (-Bx) % p.upx; if (jx0 < 0) jx0 += p.upx;
+    float acc = 0.f;
+    for (int jy = jy0; jy < p.kH; jy += p.upy) {
+      const int iy = (By + jy) / p.upy;
+      if (iy < 0 || iy >= p.inH) continue;
+      const __half *row = x + ((size_t)major * p.inH + iy) * p.inW * p.minor + mi;
+      const __half *krow = k + (size_t)(p.kH - 1 - jy) * p.kW;
+      for (int jx = jx0; jx < p.kW; jx += p.upx) {
+        const int ix = (Bx + jx) / p.upx;
+        if (ix < 0 || ix >= p.inW) continue;
+        acc += __half2float(row[(size_t)ix * p.minor]) * __half2float(krow[p.kW - 1 - jx]);
+      }
+    }
+    y[idx] = __float2half_rn(acc);
+  }
+}
+
+extern "C" int tbg_upfirdn2d_f16(const void *x, const void *k, void *y, int major, int inH, int inW, int minor, int kH,
+                                 int kW, int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1,
+                                 void *stream) {
+  UpfirdnP p;
+  if (!k) return TBG_EINVAL;
+  static const float dummy = 0.f;  // upfirdn_fill checks the pointers only for NULL
+  int rc = upfirdn_fill(p, x ? &dummy : nullptr, y ? const_cast<float *>(&dummy) : nullptr, major, inH, inW, minor, kH, kW, upx,
+                        upy, downx, downy, padx0, padx1, pady0, pady1);
+  if (rc != TBG_OK) return rc;
+  const long long total = (long long)p.major * p.outH * p.outW * p.minor;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(upfirdn2d_direct_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, tbg_stream(stream),
+                     static_cast<const __half *>(x), static_cast<const __half *>(k), static_cast<__half *>(y), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
 }
 
 // Kernel instantiation (rocprofv3 spelling) the three entries above select: a pure function of the geometry (the same
