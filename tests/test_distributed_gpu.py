@@ -60,7 +60,12 @@ def test_two_rank_step_keeps_replicas_identical(dev, use_graphs):
     assert all(abs(v) < 1e6 for v in l0)
 
 
-def _grad_worker(rank, world, port, backend, q):
+def _cfg(full_width, world):
+    from textboxgan_amd.config import Config, small_config
+    return Config(batch_size_per_gpu=4, num_replicas=world) if full_width else small_config(4, num_replicas=world)
+
+
+def _grad_worker(rank, world, port, backend, q, full_width=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from oracle import ref_model as M
@@ -72,7 +77,7 @@ def _grad_worker(rank, world, port, backend, q):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg = small_config(4, num_replicas=world)
+    cfg = _cfg(full_width, world)
     init = M.make_state(cfg, seed=0, bench_init=True)
     st = build_trainer_state(cfg, dev, seed=0)
     st["generator"].load_state_dict({k: v.clone() for k, v in init["G"].items()})
@@ -85,19 +90,20 @@ def _grad_worker(rank, world, port, backend, q):
     losses = ts.dist_train_step(b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False, 1e-4, rand=rand)
     torch.cuda.synchronize()
     cat = lambda views: torch.cat([v.reshape(-1) for v in views]).cpu().numpy()  # numpy: pickled by value (no shm fd)
+    fracs = [float(b1 - b0) / ts.d_grad.numel() for _, _, (b0, b1) in ts.d_stages]  # deepest stage first
     q.put((rank, cat(ts.g_views), cat(ts.o_views), cat(ts.d_views),
-           [float(x) for x in losses[0]] + [float(x) for x in losses[1]] + [float(losses[2])]))
+           [float(x) for x in losses[0]] + [float(x) for x in losses[1]] + [float(losses[2])], fracs))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _exchange_vs_oracle(backend):
+def _exchange_vs_oracle(backend, full_width=False):
     import torch.multiprocessing as mp
     from oracle import ref_model as M
     from textboxgan_amd.aster import AsterLikeOCR
     from textboxgan_amd.config import small_config
     world = 2
-    cfg = small_config(4, num_replicas=world)
+    cfg = _cfg(full_width, world)
     ocr = AsterLikeOCR(max_steps=cfg.max_char_number)
     sums, loss_sum = None, None
     for rank in range(world):  # the oracle, replica by replica, from the same initial weights
@@ -115,12 +121,13 @@ def _exchange_vs_oracle(backend):
                     sums[k][n] += g
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), _free_port()
-    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, backend, q, full_width)) for r in range(world)]
     [p.start() for p in procs]
     res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
     [p.join(timeout=120) for p in procs]
     l2 = lambda a, r: float((a.double() - r.double()).norm() / (r.double().norm() + 1e-30))
-    res = [(r, torch.from_numpy(g), torch.from_numpy(o), torch.from_numpy(d), l) for r, g, o, d, l in res]
+    res_fracs = [t[5] for t in res]
+    res = [(r, torch.from_numpy(g), torch.from_numpy(o), torch.from_numpy(d), l) for r, g, o, d, l, _ in res]
     (_, g0, o0, d0, l0), (_, g1, o1, d1, l1) = res
     assert torch.equal(g0, g1) and torch.equal(o0, o1) and torch.equal(d0, d1), "ranks hold different exchanged gradients"
     # the oracle's gradient dicts, concatenated in the order of the product's flat buffers
@@ -134,12 +141,18 @@ def _exchange_vs_oracle(backend):
     assert l2(g0, cat(sums["g"], gnames)) < 2e-3, "all-reduced G gradient != sum of the per-replica oracle gradients"
     assert l2(o0, cat(sums["ocr"], onames)) < 1e-2
     assert l2(d0, cat(sums["d"], dnames)) < 2e-3
+    if full_width:  # the buckets of the staged D exchange are where DESIGN section 5 says: 74 % / 20 % / 6 % of the bytes
+        fr = res_fracs[0]
+        assert len(fr) == 3 and abs(fr[0] - 0.74) < 0.03 and abs(fr[1] - 0.20) < 0.03 and abs(fr[2] - 0.06) < 0.03, fr
     for a, e in zip(l0, loss_sum):  # strategy.reduce(SUM) of the loss scalars
         assert abs(a - e) <= 2e-4 * max(1.0, abs(e)), (l0, loss_sum)
 
 
-def test_exchanged_gradients_equal_sum_of_per_replica_oracle_gradients_gloo(dev):
-    _exchange_vs_oracle("gloo")
+@pytest.mark.parametrize("full_width", [False, True], ids=["small", "full-width"])
+def test_exchanged_gradients_equal_sum_of_per_replica_oracle_gradients_gloo(dev, full_width):
+    """full-width: the real channel widths (B = 4 per rank), so the D exchange's bucket boundaries (d_cuts = (5, 3): 74 % /
+    20 % / 6 % of D's 62 MB) are exercised on the real layer sizes."""
+    _exchange_vs_oracle("gloo", full_width)
 
 
 def test_exchanged_gradients_equal_sum_of_per_replica_oracle_gradients_rccl(dev):
