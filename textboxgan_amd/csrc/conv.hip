@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   constexpr int CB = CK < 8 ? CK : 8;       // channels per halo load batch
   constexpr int NB = PF ? 2 : 1;            // LDS buffers (PF > 0: software-pipelined K loop)
   constexpr int NJC = PF ? PF : MAXNJ;      // halo positions per thread this instance can hold
-  static_assert(X3 ? (CK % 8 == 0 && PF == 0) : BF ? (CK % 16 == 0 && PF == 0) : (CK == 4 || CK % 8 == 0),
+  static_assert(X3 ? (CK % 8 == 0) : BF ? (CK % 16 == 0 && PF == 0) : (CK == 4 || CK % 8 == 0),
                 "chunk = one quad (half-waves split it) or whole unit pairs (half-wave h reads unit 2o+h); X3: whole units");
   static_assert(!PF || CK <= 8, "the pipelined variant prefetches one load batch");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   };
 
   bool done = false;
-  if constexpr (X3) {
+  if constexpr (X3 && PF == 0) {
     // f32x3 K loop with the halo tile of chunk k+1 PREFETCHED INTO REGISTERS while chunk k's MFMAs run (single LDS buffer: three
     // operand planes leave no room for a second one at 2 blocks/CU).  Per chunk: barrier | split + store the prefetched tile
     // | issue the filter DMA | issue the loads of the next tile | wait for the DMA only (counted vmcnt: the loads stay in
@@ -506,9 +506,12 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
         if (kc + 1 < kend) {
           loadx((kc + 1) * CK);
           // the DMA pieces are older than the loads just issued: leave exactly those loads outstanding
-          if (p.NJ == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NBT * CB) : "memory");
-          else if (p.NJ == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NBT * CB) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJX * NBT * CB) : "memory");
+          // (vmcnt is a 6-bit field: 63 still leaves every halo load but one in flight)
+          constexpr int V1 = NBT * CB < 63 ? NBT * CB : 63, V2 = 2 * NBT * CB < 63 ? 2 * NBT * CB : 63;
+          constexpr int V3 = NJX * NBT * CB < 63 ? NJX * NBT * CB : 63;
+          if (p.NJ == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(V1) : "memory");
+          else if (p.NJ == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(V2) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(V3) : "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
@@ -540,16 +543,16 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
       const int cur = (kc - kbeg) & 1;
       const bool more = kc + 1 < kend;
       if (more) {
-        issue_filter_dma(kc + 1, As + (cur ^ 1) * p.a_floats);
+        issue_filter_dma(kc + 1, As + (cur ^ 1) * NP * p.a_floats);
 #pragma unroll
         for (int j = 0; j < NJC; ++j)
           if (j < p.NJ) load_halo((kc + 1) * CK, j, xv[j]);
       }
-      mfma_taps(As + cur * p.a_floats, Xs + cur * xbuf_floats);
+      mfma_taps(As + cur * NP * p.a_floats, Xs + cur * NP * xbuf_floats);
       if (more) {
 #pragma unroll
         for (int j = 0; j < NJC; ++j)
-          if (j < p.NJ) store_halo((kc + 1) * CK, 0, j, xv[j], Xs + (cur ^ 1) * xbuf_floats);
+          if (j < p.NJ) store_halo((kc + 1) * CK, 0, j, xv[j], Xs + (cur ^ 1) * NP * xbuf_floats);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the filter DMA has landed (explicit, not left to the fence)
       __syncthreads();
@@ -947,6 +950,11 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
   if (x3) {  // f32x3: the tile shapes of the fp32 path, 8-channel chunks (16 for the few-tap classes), 2 blocks/CU
     if (merged) return launch_fprop<2, 2, 1, 2, 8, MAXTAPS, 0, 2, true, true, true>(p, st, maxtaps, maxTilesN, name);
     if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 5) return TBG_EUNSUPPORTED;
+    // (The 64 x 64 tile -- the small maps of both networks and the whole frozen-OCR stack, 1.6 ms of GPU time per step -- is
+    // bound by the latency of its filter stream, not by chunk count or staging: under graph replay a C = 256, M = 256 layer on
+    // 2 x 25 maps takes 56 us unsplit = 1.7 us per 8-channel chunk against 0.4 us of MFMA; 16- and 32-channel chunks and the
+    // double-buffered loop (DMA of chunk k+1 under the MFMAs of chunk k) all measured the same, profiles/r03_small_tile_forms.txt.
+    // More than one filter slice in flight per CU would need the halo tile off the register path too -- vmcnt retires in order.)
     if (BM == 128 && BN == 256) return launch_fprop<2, 2, 2, 4, 8, MAXTAPS, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
     if (maxtaps > 1 && maxtaps <= 4) {
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
