@@ -160,6 +160,29 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const BiasActBwdP p) 
   const float *oa = p.out_act + (size_t)plane * p.HW;
   const float *nz = p.e.noise ? p.e.noise + (size_t)b * p.HW : nullptr;
   float s_db = 0.f, s_dn = 0.f, s_dyy = 0.f;
+  if ((p.HW & 3) == 0) {  // 16-byte loads / stores: 4 independent quads per lane and chunk in flight
+    float *dxo = p.dx ? p.dx + (size_t)plane * p.HW : nullptr;
+    float *dpo = p.dpre_out ? p.dpre_out + (size_t)plane * p.HW : nullptr;
+#pragma unroll 4
+    for (int i = p0 + threadIdx.x * 4; i < p1; i += 1024) {
+      const float4 o4 = *reinterpret_cast<const float4 *>(oa + i);
+      const float4 d4 = *reinterpret_cast<const float4 *>(dout + i);
+      const float4 n4 = nz ? *reinterpret_cast<const float4 *>(nz + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float ov[4] = {o4.x, o4.y, o4.z, o4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w}, nv[4] = {n4.x, n4.y, n4.z, n4.w};
+      float dp[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool pos = ov[e] > 0.f;
+        dp[e] = dv[e] * gin * (pos ? g_pos : g_neg);
+        const float pre = ov[e] * (pos ? ig_pos : ig_neg);
+        s_db += dp[e];
+        s_dn += dp[e] * nv[e];
+        s_dyy += dp[e] * (pre - nv[e] * str - bias);
+      }
+      if (dxo) *reinterpret_cast<float4 *>(dxo + i) = make_float4(dp[0] * sc, dp[1] * sc, dp[2] * sc, dp[3] * sc);
+      if (dpo) *reinterpret_cast<float4 *>(dpo + i) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+    }
+  } else {
   for (int i = p0 + threadIdx.x; i < p1; i += 256) {
     const float o = oa[i];
     const bool pos = o > 0.f;
@@ -171,6 +194,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const BiasActBwdP p) 
     s_dyy += dpre * (pre - n * str - bias);
     if (p.dx) p.dx[(size_t)plane * p.HW + i] = dpre * sc;
     if (p.dpre_out) p.dpre_out[(size_t)plane * p.HW + i] = dpre;
+  }
   }
   s_db = wave_sum(s_db); s_dn = wave_sum(s_dn); s_dyy = wave_sum(s_dyy);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
