@@ -11,7 +11,9 @@ DMA = ("        issue_filter_dma(kc, As);\n        if (kc + 1 < kend) {\n       
 STG = [("        if (kc + 1 < kend) {\n          loadx((kc + 1) * CK);", "        if (kc + 1 < kend) {\n          if (kc < kbeg) loadx((kc + 1) * CK);"),
        ("          if (j < p.NJ) {\n#pragma unroll\n            for (int bt = 0; bt < NBT; ++bt) store_halo(kc * CK + bt * CB, bt, j, xr[j][bt], Xs);",
         "          if (j < p.NJ && kc == kbeg) {\n#pragma unroll\n            for (int bt = 0; bt < NBT; ++bt) store_halo(kc * CK + bt * CB, bt, j, xr[j][bt], Xs);"),
-       ("          if (p.NJ == 1) asm volatile(\"s_waitcnt vmcnt(%0) lgkmcnt(0)\" ::\"n\"(NBT * CB) : \"memory\");\n          else asm volatile(\"s_waitcnt vmcnt(%0) lgkmcnt(0)\" ::\"n\"(2 * NBT * CB) : \"memory\");",
+       ("          if (p.NJ == 1) asm volatile(\"s_waitcnt vmcnt(%0) lgkmcnt(0)\" ::\"n\"(V1) : \"memory\");\n"
+        "          else if (p.NJ == 2) asm volatile(\"s_waitcnt vmcnt(%0) lgkmcnt(0)\" ::\"n\"(V2) : \"memory\");\n"
+        "          else asm volatile(\"s_waitcnt vmcnt(%0) lgkmcnt(0)\" ::\"n\"(V3) : \"memory\");",
         "          asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\");")]
 MFMA = ("        __builtin_amdgcn_s_barrier();\n        mfma_taps(As, Xs);\n      }\n    }\n  }\n  if (done) {",
         "        __builtin_amdgcn_s_barrier();\n        if (kc == kend - 1) mfma_taps(As, Xs);\n      }\n    }\n  }\n  if (done) {")
@@ -64,15 +66,21 @@ def run():
         return l
     libs = {"product": P, **{k: load(k) for k in VARIANTS}}
     B = 16
-    for Cc, M, H, W in ((128, 128, 64, 256), (128, 128, 32, 128), (256, 256, 16, 64), (64, 64, 64, 256)):
+    strided = os.environ.get("X3_SHAPES") == "strided"
+    shapes = (((128, 128, 65, 257, 32, 128, 2, 0), (128, 256, 33, 129, 16, 64, 2, 0), (128, 128, 32, 128, 65, 257, 2, 1),
+               (256, 256, 16, 64, 33, 129, 2, 1)) if strided else
+              ((128, 128, 64, 256, 64, 256, 1, 0), (128, 128, 32, 128, 32, 128, 1, 0), (256, 256, 16, 64, 16, 64, 1, 0),
+               (64, 64, 64, 256, 64, 256, 1, 0)))
+    for Cc, M, H, W, OH, OW, st, T in shapes:
         x = torch.randn(B, Cc, H, W, device=dev)
         w = torch.randn(3, 3, Cc, M, device=dev)
-        pf = ops.pack_filter(w, False, False, bf16="f32x3")
-        y = torch.empty(B, M, H, W, device=dev)
-        d = N.ConvDesc(B, Cc, M, H, W, H, W, 3, 3, 1, 1, 1, 1, 0, 0, M, 1)
+        pf = ops.pack_filter(w, False, False, bf16="f32x3")  # timing only: the filter's orientation does not matter
+        y = torch.empty(B, M, OH, OW, device=dev)
+        pad = 1 if st == 1 else 0
+        d = N.ConvDesc(B, Cc, M, H, W, OH, OW, 3, 3, st, st, pad, pad, T, 0, M, 1)
         e = N.epilogue()
-        flops = 2.0 * B * Cc * M * 9 * H * W
-        line = f"x3 fprop {Cc}->{M} {H}x{W} [{N.conv_kernel_name(d, False, 2)}]:"
+        flops = 2.0 * B * Cc * M * 9 * (H * W if T else OH * OW)
+        line = f"x3 fprop {Cc}->{M} {H}x{W}->{OH}x{OW} s{st} T{T} [{N.conv_kernel_name(d, False, 2)}]:"
         for name, l in libs.items():
             t = timeit(lambda: l.tbg_conv2d_x3(C.byref(d), N.ptr(x), N.ptr(pf.data), N.ptr(y), None, C.byref(e), N.stream()))
             line += f"  {name} {t:7.1f} us ({flops / t / 1e6:5.1f} TF)"
