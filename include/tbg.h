@@ -53,6 +53,8 @@ unsigned int tbg_crc32c(const void *data, long long n, unsigned int crc);
  *   v   = (act == LRELU ? (v > 0 ? v : v * slope) : v) * gain
  *   out = residual ? (v + residual[...]) * res_scale : v
  * (res_first != 0: the residual is added BEFORE the activation instead -- ResNet units of the OCR.)
+ *   out = gate ? (gate[...] > 0 ? out : 0) : out      (applied last; conv / slab / bias_act launches, not with dot_aux:
+ *   the ReLU backward of a frozen ResNet unit rides on the data-gradient launch that produces its incoming gradient)
  * tbg_conv2d_f32 additionally supports a fused per-(b,m) dot product of the UNSCALED accumulator
  * with a second tensor (dot_aux/dot_out): the style gradient ds[b,i] = sum_p x[b,i,p]*dxhat[b,i,p]
  * comes out of the same launch that writes dx = s*dxhat.
@@ -66,6 +68,7 @@ typedef struct tbg_epilogue {
   const float *residual;  /* output-shaped or NULL */
   const float *dot_aux;   /* conv only: output-shaped tensor or NULL */
   float *dot_out;         /* conv only: [B*M], PRE-ZEROED; += sum_p (acc*alpha) * dot_aux[b,m,p] */
+  const float *gate;      /* output-shaped or NULL */
   float alpha;
   float bias_mul;
   float slope;

@@ -53,7 +53,7 @@ def test_header_symbols_are_exported_by_the_library():
 
 def test_ctypes_struct_layout_matches_header():
     from textboxgan_amd import native
-    assert ctypes.sizeof(native.Epilogue) == 7 * 8 + 5 * 4 + 2 * 4 + 4  # 7 pointers, 5 floats, 2 ints, tail padding
+    assert ctypes.sizeof(native.Epilogue) == 8 * 8 + 5 * 4 + 2 * 4 + 4  # 8 pointers, 5 floats, 2 ints, tail padding
     assert ctypes.sizeof(native.ConvDesc) == 17 * 4 and ctypes.sizeof(native.WgradDesc) == 17 * 4
 
 

@@ -341,6 +341,37 @@ def test_conv2d_fused_epilogue(dev):
     assert rel_err(dot, (raw * aux).sum(dim=(2, 3))) < 2e-5
 
 
+@arith_modes
+@pytest.mark.parametrize("ksplit", [None, 4])
+def test_conv2d_gate_epilogue(dev, ksplit):
+    """out = gate > 0 ? acc + residual : 0 (the frozen ResNet's backward: residual sum and ReLU gate of the unit in front on
+    the data-gradient launch), unsplit and through the split-K slab pass; 3x3 stride 1 and the strided 1x1 transposed form."""
+    from textboxgan_amd import ops, native as N
+    f = lambda t: t.float().to(dev).contiguous()
+    B, C, M, H, W = 3, 64, 48, 4, 25
+    x, w = rnd(B, C, H, W, seed=41), rnd(3, 3, C, M, seed=42)
+    res, gate = rnd(B, M, H, W, seed=43), rnd(B, M, H, W, seed=44)
+    gate = torch.where(gate.abs() < 0.3, torch.zeros_like(gate), gate)  # exact zeros gate off, as relu outputs do
+    ref = (F.conv2d(x, w.permute(3, 2, 0, 1), padding=1) + res) * (gate > 0)
+    rd, gd = f(res), f(gate)
+    ops.FORCE_KSPLIT = ksplit
+    try:
+        y = ops.conv2d_raw(f(x), f(w), M, 3, 3, (H, W), (1, 1), (1, 1), epi=N.epilogue(residual=rd, res_first=1, gate=gd))
+        assert rel_err(y, ref) < 2e-5
+        assert torch.equal(y == 0, (ref == 0).to(dev))
+        # 1x1 stride (2, 1) transposed (data gradient of a strided shortcut): three of four... here every second row has no tap
+        xs, ws = rnd(B, C, 4, 25, seed=45), rnd(1, 1, M, C, seed=46)  # forward conv M -> C, stride (2, 1): dgrad maps C -> M
+        res2, gate2 = rnd(B, M, 8, 25, seed=47), rnd(B, M, 8, 25, seed=48)
+        ref2 = (F.conv_transpose2d(xs, ws.permute(3, 2, 0, 1), stride=(2, 1), output_padding=(1, 0)) + res2) * (gate2 > 0)
+        pf = ops.pack_filter(f(ws), transpose=True, flip=False)
+        r2, g2 = f(res2), f(gate2)
+        y2 = ops.conv2d_raw(f(xs), pf, M, 1, 1, (8, 25), (2, 1), (0, 0), transposed=True,
+                            epi=N.epilogue(residual=r2, res_first=1, gate=g2))
+        assert rel_err(y2, ref2) < 2e-5
+    finally:
+        ops.FORCE_KSPLIT = None
+
+
 WG_CASES = [
     (2, 16, 32, 16, 64, 3, (1, 1), (1, 1), "3x3 s1"),
     (2, 128, 128, 16, 64, 3, (1, 1), (1, 1), "3x3 s1 128ch"),

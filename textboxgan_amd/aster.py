@@ -516,6 +516,20 @@ class AsterLikeOCRHip(AsterLikeOCR):
                     w_o=c(self.out.weight), w_oT=c(self.out.weight.t()), b_o=c(self.out.bias))
         return ops.frozen_attn_decoder(enc, self._cache["dec"], self.max_steps, self.num_classes)
 
+    def encode(self, x):
+        """stem + ResNet as one autograd node (ops.frozen_resnet): the ReLU gates and residual sums of the backward ride on the
+        data-gradient launches' epilogues."""
+        from . import ops
+        if not x.is_cuda:
+            raise RuntimeError("AsterLikeOCRHip runs on the GPU only (use AsterLikeOCR for the CPU definition)")
+        key = ("resnet", ops.compute_mode())
+        if key not in self._cache:
+            with torch.no_grad():
+                const = lambda blk: ops.FrozenConvConst(*blk.folded(), tuple(blk.conv.stride), tuple(blk.conv.padding), blk.relu)
+                self._cache[key] = (const(self.stem), [(const(u.c1), const(u.c2), const(u.short) if u.short is not None else None)
+                                                       for u in self.resnet])
+        return ops.frozen_resnet(x, *self._cache[key])
+
     def _run(self, blk: _ConvBN, x, residual=None):
         from . import ops
         if not x.is_cuda:

@@ -640,13 +640,14 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     return;
   }
   const float *const e_os = p.e.out_scale, *const e_bias = p.e.bias, *const e_res = p.e.residual, *const e_aux = p.e.dot_aux;
+  const float *const e_gate = p.e.gate;
   float *const e_dot = p.e.dot_out;
   const float e_alpha = p.e.alpha, e_bmul = p.e.bias_mul, e_slope = p.e.slope, e_gain = p.e.gain, e_rscale = p.e.res_scale;
   const bool e_lrelu = p.e.act == TBG_ACT_LRELU, e_rfirst = p.e.res_first != 0;
   const float str = p.e.noise ? p.e.strength[0] : 0.f;
   const bool split = p.ksplit > 1;
   const bool do_dot = e_aux != nullptr && !split;
-  const bool plain = !e_os && !e_bias && !p.e.noise && !e_res && !e_aux && !e_lrelu && e_gain == 1.f;
+  const bool plain = !e_os && !e_bias && !p.e.noise && !e_res && !e_aux && !e_gate && !e_lrelu && e_gain == 1.f;
   const int M = p.M, NSEGr = p.NSEG;
   float *const ybase = split ? p.y + (size_t)ks * p.slab : p.y;
   int e_pix[WTN], e_b[WTN];
@@ -713,6 +714,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
         for (int q = 0; q < RG; ++q)
 #pragma unroll
           for (int j = 0; j < WTN; ++j) axv[q][j] = e_aux[max(idx[q][j], 0)];
+      } else if (e_gate) {  // never together with the dot operand (epi_valid): the gate values share its registers
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) axv[q][j] = e_gate[max(idx[q][j], 0)];
       }
 #pragma unroll
       for (int q = 0; q < RG; ++q) {
@@ -731,6 +737,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
           if (e_rfirst) val += rsv[q][j];
           val = (e_lrelu ? (val > 0.f ? val : val * e_slope) : val) * e_gain;
           if (e_res && !e_rfirst) val = (val + rsv[q][j]) * e_rscale;
+          if (e_gate) val = axv[q][j] > 0.f ? val : 0.f;
           if (okq) p.y[idx[q][j]] = val;
         }
         if (do_dot && NSEGr == 1) {  // one image per tile: reduce the 32 pixel lanes of each half-wave
@@ -819,7 +826,7 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
   const int T = d->KH * d->KW;
   p.wplane = T * ((d->C + 7) / 8) * d->ldw * 4;
   // merged form of the stride-2 transposed 3x3 convolution (see the TM template parameter): store-only epilogues
-  const bool plain_epi = !epi || (!epi->out_scale && !epi->bias && !epi->noise && !epi->residual && !epi->dot_aux &&
+  const bool plain_epi = !epi || (!epi->out_scale && !epi->bias && !epi->noise && !epi->residual && !epi->dot_aux && !epi->gate &&
                                   epi->act == TBG_ACT_LINEAR && epi->gain == 1.f);
   // Measured (tools/bench_transposed.py, profiles/r02_transposed_forms.txt): in bf16 the merged form wins on the large maps
   // (216 vs 158 TFLOP/s on 32x128 128->128, 232 vs 124 on the 128->64 data gradient: the per-class form re-stages the halo

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const BiasActP p) {
   const float *rs = p.e.residual ? p.e.residual + (size_t)plane * p.HW : nullptr;
   float *yo = p.y + (size_t)plane * p.HW;
   const bool rf = rs && p.e.res_first;
+  const float *gt = p.e.gate ? p.e.gate + (size_t)plane * p.HW : nullptr;
   if ((p.HW & 3) == 0) {
     for (int i = p0 + threadIdx.x * 4; i < p1; i += 1024) {
       float4 v = *reinterpret_cast<const float4 *>(xin + i);
@@ -44,12 +45,17 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const BiasActP p) {
         o.x = (o.x + r.x) * p.e.res_scale; o.y = (o.y + r.y) * p.e.res_scale;
         o.z = (o.z + r.z) * p.e.res_scale; o.w = (o.w + r.w) * p.e.res_scale;
       }
+      if (gt) {
+        const float4 g = *reinterpret_cast<const float4 *>(gt + i);
+        o.x = g.x > 0.f ? o.x : 0.f; o.y = g.y > 0.f ? o.y : 0.f; o.z = g.z > 0.f ? o.z : 0.f; o.w = g.w > 0.f ? o.w : 0.f;
+      }
       *reinterpret_cast<float4 *>(yo + i) = o;
     }
   } else {
     for (int i = p0 + threadIdx.x; i < p1; i += 256) {
       float o = epi_act(p.e, xin[i] * sc + (nz ? nz[i] * str : 0.f) + bias + (rf ? rs[i] : 0.f));
       if (rs && !rf) o = (o + rs[i]) * p.e.res_scale;
+      if (gt) o = gt[i] > 0.f ? o : 0.f;
       yo[i] = o;
     }
   }
@@ -115,6 +121,7 @@ __global__ __launch_bounds__(256) void slab_epilogue_kernel(const SlabEpiP p) {
         if (rf) o += p.e.residual[i + k];
         o = epi_act(p.e, o);
         if (p.e.residual && !rf) o = (o + p.e.residual[i + k]) * p.e.res_scale;
+        if (p.e.gate) o = p.e.gate[i + k] > 0.f ? o : 0.f;
         v[k] = o;
       }
     }
@@ -253,6 +260,7 @@ extern "C" int tbg_bias_act_bwd_f32(const float *dout, const float *out_act, flo
   if (!dout || !out_act || B < 1 || M < 1 || HW < 1 || !epi || !epi_valid(epi)) return TBG_EINVAL;
   if ((double)B * M * HW > 2147483647.0) return TBG_ERANGE;
   if (part_dn && !epi->noise) return TBG_EINVAL;
+  if (epi->gate) return TBG_EINVAL;  // a forward-only epilogue term
   BiasActBwdP p{dout, out_act, dx, dpre_out, part_db, part_dn, part_dyy, B, M, HW, tbg_bias_act_bwd_chunks(HW), make_epi(epi)};
   if (HW <= 1024) {  // nchunks == 1: same partial-sum layout [B*M][1]
     hipLaunchKernelGGL(bias_act_bwd_small_kernel, dim3((B * M + 3) / 4), dim3(256), 0, tbg_stream(stream), p);

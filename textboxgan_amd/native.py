@@ -33,7 +33,7 @@ class TbgError(RuntimeError):
 
 class Epilogue(C.Structure):
     _fields_ = [("out_scale", C.c_void_p), ("bias", C.c_void_p), ("noise", C.c_void_p), ("strength", C.c_void_p),
-                ("residual", C.c_void_p), ("dot_aux", C.c_void_p), ("dot_out", C.c_void_p), ("alpha", C.c_float), ("bias_mul", C.c_float), ("slope", C.c_float),
+                ("residual", C.c_void_p), ("dot_aux", C.c_void_p), ("dot_out", C.c_void_p), ("gate", C.c_void_p), ("alpha", C.c_float), ("bias_mul", C.c_float), ("slope", C.c_float),
                 ("gain", C.c_float), ("res_scale", C.c_float), ("act", C.c_int), ("res_first", C.c_int)]
 
 
@@ -227,10 +227,10 @@ def stream() -> int:
 
 
 def epilogue(out_scale=None, bias=None, noise=None, strength=None, residual=None, alpha=1.0, bias_mul=1.0,
-             act=ACT_LINEAR, slope=0.2, gain=None, res_scale=1.0, dot_aux=None, dot_out=None, res_first=0) -> Epilogue:
+             act=ACT_LINEAR, slope=0.2, gain=None, res_scale=1.0, dot_aux=None, dot_out=None, res_first=0, gate=None) -> Epilogue:
     if gain is None:
         gain = SQRT2 if act == ACT_LRELU else 1.0
-    return Epilogue(ptr(out_scale), ptr(bias), ptr(noise), ptr(strength), ptr(residual), ptr(dot_aux), ptr(dot_out), alpha, bias_mul, slope, gain,
+    return Epilogue(ptr(out_scale), ptr(bias), ptr(noise), ptr(strength), ptr(residual), ptr(dot_aux), ptr(dot_out), ptr(gate), alpha, bias_mul, slope, gain,
                     res_scale, act, res_first)
 
 

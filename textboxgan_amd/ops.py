@@ -1558,6 +1558,74 @@ class _FrozenConv(torch.autograd.Function):
         return dx, None, None, None, None, None, (dy if has_res else None), None
 
 
+class FrozenConvConst:
+    """Constants of one frozen convolution (+ folded BatchNorm): bias, geometry, forward and data-gradient packs."""
+    __slots__ = ("b", "KH", "KW", "I", "O", "stride", "pad", "relu", "pf_fwd", "pf_bwd")
+
+    def __init__(self, w, b, stride, pad, relu):
+        self.KH, self.KW, self.I, self.O = (int(v) for v in w.shape)
+        self.b, self.stride, self.pad, self.relu = b, tuple(stride), tuple(pad), bool(relu)
+        self.pf_fwd, self.pf_bwd = frozen_conv_packs(w, self.stride)
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.pad[0] - self.KH) // self.stride[0] + 1, (W + 2 * self.pad[1] - self.KW) // self.stride[1] + 1)
+
+    def fwd(self, x, residual=None):
+        epi = N.epilogue(bias=self.b, residual=residual, res_first=1, act=ACT_LRELU if self.relu else ACT_LINEAR, slope=0.0,
+                         gain=1.0)
+        return conv2d_raw(x, self.pf_fwd, self.O, self.KH, self.KW, self.out_hw(x.shape[2], x.shape[3]), self.stride, self.pad,
+                          epi=epi)
+
+    def bwd(self, dy, xhw, residual=None, gate=None):
+        """d/dx of the convolution, + residual, then zeroed where gate <= 0 (the ReLU in front of x), in the one launch."""
+        epi = N.epilogue(residual=residual, res_first=1, gate=gate) if (residual is not None or gate is not None) else None
+        if self.stride == (1, 1):
+            return conv2d_raw(dy, self.pf_bwd, self.I, self.KH, self.KW, xhw, (1, 1),
+                              (self.KH - 1 - self.pad[0], self.KW - 1 - self.pad[1]), epi=epi)
+        assert self.KH == 1 and self.KW == 1 and self.pad == (0, 0), "strided OCR convolutions are 1x1"
+        return conv2d_raw(dy, self.pf_bwd, self.I, 1, 1, xhw, self.stride, (0, 0), transposed=True, epi=epi)
+
+
+class _FrozenResNet(torch.autograd.Function):
+    """The frozen OCR encoder's ResNet (stem + units of 1x1 -> 3x3 (+ 1x1 shortcut)) as ONE autograd node: constant
+    weights, so the backward is a chain of data-gradient launches whose epilogues carry the residual sum and the ReLU gate
+    of the unit in front -- no elementwise launches between them (they were 73 of the branch's ~630 launches)."""
+
+    @staticmethod
+    def forward(ctx, x, stem, units):
+        x = x.contiguous()
+        acts = [x.shape[2:], stem.fwd(x)]  # y0
+        for c1, c2, short in units:
+            xin = acts[-1]
+            sc = xin if short is None else short.fwd(xin)
+            h1 = c1.fwd(xin)
+            acts += [h1, c2.fwd(h1, residual=sc)]
+        ctx.consts = (stem, units)
+        ctx.in_hw = tuple(acts[0])
+        ctx.save_for_backward(*acts[1:])
+        return acts[-1]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        stem, units = ctx.consts
+        acts = ctx.saved_tensors  # y0, (h1, y) per unit
+        g = torch.ops.aten.threshold_backward(dy.contiguous(), acts[-1], 0.0)  # gradient at the last unit's pre-activation
+        for u in range(len(units) - 1, -1, -1):
+            c1, c2, short = units[u]
+            xin, h1 = acts[2 * u], acts[2 * u + 1]
+            t = c2.bwd(g, tuple(h1.shape[2:]), gate=h1)
+            res = g if short is None else short.bwd(g, tuple(xin.shape[2:]))
+            g = c1.bwd(t, tuple(xin.shape[2:]), residual=res, gate=xin)  # xin = relu output of the unit (or stem) in front
+        dx = stem.bwd(g, ctx.in_hw) if ctx.needs_input_grad[0] else None
+        return dx, None, None
+
+
+def frozen_resnet(x, stem: FrozenConvConst, units):
+    """units: [(c1, c2, short | None)] of FrozenConvConst."""
+    return _FrozenResNet.apply(x, stem, units)
+
+
 def frozen_conv_packs(w, stride):
     """(forward, data-gradient) packed filters of a frozen convolution.  The caller that owns the constant weight keeps
     them (AsterLikeOCRHip caches them per layer) -- there is deliberately no global cache keyed by address."""
