@@ -67,7 +67,9 @@ typedef struct tbg_epilogue {
   const float *strength;  /* device scalar, required with noise */
   const float *residual;  /* output-shaped or NULL */
   const float *dot_aux;   /* conv only: output-shaped tensor or NULL */
-  float *dot_out;         /* conv only: [B*M], PRE-ZEROED; += sum_p (acc*alpha) * dot_aux[b,m,p] */
+  float *dot_out;         /* conv only: [B*M*slots] partial sums of (acc*alpha) * dot_aux[b,m,p] over pixel ranges, every
+                           * element written by plain stores (no atomics): the caller sums the slots of each (b,m) in a
+                           * fixed order; slots = tbg_conv2d_dot_slots(desc, ...) */
   const float *gate;      /* output-shaped or NULL */
   float alpha;
   float bias_mul;
@@ -153,6 +155,11 @@ int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const float *w, float
  * environment knobs and the library keeps no mutable state.  Profiling aid (bench.py attributes HIP-event timings to
  * rocprofv3 kernel names with it; tests use it to prove every instantiation is compared with the oracle). */
 int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
+/* Slots per (sample, channel) of the fused dot product's partial sums for this descriptor (mode: 0 = fp32, 1 = bf16, 2 = f32x3):
+ * one per (pixel tile of the image, wave column of the tile).  0: the fused dot is not available for this launch (several
+ * images per tile, several output-parity classes, or K split) -- a launch that asks for it anyway returns TBG_EUNSUPPORTED and
+ * the caller reduces the finished output instead.  Negative: an error code. */
+int tbg_conv2d_dot_slots(const tbg_conv_desc *d, int has_in_scale, int mode);
 /* tbg_conv2d_f32 with an EXPLICIT instantiation family for 3x3 / 1x1 non-transposed-class launches (tuning and test aid):
  * variant 0 = the library's choice, 1 = software-pipelined (double-buffered LDS), 2 = plain 8-channel chunks,
  * 3 = 4-channel chunks at 4 waves/SIMD (128x128 tile only), 4 / 5 = stride-2 transposed 3x3 as one block per output-parity

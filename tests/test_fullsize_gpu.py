@@ -103,8 +103,8 @@ def test_upfirdn_gradient_is_adjoint_full_size(dev):
 
 def test_graph_replay_equals_eager_step_full_size(dev):
     """same seeded state + the same device RNG streams (the captured graph reads seed/offset of the default generator at
-    replay time): the captured step and the eager step run the same kernels on the same numbers -- only the fp32
-    atomics of the style-gradient dot reduce are order dependent.  All seven losses and the flat weight buffers of G and
+    replay time): the captured step and the eager step run the same kernels on the same numbers -- the library has no
+    atomics left (round 3); the OCR branch's torch grid_sample backward (atomic scatter) is the one order-dependent sum.  All seven losses and the flat weight buffers of G and
     D after three optimisation steps must therefore agree to ~1e-5 RELATIVE (the first round's 5e-3 absolute bound was
     the size of the Adam updates themselves and could not have detected a wrong gradient)."""
     from textboxgan_amd.config import Config

@@ -153,8 +153,8 @@ def test_short_batch_is_rejected(dev):
 def test_unread_gradient_tails_are_never_read(dev):
     """In the G-loss pass over the joint [fake; real] batch the discriminator's nodes differentiate the leading half only
     and leave the rest of their gradient tensors unwritten (ops.FLAGS.d_first_half).  Run the same step with those tails
-    filled with NaN and with zeros (FLAGS.unread_tail_fill): every loss and gradient must be finite and equal (up to the
-    run-to-run noise of the fp32 atomics in the style-gradient reductions), i.e. nothing ever reads a tail."""
+    filled with NaN and with zeros (FLAGS.unread_tail_fill): every loss and gradient must be finite and equal,
+    i.e. nothing ever reads a tail."""
     from textboxgan_amd import ops
     from textboxgan_amd.training_step import build_trainer_state
     cfg = small_config(4)
@@ -176,3 +176,8 @@ def test_unread_gradient_tails_are_never_read(dev):
     for a, c in zip(outs[0], outs[1]):
         assert torch.isfinite(a).all() and torch.isfinite(c).all()
         assert l2_err(a, c) < 1e-5
+    # run-to-run: no kernel of the library accumulates with atomics (the style-gradient dot products and the toRGB Gram are
+    # summed from per-tile partials in a fixed order), so the GAN-loss and discriminator gradient sets repeat bit for bit;
+    # the OCR-weighted set passes through torch's grid_sample backward (atomic scatter) and only repeats to rounding
+    assert torch.equal(outs[0][1], outs[1][1]), "generator (GAN loss) gradients differ between two runs"
+    assert torch.equal(outs[0][3], outs[1][3]), "discriminator gradients differ between two runs"

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtbg_hip.so")
 HOST_LIB = os.path.join(HERE, "libtbg_host.so")
 SOURCES = ["elementwise.hip", "upfirdn.hip", "conv.hip", "rgb.hip", "lstm.hip", "smalls.hip", "host_util.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
 def _digest() -> str:

@@ -77,7 +77,7 @@ struct ConvP {
   int logTW, logTHs, NSEG, IHs, IWs, IWp, HALFW, planeStride, ppc, NJ, nBG;
   int nclass, ksplit, nchunks, cps;
   long long slab;  // elements per split-K slab (= B*M*Hout*Wout)
-  int a_floats, ck_rt;
+  int a_floats, ck_rt, dot_slots;
   int wplane;  // X3: floats between two planes (hi | mid | lo) of the packed filter
   ClassInfo cls[MAXCLS];
   EpiK e;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   const bool split = p.ksplit > 1;
   const bool do_dot = e_aux != nullptr && !split;
   const bool plain = !e_os && !e_bias && !p.e.noise && !e_res && !e_aux && !e_gate && !e_lrelu && e_gain == 1.f;
-  const int M = p.M, NSEGr = p.NSEG;
+  const int M = p.M;
   float *const ybase = split ? p.y + (size_t)ks * p.slab : p.y;
   int e_pix[WTN], e_b[WTN];
   float e_nz[WTN];
@@ -728,11 +728,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
         for (int j = 0; j < WTN; ++j) {
           const bool okq = idx[q][j] >= 0;
           float val = acc[0][i][j][r0 + q] * e_alpha;
-          if (do_dot) {
-            const float pv = okq ? val * axv[q][j] : 0.f;
-            if (NSEGr == 1) dsum += pv;
-            else if (okq) atomicAdd(e_dot + e_b[j] * M + m, pv);
-          }
+          if (do_dot) dsum += okq ? val * axv[q][j] : 0.f;
           val = val * osv[q][j] + e_nz[j] + bias4[q];
           if (e_rfirst) val += rsv[q][j];
           val = (e_lrelu ? (val > 0.f ? val : val * e_slope) : val) * e_gain;
@@ -740,10 +736,12 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
           if (e_gate) val = axv[q][j] > 0.f ? val : 0.f;
           if (okq) p.y[idx[q][j]] = val;
         }
-        if (do_dot && NSEGr == 1) {  // one image per tile: reduce the 32 pixel lanes of each half-wave
+        if (do_dot) {  // one image per tile (checked on the host): reduce the 32 pixel lanes of each half-wave and store the
+          // partial of this (tile, wave column) in its own slot -- no atomics, the caller sums the slots in a fixed order
 #pragma unroll
           for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
-          if ((lane & 31) == 0 && m < M && bg < p.B) atomicAdd(e_dot + bg * M + m, dsum);
+          if ((lane & 31) == 0 && m < M && bg < p.B)
+            e_dot[((size_t)bg * M + m) * p.dot_slots + (tu * ci.tilesV + tv) * WGN + wn] = dsum;
         }
       }
     }
@@ -751,7 +749,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
 }
 
 // name-only mode (name != NULL): write the instantiation the descriptor selects (rocprofv3 spelling) and launch nothing
-struct NameOut { char *buf; int n; };
+struct NameOut { char *buf; int n; int *dot_slots; };
 
 template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false, bool TM = false, bool X3 = false>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, const NameOut *name) {
@@ -766,7 +764,12 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
                       (p.in_scale ? (size_t)p.NSEG * p.C : 0)) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   if (maxtaps > MT) return TBG_EUNSUPPORTED;
+  // fused dot product: one slot per (pixel tile of the image, wave column); needs one image per tile and one class
+  p.dot_slots = (p.NSEG == 1 && p.nclass == 1 && p.ksplit == 1 && !TM) ? p.cls[0].tilesU * p.cls[0].tilesV * WGN : 0;
+  if (p.e.dot_aux && p.dot_slots == 0) return TBG_EUNSUPPORTED;
   if (name) {
+    if (name->dot_slots) *name->dot_slots = p.dot_slots;
+    if (!name->buf) return TBG_OK;
     snprintf(name->buf, name->n, "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s>", WGM, WGN, WTM, WTN, CK, MT, PF,
              OCC, BF ? "true" : "false", TM ? "true" : "false", X3 ? "true" : "false");
     return TBG_OK;
@@ -806,7 +809,7 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
   if (d->sy < 1 || d->sy > 2 || d->sx < 1 || d->sx > 2) return TBG_EUNSUPPORTED;
   if (d->ldw < d->M || (reinterpret_cast<uintptr_t>(w) & 15) != 0) return TBG_EINVAL;
   if (d->ksplit < 1) return TBG_EINVAL;
-  if (d->ksplit > 1 && epi && (epi->out_scale || epi->bias || epi->noise || epi->residual || epi->dot_aux || epi->act != TBG_ACT_LINEAR))
+  if (d->ksplit > 1 && epi && (epi->out_scale || epi->bias || epi->noise || epi->residual || epi->dot_aux || epi->gate || epi->act != TBG_ACT_LINEAR))
     return TBG_EINVAL;
   if ((double)d->B * d->C * d->Hin * d->Win > 2147483647.0 || (double)d->B * d->M * d->Hout * d->Wout > 2147483647.0)
     return TBG_ERANGE;
@@ -1097,9 +1100,18 @@ extern "C" int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, con
 static int conv_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n, int mode) {
   if (!buf || n < 1) return TBG_EINVAL;
   buf[0] = 0;
-  NameOut no{buf, n};
+  NameOut no{buf, n, nullptr};
   static const float dummy = 0.f;  // name-only mode never dereferences; in_scale only sizes the LDS request
   return conv2d_impl(d, nullptr, nullptr, nullptr, has_in_scale ? &dummy : nullptr, nullptr, nullptr, &no, mode);
+}
+
+extern "C" int tbg_conv2d_dot_slots(const tbg_conv_desc *d, int has_in_scale, int mode) {
+  if (mode < 0 || mode > 2) return TBG_EINVAL;
+  int slots = 0;
+  NameOut no{nullptr, 0, &slots};
+  static const float dummy = 0.f;
+  const int rc = conv2d_impl(d, nullptr, nullptr, nullptr, has_in_scale ? &dummy : nullptr, nullptr, nullptr, &no, mode);
+  return rc != TBG_OK ? rc : slots;
 }
 
 extern "C" int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n) {

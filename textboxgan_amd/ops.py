@@ -295,9 +295,14 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     _flops = 2.0 * B * M * Cc * KH * KW * (Hin * Win if transposed else Hout * Wout)
     _bytes = 4.0 * (B * Cc * Hin * Win + B * M * Hout * Wout * ksplit + KH * KW * Cc * M)  # x + y (slabs) + filter, once each
     _kname = lambda: N.conv_kernel_name(d, in_scale is not None, fmt)
-    if ksplit > 1:
+    dot_slots = 0
+    if dot is not None and ksplit == 1:
+        dot_slots = N.lib().tbg_conv2d_dot_slots(C.byref(d), int(in_scale is not None), int(fmt))
+        N.check(min(dot_slots, 0), "tbg_conv2d_dot_slots")
+    if ksplit > 1 or (dot is not None and dot_slots == 0):
         # split-K: every split stores alpha*acc into its own slab (no zero-fill, no atomics); one flat pass sums the
-        # slabs and applies the real epilogue
+        # slabs and applies the real epilogue.  (Also the route of a fused dot the tiling cannot serve -- several small
+        # images per tile: one "slab", the dot from the finished accumulators.)
         slabs = torch.empty((ksplit, B, M, Hout, Wout), device=x.device, dtype=torch.float32)
         e0 = N.epilogue(alpha=epi.alpha)
         N.check(PROFILE.launch(_kname, _flops, lambda: _conv(
@@ -306,9 +311,12 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         e1.alpha = 1.0
         if dot is not None:  # the fused dot needs the complete sum: reduce first (rare: the smallest G layers' backward)
             e1.dot_aux, e1.dot_out = None, None
-            tmp = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
-            N.check(N.lib().tbg_slab_epilogue_f32(N.ptr(slabs), N.ptr(tmp), B, M, Hout * Wout, ksplit,
-                                                  C.byref(N.epilogue()), N.stream()), "tbg_slab_epilogue")
+            if ksplit == 1:
+                tmp = slabs[0]
+            else:
+                tmp = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
+                N.check(N.lib().tbg_slab_epilogue_f32(N.ptr(slabs), N.ptr(tmp), B, M, Hout * Wout, ksplit,
+                                                      C.byref(N.epilogue()), N.stream()), "tbg_slab_epilogue")
             dot[1].copy_((tmp * dot[0]).sum(dim=(2, 3)))
             slabs, nslab = tmp, 1
         else:
@@ -317,12 +325,16 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         N.check(N.lib().tbg_slab_epilogue_f32(N.ptr(slabs), N.ptr(y), B, M, Hout * Wout, nslab, C.byref(e1), N.stream()),
                 "tbg_slab_epilogue")
         return y
-    if dot is not None:
+    partial = None
+    if dot is not None:  # per-(tile, wave column) partial sums, plain stores: summed here in a fixed order (deterministic)
+        partial = torch.empty((B, M, dot_slots), device=x.device, dtype=torch.float32)
         epi = N.Epilogue.from_buffer_copy(epi)
-        epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(dot[1])
+        epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(partial)
     y = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32) if out is None else out
     N.check(PROFILE.launch(_kname, _flops, lambda: _conv(
         C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream()), _what, _bytes), _what)
+    if partial is not None:
+        torch.sum(partial, dim=2, out=dot[1].view(B, M))
     return y
 
 
@@ -923,7 +935,7 @@ class _ModConvFused(torch.autograd.Function):
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
         _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
         g = _Geom((1, 1), (KH // 2, KW // 2), KH, KW, (x.shape[2], x.shape[3]), (out.shape[2], out.shape[3]))
-        ds_conv = torch.zeros_like(s)
+        ds_conv = torch.empty_like(s)  # every element written (sum of the launch's partial slots)
         dx = _bwd_data_launch(dpre, w, g, in_scale=d, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
         db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)
         dw = None
@@ -966,7 +978,7 @@ class _ModConvUpFused(torch.autograd.Function):
         k = fir_kernel(x.device, gain=4.0)  # symmetric: flipped == itself
         dy_up = upfirdn2d_raw(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))  # [B,O,2H+1,2W+1]
         wt = pack_filter(w, transpose=True, flip=True)
-        ds_conv = torch.zeros_like(s)
+        ds_conv = torch.empty_like(s)  # every element written (sum of the launch's partial slots)
         dx = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0),
                         epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
         db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)
