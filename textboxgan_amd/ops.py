@@ -242,6 +242,7 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
 
 
 FORCE_KSPLIT = None  # experiment knob (tools/bench_ksplit.py)
+ONE_PER_CU_SPLIT = True  # measurement aid (tools/ab_step.py): two K splits for launches of exactly one tile per CU
 FORCE_VARIANT = 0    # experiment knob (tools/bench_variants_conv.py): tbg_conv2d_f32_variant's instantiation family
 
 
@@ -279,7 +280,12 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         if (transposed and tuple(stride) == (2, 2) and KH == 3 and KW == 3 and M > 32 and FORCE_VARIANT != 4 and
                 (FORCE_VARIANT in (5, 6) or (bf16 and B * Hin * Win >= 16384))):  # mirrors the library's choice (conv.hip)
             tiles = math.ceil(M / 64) * math.ceil(_npix / 128)  # merged-class kernel: 64 x 128 tiles over input positions
-        if tiles < 256 and nchunks >= 8:  # tools/bench_ksplit.py: ~300 blocks is the sweet spot (slab traffic ~ ksplit)
+        # exactly one block per CU (256 tiles) leaves the second block slot of a stride-1 tile empty -- nothing overlaps its
+        # staging: two splits there measured 165 vs 126-138 TFLOP/s (f32x3 16x64 256->256, profiles/r03_cold_conv.txt); a
+        # stride-2 f32x3 tile fills the CU's LDS alone and only loses to the slab pass (109 vs 132)
+        one_per_cu = (ONE_PER_CU_SPLIT and tiles == 256 and tuple(stride) == (1, 1) and not transposed and
+                      dot is None)  # (a fused dot needs K whole)
+        if (tiles < 256 or one_per_cu) and nchunks >= 8:  # tools/bench_ksplit.py: ~300 blocks is the sweet spot (slab traffic ~ ksplit)
             target = max(1, min(nchunks // 4, math.ceil(288 / tiles)))
             # a split that divides the chunk count keeps the splits even (32 chunks: 6 splits = 6,6,6,6,6,2 ran slower than 4)
             divs = [k for k in range(1, nchunks // 2 + 1) if nchunks % k == 0]
