@@ -164,7 +164,8 @@ int tbg_conv2d_dot_slots(const tbg_conv_desc *d, int has_in_scale, int mode);
  * variant 0 = the library's choice, 1 = software-pipelined (double-buffered LDS), 2 = plain 8-channel chunks,
  * 3 = 4-channel chunks at 4 waves/SIMD (128x128 tile only), 4 / 5 = stride-2 transposed 3x3 as one block per output-parity
  * class / as the merged-class kernel (all four classes from one staged halo tile), 6 = the merged-class kernel with
- * 16-channel chunks (fp32 only), 8 / 9 = the per-class form with the tile height halved once / twice (variant 4 keeps the
+ * 16-channel chunks (fp32 only), 7 = the register-prefetch K loop (128x128 tile: the halo tile of chunk k+1 is loaded
+ * while chunk k's MFMAs run; the library's choice for stride-1 layers), 8 / 9 = the per-class form with the tile height halved once / twice (variant 4 keeps the
  * full-height tiles; 0 picks the height by padded rows x halo overhead).  TBG_EUNSUPPORTED if the descriptor cannot take it. */
 int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                            const float *in_scale, const tbg_epilogue *epi, int variant, void *stream);
@@ -224,7 +225,8 @@ int tbg_conv2d_bf16(const tbg_conv_desc *d, const float *x, const void *w, float
                     const float *in_scale, const tbg_epilogue *epi, void *stream);
 int tbg_conv2d_bf16_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
 /* explicit instantiation family (tuning / test aid): 0 = library's choice, 1 = 128x256 tile, 2 = 32-channel chunks,
- * 4 / 5 = class-per-block / merged-class transposed form. */
+ * 3 = the register-prefetch K loop (128x128 tile; the library's choice for stride-1 layers), 4 / 5 = class-per-block /
+ * merged-class transposed form (both with the plain K loop). */
 int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                             const float *in_scale, const tbg_epilogue *epi, int variant, void *stream);
 /* filter gradient; tile rows narrower than 8 pixels (Ws <= 4) fall back to the exact fp32 kernel.  Workspace size =

@@ -114,11 +114,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   constexpr int NP = X3 ? 3 : 1;            // operand planes in LDS
   constexpr int G4 = (CK + KP - 1) / KP;    // units (fp32: channel quads, bf16: octets) per chunk
   constexpr int CB = CK < 8 ? CK : 8;       // channels per halo load batch
-  constexpr int NB = PF ? 2 : 1;            // LDS buffers (PF > 0: software-pipelined K loop)
-  constexpr int NJC = PF ? PF : MAXNJ;      // halo positions per thread this instance can hold
-  static_assert(X3 ? (CK % 8 == 0) : BF ? (CK % 16 == 0 && PF == 0) : (CK == 4 || CK % 8 == 0),
+  constexpr int NB = PF > 0 ? 2 : 1;        // LDS buffers (PF > 0: software-pipelined K loop; PF < 0: register-prefetch loop)
+  constexpr int NJC = PF > 0 ? PF : MAXNJ;  // halo positions per thread this instance can hold
+  static_assert(X3 ? (CK % 8 == 0) : BF ? (CK % 16 == 0 && PF <= 0) : (CK == 4 || CK % 8 == 0),
                 "chunk = one quad (half-waves split it) or whole unit pairs (half-wave h reads unit 2o+h); X3: whole units");
-  static_assert(!PF || CK <= 8, "the pipelined variant prefetches one load batch");
+  static_assert(PF <= 0 || CK <= 8, "the pipelined variant prefetches one load batch");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   };
 
   bool done = false;
-  if constexpr (X3 && PF == 0) {
+  if constexpr ((X3 && PF == 0) || PF < 0) {
     // f32x3 K loop with the halo tile of chunk k+1 PREFETCHED INTO REGISTERS while chunk k's MFMAs run (single LDS buffer: three
     // operand planes leave no room for a second one at 2 blocks/CU).  Per chunk: barrier | split + store the prefetched tile
     // | issue the filter DMA | issue the loads of the next tile | wait for the DMA only (counted vmcnt: the loads stay in
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
         for (int j = 0; j < NJX; ++j)
           if (j < p.NJ) {
 #pragma unroll
-            for (int bt = 0; bt < NBT; ++bt) store_halo(kc * CK + bt * CB, bt, j, xr[j][bt], Xs);
+            for (int bt = 0; bt < NBT; ++bt) store_halo(kc * CK + bt * CB, bt * (CB / KP), j, xr[j][bt], Xs);
           }
         issue_filter_dma(kc, As);
         if (kc + 1 < kend) {
@@ -760,7 +760,7 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
   p.ck_rt = CK;
   p.nchunks = ceil_div(p.C, CK);
   p.cps = ceil_div(p.nchunks, p.ksplit);  // splits past the last chunk run no K loop and store zeros: every slab is fully written
-  const size_t lds = ((size_t)(PF ? 2 : 1) * (X3 ? 3 : 1) * ((size_t)p.a_floats + (size_t)G4 * 4 * p.planeStride) +
+  const size_t lds = ((size_t)(PF > 0 ? 2 : 1) * (X3 ? 3 : 1) * ((size_t)p.a_floats + (size_t)G4 * 4 * p.planeStride) +
                       (p.in_scale ? (size_t)p.NSEG * p.C : 0)) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   if (maxtaps > MT) return TBG_EUNSUPPORTED;
@@ -1005,6 +1005,14 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
     }
     if (variant == 2 && BM == 128 && BN == 128 && maxtaps > 4)  // 32-channel chunks: half the barriers
       return launch_fprop<2, 2, 2, 2, 32, MAXTAPS, 0, 2, true>(p, st, maxtaps, maxTilesN, name);
+    // 128 x 128 tiles of the stride-1 layers: the register-prefetch K loop of the f32x3 path (PF = -1: the halo of chunk k+1
+    // is loaded while chunk k's MFMAs run) -- 628 vs 518 TFLOP/s on 64x256 128->128, 565 vs 510 on 32x128, 702 vs 659 on
+    // 16x64 256->256 at B = 32 (profiles/r03_bf16_regprefetch.txt); the small tiles and the strided layers measured -2 %.
+    // variant 3 forces it, variant 4 / 5 keep the plain loop.
+    if (maxtaps > 4 && BM == 128 && BN == 128 &&
+        (variant == 3 || (variant == 0 && !d->transposed && d->sy == 1 && d->sx == 1)))
+      return launch_fprop<2, 2, 2, 2, 16, MAXTAPS, -1, 3, true>(p, st, maxtaps, maxTilesN, name);
+    if (variant == 3) return TBG_EUNSUPPORTED;
     if (variant != 0 && variant != 4 && variant != 5) return TBG_EUNSUPPORTED;
     if (maxtaps > 1 && maxtaps <= 4) {
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
@@ -1040,6 +1048,8 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
     }
     if (variant == 3 && BM == 128 && BN == 128 && p.NJ <= 3 && p.ksplit == 1)  // CK = 4 at 4 waves/SIMD
       return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 0, 4>(p, st, maxtaps, maxTilesN, name);
+    if (variant == 7 && BM == 128 && BN == 128)  // register-prefetch K loop
+      return launch_fprop<2, 2, 2, 2, 8, MAXTAPS, -1, 3>(p, st, maxtaps, maxTilesN, name);
     return TBG_EUNSUPPORTED;
   }
   // Software-pipelined variant (double-buffered LDS, one barrier per chunk).  Measured (tools/bench_conv.py): +12% on
@@ -1061,6 +1071,9 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
   // 3-blocks/CU instance lose with CK=4 (more barriers per FLOP: 116 vs 124 at 512 tiles) and keep CK=8.
   if (maxtaps == 9 && p.NJ <= 3 && (long long)maxTilesN * ceil_div(p.M, BM) * p.nclass > 768 && p.ksplit == 1)
     return launch_fprop<2, 2, 2, 2, 4, MAXTAPS, 0, 4>(p, st, maxtaps, maxTilesN, name);
+  // stride-1 layers: the register-prefetch K loop (PF = -1), +3..4 % over the plain loop (profiles/r03_f32_regprefetch.txt)
+  if (!d->transposed && d->sy == 1 && d->sx == 1)
+    return launch_fprop<2, 2, 2, 2, 8, MAXTAPS, -1, 3>(p, st, maxtaps, maxTilesN, name);
   return launch_fprop<2, 2, 2, 2, 8, MAXTAPS>(p, st, maxtaps, maxTilesN, name);
 }
 
@@ -1071,13 +1084,13 @@ extern "C" int tbg_conv2d_f32(const tbg_conv_desc *d, const float *x, const floa
 
 extern "C" int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, const float *w, float *y,
                                       const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant < 0 || variant == 7 || variant > 9) return TBG_EINVAL;
+  if (variant < 0 || variant > 9) return TBG_EINVAL;
   return conv2d_impl(d, x, w, y, in_scale, epi, stream, nullptr, false, variant);
 }
 
 extern "C" int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                                        const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant < 0 || variant == 3 || variant > 5) return TBG_EINVAL;
+  if (variant < 0 || variant > 5) return TBG_EINVAL;
   return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, 1, variant);
 }
 

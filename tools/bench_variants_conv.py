@@ -24,7 +24,7 @@ L = [("64x256 128->128", 128, 128, 64, 256, (1, 1)), ("32x128 128->128", 128, 12
      ("64x256 64->64", 64, 64, 64, 256, (1, 1)), ("32x128 256->128 (dgrad shape)", 256, 128, 32, 128, (1, 1)),
      ("down 66x258 64->128", 64, 128, 66, 258, (2, 2)), ("down 34x130 128->128", 128, 128, 34, 130, (2, 2)),
      ("down 18x66 128->256", 128, 256, 18, 66, (2, 2)), ("down 10x34 256->256 (w only)", 256, 256, 8, 34, (1, 2))]
-names = {0: "auto", 7: "scalar-halo", 1: "tile128x256", 2: "ck32"} if BF16 else {0: "auto", 7: "scalar-halo", 1: "pipelined", 2: "plain", 3: "occ4"}
+names = {0: "auto", 3: "regprefetch", 4: "plain-loop"} if BF16 else {0: "auto", 7: "regprefetch", 1: "pipelined", 2: "plain", 3: "occ4"}
 if X3:
     names = {0: "auto", 1: "tile128x256", 2: "tile128x128"}
 print(f"B={B}  TFLOP/s per variant (ksplit as the heuristic picks it)")
