@@ -10,6 +10,8 @@ import math
 import pytest
 import torch
 
+from conftest import arith_modes
+
 pytestmark = pytest.mark.gpu
 
 
@@ -31,6 +33,7 @@ FULL_LAYERS = [
 ]
 
 
+@arith_modes
 @pytest.mark.parametrize("layer", FULL_LAYERS, ids=[l[0] for l in FULL_LAYERS])
 def test_conv_adjoint_identities_full_size(dev, layer):
     from textboxgan_amd import ops
@@ -55,8 +58,12 @@ def test_conv_adjoint_identities_full_size(dev, layer):
     lhs = ops._fwd_launch(2.5 * x + x2, w, geom)
     rhs = 2.5 * y + ops._fwd_launch(x2, w, geom)
     assert float((lhs - rhs).abs().max()) <= 2e-4 * float(rhs.abs().max())
+    # no atomics anywhere (slabs, partial tiles, fixed-order reductions): a repeated launch repeats bit for bit
+    assert torch.equal(ops._fwd_launch(x, w, geom), y) and torch.equal(ops._bwd_data_launch(dy, w, geom), dx)
+    assert torch.equal(ops._bwd_weight_launch(x, dy, geom, C, M), dw)
 
 
+@arith_modes
 def test_transposed_up_conv_adjoint_full_size(dev):
     """up-conv (stride-2 transposed 3x3, upfirdn_2d_v2.py:65-103): <convT(x), dy> == <x, strided conv(dy)>."""
     from textboxgan_amd import ops
@@ -71,6 +78,7 @@ def test_transposed_up_conv_adjoint_full_size(dev):
     assert _close(_dot(y, dy), _dot(x, dx), 2e-4)
 
 
+@arith_modes
 def test_split_k_slabs_equal_unsplit(dev):
     from textboxgan_amd import ops
     B, C, M, H, W = 16, 512, 512, 4, 16

@@ -22,7 +22,24 @@ PRIO = [("        __builtin_amdgcn_s_barrier();\n        mfma_taps(As, Xs);\n   
          "        __builtin_amdgcn_s_barrier();\n        __builtin_amdgcn_s_setprio(2);\n        mfma_taps(As, Xs);\n        __builtin_amdgcn_s_setprio(0);\n      }\n    }\n  }\n  if (done) {")]
 VARIANTS = {"skew32": SKEW(32), "skew64": SKEW(64), "skew100": SKEW(100), "prio": PRIO, "skew64prio": SKEW(64) + PRIO}
 NOLDS = [("          const int cb = st & 1;\n          if (st + 1 < NS) ld(st + 1, cb ^ 1);\n", "          const int cb = 0;\n")]
-if os.environ.get("X3_ABLATE") == "2":
+DMAFIRST = [("""#pragma unroll
+        for (int j = 0; j < NJX; ++j)
+          if (j < p.NJ) {
+#pragma unroll
+            for (int bt = 0; bt < NBT; ++bt) store_halo(kc * CK + bt * CB, bt * (CB / KP), j, xr[j][bt], Xs);
+          }
+        issue_filter_dma(kc, As);
+""", """        issue_filter_dma(kc, As);
+#pragma unroll
+        for (int j = 0; j < NJX; ++j)
+          if (j < p.NJ) {
+#pragma unroll
+            for (int bt = 0; bt < NBT; ++bt) store_halo(kc * CK + bt * CB, bt * (CB / KP), j, xr[j][bt], Xs);
+          }
+""")]
+if os.environ.get("X3_ABLATE") == "3":
+    VARIANTS = {"dmafirst": DMAFIRST}
+elif os.environ.get("X3_ABLATE") == "2":
     VARIANTS = {"noboth": [DMA] + STG, "noboth_nolds": [DMA] + STG + NOLDS, "nolds": NOLDS}
 elif os.environ.get("X3_ABLATE"):
     VARIANTS = {"nodma": [DMA], "nostage": STG, "nomfma": [MFMA], "noboth": [DMA] + STG}
@@ -66,11 +83,11 @@ def run():
         return l
     libs = {"product": P, **{k: load(k) for k in VARIANTS}}
     B = 16
-    strided = os.environ.get("X3_SHAPES") == "strided"
-    shapes = (((128, 128, 65, 257, 32, 128, 2, 0), (128, 256, 33, 129, 16, 64, 2, 0), (128, 128, 32, 128, 65, 257, 2, 1),
-               (256, 256, 16, 64, 33, 129, 2, 1)) if strided else
-              ((128, 128, 64, 256, 64, 256, 1, 0), (128, 128, 32, 128, 32, 128, 1, 0), (256, 256, 16, 64, 16, 64, 1, 0),
-               (64, 64, 64, 256, 64, 256, 1, 0)))
+    S2 = ((128, 128, 65, 257, 32, 128, 2, 0), (128, 256, 33, 129, 16, 64, 2, 0), (128, 128, 32, 128, 65, 257, 2, 1),
+          (256, 256, 16, 64, 33, 129, 2, 1))
+    S1 = ((128, 128, 64, 256, 64, 256, 1, 0), (128, 128, 32, 128, 32, 128, 1, 0), (256, 256, 16, 64, 16, 64, 1, 0),
+          (64, 64, 64, 256, 64, 256, 1, 0))
+    shapes = {"strided": S2, "all": S1 + S2}.get(os.environ.get("X3_SHAPES"), S1)
     for Cc, M, H, W, OH, OW, st, T in shapes:
         x = torch.randn(B, Cc, H, W, device=dev)
         w = torch.randn(3, 3, Cc, M, device=dev)
