@@ -965,6 +965,12 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
     // 2 x 25 maps takes 56 us unsplit = 1.7 us per 8-channel chunk against 0.4 us of MFMA; 16- and 32-channel chunks and the
     // double-buffered loop (DMA of chunk k+1 under the MFMAs of chunk k) all measured the same, profiles/r03_small_tile_forms.txt.
     // More than one filter slice in flight per CU would need the halo tile off the register path too -- vmcnt retires in order.)
+    // (Round 3, large tiles: a "split-filter pipeline" -- the filter tile DMA'd in two tap halves, each re-filled for chunk k+1
+    // as soon as every wave is done with it in chunk k, three barriers per chunk -- was built and measured: bit-identical
+    // results, +0..4 % on the 64x256 layers, -1..-5 % elsewhere.  The exposed DMA wait is worth +10..20 % in the ablation
+    // (profiles/r03_x3_fprop_time_split.txt), but the halo tile's register prefetch shares vmcnt with the DMA: hipcc puts
+    // s_waitcnt vmcnt(0) in front of the halo stores of a loop that also issues DMA pieces -- even with every VMEM instruction
+    // issued unconditionally and in the same order on every path -- which waits for the half just issued.  Not adopted.)
     if (BM == 128 && BN == 256) return launch_fprop<2, 2, 2, 4, 8, MAXTAPS, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
     if (maxtaps > 1 && maxtaps <= 4) {
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
