@@ -258,3 +258,13 @@ def test_aster_weight_import_from_a_savedmodel_variables_bundle(tmp_path):
     assert torch.equal(net.cell.weight_hh, torch.from_numpy(torch_order[n_in:].T.copy()))
     with pytest.raises(KeyError):
         net.load_weights_tf(str(sm), {"out.bias": "no/such/variable"})
+    # the cell's single TF bias (gate order i, j, f, o): lands in one torch bias in torch order with TF's run-time
+    # forget_bias added to the f gate; the paired torch bias is zeroed (torch adds both) -- ADVICE round 2
+    lb = g.standard_normal((4 * H,)).astype(np.float32)
+    T.write_bundle(str(sm / "variables" / "variables"), {"Forward/Predictor/lstm_cell/bias" + T.VAR_SUFFIX: lb})
+    with torch.no_grad():
+        net.cell.bias_hh.fill_(0.5)
+    net.load_weights_tf(str(sm), {"cell.bias_ih": ("Forward/Predictor/lstm_cell/bias", "lstm_bias")}, forget_bias=1.0)
+    bi, bj, bf, bo = np.split(lb, 4)
+    assert torch.equal(net.cell.bias_ih, torch.from_numpy(np.concatenate([bi, bf + 1.0, bj, bo])))
+    assert float(net.cell.bias_hh.abs().max()) == 0.0

@@ -338,10 +338,13 @@ class AsterLikeOCR(nn.Module):
             return np.ascontiguousarray(re[:n_in].T), np.ascontiguousarray(re[n_in:].T)
         raise ValueError(kind)
 
-    def load_weights_tf(self, path: str, name_map: dict, strict: bool = True):
+    def load_weights_tf(self, path: str, name_map: dict, strict: bool = True, forget_bias: float = 0.0):
         """Import variables of a SavedModel directory / checkpoint prefix.  name_map: parameter name -> variable name or
         (variable name, kind) with kind as in tf_to_torch_layout (default: "conv" for 4-D, "dense" for 2-D, else "same").
-        An LSTM's fused kernel maps from its ``weight_ih`` name and fills the matching ``weight_hh`` too."""
+        An LSTM's fused kernel maps from its ``weight_ih`` name and fills the matching ``weight_hh`` too.  An LSTM's single
+        TF bias maps from one torch bias name (``bias_ih*`` or ``bias_hh*``): the PAIRED torch bias is zeroed (torch adds
+        both), and ``forget_bias`` (TF's BasicLSTMCell adds it to the f gate at run time, default 1.0 there) is added to the
+        f-gate slice of the imported bias."""
         from . import tf_checkpoint as T
         import os
         prefix = os.path.join(path, "variables", "variables") if os.path.isdir(path) else path
@@ -363,6 +366,14 @@ class AsterLikeOCR(nn.Module):
                 if kind == "lstm_kernel":
                     sd[pname].copy_(torch.from_numpy(conv[0]))
                     sd[pname.replace("weight_ih", "weight_hh")].copy_(torch.from_numpy(conv[1]))
+                elif kind == "lstm_bias":
+                    b = torch.from_numpy(np.ascontiguousarray(conv)).reshape(sd[pname].shape).clone()
+                    h = b.numel() // 4
+                    b[h: 2 * h] += forget_bias  # torch gate order i, f, g, o
+                    sd[pname].copy_(b)
+                    pair = pname.replace("bias_ih", "bias_hh") if "bias_ih" in pname else pname.replace("bias_hh", "bias_ih")
+                    if pair != pname and pair in sd:
+                        sd[pair].zero_()
                 else:
                     sd[pname].copy_(torch.from_numpy(np.ascontiguousarray(conv)).reshape(sd[pname].shape))
         if missing and strict:
