@@ -44,15 +44,31 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const float (&v)[8]) {
 // fp32 -> three bf16 terms hi + mid + lo (8 + 8 + 8 significand bits: exact for every fp32 value whose low terms stay
 // in the normal range).  Products of two bf16 values are exact in fp32, so the six largest partial products of
 // (a_hi + a_mid + a_lo)(b_hi + b_mid + b_lo) reproduce a * b to ~2^-24 relative -- the "f32x3" arithmetic of the X3 kernels.
+// Two values at a time, on packed instructions: v_cvt_pk_bf16_f32 (both conversions), shift / mask (the bf16 pair back to
+// fp32), v_pk_add_f32 (both residuals) -- 9 VALU instructions per pair.  The element-wise form ((__bf16)v, (float)b per element)
+// compiled to one conversion and one v_perm per ELEMENT and term: ~10 instructions per element in the staging passes
+// (profiles/r03_split3_packed.txt).  Same roundings, same bits.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+  const f32x2v v = {a, b};
+  const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2p));
+  const f32x2v hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
+  const f32x2v r1 = v - hf;
+  const unsigned mu = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2p));
+  const f32x2v mf = {__builtin_bit_cast(float, mu << 16), __builtin_bit_cast(float, mu & 0xffff0000u)};
+  const f32x2v r2 = r1 - mf;
+  h = hu; m = mu; l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2p));
+}
 __device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+  unsigned hu[4], mu[4], lu[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 bh = (__bf16)v[i];
-    const float r1 = v[i] - (float)bh;
-    const __bf16 bm = (__bf16)r1;
-    const float r2 = r1 - (float)bm;
-    h[i] = bh; m[i] = bm; l[i] = (__bf16)r2;
-  }
+  for (int i = 0; i < 4; ++i) split3_pair(v[2 * i], v[2 * i + 1], hu[i], mu[i], lu[i]);
+  h = __builtin_bit_cast(bf16x8, u32x4v{hu[0], hu[1], hu[2], hu[3]});
+  m = __builtin_bit_cast(bf16x8, u32x4v{mu[0], mu[1], mu[2], mu[3]});
+  l = __builtin_bit_cast(bf16x8, u32x4v{lu[0], lu[1], lu[2], lu[3]});
 }
 
 #define MAXCLS 4
@@ -1774,32 +1790,19 @@ typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 // four / two consecutive places: one 8-byte / 4-byte store per plane
 __device__ __forceinline__ void split3_store4(__bf16 *dst, int plane_stride, float v0, float v1, float v2, float v3) {
-  const float v[4] = {v0, v1, v2, v3};
-  bf16x4v h, m, l;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const __bf16 bh = (__bf16)v[e];
-    const float r1 = v[e] - (float)bh;
-    const __bf16 bm = (__bf16)r1;
-    h[e] = bh; m[e] = bm; l[e] = (__bf16)(r1 - (float)bm);
-  }
-  *reinterpret_cast<bf16x4v *>(dst) = h;
-  *reinterpret_cast<bf16x4v *>(dst + plane_stride) = m;
-  *reinterpret_cast<bf16x4v *>(dst + 2 * plane_stride) = l;
+  unsigned h0, m0, l0, h1, m1, l1;
+  split3_pair(v0, v1, h0, m0, l0);
+  split3_pair(v2, v3, h1, m1, l1);
+  *reinterpret_cast<u32x2v *>(dst) = u32x2v{h0, h1};
+  *reinterpret_cast<u32x2v *>(dst + plane_stride) = u32x2v{m0, m1};
+  *reinterpret_cast<u32x2v *>(dst + 2 * plane_stride) = u32x2v{l0, l1};
 }
 __device__ __forceinline__ void split3_store2(__bf16 *dst, int plane_stride, float v0, float v1) {
-  const float v[2] = {v0, v1};
-  bf16x2v h, m, l;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const __bf16 bh = (__bf16)v[e];
-    const float r1 = v[e] - (float)bh;
-    const __bf16 bm = (__bf16)r1;
-    h[e] = bh; m[e] = bm; l[e] = (__bf16)(r1 - (float)bm);
-  }
-  *reinterpret_cast<bf16x2v *>(dst) = h;
-  *reinterpret_cast<bf16x2v *>(dst + plane_stride) = m;
-  *reinterpret_cast<bf16x2v *>(dst + 2 * plane_stride) = l;
+  unsigned h, m, l;
+  split3_pair(v0, v1, h, m, l);
+  *reinterpret_cast<unsigned *>(dst) = h;
+  *reinterpret_cast<unsigned *>(dst + plane_stride) = m;
+  *reinterpret_cast<unsigned *>(dst + 2 * plane_stride) = l;
 }
 
 // issue every global load of one chunk (branch-free: clamped addresses, scale factor 0 for padding / out-of-range)
