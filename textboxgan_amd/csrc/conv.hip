@@ -1830,7 +1830,7 @@ __device__ __forceinline__ void wgrad_x3_load(const WgradP &p, WgX3Regs<VEC> &r,
       const bool ok = l_in && cl0 + l_ch + 8 * i < p.CL;
       r.lok |= ok ? (1u << i) : 0u;
       r.lv[i] = *reinterpret_cast<const f32x4u *>(p.L + (ok ? l_g0 + (unsigned)(8 * i * HWl) : 0u));
-      r.lsc[i] = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + 8 * i) : 0u];
+      if (hl) r.lsc[i] = lsp[ok ? (unsigned)(b * p.CL + cl0 + l_ch + 8 * i) : 0u];
     }
     const int s_ch = tid >> 4, s_pq = (tid & 15) * 4;
     const int s_u = u0 + (s_pq >> 5), s_v = v0 + (s_pq & 31);
@@ -1841,7 +1841,7 @@ __device__ __forceinline__ void wgrad_x3_load(const WgradP &p, WgX3Regs<VEC> &r,
       const bool ok = s_in && cs0 + s_ch + 16 * i < p.CS;
       r.sok |= ok ? (1u << i) : 0u;
       r.sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(16 * i * HWs) : 0u));
-      r.ssc[i] = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 16 * i) : 0u];
+      if (hs) r.ssc[i] = ssp[ok ? (unsigned)(b * p.CS + cs0 + s_ch + 16 * i) : 0u];
     }
     // the two places the quads leave: 32 and 33 (x = v0 + 31, v0 + 32)
     const int e_ch = tid >> 3, e_row = (tid >> 1) & 3, e_side = tid & 1;
@@ -1853,7 +1853,7 @@ __device__ __forceinline__ void wgrad_x3_load(const WgradP &p, WgX3Regs<VEC> &r,
       const bool ok = e_in && cl0 + e_ch + 32 * i < p.CL;
       r.eok |= ok ? (1u << i) : 0u;
       r.ev[i] = p.L[ok ? e_g0 + (unsigned)(32 * i * HWl) : 0u];
-      r.esc[i] = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch + 32 * i) : 0u];
+      if (hl) r.esc[i] = lsp[ok ? (unsigned)(b * p.CL + cl0 + e_ch + 32 * i) : 0u];
     }
   } else {
     r.edge = 0; r.lok = 0; r.sok = 0; r.eok = 0;
@@ -1866,7 +1866,7 @@ __device__ __forceinline__ void wgrad_x3_load(const WgradP &p, WgX3Regs<VEC> &r,
       const bool ok = iy0 + row >= 0 && iy0 + row < p.Hl && cl0 + l_ch + ci < p.CL;
       r.lok |= ok ? (1u << ii) : 0u;
       r.lv[ii] = *reinterpret_cast<const f32x4u *>(p.L + (ok ? l_g0 + (unsigned)(ci * HWl + (row + min(iy0, 0)) * p.Wl) : 0u));
-      r.lsc[ii] = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
+      if (hl) r.lsc[ii] = lsp[ok ? (unsigned)(b * p.CL + cl0 + l_ch + ci) : 0u];
     }
     const int s_ch = tid >> 3, s_pq = (tid & 7) * 4;
     const bool s_in = u0 < p.Hs && v0 + s_pq < p.Ws;
@@ -1876,14 +1876,14 @@ __device__ __forceinline__ void wgrad_x3_load(const WgradP &p, WgX3Regs<VEC> &r,
       const bool ok = s_in && cs0 + s_ch + 32 * i < p.CS;
       r.sok |= ok ? (1u << i) : 0u;
       r.sv[i] = *reinterpret_cast<const float4 *>(p.S + (ok ? s_g0 + (unsigned)(32 * i * HWs) : 0u));
-      r.ssc[i] = ssp[(hs && ok) ? (unsigned)(b * p.CS + cs0 + s_ch + 32 * i) : 0u];
+      if (hs) r.ssc[i] = ssp[ok ? (unsigned)(b * p.CS + cs0 + s_ch + 32 * i) : 0u];
     }
     {  // the 65th column of each halo row (even part, place 32): 64 channels x 3 rows, lanes 0..191
       const int e_ch = tid & 63, e_row = min(tid >> 6, 2);
       const bool ok = tid < 192 && iy0 + e_row >= 0 && iy0 + e_row < p.Hl && cl0 + e_ch < p.CL && 2 * v0 + 64 < p.Wl;
       r.eok = ok ? 1u : 0u;
       r.ev[0] = p.L[ok ? (unsigned)((b * p.CL + cl0 + e_ch) * HWl + (iy0 + e_row) * p.Wl + 2 * v0 + 64) : 0u];
-      r.esc[0] = lsp[(hl && ok) ? (unsigned)(b * p.CL + cl0 + e_ch) : 0u];
+      if (hl) r.esc[0] = lsp[ok ? (unsigned)(b * p.CL + cl0 + e_ch) : 0u];
     }
   }
 }
@@ -1971,7 +1971,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(const WgradP p) {
     bg = t2 / p.tilesU;
     u0 = tu << (VEC == 1 ? 1 : 0); v0 = tv << 5;
   };
-  WgX3Regs<VEC> rg;
+  WgX3Regs<VEC> rg = {};  // (scale slots stay unread when the operand has no scale)
   int chunk = blockIdx.z;
   if (chunk < p.nchunks) {
     int bg, u0, v0;
