@@ -917,6 +917,10 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
       if (x3 && !d->transposed && d->sy == 1 && d->sx == 1 && T == 9 && BM == 128 && d->ksplit == 1 &&
           (variant == 1 || (variant == 0 && tiles128 >= 1024)))
         BN = 256;
+      // f32x3 stride-2 forward: the 9 x 66 halo of a 128-pixel tile (three planes, 28.5 KB) beside the 55.3 KB filter tile
+      // leaves ONE block per CU; a 64-pixel tile (5 x 34 x 2 halo: 14.4 KB) fits two.  +5..9 % per layer in isolation
+      // (profiles/r03_x3_half_tiles.txt).  variant 2 keeps the 128-pixel tile.
+      if (x3 && !d->transposed && d->sy == 2 && d->sx == 2 && T == 9 && BM == 128 && BN == 128 && variant == 0) BN = 64;
     }
   }
   constexpr int twmax = 32;  // tile rows of at most 32 pixels (wider rows were measured slower: fewer rows per halo)
@@ -988,6 +992,7 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
     // s_waitcnt vmcnt(0) in front of the halo stores of a loop that also issues DMA pieces -- even with every VMEM instruction
     // issued unconditionally and in the same order on every path -- which waits for the half just issued.  Not adopted.)
     if (BM == 128 && BN == 256) return launch_fprop<2, 2, 2, 4, 8, MAXTAPS, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
+    if (BM == 128 && BN == 64) return launch_fprop<2, 2, 2, 1, 8, MAXTAPS, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
     if (maxtaps > 1 && maxtaps <= 4) {
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
