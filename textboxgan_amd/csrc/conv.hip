@@ -993,7 +993,7 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
     // issued unconditionally and in the same order on every path -- which waits for the half just issued.  Not adopted.)
     if (BM == 128 && BN == 256) return launch_fprop<2, 2, 2, 4, 8, MAXTAPS, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
     if (BM == 128 && BN == 64) return launch_fprop<2, 2, 2, 1, 8, MAXTAPS, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
-    if (maxtaps > 1 && maxtaps <= 4) {
+    if (maxtaps <= 4) {
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64) return launch_fprop<1, 4, 2, 2, 16, 4, 0, 2, true, false, true>(p, st, maxtaps, maxTilesN, name);
