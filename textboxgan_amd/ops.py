@@ -242,6 +242,8 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
 
 
 FORCE_KSPLIT = None  # experiment knob (tools/bench_ksplit.py)
+KSPLIT_TARGET_BLOCKS = 448  # blocks a split-K launch aims for (A/B on one box, tools/ab_step.py: 288 -> 21.22, 448 -> 21.11,
+                            # 512 -> 20.97 vs 448 -> 20.94, 640 -> 21.02, 900 -> 21.04, 200 -> 21.50 ms per step)
 ONE_PER_CU_SPLIT = True  # measurement aid (tools/ab_step.py): two K splits for launches of exactly one tile per CU
 FORCE_VARIANT = 0    # experiment knob (tools/bench_variants_conv.py): tbg_conv2d_f32_variant's instantiation family
 
@@ -286,7 +288,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         one_per_cu = (ONE_PER_CU_SPLIT and tiles == 256 and tuple(stride) == (1, 1) and not transposed and
                       dot is None)  # (a fused dot needs K whole)
         if (tiles < 256 or one_per_cu) and nchunks >= 8:  # tools/bench_ksplit.py: ~300 blocks is the sweet spot (slab traffic ~ ksplit)
-            target = max(1, min(nchunks // 4, math.ceil(288 / tiles)))
+            target = max(1, min(nchunks // 4, math.ceil(KSPLIT_TARGET_BLOCKS / tiles)))
             # a split that divides the chunk count keeps the splits even (32 chunks: 6 splits = 6,6,6,6,6,2 ran slower than 4)
             divs = [k for k in range(1, nchunks // 2 + 1) if nchunks % k == 0]
             ksplit = min(divs, key=lambda k: abs(math.log(k / target)))
