@@ -47,7 +47,7 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const float (&v)[8]) {
 // Two values at a time, on packed instructions: v_cvt_pk_bf16_f32 (both conversions), shift / mask (the bf16 pair back to
 // fp32), v_pk_add_f32 (both residuals) -- 9 VALU instructions per pair.  The element-wise form ((__bf16)v, (float)b per element)
 // compiled to one conversion and one v_perm per ELEMENT and term: ~10 instructions per element in the staging passes
-// (profiles/r03_split3_packed.txt).  Same roundings, same bits.
+// (profiles/r03_ab_one_box.txt).  Same roundings, same bits.
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
@@ -2186,8 +2186,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradP p) 
   }
 }
 
-static int wgrad_ksplit(int tiles, int nchunks) {
-  int ksplit = ceil_div(512, tiles);  // ~2 resident blocks per CU
+static int wgrad_ksplit(int tiles, int nchunks, int blocks = 512) {
+  int ksplit = ceil_div(blocks, tiles);  // 512: ~2 resident blocks per CU
   if (ksplit > nchunks) ksplit = nchunks;
   if (ksplit < 1) ksplit = 1;
   return ksplit;
@@ -2402,7 +2402,7 @@ static int launch_wgrad_x3(WgradP &p, hipStream_t st, size_t ws_bytes, const Nam
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return TBG_EHIP;
   const int tx = ceil_div(p.CS, 64), ty = ceil_div(p.CL, 64);
-  p.ksplit = wgrad_ksplit(tx * ty, p.nchunks);
+  p.ksplit = wgrad_ksplit(tx * ty, p.nchunks, 256);  // one block per CU (84 KB of LDS, 348 registers): one round, half the partials
   if ((size_t)p.ksplit * tx * ty * 9 * 16 * 256 * sizeof(float) > ws_bytes) return TBG_EINVAL;
   hipLaunchKernelGGL(kern, dim3(tx, ty, p.ksplit), dim3(256), lds, st, p);
   TBG_LAUNCH_CHECK();
