@@ -16,8 +16,9 @@ L = [("G up 32x128 128->128", 128, 128, 32, 128), ("G up 16x64 256->128", 256, 1
      ("G up 4x16 512->256", 512, 256, 4, 16), ("G up 2x8 128->512", 128, 512, 2, 8),
      ("D dgrad 32x128 128->64", 128, 64, 32, 128), ("D dgrad 16x64 128->128", 128, 128, 16, 64), ("D dgrad 8x32 256->128", 256, 128, 8, 32),
      ("D dgrad 4x16 256->256", 256, 256, 4, 16)]
-for B, bf in ((16, False), (32, True)):
-    print(f"--- B={B} {'bf16' if bf else 'fp32'}: TFLOP/s auto | per-class, full-height tiles (variant 4) | [fp32: tile height / 2 (8) | / 4 (9)] | merged (5)")
+MODES = ((16, "f32x3"), (32, "f32x3")) if len(sys.argv) > 1 and sys.argv[1] == "f32x3" else ((16, False), (32, True))
+for B, bf in MODES:
+    print(f"--- B={B} {bf if isinstance(bf, str) else 'bf16' if bf else 'fp32'}: TFLOP/s auto | per-class, full-height tiles (variant 4) | [fp32: tile height / 2 (8) | / 4 (9)] | merged (5)")
     for name, C, M, H, W in L:
         x = torch.randn(B, C, H, W, device=dev)
         wp = ops.pack_filter(torch.randn(3, 3, C, M, device=dev), False, False, bf16=bf)
