@@ -244,6 +244,7 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
 FORCE_KSPLIT = None  # experiment knob (tools/bench_ksplit.py)
 KSPLIT_TARGET_BLOCKS = 448  # blocks a split-K launch aims for (A/B on one box, tools/ab_step.py: 288 -> 21.22, 448 -> 21.11,
                             # 512 -> 20.97 vs 448 -> 20.94, 640 -> 21.02, 900 -> 21.04, 200 -> 21.50 ms per step)
+FOLD_RES_SCALE = True  # measurement aid (tools/ab_step.py): DiscriminatorBlock folds 1/sqrt(2) into its two branches
 ONE_PER_CU_SPLIT = True  # measurement aid (tools/ab_step.py): two K splits for launches of exactly one tile per CU
 FORCE_VARIANT = 0    # experiment knob (tools/bench_variants_conv.py): tbg_conv2d_f32_variant's instantiation family
 
@@ -1038,17 +1039,26 @@ class _ConvBiasActFused(torch.autograd.Function):
     conv.py:51-73 + bias_act.py:25-34; discriminator.py:68-84 for the residual form."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, stride, pad, act, res_scale, role):
+    def forward(ctx, x, w, b, residual, stride, pad, act, res_scale, role, out_mul=1.0):
+        """out_mul: a constant folded into the launch -- the conv scale of a linear layer, the gain of an lrelu layer
+        (DiscriminatorBlock folds its 1/sqrt(2) into both branches so that no pass has to scale the sum or its gradient)."""
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
+        gain = SQRT2 if act == ACT_LRELU else 1.0
+        if act == ACT_LRELU:
+            gain *= out_mul
+        else:
+            coef *= out_mul
+            assert b is None or out_mul == 1.0, "a bias would need the factor too"
         x = x.contiguous()
         H, W = x.shape[2], x.shape[3]
         yhw = ((H + 2 * pad[0] - KH) // stride[0] + 1, (W + 2 * pad[1] - KW) // stride[1] + 1)
-        epi = N.epilogue(alpha=coef, bias=b, act=act, residual=residual, res_scale=res_scale)
+        epi = N.epilogue(alpha=coef, bias=b, act=act, gain=gain, residual=residual, res_scale=res_scale)
         out = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, yhw, stride, pad, epi=epi)
         ctx.save_for_backward(x, w, b, out if act == ACT_LRELU else None)
         ctx.cfgv = (stride, pad, act, res_scale, coef, residual is not None, yhw)
         ctx.role = role
+        ctx.gain = gain
         return out
 
     @staticmethod
@@ -1066,8 +1076,13 @@ class _ConvBiasActFused(torch.autograd.Function):
         dres = None
         if act == ACT_LRELU:
             assert not has_res
-            _, dpre, pdb, _, _ = bias_act_bwd_raw(dout, out, _lrelu_epi(bias=b), want_db=b is not None)
+            _, dpre, pdb, _, _ = bias_act_bwd_raw(dout, out, N.epilogue(act=ACT_LRELU, slope=0.2, gain=ctx.gain, bias=b),
+                                                  want_db=b is not None)
             db = pdb.sum(dim=(0, 2)) if b is not None else None
+        elif has_res and res_scale == 1.0:  # (the sum's scale folded into both branches: the gradient passes through as it is)
+            dpre = dout
+            dres = dout_f if h else dout
+            db = dpre.sum(dim=(0, 2, 3)) if b is not None else None
         elif has_res and h:  # the residual branch continues into another "d" node: full-size tensor, leading part written
             dres = _tail_empty(dout_f.shape, dout_f.device)
             dpre = torch.mul(dout, res_scale, out=dres[:h])
@@ -1099,7 +1114,7 @@ class _ConvBiasActFused(torch.autograd.Function):
                 dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef)
         else:
             db = None
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
 def modconv_fused(x, w, s, noise, strength, b):
@@ -1116,11 +1131,12 @@ def torgb_fused(x, w, s, b, skip=None, colmask=None, mask_cw=0):
     return _ToRGBFused.apply(x, w, s, b, skip, colmask, int(mask_cw))
 
 
-def conv_bias_act_fused(x, w, b, stride=(1, 1), pad=(0, 0), act=ACT_LRELU, residual=None, res_scale=1.0, role=None):
+def conv_bias_act_fused(x, w, b, stride=(1, 1), pad=(0, 0), act=ACT_LRELU, residual=None, res_scale=1.0, role=None,
+                        out_mul=1.0):
     """role: None (never pruned), "d" (a discriminator layer: its filter/bias gradients are skipped while
     FLAGS.skip_d_wgrad), "d_image" (the discriminator's fromRGB: additionally its input gradient is skipped while
     FLAGS.skip_image_grad)."""
-    return _ConvBiasActFused.apply(x, w, b, residual, tuple(stride), tuple(pad), act, res_scale, role)
+    return _ConvBiasActFused.apply(x, w, b, residual, tuple(stride), tuple(pad), act, res_scale, role, float(out_mul))
 
 
 class _DemodCoefs(torch.autograd.Function):
