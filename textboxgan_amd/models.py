@@ -365,9 +365,12 @@ class DiscriminatorBlock(nn.Module):
         if mode == "fused":
             t = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1), role="d")
             tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3), role="d")  # conv_downsample_2d, upfirdn_2d_v2.py:106-113
-            if ops.FOLD_RES_SCALE:
+            if ops.FOLD_RES_SCALE and ops.compute_mode() != "bf16":
                 # (u + skip) / sqrt(2) with the factor folded into u's lrelu gain and the skip conv's scale: the sum and its
-                # gradient need no scaling pass (13 elementwise passes over block-sized tensors per step otherwise)
+                # gradient need no scaling pass (13 elementwise passes over block-sized tensors per step otherwise).
+                # fp32-grade arithmetics only: the full-width step's G-gradient error against the oracle is unchanged there
+                # (5.05e-5 -> 5.08e-5 in f32x3) but went from 3.8e-2 to 9.6e-2 in bf16 mode (bar 8e-2) -- the same sums in a
+                # different order land on other bf16 rounding boundaries of the operands, and that metric is that sensitive
                 u = ops.conv_bias_act_fused(tb, self.conv_1.w, self.apply_bias_act_1.b, stride=(sh, 2), role="d", out_mul=rs)
                 return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=1.0, role="d",
                                                out_mul=rs)
