@@ -909,7 +909,7 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
     else if (d->M <= 64) { BM = 64; BN = (npix + 255) / 256 < 96 ? 64 : 256; }
     else {
       const long long tiles128 = (long long)ceil_div(d->M, 128) * ((npix + 127) / 128);
-      if (tiles128 <= 16) { BM = 64; BN = 64; }  // tiny-spatial / wide-channel: more, smaller blocks
+      if (tiles128 <= (x3 ? 32 : 16)) { BM = 64; BN = 64; }  // tiny-spatial / wide-channel: more, smaller blocks
       else { BM = 128; BN = 128; }
       // f32x3, launches of >= 1024 128x128 tiles (the 64x256 layers; the joint discriminator pass's 32x128 layers): a
       // 128 x 256 tile halves the filter DMA per MFMA and the barrier count and still fills whole rounds of the 512 slots.

@@ -168,13 +168,18 @@ class _Profile:
 PROFILE = _Profile()
 
 
-def _fprop_tile(M, npix):
-    """mirror of the tile choice in tbg_conv2d_f32 (csrc/conv.hip)."""
+# launches of at most this many 128 x 128 tiles run on 64 x 64 tiles (mirror of conv.hip; by filter format FMT_*: f32x3 takes
+# the small tile up to 32 -- A/B on one box 20.57 -> 20.52 ms per step, 64: 20.92 -> 21.03 -- profiles/r03_ab_one_box.txt)
+SMALL_TILE_MAX = (16, 16, 32)
+
+
+def _fprop_tile(M, npix, fmt=0):
+    """mirror of the tile choice in tbg_conv2d_{f32,bf16,x3} (csrc/conv.hip)."""
     if M <= 32:
         return 32, 256, "1,4,1,2,8"
     if M <= 64:
         return (64, 64, "2,2,1,1,8") if math.ceil(npix / 256) < 96 else (64, 256, "1,4,2,2,8")
-    if math.ceil(M / 128) * math.ceil(npix / 128) <= 16:
+    if math.ceil(M / 128) * math.ceil(npix / 128) <= SMALL_TILE_MAX[int(fmt)]:
         return 64, 64, "2,2,1,1,8"
     return 128, 128, "2,2,2,2,8"
 
@@ -249,8 +254,8 @@ ONE_PER_CU_SPLIT = True  # measurement aid (tools/ab_step.py): two K splits for 
 FORCE_VARIANT = 0    # experiment knob (tools/bench_variants_conv.py): tbg_conv2d_f32_variant's instantiation family
 
 
-def _conv_tiles(M, npix):
-    bm, bn, _ = _fprop_tile(M, npix)
+def _conv_tiles(M, npix, fmt=0):
+    bm, bn, _ = _fprop_tile(M, npix, fmt)
     return math.ceil(M / bm) * math.ceil(npix / bn)
 
 
@@ -279,7 +284,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     ksplit = 1
     _npix = B * (math.ceil(Hout / stride[0]) * math.ceil(Wout / stride[1]) if transposed else Hout * Wout)
     if allow_split:
-        tiles = _conv_tiles(M, _npix) * (stride[0] * stride[1] if transposed else 1)  # one launch covers all classes
+        tiles = _conv_tiles(M, _npix, fmt) * (stride[0] * stride[1] if transposed else 1)  # one launch covers all classes
         if (transposed and tuple(stride) == (2, 2) and KH == 3 and KW == 3 and M > 32 and FORCE_VARIANT != 4 and
                 (FORCE_VARIANT in (5, 6) or (bf16 and B * Hin * Win >= 16384))):  # mirrors the library's choice (conv.hip)
             tiles = math.ceil(M / 64) * math.ceil(_npix / 128)  # merged-class kernel: 64 x 128 tiles over input positions

@@ -6,6 +6,9 @@ if sys.argv[1] == "--child":
     sys.path.insert(0, ROOT)
     from textboxgan_amd import native
     native.LIB_PATH = os.path.abspath(sys.argv[2])
+    if len(sys.argv) > 3 and "=" in sys.argv[3]:  # an ops attribute that has to change with the library (mirrored rules)
+        from textboxgan_amd import ops as _ops
+        setattr(_ops, sys.argv[3].split("=")[0], eval(sys.argv[3].split("=")[1]))
     import torch, time
     from textboxgan_amd.config import Config
     from textboxgan_amd.training_step import build_trainer_state
@@ -27,10 +30,11 @@ if sys.argv[1] == "--child":
 else:
     libs = sys.argv[1:3]
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    extra = {libs[0]: sys.argv[4:5], libs[1]: sys.argv[5:6]}  # optional "ATTR=value" per library
     out = {l: [] for l in libs}
     for r in range(rounds):
         for l in libs:
-            o = subprocess.run([sys.executable, __file__, "--child", l], capture_output=True, text=True).stdout
+            o = subprocess.run([sys.executable, __file__, "--child", l] + extra[l], capture_output=True, text=True).stdout
             out[l].append(float([x for x in o.splitlines() if x.startswith("MS")][0].split()[1]))
     for l, v in out.items():
         print(f"{l}: " + " ".join(f"{x:.3f}" for x in v) + f"  mean {sum(v) / len(v):.3f} ms/step (plain step, graph replay)")
