@@ -12,9 +12,11 @@ Workload = BASELINE.json configs[1]: per-GPU batch 16, 64x256 boxes, fp32, weak 
 (global batch = 16 * N, the reference's rule config.py:141).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     : the dominant kernel (the fp32-MFMA implicit-GEMM convolution), algorithmic
-                 FLOPs of its launches / their HIP-event durations, measured in a separate
-                 instrumented pass over the same step (events on the launch stream).
+  roofline     : the dominant kernel -- the MFMA implicit-GEMM instantiation (forward / data gradient
+                 or filter gradient) with the largest summed time -- algorithmic FLOPs of its
+                 launches / their HIP-event durations, measured in a separate instrumented pass
+                 over the same step (events on the launch stream); every other instantiation
+                 is listed under roofline.all_kernels.
   cpu_baseline : the CPU restatement of the same step (oracle/, PyTorch-oneDNN, "port") timed on
                  this box's host cores on a bounded sample.
 """
@@ -161,9 +163,11 @@ HBM_PEAK_TBS = 8.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 achievable)
 
 
 def roofline_record(recs, dtype="f32"):
-    """dominant conv instantiation (largest summed time): algorithmic FLOPs / HIP-event time of its launches."""
+    """dominant MFMA kernel instantiation (largest summed time over the forward / data-gradient AND filter-gradient
+    instantiations): algorithmic FLOPs / HIP-event time of its launches.  (A filter-gradient record brackets the C-ABI call,
+    i.e. the kernel plus its partial-tile reduce launch; rocprofv3's average in profiles/ is the kernel alone.)"""
     convs = {k: v for k, v in recs.items() if k.startswith("conv_")}
-    name, r = max(((k, v) for k, v in convs.items() if "fprop" in k), key=lambda kv: kv[1]["ms"])
+    name, r = max(((k, v) for k, v in convs.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
     achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
     # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 --pmc passes over
     # `bench.py --roofline-only` (tools/pmc_report.sh, tools/make_traffic_json.py), matched by kernel instantiation; null if
