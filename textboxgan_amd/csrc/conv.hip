@@ -1901,13 +1901,18 @@ __device__ __forceinline__ void wgrad_x3_store(const WgradP &p, WgX3Regs<VEC> &r
   {  // first touch of the loaded values: scale factors (0 for padding / out of range) and the row-edge shifts
     const bool hs = p.s_scale != nullptr, hl = p.l_scale != nullptr;
 #pragma unroll
-    for (int i = 0; i < WgX3<VEC>::NL; ++i) {
-      r.lsc[i] = !((r.lok >> i) & 1u) ? 0.f : (hl ? r.lsc[i] : 1.f);
-      if constexpr (VEC == 1) {
-        f32x4u v = r.lv[i];
-        if (r.edge & 1u) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }
-        if (r.edge & 2u) { v[0] = v[3]; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
-        r.lv[i] = v;
+    for (int i = 0; i < WgX3<VEC>::NL; ++i) r.lsc[i] = !((r.lok >> i) & 1u) ? 0.f : (hl ? r.lsc[i] : 1.f);
+    if constexpr (VEC == 1) {
+      // the row-edge shifts touch the first / last column tiles only: a wave-uniform test skips their 8 selects per quad on
+      // every other chunk (7 of 8 on 256-wide maps)
+      if (__builtin_amdgcn_ballot_w64(r.edge != 0u) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < WgX3<VEC>::NL; ++i) {
+          f32x4u v = r.lv[i];
+          if (r.edge & 1u) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }
+          if (r.edge & 2u) { v[0] = v[3]; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+          r.lv[i] = v;
+        }
       }
     }
 #pragma unroll
