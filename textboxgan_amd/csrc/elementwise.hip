@@ -5,7 +5,7 @@
 // ============================================================================================
 // bias_act forward / backward
 // ============================================================================================
-#define BA_CHUNK 4096  // elements of one (b,m) plane handled by one block
+#define BA_CHUNK 8192  // elements of one (b,m) plane handled by one block
 
 extern "C" int tbg_bias_act_bwd_chunks(int HW) { return HW < 1 ? 0 : (HW + BA_CHUNK - 1) / BA_CHUNK; }
 
