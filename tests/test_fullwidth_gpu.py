@@ -88,13 +88,13 @@ def test_discriminator_full_width_forward_backward(dev, full4):
 # one whole dist_train_step at the real Config against the CPU oracle, per arithmetic
 # ----------------------------------------------------------------------------------------------------------------
 # fp32 bars (unchanged since round 2; "f32x3" -- three bf16 terms per operand on the bf16 pipe -- must meet the SAME bars).
-_TOL_F32 = dict(loss=5e-4, g=5e-3, ocr=2e-2, ocr_scalar=6e-2, ocr_scalar_abs=2e-3, d=5e-3, flat_g=2e-3, flat_o=5e-3, flat_d=2e-3, pl_mean=2e-4,
+_TOL_F32 = dict(loss=5e-4, g=5e-3, ocr=2e-2, d=5e-3, flat_g=2e-3, flat_o=5e-3, flat_d=2e-3, pl_mean=2e-4,
                 adam=1e-3)
 # bf16 mode has no counterpart in the (fp32-only) reference; the bars are the mode-accuracy bars of tests/test_bf16_gpu.py's
 # docstring: unit round-off 2^-9 per operand through 12 + 7 layers and their backward -> losses 3e-2, gradient SETS 8e-2
 # relative L2; single tensors (few elements, sums with cancellation) 2.5e-1; the post-Adam comparison is dropped (with
 # beta1 = 0 a step is ~lr*sign(g): a sign flip of a near-zero gradient is not an error of the mode).
-_TOL_BF16 = dict(loss=3e-2, g=2.5e-1, ocr=None, ocr_scalar=5e-1, ocr_scalar_abs=5e-2, d=2.5e-1, flat_g=8e-2, flat_o=8e-2, flat_d=8e-2, pl_mean=3e-2,
+_TOL_BF16 = dict(loss=3e-2, g=2.5e-1, ocr=None, d=2.5e-1, flat_g=8e-2, flat_o=8e-2, flat_d=8e-2, pl_mean=3e-2,
                  adam=None)
 STEP_TOL = {"f32": _TOL_F32, "f32x3": _TOL_F32, "bf16": _TOL_BF16}
 _ORACLE_STEPS, _PRODUCT_STEPS = {}, {}
@@ -170,16 +170,15 @@ def _step_vs_oracle(dev, arith, B, reg, tol_override=None):
         onames = []
     worst = max([(l2_err(v, ref_grads["ocr"][n]), n) for n, v in zip(onames, ts.o_views) if v.numel() > 1] or [(0.0, "-")])
     assert worst[0] < (tol["ocr"] or 1.0), (arith, "ocr", worst)
-    # scalars: relative error, or -- for a scalar that is a small part of the set -- its absolute error against the SET's
-    # norm.  Measured (tools/diag_step_errors.py, profiles/r03_step_error_tables.txt): every tensor of this set carries an
-    # absolute error of 1e-4 .. 1.2e-3 of the set norm in both fp32 arithmetics; on a scalar holding 1.4 % of the norm that
-    # reads as 8e-2 relative, and the fp32 CPU oracle's own value of such a scalar moves by up to 1e-1 with its thread count.
-    o_norm = float(torch.sqrt(sum([ref_grads["ocr"][n].double().square().sum() for n in onames] or [torch.zeros(())])))
-    for n, v in zip(onames, ts.o_views):
-        if v.numel() == 1:
-            e = ref_grads["ocr"][n].double()
-            err = float((v.detach().double().cpu() - e).abs())
-            assert err <= tol["ocr_scalar"] * float(e.abs()) or err <= tol["ocr_scalar_abs"] * o_norm, (arith, "ocr scalar", n, err, float(e), o_norm)
+    # the set's SCALAR parameters (the ten noise strengths: one heavily cancelling sum each) are compared as ONE vector at the
+    # per-tensor bar -- a single criterion for both fp32 arithmetics (a lone scalar has no norm to be relative to; measured
+    # absolute errors are 1e-4 .. 1.2e-3 of the set norm on every tensor of this set, profiles/r03_step_error_tables.txt).
+    sc = [(v.detach().double().cpu().reshape(()), ref_grads["ocr"][n].double().reshape(())) for n, v in zip(onames, ts.o_views)
+          if v.numel() == 1]
+    if sc:
+        a, e = torch.stack([x for x, _ in sc]), torch.stack([y for _, y in sc])
+        err = float((a - e).norm() / (e.norm() + 1e-30))
+        assert err < tol["ocr"], (arith, "ocr scalars as one vector", err)
     worst = max((l2_err(v, ref_grads["d"][n]), n) for n, v in zip(prod["discriminator"]._flat.names, ts.d_views))
     assert worst[0] < tol["d"], (arith, "d", worst)
     # whole flat gradient buffers (what Adam / the all-reduce consume)

@@ -48,7 +48,12 @@ def test_header_symbols_are_exported_by_the_library():
     assert set(native.EXPORTS) == set(declared)
     lib.tbg_strerror.restype = ctypes.c_char_p
     assert lib.tbg_version() >= 100 and b"ok" in lib.tbg_strerror(0) and b"HIP" in lib.tbg_strerror(-3)
-    assert lib.tbg_bias_act_bwd_chunks(16384) == 4 and lib.tbg_bias_act_bwd_chunks(64) == 1
+    # the chunk size is the library's own constant: read it from the source the library was built from
+    src = open(os.path.join(ROOT, "textboxgan_amd", "csrc", "elementwise.hip")).read()
+    chunk = int(re.search(r"#define\s+BA_CHUNK\s+(\d+)", src).group(1))
+    for hw in (1, 64, chunk, chunk + 1, 16384, 5 * chunk - 1):
+        assert lib.tbg_bias_act_bwd_chunks(hw) == -(-hw // chunk)
+    assert lib.tbg_bias_act_bwd_chunks(0) == 0
 
 
 def test_ctypes_struct_layout_matches_header():

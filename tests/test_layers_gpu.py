@@ -69,21 +69,25 @@ def test_modconv_fused_fwd_bwd(dev, up, shape):
     outd = fn(xd, wd, s, nd, std, bd)  # demodulation inside the node
     assert rel_err(outd, out) < 3e-5
     gd = torch.autograd.grad(outd, (xd, wd, mwd, mbd, std, bd), f(dout))
-    # A pre-activation within rounding of zero can take the other LeakyReLU branch under a different (equally valid) fp32
-    # summation order.  Count such flips explicitly: with none, the gradients must agree element-wise; ONE flipped activation
-    # (b, o, y, x) moves a whole filter column of dw, the style gradient of its sample (hence ~half of dmod_w) and a patch of
-    # dx by up to ~2e-2 of max (measured: f32x3 on the 128-channel up layer, 1 flip of 1048576 activations: dw 973 elements in
-    # one column, dmod_w 1035 of 2560 elements <= 2.6e-3), so then the bar is relative L2.
-    flips = int(((outd.detach().cpu() > 0) != (out.detach() > 0)).sum())
+    # ONE criterion, element-wise 2e-4 of max, for every gradient.  LeakyReLU is piecewise linear: a pre-activation within
+    # rounding of zero can take the other branch under a different (equally valid) fp32 summation order, and the gradient of
+    # THAT branch is what the product must deliver.  So the expected gradients are the oracle's float64 gradients of the
+    # branch assignment the product's forward took (its output signs); with no flipped activation that is the oracle's own
+    # lrelu gradient bit for bit.  The flips themselves are bounded separately: few, and only where the oracle's
+    # pre-activation is within fp32 rounding of zero.
+    pre = R.t_bias_act(R.t_noise(y, noise, strength), bias, "linear")
+    took_pos = outd.detach().cpu() > 0
+    flipped = took_pos != (pre.detach() > 0)
+    flips = int(flipped.sum())
     assert flips <= 1e-5 * out.numel() + 1, flips
+    if flips:
+        assert float(pre.detach()[flipped].abs().max()) <= 2e-5 * float(pre.detach().abs().max()), "flip away from the kink"
+    slope = torch.where(took_pos, 1.0, 0.2).double() * math.sqrt(2.0)
+    grads = torch.autograd.grad(pre * slope, leaves, dout)
     for name, a, b in zip(("dx", "dw", "dmod_w", "dmod_b", "dstrength", "dbias"), gd, grads):
-        if flips:
-            d = a.detach().double().cpu() - b.detach().double()
-            assert float(d.norm() / (b.detach().double().norm() + 1e-30)) < 5e-3 and float(d.abs().max() / b.detach().abs().max()) < 5e-2, (name, flips)
-            continue
         err = (a.detach().double().cpu() - b.detach().double()).abs() / (b.detach().double().abs().max() + 1e-30)
         n_bad = int((err > 2e-4).sum())
-        assert n_bad == 0, (name, n_bad, float(err.max()))
+        assert n_bad == 0, (name, n_bad, float(err.max()), flips)
 
 
 @pytest.mark.parametrize("dims", [(5, 24, 40), (32, 256, 256), (16, 256, 512), (64, 100, 130), (16, 512, 1), (33, 96, 65),
