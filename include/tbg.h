@@ -160,6 +160,10 @@ int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, 
  * images per tile, several output-parity classes, or K split) -- a launch that asks for it anyway returns TBG_EUNSUPPORTED and
  * the caller reduces the finished output instead.  Negative: an error code. */
 int tbg_conv2d_dot_slots(const tbg_conv_desc *d, int has_in_scale, int mode);
+/* Thread blocks the launch of this descriptor consists of (pixel tiles x channel tiles x output-parity classes x d->ksplit;
+ * mode as above) -- the tile choice belongs to the library, so a caller that sizes a K split (d->ksplit) asks for the
+ * count at ksplit = 1 instead of mirroring the choice.  Negative: an error code. */
+int tbg_conv2d_blocks(const tbg_conv_desc *d, int has_in_scale, int mode);
 /* tbg_conv2d_f32 with an EXPLICIT instantiation family for 3x3 / 1x1 non-transposed-class launches (tuning and test aid):
  * variant 0 = the library's choice, 1 = software-pipelined (double-buffered LDS), 2 = plain 8-channel chunks,
  * 3 = 4-channel chunks at 4 waves/SIMD (128x128 tile only), 4 / 5 = stride-2 transposed 3x3 as one block per output-parity

@@ -91,19 +91,22 @@ def _grad_worker(rank, world, port, backend, q, full_width=False):
     torch.cuda.synchronize()
     cat = lambda views: torch.cat([v.reshape(-1) for v in views]).cpu().numpy()  # numpy: pickled by value (no shm fd)
     fracs = [float(b1 - b0) / ts.d_grad.numel() for _, _, (b0, b1) in ts.d_stages]  # deepest stage first
+    # post-Adam replica state (exact checksums: the replicas must stay BIT-identical) and the loss normalisation in use
+    post = (float(st["generator"]._flat.flat.double().sum()), float(st["generator"]._flat.flat.double().abs().sum()),
+            float(st["discriminator"]._flat.flat.double().sum()), float(st["discriminator"]._flat.flat.double().abs().sum()))
     q.put((rank, cat(ts.g_views), cat(ts.o_views), cat(ts.d_views),
-           [float(x) for x in losses[0]] + [float(x) for x in losses[1]] + [float(losses[2])], fracs))
+           [float(x) for x in losses[0]] + [float(x) for x in losses[1]] + [float(losses[2])], fracs, post, ts.batch_size))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _exchange_vs_oracle(backend, full_width=False):
+def _exchange_vs_oracle(backend, full_width=False, world=2):
     import torch.multiprocessing as mp
     from oracle import ref_model as M
     from textboxgan_amd.aster import AsterLikeOCR
     from textboxgan_amd.config import small_config
-    world = 2
     cfg = _cfg(full_width, world)
+    assert cfg.batch_size == 4 * world  # config/config.py:140-141: the losses are divided by the GLOBAL batch
     ocr = AsterLikeOCR(max_steps=cfg.max_char_number)
     sums, loss_sum = None, None
     for rank in range(world):  # the oracle, replica by replica, from the same initial weights
@@ -127,9 +130,14 @@ def _exchange_vs_oracle(backend, full_width=False):
     [p.join(timeout=120) for p in procs]
     l2 = lambda a, r: float((a.double() - r.double()).norm() / (r.double().norm() + 1e-30))
     res_fracs = [t[5] for t in res]
-    res = [(r, torch.from_numpy(g), torch.from_numpy(o), torch.from_numpy(d), l) for r, g, o, d, l, _ in res]
-    (_, g0, o0, d0, l0), (_, g1, o1, d1, l1) = res
-    assert torch.equal(g0, g1) and torch.equal(o0, o1) and torch.equal(d0, d1), "ranks hold different exchanged gradients"
+    assert all(t[6] == res[0][6] for t in res), "replicas are not bit-identical after the Adam updates"
+    assert all(t[7] == cfg.batch_size for t in res), "loss normalisation is not the global batch"
+    assert all(t[5] == res_fracs[0] for t in res), "ranks disagree on the D bucket table"
+    res = [(r, torch.from_numpy(g), torch.from_numpy(o), torch.from_numpy(d), l) for r, g, o, d, l, _, _, _ in res]
+    (_, g0, o0, d0, l0) = res[0]
+    for (_, g1, o1, d1, l1) in res[1:]:
+        assert torch.equal(g0, g1) and torch.equal(o0, o1) and torch.equal(d0, d1), "ranks hold different exchanged gradients"
+        assert l0 == l1, "loss scalars must be reduced over ranks"
     # the oracle's gradient dicts, concatenated in the order of the product's flat buffers
     from textboxgan_amd.training_step import build_trainer_state
     names = build_trainer_state(cfg, torch.device("cpu"), seed=0)
@@ -153,6 +161,15 @@ def test_exchanged_gradients_equal_sum_of_per_replica_oracle_gradients_gloo(dev,
     """full-width: the real channel widths (B = 4 per rank), so the D exchange's bucket boundaries (d_cuts = (5, 3): 74 % /
     20 % / 6 % of D's 62 MB) are exercised on the real layer sizes."""
     _exchange_vs_oracle("gloo", full_width)
+
+
+def test_eight_rank_exchange_matches_sum_of_eight_oracle_replicas_gloo(dev):
+    """BASELINE configs[3] has EIGHT replicas (global batch 8 x per-GPU batch): eight processes on one GPU over gloo run one
+    step each on its own shard with its own randomness.  Asserted: the exchanged flat buffers equal the SUM of the eight
+    per-replica CPU-oracle gradient sets (G, OCR, D), the seven loss scalars SUM to the oracle's (every replica divides by
+    Bg = 8 * B, config/config.py:140-141), all eight replicas are bit-identical after the three Adam updates, and every rank
+    uses the same deepest-first D bucket table (training_step.py:91-136,233-235 of the reference)."""
+    _exchange_vs_oracle("gloo", full_width=False, world=8)
 
 
 def test_exchanged_gradients_equal_sum_of_per_replica_oracle_gradients_rccl(dev):

@@ -153,18 +153,21 @@ def _exchange_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gradient_exchange_two_processes_gloo():
-    """the N>1 path: SUM all-reduce of the three flat gradient buffers + the loss scalars, world_size 2."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_gradient_exchange_processes_gloo(world):
+    """the N>1 path: SUM all-reduce of the three flat gradient buffers + the loss scalars; world_size 2 and 8 (BASELINE
+    configs[3] is eight replicas: the collectives and the SUM convention at the real replica count)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), _free_port()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=240) for _ in range(world))
     [p.join(timeout=60) for p in procs]
+    tri = float(world * (world + 1) // 2)  # sum of (rank + 1)
     for rank, firsts, sums, scal, more, ws in res:
-        assert firsts == [3.0, 6.0, 9.0] and sums == [3000.0, 6.0 * 37, 9.0 * 5003]
-        assert scal == [3.0, 30.0] and more == 3.0 and ws == 2
+        assert firsts == [tri, 2 * tri, 3 * tri] and sums == [tri * 1000, 2 * tri * 37, 3 * tri * 5003]
+        assert scal == [tri, 10 * tri] and more == tri and ws == world
 
 
 def test_grad_exchange_is_a_noop_single_process():

@@ -84,9 +84,11 @@ def test_training_step_matches_oracle(dev, reg):
     #  (a) the product's theta1 equals float64 Keras-Adam (the oracle's AdamTF) applied to the product's OWN gradient buffers,
     #      element-wise to fp32 rounding of theta -- exact, no conditioning involved;
     #  (b) against the oracle's end state: relative L2 < 5e-3 on theta1 (parameters with theta0 != 0), and for EVERY parameter
-    #      the update theta1 - theta0 itself, relative L2 < 5e-3 over the elements whose step is determined by the gradient
-    #      (|g_ref| > 10 eps' in the set that owns the parameter, same sign in product and oracle; sign disagreements counted
-    #      and bounded: they can only be gradient elements smaller than the gradient error the bars above admit).
+    #      the update theta1 - theta0 itself, relative L2 < 5e-3 over the elements whose step is determined by the gradient's
+    #      SIGN in every optimiser that owns the parameter (|g_ref| > 10 eps', same sign in product and oracle; disagreements
+    #      counted and bounded: they can only be gradient elements smaller than the gradient error the bars above admit).
+    #      Elements in an optimiser's linear regime (|g| < 10 eps': the 1e-4-weighted OCR set) carry the gradient's own
+    #      relative error undamped and are covered by (a) + the gradient bars, not by a third bar.
     names_of = dict(G=list(st["G"].keys()), D=list(st["D"].keys()))
     G0 = M.init_generator(cfg, seed=0, bench_init=True)
     D0 = M.init_discriminator(cfg, seed=1, bench_init=True)
@@ -110,28 +112,31 @@ def test_training_step_matches_oracle(dev, reg):
     def eps_prime(o):
         return o.epsilon / math.sqrt(1.0 - o.beta2)
 
-    def update_parity(tag, n, theta1, theta0, theta1_ref, g_ref, g_prod, o):
+    def update_parity(tag, n, theta1, theta0, theta1_ref, sets, o):
+        """sets: [(g_ref, g_prod)] of every optimiser that owns the parameter"""
         if float(theta0.abs().max()) != 0.0:
             assert l2_err(theta1, theta1_ref) < 5e-3 and rel_err(theta1, theta1_ref) < 5e-2, (tag, n)
-        if g_ref is None:
-            return
-        g_ref, g_prod = g_ref.double(), g_prod.double()
-        big = g_ref.abs() > 10.0 * eps_prime(o)
-        same = torch.sign(g_ref) == torch.sign(g_prod)
-        n_big, n_flip = int(big.sum()), int((big & ~same).sum())
-        assert n_flip <= 1e-3 * n_big + 1, (tag, n, "gradient sign disagreements", n_flip, n_big)
-        keep = big & same
-        if int(keep.sum()):
+        keep = torch.ones_like(theta0, dtype=torch.bool)
+        for g_ref, g_prod in sets:
+            g_ref, g_prod = g_ref.double(), g_prod.double()
+            big = g_ref.abs() > 10.0 * eps_prime(o)
+            same = torch.sign(g_ref) == torch.sign(g_prod)
+            n_big, n_flip = int(big.sum()), int((big & ~same).sum())
+            assert n_flip <= 1e-3 * n_big + 1, (tag, n, "gradient sign disagreements", n_flip, n_big)
+            keep &= big & same
+        if sets and int(keep.sum()):
             du, du_ref = (theta1.double() - theta0.double())[keep], (theta1_ref.double() - theta0.double())[keep]
             assert float((du - du_ref).norm() / (du_ref.norm() + 1e-30)) < 5e-3, (tag, n, "update", int(keep.sum()))
+        return int(keep.sum()) if sets else 0
 
     go, do_ = cfg.g_opt.lazy_reg_rescaled(), cfg.d_opt.lazy_reg_rescaled()
+    n_checked = 0
     for n, v in sdG.items():
-        owner = ref_grads["g"] if n in ref_grads["g"] else ref_grads["ocr"]
-        mine = prod_g if n in prod_g else prod_o
-        update_parity("G", n, v, G0[n], st["G"][n], owner.get(n), mine.get(n), go)
+        sets = [(ref_grads[k][n], mine[n]) for k, mine in (("g", prod_g), ("ocr", prod_o)) if n in mine]
+        n_checked += update_parity("G", n, v, G0[n], st["G"][n], sets, go)
     for n, v in sdD.items():
-        update_parity("D", n, v, D0[n], st["D"][n], ref_grads["d"].get(n), prod_d.get(n), do_)
+        n_checked += update_parity("D", n, v, D0[n], st["D"][n], [(ref_grads["d"][n], prod_d[n])] if n in prod_d else [], do_)
+    assert n_checked > 1000, n_checked  # the element-wise update comparison is not vacuous
     # the caller's g_clone EMA: lerp(theta1, theta0, 0.99) -- same conditioning as theta1 / 100, so it is compared with the EMA
     # rule applied to the PRODUCT's generator (exact) and, for theta0 != 0, with the oracle's clone
     expC = {k: v.clone() for k, v in G0.items()}

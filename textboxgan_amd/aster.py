@@ -338,13 +338,14 @@ class AsterLikeOCR(nn.Module):
             return np.ascontiguousarray(re[:n_in].T), np.ascontiguousarray(re[n_in:].T)
         raise ValueError(kind)
 
-    def load_weights_tf(self, path: str, name_map: dict, strict: bool = True, forget_bias: float = 0.0):
+    def load_weights_tf(self, path: str, name_map: dict, strict: bool = True, forget_bias: float = 1.0):
         """Import variables of a SavedModel directory / checkpoint prefix.  name_map: parameter name -> variable name or
         (variable name, kind) with kind as in tf_to_torch_layout (default: "conv" for 4-D, "dense" for 2-D, else "same").
         An LSTM's fused kernel maps from its ``weight_ih`` name and fills the matching ``weight_hh`` too.  An LSTM's single
         TF bias maps from one torch bias name (``bias_ih*`` or ``bias_hh*``): the PAIRED torch bias is zeroed (torch adds
-        both), and ``forget_bias`` (TF's BasicLSTMCell adds it to the f gate at run time, default 1.0 there) is added to the
-        f-gate slice of the imported bias."""
+        both), and ``forget_bias`` is added to the f-gate slice of the imported bias: TF's LSTMCell / BasicLSTMCell add it to the f
+        gate at RUN time (it is not in the stored variable) and default to 1.0, which is what the ASTER SavedModel of
+        aster_inferer.py:24-26 was exported with -- hence the default here; pass 0.0 only for cells built with forget_bias=0."""
         from . import tf_checkpoint as T
         import os
         prefix = os.path.join(path, "variables", "variables") if os.path.isdir(path) else path

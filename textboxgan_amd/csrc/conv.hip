@@ -519,6 +519,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
             for (int bt = 0; bt < NBT; ++bt) store_halo(kc * CK + bt * CB, bt * (CB / KP), j, xr[j][bt], Xs);
           }
         issue_filter_dma(kc, As);
+        // the counted s_waitcnt below assumes every DMA piece was issued BEFORE the halo loads of the next chunk: pin that order
+        // (nothing else keeps the compiler from hoisting a global load above the LDS-DMA builtins)
+        __builtin_amdgcn_sched_barrier(0);
         if (kc + 1 < kend) {
           loadx((kc + 1) * CK);
           // the DMA pieces are older than the loads just issued: leave exactly those loads outstanding
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
 }
 
 // name-only mode (name != NULL): write the instantiation the descriptor selects (rocprofv3 spelling) and launch nothing
-struct NameOut { char *buf; int n; int *dot_slots; };
+struct NameOut { char *buf; int n; int *dot_slots; int *blocks; };
 
 template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false, bool TM = false, bool X3 = false>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, const NameOut *name) {
@@ -785,6 +788,7 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
   if (p.e.dot_aux && p.dot_slots == 0) return TBG_EUNSUPPORTED;
   if (name) {
     if (name->dot_slots) *name->dot_slots = p.dot_slots;
+    if (name->blocks) *name->blocks = maxTilesN * ceil_div(p.M, BM) * p.nclass * p.ksplit;
     if (!name->buf) return TBG_OK;
     snprintf(name->buf, name->n, "conv_fprop_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s>", WGM, WGN, WTM, WTN, CK, MT, PF,
              OCC, BF ? "true" : "false", TM ? "true" : "false", X3 ? "true" : "false");
@@ -1140,7 +1144,7 @@ extern "C" int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, con
 static int conv_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n, int mode) {
   if (!buf || n < 1) return TBG_EINVAL;
   buf[0] = 0;
-  NameOut no{buf, n, nullptr};
+  NameOut no{buf, n, nullptr, nullptr};
   static const float dummy = 0.f;  // name-only mode never dereferences; in_scale only sizes the LDS request
   return conv2d_impl(d, nullptr, nullptr, nullptr, has_in_scale ? &dummy : nullptr, nullptr, nullptr, &no, mode);
 }
@@ -1148,10 +1152,19 @@ static int conv_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n,
 extern "C" int tbg_conv2d_dot_slots(const tbg_conv_desc *d, int has_in_scale, int mode) {
   if (mode < 0 || mode > 2) return TBG_EINVAL;
   int slots = 0;
-  NameOut no{nullptr, 0, &slots};
+  NameOut no{nullptr, 0, &slots, nullptr};
   static const float dummy = 0.f;
   const int rc = conv2d_impl(d, nullptr, nullptr, nullptr, has_in_scale ? &dummy : nullptr, nullptr, nullptr, &no, mode);
   return rc != TBG_OK ? rc : slots;
+}
+
+extern "C" int tbg_conv2d_blocks(const tbg_conv_desc *d, int has_in_scale, int mode) {
+  if (mode < 0 || mode > 2) return TBG_EINVAL;
+  int blocks = 0;
+  NameOut no{nullptr, 0, nullptr, &blocks};
+  static const float dummy = 0.f;
+  const int rc = conv2d_impl(d, nullptr, nullptr, nullptr, has_in_scale ? &dummy : nullptr, nullptr, nullptr, &no, mode);
+  return rc != TBG_OK ? rc : blocks;
 }
 
 extern "C" int tbg_conv2d_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n) {

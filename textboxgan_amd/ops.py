@@ -168,22 +168,6 @@ class _Profile:
 PROFILE = _Profile()
 
 
-# launches of at most this many 128 x 128 tiles run on 64 x 64 tiles (mirror of conv.hip; by filter format FMT_*: f32x3 takes
-# the small tile up to 32 -- A/B on one box 20.57 -> 20.52 ms per step, 64: 20.92 -> 21.03 -- profiles/r03_ab_one_box.txt)
-SMALL_TILE_MAX = (16, 16, 32)
-
-
-def _fprop_tile(M, npix, fmt=0):
-    """mirror of the tile choice in tbg_conv2d_{f32,bf16,x3} (csrc/conv.hip)."""
-    if M <= 32:
-        return 32, 256, "1,4,1,2,8"
-    if M <= 64:
-        return (64, 64, "2,2,1,1,8") if math.ceil(npix / 256) < 96 else (64, 256, "1,4,2,2,8")
-    if math.ceil(M / 128) * math.ceil(npix / 128) <= SMALL_TILE_MAX[int(fmt)]:
-        return 64, 64, "2,2,1,1,8"
-    return 128, 128, "2,2,2,2,8"
-
-
 # ----------------------------------------------------------------------------------------
 # FIR filters (upfirdn_2d_v2.py:18-25) cached per device
 # ----------------------------------------------------------------------------------------
@@ -254,11 +238,6 @@ ONE_PER_CU_SPLIT = True  # measurement aid (tools/ab_step.py): two K splits for 
 FORCE_VARIANT = 0    # experiment knob (tools/bench_variants_conv.py): tbg_conv2d_f32_variant's instantiation family
 
 
-def _conv_tiles(M, npix, fmt=0):
-    bm, bn, _ = _fprop_tile(M, npix, fmt)
-    return math.ceil(M / bm) * math.ceil(npix / bn)
-
-
 def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_hw: Tuple[int, int], stride=(1, 1),
                pad=(0, 0), transposed=False, flip=False, in_scale=None, epi: Optional[N.Epilogue] = None,
                ldw: Optional[int] = None, allow_split=True, dot=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -282,12 +261,13 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     Hout, Wout = out_hw
     nchunks = math.ceil(Cc / (16 if fmt == FMT_BF16 else 8))
     ksplit = 1
-    _npix = B * (math.ceil(Hout / stride[0]) * math.ceil(Wout / stride[1]) if transposed else Hout * Wout)
     if allow_split:
-        tiles = _conv_tiles(M, _npix, fmt) * (stride[0] * stride[1] if transposed else 1)  # one launch covers all classes
-        if (transposed and tuple(stride) == (2, 2) and KH == 3 and KW == 3 and M > 32 and FORCE_VARIANT != 4 and
-                (FORCE_VARIANT in (5, 6) or (bf16 and B * Hin * Win >= 16384))):  # mirrors the library's choice (conv.hip)
-            tiles = math.ceil(M / 64) * math.ceil(_npix / 128)  # merged-class kernel: 64 x 128 tiles over input positions
+        # the tile choice belongs to the library: ask it how many blocks this descriptor launches unsplit (all output-parity
+        # classes of a transposed launch included) instead of mirroring its rules here
+        d1 = N.ConvDesc(B, Cc, M, Hin, Win, Hout, Wout, KH, KW, stride[0], stride[1], pad[0], pad[1], int(transposed),
+                        int(flip), ldw, 1)
+        tiles = N.lib().tbg_conv2d_blocks(C.byref(d1), int(in_scale is not None), int(fmt))
+        N.check(min(tiles, 0), "tbg_conv2d_blocks")
         # exactly one block per CU (256 tiles) leaves the second block slot of a stride-1 tile empty -- nothing overlaps its
         # staging: two splits there measured 165 vs 126-138 TFLOP/s (f32x3 16x64 256->256, profiles/r03_cold_conv.txt); a
         # stride-2 f32x3 tile fills the CU's LDS alone and only loses to the slab pass (109 vs 132)
@@ -573,10 +553,22 @@ def bias_act_fwd_raw(x, epi: N.Epilogue):
     return y
 
 
+def _check_colmask(colmask, B, W, mask_cw):
+    """the kernels index colmask[b * ceil(W / mask_cw) + column // mask_cw] unchecked: a mask of another batch / width would
+    be read out of bounds or from the wrong row, where the mask_text_box multiply it replaces raised a broadcast error."""
+    if colmask is None:
+        return
+    nb = -(-W // int(mask_cw)) if mask_cw > 0 else -1
+    if (tuple(colmask.shape) != (B, nb) or colmask.dtype != torch.float32 or not colmask.is_contiguous()):
+        raise ValueError(f"colmask must be a contiguous float32 [{B}, {nb}] tensor (W = {W}, mask_cw = {mask_cw}), got "
+                         f"{tuple(colmask.shape)} {colmask.dtype}")
+
+
 def rgb_project_raw(x, w2d, O, scale, bias, skip, alpha, bias_mul=1.0, out=None, colmask=None, mask_cw=0):
     """y[b,o,p] = (alpha * sum_c x[b,c,p] w2d[c,o] scale[b,c] + bias[o] + skip[b,o,p]) * m   (O <= 4; w2d rows of ldw = O).
     colmask [B, W // mask_cw]: m = colmask[b, column // mask_cw] (mask_text_box as the epilogue)."""
     B, Cc, H, W = x.shape
+    _check_colmask(colmask, B, W, mask_cw)
     y = torch.empty((B, O, H, W), device=x.device, dtype=torch.float32) if out is None else out
     _nb = 4.0 * (x.numel() + y.numel() * (2 if skip is not None else 1))
     N.check(PROFILE.launch("rgb_project_kernel", 0.0, lambda: N.lib().tbg_rgb_project_f32(
@@ -591,6 +583,7 @@ def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True, col
     returns (dx, G) or (dx, G, dym)."""
     B, Cc, H, W = x.shape
     O = dy.shape[1]
+    _check_colmask(colmask, B, W, mask_cw)
     dx = torch.empty_like(x) if want_dx else None
     nchunk = N.lib().tbg_rgb_backproject_chunks(H * W)
     Gp = torch.empty((B, Cc, nchunk, O), device=x.device, dtype=torch.float32) if want_G else None
