@@ -271,6 +271,30 @@ int tbg_conv2d_wgrad_x3_kernel_name(const tbg_wgrad_desc *d, char *buf, int n);
 int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,
                           const tbg_epilogue *epi, int variant, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * UNIT TENSORS: convolution operands written ONCE in the form the matrix-core kernels consume, so that forward, data-gradient
+ * and filter-gradient launches stage their tiles by LDS-DMA alone (no per-launch re-scaling / re-splitting / re-rounding on
+ * the VALU).  The unit tensor of x[B][C][H][W] is
+ *     U[plane][b][c / 8][1 + y][1 + x][c % 8]     bf16, 16-byte aligned, tbg_units_bytes(B, C, H, W, planes) bytes
+ * planes = 3: the f32x3 terms hi | mid | lo of x (exact split, see "f32x3 forms"); planes = 1: RNE(x) (bf16 mode).
+ * One 16-byte unit = 8 consecutive channels of one pixel; every (b, c/8) plane is (H + 2) x (W + 2) units with a ring of ZERO
+ * units (the padding of a 3x3 convolution is read from it), channels past C are zero.
+ * tbg_units_pack_f32: U <- x * (scale ? scale[b*C + c] : 1)  (the style modulation of modulated_conv2d.py:94-96 -- both
+ * the forward convolution and its filter gradient consume exactly this product); writes every unit incl. ring and tail.
+ * ---------------------------------------------------------------------------------------- */
+long long tbg_units_bytes(int B, int C, int H, int W, int planes);
+int tbg_units_pack_f32(const float *x, const float *scale, void *U, int B, int C, int H, int W, int planes, void *stream);
+
+/* Filter gradient from unit tensors: tbg_conv2d_wgrad_ex_f32's result (same descriptor, dW strides, alpha, addw / addq /
+ * gamma) with S and L given as unit tensors SU (of [B,CS,Hs,Ws]) and LU (of [B,CL,Hl,Wl]) of `planes` planes each (their
+ * scales already inside).  planes = 3: f32x3 arithmetic (six products per tap, fp32 accumulate); planes = 1: bf16 operands.
+ * Geometry: 3x3, stride 1, pad 1, Ws % 32 == 0, Hs % 2 == 0, CS % 64 == 0, CL % 64 == 0 -- TBG_EUNSUPPORTED otherwise (the
+ * caller keeps the NCHW entry for those).  workspace: tbg_conv2d_wgrad_units_workspace_bytes(d) bytes. */
+long long tbg_conv2d_wgrad_units_workspace_bytes(const tbg_wgrad_desc *d);
+int tbg_conv2d_wgrad_units(const tbg_wgrad_desc *d, const void *SU, const void *LU, int planes, float *dW,
+                           const float *addw, const float *addq, float gamma, float *workspace,
+                           long long workspace_bytes, void *stream);
+
 /* Multi-tensor filter packing: items_dev is a DEVICE array of n_items descriptors; item k is packed exactly as
  * tbg_weight_pack_f32 (bf16 = 0) / tbg_weight_pack_bf16 (bf16 = 1) / tbg_weight_pack_x3 (bf16 = 2) would pack
  * (src, dst, T, I, O, transpose, flip).

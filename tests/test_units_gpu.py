@@ -1,0 +1,99 @@
+"""-m gpu: convolution operands in the 8-channel-unit layout (tbg.h "unit tensors", csrc/conv_units.hip): the stand-alone
+producer against its definition, and the kernels that consume unit tensors against float64 at the tolerances of the NCHW
+kernels they replace (tests/test_x3_gpu.py for f32x3, tests/test_bf16_gpu.py for bf16)."""
+import math
+
+import pytest
+import torch
+
+from textboxgan_amd import native as N, ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64)
+
+
+def _rel(a, r):
+    return float((a.double().cpu() - r).abs().max() / (r.abs().max() + 1e-30))
+
+
+def _planes(U):
+    """[planes, B, C8, H+2, W+2, 8] float64 view of a unit tensor"""
+    return U.data.float().double().reshape(U.planes, U.B, (U.C + 7) // 8, U.H + 2, U.W + 2, 8)
+
+
+@pytest.mark.parametrize("planes", [3, 1])
+@pytest.mark.parametrize("shape", [(2, 20, 5, 9), (3, 64, 8, 32), (1, 130, 2, 33)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_units_pack_is_the_definition(dev, planes, shape, scaled):
+    """U[pl][b][c/8][1+y][1+x][c%8]: planes = 3 sums EXACTLY to the fp32 product x * s (hi = its RNE bf16), planes = 1 is
+    its RNE bf16; ring and channel tail are zero; every unit is written (the buffer starts as NaN)."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(B, C, H, W, generator=g) * torch.exp(3 * torch.randn(B, C, H, W, generator=g))).to(dev)
+    s = (torch.rand(B, C, generator=g) + 0.5).to(dev) if scaled else None
+    U = ops.units_pack(x, s, planes=planes)
+    assert U.data.numel() * 2 == N.lib().tbg_units_bytes(B, C, H, W, planes)
+    P = _planes(U)
+    assert torch.isfinite(P).all()
+    v = (x * s[:, :, None, None]) if scaled else x  # the fp32 product the kernels form
+    C8 = (C + 7) // 8
+    exp = torch.zeros(B, C8 * 8, H + 2, W + 2, device=dev, dtype=torch.float32)
+    exp[:, :C, 1:-1, 1:-1] = v
+    exp = exp.reshape(B, C8, 8, H + 2, W + 2).permute(0, 1, 3, 4, 2)
+    if planes == 3:
+        assert torch.equal(P.sum(0), exp.double()), float((P.sum(0) - exp.double()).abs().max())
+        assert torch.equal(P[0], exp.bfloat16().double())
+    else:
+        assert torch.equal(P[0], exp.bfloat16().double())
+
+
+WG_UNITS = [(2, 64, 64, 2, 32), (2, 64, 128, 8, 32), (3, 128, 64, 6, 64), (4, 128, 128, 16, 64), (1, 64, 64, 64, 256)]
+
+
+@pytest.mark.parametrize("planes", [3, 1])
+@pytest.mark.parametrize("case", WG_UNITS, ids=[str(c) for c in WG_UNITS])
+def test_wgrad_units_matches_float64(dev, planes, case):
+    """tbg_conv2d_wgrad_units (LDS-DMA staged, transposing operand reads) with both operands scaled and the fused additive
+    term, against float64 on the operands the kernels see.  planes = 3: the fp32 bar of conv_wgrad_x3_kernel (3e-5) and not
+    worse than 2x the exact fp32 kernel; planes = 1: float64 on the bf16-rounded operands (products exact: 3e-5)."""
+    import torch.nn.functional as F
+    B, C, M, H, W = case
+    x, dy = _rnd(B, C, H, W, seed=40), _rnd(B, M, H, W, seed=41)
+    xs, ds = _rnd(B, C, seed=42).abs() + 0.5, _rnd(B, M, seed=43).abs() + 0.5
+    addw, addq = _rnd(3, 3, C, M, seed=44), _rnd(C, M, seed=45)
+    f32 = lambda t: t.float().double()
+    xr = (f32(x) * f32(xs)[:, :, None, None]).float()
+    dyr = (f32(dy) * f32(ds)[:, :, None, None]).float()
+    if planes == 1:
+        xr, dyr = xr.bfloat16().float(), dyr.bfloat16().float()
+    w = torch.zeros(3, 3, C, M, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xr.double(), w.permute(3, 2, 0, 1), padding=1), w, dyr.double())
+    ref = 0.7 * ref + 0.3 * f32(addw) * f32(addq)[None, None]
+    f = lambda t: t.float().to(dev).contiguous()
+    assert ops.wgrad_units_ok(M, C, H, W, H, W, 3, 3, (1, 1), (1, 1))
+    SU, LU = ops.units_pack(f(dy), f(ds), planes=planes), ops.units_pack(f(x), f(xs), planes=planes)
+    dw = torch.full((3, 3, C, M), float("nan"), device=dev)
+    ops.wgrad_units_raw(SU, LU, dw, C * M, M, 1, 0.7, add=(f(addw), f(addq), 0.3))
+    err = _rel(dw, ref)
+    if planes == 3:
+        g = ops._Geom((1, 1), (1, 1), 3, 3, (H, W), (H, W))
+        with ops.compute_dtype("f32"):
+            dw32 = ops._bwd_weight_launch(f(x), f(dy), g, C, M, alpha=0.7, x_scale=f(xs), dy_scale=f(ds), add=(f(addw), f(addq), 0.3))
+        e32 = _rel(dw32, ref)
+        print(f"\nWGUNITS {case}: f32 {e32:.3e}  units x3 {err:.3e}")
+        assert err < 3e-5 and err <= max(2.0 * e32, 1e-6), (err, e32)
+    else:
+        print(f"\nWGUNITS bf16 {case}: {err:.3e}")
+        assert err < 3e-5, err
+
+
+def test_wgrad_units_refuses_other_geometries(dev):
+    import ctypes as C
+    for d in (N.WgradDesc(2, 64, 64, 4, 16, 4, 16, 3, 3, 1, 1, 1, 1, 64 * 64, 64, 1, 1.0),      # 16-pixel rows
+              N.WgradDesc(2, 64, 72, 8, 32, 8, 32, 3, 3, 1, 1, 1, 1, 72 * 64, 64, 1, 1.0),      # partial channel tile
+              N.WgradDesc(2, 64, 64, 8, 32, 17, 65, 3, 3, 2, 2, 0, 0, 64 * 64, 64, 1, 1.0)):    # strided
+        assert N.lib().tbg_conv2d_wgrad_units_workspace_bytes(C.byref(d)) == -4  # TBG_EUNSUPPORTED

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtbg_hip.so")
 HOST_LIB = os.path.join(HERE, "libtbg_host.so")
-SOURCES = ["elementwise.hip", "upfirdn.hip", "conv.hip", "rgb.hip", "lstm.hip", "smalls.hip", "host_util.hip"]
+SOURCES = ["elementwise.hip", "upfirdn.hip", "conv.hip", "conv_units.hip", "rgb.hip", "lstm.hip", "smalls.hip", "host_util.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
@@ -33,7 +33,34 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
             and open(stamp).read().strip() == dig):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, "-shared", "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
+    # one object per translation unit, compiled in parallel and cached by content (sources + headers + flags) under
+    # csrc/.obj (git-ignored): editing one kernel file recompiles that file only
+    objdir = os.path.join(CSRC, ".obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)) + ["../../include/tbg.h"]:
+        if name.endswith(".h"):
+            with open(os.path.join(CSRC, name), "rb") as f:
+                hdr.update(name.encode() + b"\0" + f.read())
+    hdr.update(" ".join(FLAGS).encode())
+    jobs, objs = [], []
+    for src in SOURCES:
+        with open(os.path.join(CSRC, src), "rb") as f:
+            key = hashlib.sha256(hdr.digest() + f.read()).hexdigest()[:16]
+        obj = os.path.join(objdir, f"{src}.{key}.o")
+        objs.append(obj)
+        if force or not os.path.exists(obj):
+            for old in os.listdir(objdir):
+                if old.startswith(src + "."):
+                    os.remove(os.path.join(objdir, old))
+            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print("[tbg build]", " ".join(cmd), flush=True)
+            jobs.append((src, subprocess.Popen(cmd)))
+    for src, job in jobs:
+        if job.wait() != 0:
+            raise subprocess.CalledProcessError(job.returncode, f"hipcc -c {src}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
         print("[tbg build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

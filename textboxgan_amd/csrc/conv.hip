@@ -27,49 +27,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "common.h"
+#include "conv_common.h"
 #include <type_traits>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// 8 floats -> 8 bf16 (round to nearest even: v_cvt_pk_bf16_f32), one 16-byte LDS unit
-__device__ __forceinline__ bf16x8 pack_bf16x8(const float (&v)[8]) {
-  bf16x8 r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
-  return r;
-}
-
-// fp32 -> three bf16 terms hi + mid + lo (8 + 8 + 8 significand bits: exact for every fp32 value whose low terms stay
-// in the normal range).  Products of two bf16 values are exact in fp32, so the six largest partial products of
-// (a_hi + a_mid + a_lo)(b_hi + b_mid + b_lo) reproduce a * b to ~2^-24 relative -- the "f32x3" arithmetic of the X3 kernels.
-// Two values at a time, on packed instructions: v_cvt_pk_bf16_f32 (both conversions), shift / mask (the bf16 pair back to
-// fp32), v_pk_add_f32 (both residuals) -- 9 VALU instructions per pair.  The element-wise form ((__bf16)v, (float)b per element)
-// compiled to one conversion and one v_perm per ELEMENT and term: ~10 instructions per element in the staging passes
-// (profiles/r03_ab_one_box.txt).  Same roundings, same bits.
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
-  const f32x2v v = {a, b};
-  const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2p));
-  const f32x2v hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
-  const f32x2v r1 = v - hf;
-  const unsigned mu = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2p));
-  const f32x2v mf = {__builtin_bit_cast(float, mu << 16), __builtin_bit_cast(float, mu & 0xffff0000u)};
-  const f32x2v r2 = r1 - mf;
-  h = hu; m = mu; l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2p));
-}
-__device__ __forceinline__ void split3_bf16x8(const float (&v)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
-  unsigned hu[4], mu[4], lu[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) split3_pair(v[2 * i], v[2 * i + 1], hu[i], mu[i], lu[i]);
-  h = __builtin_bit_cast(bf16x8, u32x4v{hu[0], hu[1], hu[2], hu[3]});
-  m = __builtin_bit_cast(bf16x8, u32x4v{mu[0], mu[1], mu[2], mu[3]});
-  l = __builtin_bit_cast(bf16x8, u32x4v{lu[0], lu[1], lu[2], lu[3]});
-}
 
 #define MAXCLS 4
 #define MAXTAPS 9
@@ -99,9 +58,6 @@ struct ConvP {
   EpiK e;
 };
 
-static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
-static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // BF = true: the bf16-in / fp32-accumulate form (BASELINE configs[2]).  Activations stay fp32 in HBM; they are rounded to
 // bf16 (RNE) on their way into LDS, the filter arrives pre-packed in bf16 (tbg_weight_pack_bf16) and the contraction runs on
@@ -767,8 +723,6 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   }
 }
 
-// name-only mode (name != NULL): write the instantiation the descriptor selects (rocprofv3 spelling) and launch nothing
-struct NameOut { char *buf; int n; int *dot_slots; int *blocks; };
 
 template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false, bool TM = false, bool X3 = false>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, const NameOut *name) {
@@ -1182,18 +1136,6 @@ extern "C" int tbg_conv2d_x3_kernel_name(const tbg_conv_desc *d, int has_in_scal
 // ============================================================================================
 // weight gradient
 // ============================================================================================
-#define WG_MAXNJ 4
-
-struct WgradP {
-  const float *S, *L, *s_scale, *l_scale, *addw, *addq;
-  float *dW, *ws;
-  float gamma;
-  int B, CS, CL, Hs, Ws, Hl, Wl, KW, sy, sx, py, px;
-  int st_t, st_l, st_s;
-  float alpha;
-  int logTW, logTHs, NSEG, IHs, IWs, IWp, HALFW, lplane, ppc, NJ, nBG, tilesU, tilesV, nchunks, ksplit;
-};
-
 // ---- float4 staging of one 32 x 2 pixel chunk of a stride-1 3x3 filter gradient (NSEG == 1, Ws % 4 == Wl % 4 == 0, px == 1):
 // the S tile and the interior of the 4 x 34 L halo tile are read as float4 (4 + 8 loads per lane instead of 16 + 48 scalars),
 // the two halo columns as scalars, all issued together (the compiler merges the two source-level rounds: 241 VGPRs, no
@@ -2113,102 +2055,6 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(const WgradP p) {
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r16 = 0; r16 < 16; ++r16) wsp[(t * 16 + r16) * 256 + tid] = acc[t][r16];
-}
-
-// few output tiles, many partials: one block per (tile, tap, accumulator register) -- 16x more blocks than the
-// transposing kernel below, scattered 4-byte stores
-template <int WGS, int WGL, int NT>
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_wide_kernel(const WgradP p) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ws_ = wave / WGL, wl = wave - ws_ * WGL;
-  const int cs0 = blockIdx.x * (WGS * 32), cl0 = blockIdx.y * (WGL * 32);
-  const int tr = blockIdx.z;  // (t, r16)
-  const int t = tr >> 4, r16 = tr & 15;
-  const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-  const size_t per_split = (size_t)gridDim.x * gridDim.y;
-  float a = 0.f;
-  const float *src = p.ws + tile * (size_t)(NT * 16 * 256) + (size_t)tr * 256 + tid;
-  const size_t kstride = per_split * (size_t)(NT * 16 * 256);
-  int kz = 0;
-  for (; kz + 16 <= p.ksplit; kz += 16) {  // 16 partial tiles in flight per lane; summed in split order (deterministic)
-    float v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(kz + u) * kstride];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) a += v[u];
-  }
-  for (; kz + 4 <= p.ksplit; kz += 4) {
-    float v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(kz + u) * kstride];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) a += v[u];
-  }
-  for (; kz < p.ksplit; ++kz) a += src[(size_t)kz * kstride];
-  const int cl = cl0 + wl * 32 + (lane & 31);
-  const int cs = cs0 + ws_ * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
-  if (cl < p.CL && cs < p.CS)
-  {
-    const long long iq = (long long)cl * p.st_l + (long long)cs * p.st_s, idx = (long long)t * p.st_t + iq;
-    float v = a * p.alpha;
-    if (p.addw) v += p.gamma * p.addw[idx] * p.addq[iq];
-    p.dW[idx] = v;
-  }
-}
-
-// sum the ksplit partial tiles of one (output tile, tap) and write dW (alpha applied once).  The 64x64 tile is
-// transposed through LDS so that the dW rows are written as contiguous runs along whichever of (cs, cl) has unit stride.
-template <int WGS, int WGL, int NT>
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradP p) {
-  constexpr int BS = WGS * 32, BL = WGL * 32;
-  __shared__ float tile[BL][BS + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ws_ = wave / WGL, wl = wave - ws_ * WGL;
-  const int cs0 = blockIdx.x * BS, cl0 = blockIdx.y * BL;
-  const int t = blockIdx.z;
-  const size_t tl = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-  const size_t per_split = (size_t)gridDim.x * gridDim.y;
-  float a[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = 0.f;
-  int kz = 0;
-  for (; kz + 2 <= p.ksplit; kz += 2) {  // 32 independent coalesced loads in flight
-    const float *s0 = p.ws + ((size_t)kz * per_split + tl) * (size_t)(NT * 16 * 256) + (size_t)t * 16 * 256 + tid;
-    const float *s1 = s0 + per_split * (size_t)(NT * 16 * 256);
-    float v0[16], v1[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { v0[r] = s0[r * 256]; v1[r] = s1[r * 256]; }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { a[r] += v0[r]; a[r] += v1[r]; }
-  }
-  for (; kz < p.ksplit; ++kz) {
-    const float *src = p.ws + ((size_t)kz * per_split + tl) * (size_t)(NT * 16 * 256) + (size_t)t * 16 * 256 + tid;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] += src[r * 256];
-  }
-  const int cl_l = wl * 32 + (lane & 31);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) tile[cl_l][ws_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = a[r];
-  __syncthreads();
-  const bool s_fast = p.st_s == 1 || p.st_l != 1;
-  for (int idx = tid; idx < BS * BL; idx += 256) {
-    const int cl = s_fast ? idx / BS : idx % BL;
-    const int cs = s_fast ? idx % BS : idx / BL;
-    if (cl0 + cl < p.CL && cs0 + cs < p.CS)
-    {
-      const long long iq = (long long)(cl0 + cl) * p.st_l + (long long)(cs0 + cs) * p.st_s, idx = (long long)t * p.st_t + iq;
-      float v = tile[cl][cs] * p.alpha;
-      if (p.addw) v += p.gamma * p.addw[idx] * p.addq[iq];
-      p.dW[idx] = v;
-    }
-  }
-}
-
-static int wgrad_ksplit(int tiles, int nchunks, int blocks = 512) {
-  int ksplit = ceil_div(blocks, tiles);  // 512: ~2 resident blocks per CU
-  if (ksplit > nchunks) ksplit = nchunks;
-  if (ksplit < 1) ksplit = 1;
-  return ksplit;
 }
 
 template <int WGS, int WGL, int NT, int PIX, bool GRP, int VEC = 0>

@@ -1,0 +1,319 @@
+// Convolution operands in the 8-CHANNEL-UNIT layout, and the kernels that consume them without a staging pass.
+//
+// Unit tensor of an activation x[B][C][H][W] (tbg.h "unit tensors"):
+//     U[plane][b][c/8][1 + y][1 + x][c % 8]   bf16,   planes = 1 (bf16 mode: RNE(x)) or 3 (f32x3: hi | mid | lo, split3)
+// i.e. one 16-byte UNIT = 8 consecutive channels of one pixel, rows of W + 2 units, H + 2 rows: a ring of ZERO units
+// around every (b, c/8) plane, channels past C zero.  Why this layout:
+//   * a 16-byte unit is the LDS-DMA granule (global_load_lds_dwordx4: 16 B per lane, lane-linear LDS image, arbitrary per-lane
+//     source address), so ANY tile -- halo included, the padding served by the zero ring -- goes HBM -> LDS with no staging
+//     registers and no VALU work: the x * s modulation, the fp32 -> 3 x bf16 split and the bf16 rounding were done ONCE by
+//     the producer instead of once per consumer tile (conv.hip re-does them in every forward, data-gradient and
+//     filter-gradient launch: 25-40 % of those kernels);
+//   * forward / data gradient contract over CHANNELS: the unit is one ds_read_b128 MFMA operand (K = 8 channels per half-wave);
+//   * the filter gradient contracts over PIXELS: gfx950's transposing LDS read (ds_read_b64_tr_b16) turns a [4 pixels][16
+//     channels] block of the same image into "4 consecutive pixels of one channel per lane", so the SAME tensor feeds it --
+//     and a tap shift is an address offset (the NCHW bf16 form needed a 10-pixel window cut with v_alignbit per tap row).
+#include "conv_common.h"
+
+#define UNIT_RING 1
+
+static inline long long units_per_plane(int B, int C, int H, int W) {
+  return (long long)B * ((C + 7) / 8) * (H + 2 * UNIT_RING) * (W + 2 * UNIT_RING);
+}
+
+extern "C" long long tbg_units_bytes(int B, int C, int H, int W, int planes) {
+  if (B < 1 || C < 1 || H < 1 || W < 1 || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  return units_per_plane(B, C, H, W) * planes * 16;
+}
+
+// ---- producer of last resort: NCHW fp32 (x optional per-(b,c) scale) -> unit tensor, ring and channel tail included.
+// One lane per unit: 8 channel loads (each coalesced along x across the wave), one 16-byte store per plane.
+template <int NP>
+__global__ __launch_bounds__(256) void units_pack_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                         bf16x8 *__restrict__ U, int B, int C, int H, int W, long long plane) {
+  const int Wp = W + 2, Hp = H + 2, C8 = (C + 7) >> 3;
+  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= plane) return;
+  const int xp = (int)(n % Wp);
+  long long t = n / Wp;
+  const int yp = (int)(t % Hp);
+  t /= Hp;
+  const int cu = (int)(t % C8), b = (int)(t / C8);
+  const bool inside = xp >= 1 && xp <= W && yp >= 1 && yp <= H;
+  float v[8];
+  const long long HW = (long long)H * W;
+  const long long g0 = ((long long)b * C + cu * 8) * HW + (long long)(yp - 1) * W + (xp - 1);
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    const bool ok = inside && cu * 8 + cc < C;
+    float a = x[ok ? g0 + cc * HW : 0];
+    if (scale) a *= scale[ok ? b * C + cu * 8 + cc : 0];
+    v[cc] = ok ? a : 0.f;
+  }
+  if constexpr (NP == 3) {
+    bf16x8 h, m, l;
+    split3_bf16x8(v, h, m, l);
+    U[n] = h; U[plane + n] = m; U[2 * plane + n] = l;
+  } else {
+    U[n] = pack_bf16x8(v);
+  }
+}
+
+extern "C" int tbg_units_pack_f32(const float *x, const float *scale, void *U, int B, int C, int H, int W, int planes,
+                                  void *stream) {
+  if (!x || !U || B < 1 || C < 1 || H < 1 || W < 1 || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(U) & 15) != 0) return TBG_EINVAL;
+  const long long plane = units_per_plane(B, C, H, W);
+  if (plane * 8 > 2147483647LL || (long long)B * C * H * W > 2147483647LL) return TBG_ERANGE;
+  const dim3 grid((unsigned)((plane + 255) / 256));
+  if (planes == 3)
+    hipLaunchKernelGGL(units_pack_kernel<3>, grid, dim3(256), 0, tbg_stream(stream), x, scale, reinterpret_cast<bf16x8 *>(U), B, C,
+                       H, W, plane);
+  else
+    hipLaunchKernelGGL(units_pack_kernel<1>, grid, dim3(256), 0, tbg_stream(stream), x, scale, reinterpret_cast<bf16x8 *>(U), B, C,
+                       H, W, plane);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// ============================================================================================
+// filter gradient from unit tensors (3x3, stride 1, pad 1)
+// ============================================================================================
+// dW[t][cl][cs] = sum_{b,u,v} S[b,cs,u,v] * L[b,cl,u-1+kh,v-1+kw] with S, L given as unit tensors (their scales / splits already
+// inside).  Block = 64 S-channels x 64 L-channels, wave = 32 x 32 with the 9 taps as 9 accumulators (144 registers), K = pixels in
+// chunks of 2 rows x 32 columns -- the block / wave / partial-tile structure of conv_wgrad_x3_kernel, so the reduce kernels are
+// shared.  What differs: the chunk's tiles (S: 8 units x 64 pixels, L: 8 units x 4 x 34 halo positions, per plane) arrive by
+// LDS-DMA into one of TWO buffers (the NCHW kernel's split + store pass, ~3400 cycles per chunk with one wave per SIMD, is gone:
+// the DMA of chunk k+1 is issued between the MFMAs of chunk k), and the MFMA operands are read with ds_read_b64_tr_b16.
+//
+// LDS image of one buffer, in 16-byte units:  S rows [plane][8][S_ROW = 68]  then  L rows [plane][8][L_ROW = 140]
+// (64 / 136 used: the row pitches put the four channel units a transposing read touches on disjoint banks).  The whole
+// buffer is ONE lane-linear DMA target of BUF/64 pieces; which global unit a lane fetches for a piece does not depend on the
+// chunk (only a wave-uniform base does), so the per-lane source offsets are computed once.
+struct WgUnitsP {
+  const char *SU, *LU;
+  long long s_plane, l_plane;  // units per plane
+  int CS8, CL8, Hps, Wps, Hpl, Wpl;
+  int tilesU, tilesV, nchunks, ksplit;
+  float *ws;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to the lane-linear LDS range starting at the
+// wave-uniform byte address `lds_base` (M0).  Inline assembly ON PURPOSE: hipcc's waitcnt pass treats a
+// __builtin_amdgcn_global_load_lds in flight as a pending write to ALL of LDS and puts s_waitcnt vmcnt(0) in front of every
+// later LDS read -- including the operand reads of the OTHER buffer, which serialises the DMA with the MFMA phase it is
+// meant to hide under (seen in the ISA of this kernel's builtin form, and in conv.hip's split-filter pipeline).
+// The kernel orders the pieces itself: s_waitcnt vmcnt(0) + s_barrier before a buffer is read.
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
+}
+
+template <int NP>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_units_kernel(const WgUnitsP p) {
+  constexpr int S_ROW = 68, L_ROW = 140, NT = 9;
+  constexpr int S_UNITS = NP * 8 * S_ROW, L_UNITS = NP * 8 * L_ROW, BUF = S_UNITS + L_UNITS;
+  static_assert(BUF % 64 == 0, "the buffer is a whole number of 64-unit DMA pieces");
+  constexpr int NPIECE = BUF / 64, PPW = (NPIECE + 3) / 4;
+  constexpr int NQ = NP == 3 ? 6 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][BUF] units
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ws = wave >> 1, wl = wave & 1;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+
+  // ---- DMA descriptors of this wave's pieces (piece q = wave + 4 k): source offset in units relative to the chunk base of
+  // its tensor, and which tensor.  Pad slots of a row are never read: they fetch the row's first unit.
+  int doff[PPW];
+  unsigned isl = 0;
+#pragma unroll
+  for (int k = 0; k < PPW; ++k) {
+    const int n = (wave + 4 * k) * 64 + lane;
+    int off = 0;
+    if (n < S_UNITS) {
+      const int row = n / S_ROW, pix = min(n - row * S_ROW, 63);
+      const int pl = row >> 3, su = row & 7;
+      off = (int)(pl * p.s_plane) + (su * p.Hps + (pix >> 5)) * p.Wps + (pix & 31);
+    } else if (n < BUF) {
+      const int m = n - S_UNITS;
+      const int row = m / L_ROW, pos = min(m - row * L_ROW, 135);
+      const int pl = row >> 3, lu = row & 7;
+      const int r = pos / 34, c = pos - r * 34;
+      off = (int)(pl * p.l_plane) + (lu * p.Hpl + r) * p.Wpl + c;
+      isl |= 1u << k;
+    }
+    doff[k] = off;
+  }
+  const int cs8 = blockIdx.x * 8, cl8 = blockIdx.y * 8;
+
+  auto chunk_bases = [&](int chunk, int &sb, int &lb) {
+    const int tv = chunk % p.tilesV;
+    const int t2 = chunk / p.tilesV;
+    const int tu = t2 % p.tilesU, b = t2 / p.tilesU;
+    const int u0 = tu * 2, v0 = tv * 32;
+    sb = ((b * p.CS8 + cs8) * p.Hps + u0 + 1) * p.Wps + v0 + 1;  // interior starts at (1, 1)
+    lb = ((b * p.CL8 + cl8) * p.Hpl + u0) * p.Wpl + v0;          // halo: y = u0 - 1 -> padded row u0
+  };
+  // (branch-free: a wave whose last slot is past the buffer re-issues its previous piece -- same bytes to the same place)
+  auto issue_piece = [&](int k, int sb, int lb, int buf) {
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int kk = (wv + 4 * k < NPIECE) ? k : k - 1;
+    const int q = wv + 4 * kk;
+    const bool l = (isl >> kk) & 1u;
+    const char *src = (l ? p.LU : p.SU) + ((long long)((l ? lb : sb) + (kk == k ? doff[k] : doff[k > 0 ? k - 1 : 0])) << 4);
+    dma16(src, lds0 + (unsigned)((buf * BUF + q * 64) * 16));
+  };
+
+  // ---- operand addressing.  A transposing read serves 16 lanes with a [4 pixels][16 channels] block: lane i of the group
+  // supplies the address of (pixel j = i / 4, channels 4 (i % 4) .. + 3) = half a unit, and receives channel i at the 4 pixels.
+  // Groups 0 / 1 = channels 0-15 / 16-31 of the wave's 32 at K half 0, groups 2 / 3 the same at K half 1 (pixels + 8): two
+  // reads (pixels +0..3, +4..7) make one v_mfma_f32_32x32x16_bf16 operand.
+  const int i16 = lane & 15, grp = lane >> 4;
+  const int jj = i16 >> 2, cq = i16 & 3, chblk = grp & 1, khalf = grp >> 1;
+  const int a_lane = ((ws * 4 + chblk * 2 + (cq >> 1)) * S_ROW + 8 * khalf + jj) * 16 + (cq & 1) * 8;
+  const int b_lane = S_UNITS * 16 + ((wl * 4 + chblk * 2 + (cq >> 1)) * L_ROW + 8 * khalf + jj) * 16 + (cq & 1) * 8;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto rd = [&](const char *ptr) -> bf16x8 {  // 8 consecutive pixels of this lane's channel
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(ptr));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(ptr + 64));
+    return __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+  };
+
+  int chunk = blockIdx.z;
+  int sb = 0, lb = 0;
+  if (chunk < p.nchunks) {
+    chunk_bases(chunk, sb, lb);
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) issue_piece(k, sb, lb, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  for (; chunk < p.nchunks; chunk += p.ksplit) {
+    // tiles of the next chunk -> the other buffer (the last chunk re-fetches itself: no branch in the loop body)
+    chunk_bases(chunk + p.ksplit < p.nchunks ? chunk + p.ksplit : chunk, sb, lb);
+    const char *Ab = smem + (size_t)buf * BUF * 16 + a_lane;
+    const char *Bb = smem + (size_t)buf * BUF * 16 + b_lane;
+    // 12 steps of (16-pixel group g, filter row kh), 6 x 3 MFMAs each.  The instruction stream is laid out by hand and pinned
+    // (one sched_barrier per MFMA): with ONE wave per SIMD nothing else fills the matrix pipe while this wave issues anything
+    // else, so every LDS read of step i+1 (two register sets) and every DMA piece of the next chunk sits in the shadow of an
+    // MFMA of step i -- never in a block of its own between two steps.
+    constexpr int NST = 12, NM = NQ * 3;
+    constexpr int DMA_PER_STEP = (PPW + NST - 1) / NST;
+    bf16x8 a[2][NP], bv[2][NP][3];
+    auto ld1 = [&](int st, int bs, int idx) {  // load idx of step st's operand set: the 3 NP B operands, then (kh == 0) the NP A operands
+      const int g = st / 3, kh = st - 3 * g;
+      if (idx < 3 * NP) {
+        const int pl = idx / 3, kw = idx - 3 * pl;
+        bv[bs][pl][kw] = rd(Bb + (pl * 8 * L_ROW + ((g >> 1) + kh) * 34 + (g & 1) * 16 + kw) * 16);
+      } else if (kh == 0 && idx < 4 * NP) {
+        const int pl = idx - 3 * NP;
+        a[g & 1][pl] = rd(Ab + (pl * 8 * S_ROW + 16 * g) * 16);
+      }
+    };
+#pragma unroll
+    for (int idx = 0; idx < 4 * NP; ++idx) ld1(0, 0, idx);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int bs = st & 1, g = st / 3, kh = st - 3 * g;
+      __builtin_amdgcn_sched_barrier(0);
+      // six partial products per tap, smallest first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const int q = m / 3, kw = m - 3 * q;
+        acc[3 * kh + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g & 1][NP == 3 ? PA[q] : 0], bv[bs][NP == 3 ? PB[q] : 0][kw],
+                                                                   acc[3 * kh + kw], 0, 0, 0);
+        // behind this MFMA: one operand load of the next step (NM >= 4 NP slots only in f32x3; bf16 doubles up) ...
+        if (st + 1 < NST) {
+          constexpr int LPM = (4 * NP + NM - 1) / NM;
+#pragma unroll
+          for (int e = 0; e < LPM; ++e) ld1(st + 1, bs ^ 1, m * LPM + e);
+        }
+        // ... and the step's DMA pieces behind its 2nd, 8th, ... MFMA
+        if (m % 6 == 1 && st * DMA_PER_STEP + m / 6 < PPW && m / 6 < DMA_PER_STEP) issue_piece(st * DMA_PER_STEP + m / 6, sb, lb, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's tiles have landed
+    __syncthreads();                                   // ... for every wave, and every wave is done with this buffer
+    buf ^= 1;
+  }
+
+  const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float *wsp = p.ws + blk * (size_t)(NT * 16 * 256);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r16 = 0; r16 < 16; ++r16) wsp[(t * 16 + r16) * 256 + tid] = acc[t][r16];
+}
+
+// geometry the unit kernel takes: 3x3, stride 1, pad 1, whole 2 x 32-pixel chunks, whole 64-channel tiles
+static bool wgrad_units_ok(const tbg_wgrad_desc *d) {
+  return d->KH == 3 && d->KW == 3 && d->sy == 1 && d->sx == 1 && d->py == 1 && d->px == 1 && d->Hl == d->Hs && d->Wl == d->Ws &&
+         (d->Ws % 32) == 0 && (d->Hs % 2) == 0 && (d->CS % 64) == 0 && (d->CL % 64) == 0;
+}
+
+static int wgrad_units_ksplit(const tbg_wgrad_desc *d) {
+  const int tiles = (d->CS / 64) * (d->CL / 64);
+  const int nchunks = d->B * (d->Hs / 2) * (d->Ws / 32);
+  return wgrad_ksplit(tiles, nchunks, 256);  // one block per CU (two 78 KB LDS buffers)
+}
+
+extern "C" long long tbg_conv2d_wgrad_units_workspace_bytes(const tbg_wgrad_desc *d) {
+  if (!d || d->B < 1 || d->CS < 1 || d->CL < 1 || d->Hs < 1 || d->Ws < 1) return TBG_EINVAL;
+  if (!wgrad_units_ok(d)) return TBG_EUNSUPPORTED;
+  return (long long)wgrad_units_ksplit(d) * (d->CS / 64) * (d->CL / 64) * 9 * 16 * 256 * (long long)sizeof(float);
+}
+
+template <int NP>
+static int launch_wgrad_units(WgUnitsP &u, WgradP &p, hipStream_t st, const char **name) {
+  if (name) { *name = NP == 3 ? "conv_wgrad_units_kernel<3>" : "conv_wgrad_units_kernel<1>"; return TBG_OK; }
+  constexpr int BUF = NP * 8 * (68 + 140);
+  const size_t lds = (size_t)2 * BUF * 16;
+  auto kern = conv_wgrad_units_kernel<NP>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return TBG_EHIP;
+  const int tx = p.CS / 64, ty = p.CL / 64;
+  hipLaunchKernelGGL(kern, dim3(tx, ty, u.ksplit), dim3(256), lds, st, u);
+  TBG_LAUNCH_CHECK();
+  if (tx * ty * 9 >= 256)
+    hipLaunchKernelGGL((conv_wgrad_reduce_kernel<2, 2, 9>), dim3(tx, ty, 9), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_reduce_wide_kernel<2, 2, 9>), dim3(tx, ty, 9 * 16), dim3(256), 0, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_conv2d_wgrad_units(const tbg_wgrad_desc *d, const void *SU, const void *LU, int planes, float *dW,
+                                      const float *addw, const float *addq, float gamma, float *workspace,
+                                      long long workspace_bytes, void *stream) {
+  if (!d || !SU || !LU || !dW || !workspace || ((addw == nullptr) != (addq == nullptr)) || (planes != 1 && planes != 3))
+    return TBG_EINVAL;
+  if (d->B < 1 || d->CS < 1 || d->CL < 1 || d->Hs < 1 || d->Ws < 1 || d->Hl < 1 || d->Wl < 1) return TBG_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(SU) | reinterpret_cast<uintptr_t>(LU)) & 15) != 0) return TBG_EINVAL;
+  if (!wgrad_units_ok(d)) return TBG_EUNSUPPORTED;
+  const long long s_plane = units_per_plane(d->B, d->CS, d->Hs, d->Ws), l_plane = units_per_plane(d->B, d->CL, d->Hl, d->Wl);
+  if (s_plane * planes > 2147483647LL / 2 || l_plane * planes > 2147483647LL / 2) return TBG_ERANGE;
+  WgUnitsP u{};
+  u.SU = reinterpret_cast<const char *>(SU); u.LU = reinterpret_cast<const char *>(LU);
+  u.s_plane = s_plane; u.l_plane = l_plane;
+  u.CS8 = d->CS / 8; u.CL8 = d->CL / 8;
+  u.Hps = d->Hs + 2; u.Wps = d->Ws + 2; u.Hpl = d->Hl + 2; u.Wpl = d->Wl + 2;
+  u.tilesU = d->Hs / 2; u.tilesV = d->Ws / 32;
+  u.nchunks = d->B * u.tilesU * u.tilesV;
+  u.ksplit = wgrad_units_ksplit(d);
+  u.ws = workspace;
+  if ((long long)u.ksplit * (d->CS / 64) * (d->CL / 64) * 9 * 16 * 256 * (long long)sizeof(float) > workspace_bytes) return TBG_EINVAL;
+  WgradP p{};  // what the reduce kernels read
+  p.CS = d->CS; p.CL = d->CL; p.st_t = d->st_t; p.st_l = d->st_l; p.st_s = d->st_s; p.alpha = d->alpha;
+  p.dW = dW; p.ws = workspace; p.addw = addw; p.addq = addq; p.gamma = gamma; p.ksplit = u.ksplit;
+  return planes == 3 ? launch_wgrad_units<3>(u, p, tbg_stream(stream), nullptr) : launch_wgrad_units<1>(u, p, tbg_stream(stream), nullptr);
+}

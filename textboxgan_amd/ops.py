@@ -367,6 +367,59 @@ def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, o
     return out
 
 
+class UnitTensor(NamedTuple):
+    """an activation in the 8-channel-unit layout (tbg.h "unit tensors"): U[planes][B][ceil(C/8)][H+2][W+2][8] bf16 -- the form
+    the matrix-core kernels DMA straight into LDS.  planes = 3: f32x3 terms (hi | mid | lo), 1: bf16."""
+    data: torch.Tensor  # flat bf16
+    B: int
+    C: int
+    H: int
+    W: int
+    planes: int
+
+
+def unit_planes(fmt=None) -> int:
+    fmt = _FMT[_TLS.compute] if fmt is None else fmt
+    return {FMT_BF16: 1, FMT_X3: 3}[fmt]
+
+
+def units_pack(x: torch.Tensor, scale: Optional[torch.Tensor] = None, planes: Optional[int] = None) -> UnitTensor:
+    """x [B,C,H,W] fp32 (x scale[b,c]) -> its unit tensor (stand-alone producer; fused producers write it from their epilogue)."""
+    B, Cc, H, W = x.shape
+    planes = unit_planes() if planes is None else planes
+    nbytes = N.lib().tbg_units_bytes(B, Cc, H, W, planes)
+    N.check(min(nbytes, 0), "tbg_units_bytes")
+    U = torch.empty(nbytes // 2, device=x.device, dtype=torch.bfloat16)
+    N.check(PROFILE.launch("units_pack_kernel", 0.0, lambda: N.lib().tbg_units_pack_f32(
+        N.ptr(x), N.ptr(scale), N.ptr(U), B, Cc, H, W, planes, N.stream()), nbytes=4.0 * x.numel() + nbytes), "tbg_units_pack")
+    return UnitTensor(U, B, Cc, H, W, planes)
+
+
+def wgrad_units_ok(CS, CL, Hs, Ws, Hl, Wl, KH, KW, stride, pad) -> bool:
+    """geometry of tbg_conv2d_wgrad_units (3x3 stride-1 pad-1 layers with whole 2 x 32-pixel chunks and 64-channel tiles)"""
+    return (KH == 3 and KW == 3 and tuple(stride) == (1, 1) and tuple(pad) == (1, 1) and (Hl, Wl) == (Hs, Ws) and Ws % 32 == 0
+            and Hs % 2 == 0 and CS % 64 == 0 and CL % 64 == 0)
+
+
+def wgrad_units_raw(SU: UnitTensor, LU: UnitTensor, out: torch.Tensor, st_t: int, st_l: int, st_s: int, alpha: float,
+                    out_offset: int = 0, add=None):
+    """filter gradient of a 3x3 stride-1 pad-1 convolution from the unit tensors of S (output-grid tensor, scale inside) and
+    L (input-grid tensor, scale inside).  Overwrites ``out`` like wgrad_raw."""
+    assert SU.planes == LU.planes and SU.B == LU.B
+    d = N.WgradDesc(SU.B, SU.C, LU.C, SU.H, SU.W, LU.H, LU.W, 3, 3, 1, 1, 1, 1, st_t, st_l, st_s, alpha)
+    nbytes = N.lib().tbg_conv2d_wgrad_units_workspace_bytes(C.byref(d))
+    N.check(min(nbytes, 0), "tbg_conv2d_wgrad_units_workspace_bytes")
+    ws = _workspace(out.device, nbytes)
+    addw, addq, gamma = add if add is not None else (None, None, 0.0)
+    _flops = 2.0 * SU.B * SU.C * LU.C * SU.H * SU.W * 9
+    N.check(PROFILE.launch(f"conv_wgrad_units_kernel<{SU.planes}>", _flops, lambda: N.lib().tbg_conv2d_wgrad_units(
+        C.byref(d), N.ptr(SU.data), N.ptr(LU.data), SU.planes, N.ptr(out) + 4 * out_offset,
+        (N.ptr(addw) + 4 * out_offset) if addw is not None else None, N.ptr(addq), gamma, N.ptr(ws), ws.numel() * 4, N.stream()),
+        f"wgrad_units[B={SU.B} CS={SU.C} CL={LU.C} {SU.H}x{SU.W}]",
+        2.0 * SU.planes * (SU.data.numel() + LU.data.numel()) / SU.planes + 36.0 * SU.C * LU.C), "tbg_conv2d_wgrad_units")
+    return out
+
+
 HAVE_WGRAD_X3 = True  # tbg_conv2d_wgrad_x3 (falls back to the exact fp32 kernel inside the library for the small geometries)
 
 

@@ -1,0 +1,30 @@
+"""isolated timings of the unit-tensor kernels against the NCHW kernels they replace: python tools/bench_units.py [B]"""
+import sys, torch
+sys.path.insert(0, ".")
+from textboxgan_amd import ops
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+for (C, M, H, W) in [(128, 128, 64, 256), (128, 128, 32, 128), (256, 256, 16, 64), (512, 512, 8, 32), (64, 64, 64, 256)]:
+    x, dy = torch.randn(B, C, H, W, device=dev), torch.randn(B, M, H, W, device=dev)
+    xs, ds = torch.rand(B, C, device=dev) + 0.5, torch.rand(B, M, device=dev) + 0.5
+    dw = torch.empty(3, 3, C, M, device=dev)
+    g = ops._Geom((1, 1), (1, 1), 3, 3, (H, W), (H, W))
+    fl = 2.0 * B * C * M * H * W * 9
+    row = f"B={B} {C}->{M} {H}x{W}:"
+    for mode, planes in (("f32x3", 3), ("bf16", 1)):
+        with ops.compute_dtype(mode):
+            t_old = timeit(lambda: ops._bwd_weight_launch(x, dy, g, C, M, alpha=1.0, x_scale=xs, dy_scale=ds))
+        t_pack = timeit(lambda: ops.units_pack(x, xs, planes=planes))
+        SU, LU = ops.units_pack(dy, ds, planes=planes), ops.units_pack(x, xs, planes=planes)
+        t_new = timeit(lambda: ops.wgrad_units_raw(SU, LU, dw, C * M, M, 1, 1.0))
+        row += (f"  [{mode}] nchw {t_old:7.1f} us ({fl / t_old / 1e6:6.1f} TF)  units {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF)"
+                f"  pack {t_pack:6.1f} us ({(4 + 2 * planes) * x.numel() / t_pack / 1e6:5.2f} TB/s)")
+    print(row, flush=True)
