@@ -285,6 +285,15 @@ int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, const void *w,
 long long tbg_units_bytes(int B, int C, int H, int W, int planes);
 int tbg_units_pack_f32(const float *x, const float *scale, void *U, int B, int C, int H, int W, int planes, void *stream);
 
+/* Forward / data-gradient convolution from a unit tensor: tbg_conv2d_x3 (planes = 3) / tbg_conv2d_bf16 (planes = 1) with the
+ * input given as the unit tensor XU of x * in_scale (so there is no in_scale argument) -- same descriptor, packed filter
+ * (tbg_weight_pack_x3 / tbg_weight_pack_bf16), epilogue (fused dot included: tbg_conv2d_units_dot_slots slots per (b, m)) and
+ * fp32 NCHW output.  Geometry: 3x3, stride 1, pad 1, not transposed, Hin % 8 == 0, Win % 32 == 0, M % 64 == 0, C % 8 == 0
+ * (planes = 1: C % 16 == 0), ksplit == 1 -- TBG_EUNSUPPORTED otherwise (the caller keeps the NCHW entry for those). */
+int tbg_conv2d_units_dot_slots(const tbg_conv_desc *d, int planes);
+int tbg_conv2d_units(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
+                     const tbg_epilogue *epi, void *stream);
+
 /* Filter gradient from unit tensors: tbg_conv2d_wgrad_ex_f32's result (same descriptor, dW strides, alpha, addw / addq /
  * gamma) with S and L given as unit tensors SU (of [B,CS,Hs,Ws]) and LU (of [B,CL,Hl,Wl]) of `planes` planes each (their
  * scales already inside).  planes = 3: f32x3 arithmetic (six products per tap, fp32 accumulate); planes = 1: bf16 operands.

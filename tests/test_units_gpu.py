@@ -97,3 +97,60 @@ def test_wgrad_units_refuses_other_geometries(dev):
               N.WgradDesc(2, 64, 72, 8, 32, 8, 32, 3, 3, 1, 1, 1, 1, 72 * 64, 64, 1, 1.0),      # partial channel tile
               N.WgradDesc(2, 64, 64, 8, 32, 17, 65, 3, 3, 2, 2, 0, 0, 64 * 64, 64, 1, 1.0)):    # strided
         assert N.lib().tbg_conv2d_wgrad_units_workspace_bytes(C.byref(d)) == -4  # TBG_EUNSUPPORTED
+
+
+CONV_UNITS = [(2, 64, 64, 8, 32), (2, 128, 64, 16, 64), (3, 128, 192, 8, 96), (1, 256, 256, 16, 64), (2, 64, 64, 64, 256)]
+
+
+@pytest.mark.parametrize("mode", ["f32x3", "bf16"])
+@pytest.mark.parametrize("case", CONV_UNITS, ids=[str(c) for c in CONV_UNITS])
+def test_conv_units_matches_float64_and_the_nchw_kernel(dev, mode, case):
+    """tbg_conv2d_units (all-DMA staging from the unit tensor, double-buffered tiles, 512-thread blocks) with the full fused
+    epilogue (demodulation, noise, bias, LeakyReLU) and, as a data gradient, with flip + out_scale + the fused dot product:
+    against float64 on the operands the kernels see at the NCHW kernels' bar, and against the NCHW kernel of the same
+    arithmetic (same products, same accumulation order)."""
+    import torch.nn.functional as F
+    B, C, M, H, W = case
+    if mode == "bf16" and C % 16:
+        pytest.skip("bf16 units need whole 16-channel chunks")
+    planes = 3 if mode == "f32x3" else 1
+    x, w = _rnd(B, C, H, W, seed=1), _rnd(3, 3, C, M, seed=2) / math.sqrt(9 * C)
+    s, dmod = _rnd(B, C, seed=3).abs() + 0.5, _rnd(B, M, seed=4).abs() + 0.5
+    noise, bias = _rnd(B, 1, H, W, seed=5), _rnd(M, seed=6) * 0.2
+    f = lambda t: t.float().to(dev).contiguous()
+    xd, wd, sd, dd, nd, bd = f(x), f(w), f(s), f(dmod), f(noise), f(bias)
+    strength = torch.tensor(0.3, device=dev)
+    xs = (xd * sd[:, :, None, None])
+    w_ref = wd.double().cpu()
+    if mode == "bf16":
+        xs, w_ref = xs.bfloat16().float(), wd.bfloat16().double().cpu()
+    with ops.compute_dtype(mode):
+        assert ops.conv_units_ok(C, M, H, W, 3, 3, (1, 1), (1, 1), False, planes)
+        XU = ops.units_pack(xd, sd, planes=planes)
+        pf = ops.pack_filter(wd, False, False)
+        epi = lambda: N.epilogue(out_scale=dd, bias=bd, noise=nd, strength=strength, alpha=0.9, act=N.ACT_LRELU)
+        y = ops.conv2d_units_raw(XU, pf, M, epi=epi())
+        y_nchw = ops.conv2d_raw(xd, pf, M, 3, 3, (H, W), (1, 1), (1, 1), in_scale=sd, epi=epi(), allow_split=False)
+        pre = 0.9 * F.conv2d(xs.double().cpu(), w_ref.permute(3, 2, 0, 1), padding=1) * dd.double().cpu()[:, :, None, None]
+        pre = pre + nd.double().cpu() * 0.3 + bd.double().cpu()[None, :, None, None]
+        ref = F.leaky_relu(pre, 0.2) * math.sqrt(2.0)
+        err, dn = _rel(y, ref), float((y - y_nchw).abs().max() / y_nchw.abs().max())
+        # data-gradient form: transposed + flipped pack, per-(b, channel) output scale, fused dot with a second tensor
+        dy, aux = f(_rnd(B, M, H, W, seed=7)), f(_rnd(B, C, H, W, seed=8))
+        DU = ops.units_pack(dy, dd, planes=planes)
+        pft = ops.pack_filter(wd, True, True)
+        dot_u, dot_n = torch.empty(B, C, device=dev), torch.empty(B, C, device=dev)
+        dx = ops.conv2d_units_raw(DU, pft, C, epi=N.epilogue(out_scale=sd), dot=(aux, dot_u))
+        dx_n = ops.conv2d_raw(dy, pft, C, 3, 3, (H, W), (1, 1), (1, 1), in_scale=dd, epi=N.epilogue(out_scale=sd), dot=(aux, dot_n),
+                              allow_split=False)
+        dys = dy * dd[:, :, None, None]
+        if mode == "bf16":
+            dys = dys.bfloat16().float()
+        gref = F.conv_transpose2d(dys.double().cpu(), w_ref.permute(3, 2, 0, 1), padding=1)
+        dref = (gref * aux.double().cpu()).sum((2, 3))
+        gref = gref * sd.double().cpu()[:, :, None, None]
+        errs = (err, _rel(dx, gref), _rel(dot_u, dref))
+        dns = (dn, float((dx - dx_n).abs().max() / dx_n.abs().max()), float((dot_u - dot_n).abs().max() / dot_n.abs().max()))
+    print(f"\nCONVUNITS {mode} {case}: vs float64 {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}   vs nchw kernel {dns[0]:.1e} {dns[1]:.1e} {dns[2]:.1e}")
+    assert max(errs) < 3e-5, errs
+    assert max(dns) < 2e-6, dns

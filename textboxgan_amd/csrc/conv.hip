@@ -583,10 +583,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     }
   }
 
-  // ---- epilogue.  Every pointer / scalar of the epilogue descriptor is hoisted into locals first, and the loads a row
-  // group needs (demodulation, residual, dot operand) are issued together before any arithmetic or store: the first
-  // version interleaved kernarg reloads, loads and stores element by element (521 s_waitcnt in 6.8k instructions) and
-  // cost 45-80 us per large launch -- more than the output write itself (a 134 MB fill takes 21 us).
+  // ---- epilogue (conv_common.h conv_epilogue)
   const int HWout = p.Hout * p.Wout;
   if constexpr (TM) {  // the four classes of input position (u, v) land on outputs (2u + cy, 2v + cx)
     float *const yb = p.ksplit > 1 ? p.y + (size_t)ks * p.slab : p.y;
@@ -614,19 +611,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     }
     return;
   }
-  const float *const e_os = p.e.out_scale, *const e_bias = p.e.bias, *const e_res = p.e.residual, *const e_aux = p.e.dot_aux;
-  const float *const e_gate = p.e.gate;
-  float *const e_dot = p.e.dot_out;
-  const float e_alpha = p.e.alpha, e_bmul = p.e.bias_mul, e_slope = p.e.slope, e_gain = p.e.gain, e_rscale = p.e.res_scale;
-  const bool e_lrelu = p.e.act == TBG_ACT_LRELU, e_rfirst = p.e.res_first != 0;
-  const float str = p.e.noise ? p.e.strength[0] : 0.f;
-  const bool split = p.ksplit > 1;
-  const bool do_dot = e_aux != nullptr && !split;
-  const bool plain = !e_os && !e_bias && !p.e.noise && !e_res && !e_aux && !e_gate && !e_lrelu && e_gain == 1.f;
-  const int M = p.M;
-  float *const ybase = split ? p.y + (size_t)ks * p.slab : p.y;
   int e_pix[WTN], e_b[WTN];
-  float e_nz[WTN];
 #pragma unroll
   for (int j = 0; j < WTN; ++j) {
     const int n = (wn * WTN + j) * 32 + (lane & 31);
@@ -637,92 +622,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     const int Y = u * p.osy + ci.ooy, X = v * p.osx + ci.oox;
     e_pix[j] = okpix ? Y * p.Wout + X : -1;
     e_b[j] = okpix ? b : 0;
-    e_nz[j] = (okpix && p.e.noise) ? p.e.noise[(size_t)b * HWout + e_pix[j]] * str : 0.f;
-  }
-  if (split || plain) {  // store-only: alpha * acc (split-K slabs, plain data gradients)
-#pragma unroll
-    for (int i = 0; i < WTM; ++i)
-#pragma unroll
-      for (int r16 = 0; r16 < 16; ++r16) {
-        const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
-#pragma unroll
-        for (int j = 0; j < WTN; ++j)
-          if (m < M && e_pix[j] >= 0) ybase[(e_b[j] * M + m) * HWout + e_pix[j]] = acc[0][i][j][r16] * e_alpha;
-      }
-    return;
   }
   constexpr int RG = OCC == 4 ? 2 : 4;  // rows per load batch (register budget: the epilogue must not raise the kernel's allocation)
-#pragma unroll
-  for (int i = 0; i < WTM; ++i) {
-#pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += RG) {  // accumulator rows r0 .. r0+RG-1
-      int idx[RG][WTN];  // output offsets fit 31 bits (checked on the host)
-      int mrow[RG];
-      float bias4[RG], osv[RG][WTN], rsv[RG][WTN], axv[RG][WTN];
-#pragma unroll
-      for (int q = 0; q < RG; ++q) {
-        const int r16 = r0 + q;
-        const int m = m0 + (wm * WTM + i) * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
-        mrow[q] = m;
-        const bool okm = m < M;
-        bias4[q] = (okm && e_bias) ? e_bias[m] * e_bmul : 0.f;
-#pragma unroll
-        for (int j = 0; j < WTN; ++j) {
-          idx[q][j] = (okm && e_pix[j] >= 0) ? (e_b[j] * M + m) * HWout + e_pix[j] : -1;
-          osv[q][j] = 1.f; rsv[q][j] = 0.f; axv[q][j] = 0.f;
-        }
-      }
-      if (e_os) {
-#pragma unroll
-        for (int q = 0; q < RG; ++q)
-#pragma unroll
-          for (int j = 0; j < WTN; ++j) osv[q][j] = e_os[idx[q][j] >= 0 ? e_b[j] * M + mrow[q] : 0];
-      }
-      if (e_res) {
-#pragma unroll
-        for (int q = 0; q < RG; ++q)
-#pragma unroll
-          for (int j = 0; j < WTN; ++j) rsv[q][j] = e_res[max(idx[q][j], 0)];  // clamped: branch-free
-      }
-      if (do_dot) {
-#pragma unroll
-        for (int q = 0; q < RG; ++q)
-#pragma unroll
-          for (int j = 0; j < WTN; ++j) axv[q][j] = e_aux[max(idx[q][j], 0)];
-      } else if (e_gate) {  // never together with the dot operand (epi_valid): the gate values share its registers
-#pragma unroll
-        for (int q = 0; q < RG; ++q)
-#pragma unroll
-          for (int j = 0; j < WTN; ++j) axv[q][j] = e_gate[max(idx[q][j], 0)];
-      }
-#pragma unroll
-      for (int q = 0; q < RG; ++q) {
-        const int m = mrow[q];
-        float dsum = 0.f;
-#pragma unroll
-        for (int j = 0; j < WTN; ++j) {
-          const bool okq = idx[q][j] >= 0;
-          float val = acc[0][i][j][r0 + q] * e_alpha;
-          if (do_dot) dsum += okq ? val * axv[q][j] : 0.f;
-          val = val * osv[q][j] + e_nz[j] + bias4[q];
-          if (e_rfirst) val += rsv[q][j];
-          val = (e_lrelu ? (val > 0.f ? val : val * e_slope) : val) * e_gain;
-          if (e_res && !e_rfirst) val = (val + rsv[q][j]) * e_rscale;
-          if (e_gate) val = axv[q][j] > 0.f ? val : 0.f;
-          if (okq) p.y[idx[q][j]] = val;
-        }
-        if (do_dot) {  // one image per tile (checked on the host): reduce the 32 pixel lanes of each half-wave and store the
-          // partial of this (tile, wave column) in its own slot -- no atomics, the caller sums the slots in a fixed order
-#pragma unroll
-          for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
-          if ((lane & 31) == 0 && m < M && bg < p.B)
-            e_dot[((size_t)bg * M + m) * p.dot_slots + (tu * ci.tilesV + tv) * WGN + wn] = dsum;
-        }
-      }
-    }
-  }
+  conv_epilogue<WTM, WTN, RG>(acc[0], p.e, p.y, p.ksplit > 1 ? p.y + (size_t)ks * p.slab : nullptr, p.M, HWout,
+                              m0 + wm * WTM * 32, lane, e_pix, e_b, bg < p.B, bg, p.dot_slots, (tu * ci.tilesV + tv) * WGN + wn);
 }
-
 
 template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false, bool TM = false, bool X3 = false>
 static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, const NameOut *name) {

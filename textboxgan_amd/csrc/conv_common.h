@@ -55,6 +55,116 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // name-only mode (name != NULL): write the instantiation the descriptor selects (rocprofv3 spelling) and launch nothing
 struct NameOut { char *buf; int n; int *dot_slots; int *blocks; };
 
+// ---- fused epilogue of the implicit-GEMM convolution kernels (tbg.h tbg_epilogue), for a wave that holds WTM x WTN 32x32 MFMA
+// accumulator tiles: rows = output channels mrow0 + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column (lane & 31) of tile j =
+// the output pixel e_pix[j] (offset inside the [Hout*Wout] plane, -1: not an output) of sample e_b[j].  slab != NULL: store-only
+// alpha * acc into this split's slab.  Every pointer / scalar of the descriptor is hoisted into locals first, and the loads a row
+// group needs (demodulation, residual, dot operand) are issued together before any arithmetic or store: the first version
+// interleaved kernarg reloads, loads and stores element by element (521 s_waitcnt in 6.8k instructions) and cost 45-80 us per
+// large launch -- more than the output write itself (a 134 MB fill takes 21 us).
+// Fused dot (e.dot_aux): one image per tile; the partial of this (tile, wave column) goes to its own slot
+// dot_out[(dot_b * M + m) * dot_slots + dot_slot] -- no atomics, the caller sums the slots in a fixed order.
+template <int WTM, int WTN, int RG>
+__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], const EpiK &e, float *y, float *slab, int M_, int HWout,
+                                              int mrow0, int lane, const int (&e_pix)[WTN], const int (&e_b)[WTN], bool dot_ok,
+                                              int dot_b, int dot_slots, int dot_slot) {
+  const float *const e_os = e.out_scale, *const e_bias = e.bias, *const e_res = e.residual, *const e_aux = e.dot_aux;
+  const float *const e_gate = e.gate;
+  float *const e_dot = e.dot_out;
+  const float e_alpha = e.alpha, e_bmul = e.bias_mul, e_slope = e.slope, e_gain = e.gain, e_rscale = e.res_scale;
+  const bool e_lrelu = e.act == TBG_ACT_LRELU, e_rfirst = e.res_first != 0;
+  const float str = e.noise ? e.strength[0] : 0.f;
+  const bool split = slab != nullptr;
+  const bool do_dot = e_aux != nullptr && !split;
+  const bool plain = !e_os && !e_bias && !e.noise && !e_res && !e_aux && !e_gate && !e_lrelu && e_gain == 1.f;
+  const int M = M_;
+  float *const ybase = split ? slab : y;
+  float e_nz[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) e_nz[j] = (e_pix[j] >= 0 && e.noise) ? e.noise[(size_t)e_b[j] * HWout + e_pix[j]] * str : 0.f;
+  if (split || plain) {  // store-only: alpha * acc (split-K slabs, plain data gradients)
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int m = mrow0 + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+          if (m < M && e_pix[j] >= 0) ybase[(e_b[j] * M + m) * HWout + e_pix[j]] = acc[i][j][r16] * e_alpha;
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += RG) {  // accumulator rows r0 .. r0+RG-1
+      int idx[RG][WTN];  // output offsets fit 31 bits (checked on the host)
+      int mrow[RG];
+      float bias4[RG], osv[RG][WTN], rsv[RG][WTN], axv[RG][WTN];
+#pragma unroll
+      for (int q = 0; q < RG; ++q) {
+        const int r16 = r0 + q;
+        const int m = mrow0 + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+        mrow[q] = m;
+        const bool okm = m < M;
+        bias4[q] = (okm && e_bias) ? e_bias[m] * e_bmul : 0.f;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+          idx[q][j] = (okm && e_pix[j] >= 0) ? (e_b[j] * M + m) * HWout + e_pix[j] : -1;
+          osv[q][j] = 1.f; rsv[q][j] = 0.f; axv[q][j] = 0.f;
+        }
+      }
+      if (e_os) {
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) osv[q][j] = e_os[idx[q][j] >= 0 ? e_b[j] * M + mrow[q] : 0];
+      }
+      if (e_res) {
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) rsv[q][j] = e_res[max(idx[q][j], 0)];  // clamped: branch-free
+      }
+      if (do_dot) {
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) axv[q][j] = e_aux[max(idx[q][j], 0)];
+      } else if (e_gate) {  // never together with the dot operand (epi_valid): the gate values share its registers
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) axv[q][j] = e_gate[max(idx[q][j], 0)];
+      }
+#pragma unroll
+      for (int q = 0; q < RG; ++q) {
+        const int m = mrow[q];
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+          const bool okq = idx[q][j] >= 0;
+          float val = acc[i][j][r0 + q] * e_alpha;
+          if (do_dot) dsum += okq ? val * axv[q][j] : 0.f;
+          val = val * osv[q][j] + e_nz[j] + bias4[q];
+          if (e_rfirst) val += rsv[q][j];
+          val = (e_lrelu ? (val > 0.f ? val : val * e_slope) : val) * e_gain;
+          if (e_res && !e_rfirst) val = (val + rsv[q][j]) * e_rscale;
+          if (e_gate) val = axv[q][j] > 0.f ? val : 0.f;
+          if (okq) y[idx[q][j]] = val;
+        }
+        if (do_dot) {  // one image per tile (checked on the host): reduce the 32 pixel lanes of each half-wave and store the
+          // partial of this (tile, wave column) in its own slot -- no atomics, the caller sums the slots in a fixed order
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+          if ((lane & 31) == 0 && m < M && dot_ok)
+            e_dot[((size_t)dot_b * M + m) * dot_slots + dot_slot] = dsum;
+        }
+      }
+    }
+  }
+}
+
 #define WG_MAXNJ 4
 
 struct WgradP {

@@ -123,27 +123,27 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_units_kernel(const WgUnitsP
   const int ws = wave >> 1, wl = wave & 1;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
 
-  // ---- DMA descriptors of this wave's pieces (piece q = wave + 4 k): source offset in units relative to the chunk base of
-  // its tensor, and which tensor.  Pad slots of a row are never read: they fetch the row's first unit.
-  int doff[PPW];
+  // ---- DMA descriptors of this wave's pieces (piece q = wave + 4 k): per-lane source ADDRESS relative to the chunk base of its
+  // tensor (held in registers: nothing about a piece is re-derived from kernel arguments inside the K loop), and which tensor.
+  // Pad slots of a row are never read: they fetch the row's last unit.
+  const char *dsrc[PPW];
   unsigned isl = 0;
+  const char *const su_ = p.SU, *const lu_ = p.LU;
 #pragma unroll
   for (int k = 0; k < PPW; ++k) {
-    const int n = (wave + 4 * k) * 64 + lane;
-    int off = 0;
+    const int n = min(wave + 4 * k, NPIECE - 1) * 64 + lane;
     if (n < S_UNITS) {
       const int row = n / S_ROW, pix = min(n - row * S_ROW, 63);
       const int pl = row >> 3, su = row & 7;
-      off = (int)(pl * p.s_plane) + (su * p.Hps + (pix >> 5)) * p.Wps + (pix & 31);
-    } else if (n < BUF) {
+      dsrc[k] = su_ + ((pl * p.s_plane + (long long)(su * p.Hps + (pix >> 5)) * p.Wps + (pix & 31)) << 4);
+    } else {
       const int m = n - S_UNITS;
       const int row = m / L_ROW, pos = min(m - row * L_ROW, 135);
       const int pl = row >> 3, lu = row & 7;
       const int r = pos / 34, c = pos - r * 34;
-      off = (int)(pl * p.l_plane) + (lu * p.Hpl + r) * p.Wpl + c;
+      dsrc[k] = lu_ + ((pl * p.l_plane + (long long)(lu * p.Hpl + r) * p.Wpl + c) << 4);
       isl |= 1u << k;
     }
-    doff[k] = off;
   }
   const int cs8 = blockIdx.x * 8, cl8 = blockIdx.y * 8;
 
@@ -155,14 +155,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_units_kernel(const WgUnitsP
     sb = ((b * p.CS8 + cs8) * p.Hps + u0 + 1) * p.Wps + v0 + 1;  // interior starts at (1, 1)
     lb = ((b * p.CL8 + cl8) * p.Hpl + u0) * p.Wpl + v0;          // halo: y = u0 - 1 -> padded row u0
   };
-  // (branch-free: a wave whose last slot is past the buffer re-issues its previous piece -- same bytes to the same place)
+  // (branch-free: a slot past the buffer re-issues the last piece -- same bytes to the same place)
   auto issue_piece = [&](int k, int sb, int lb, int buf) {
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int kk = (wv + 4 * k < NPIECE) ? k : k - 1;
-    const int q = wv + 4 * kk;
-    const bool l = (isl >> kk) & 1u;
-    const char *src = (l ? p.LU : p.SU) + ((long long)((l ? lb : sb) + (kk == k ? doff[k] : doff[k > 0 ? k - 1 : 0])) << 4);
-    dma16(src, lds0 + (unsigned)((buf * BUF + q * 64) * 16));
+    const int q = min(__builtin_amdgcn_readfirstlane(wave) + 4 * k, NPIECE - 1);
+    const int cb = ((isl >> k) & 1u) ? lb : sb;  // (one piece straddles the S / L regions: per-lane select)
+    dma16(dsrc[k] + ((long long)cb << 4), lds0 + (unsigned)((buf * BUF + q * 64) * 16));
   };
 
   // ---- operand addressing.  A transposing read serves 16 lanes with a [4 pixels][16 channels] block: lane i of the group
@@ -206,7 +203,6 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_units_kernel(const WgUnitsP
     // else, so every LDS read of step i+1 (two register sets) and every DMA piece of the next chunk sits in the shadow of an
     // MFMA of step i -- never in a block of its own between two steps.
     constexpr int NST = 12, NM = NQ * 3;
-    constexpr int DMA_PER_STEP = (PPW + NST - 1) / NST;
     bf16x8 a[2][NP], bv[2][NP][3];
     auto ld1 = [&](int st, int bs, int idx) {  // load idx of step st's operand set: the 3 NP B operands, then (kh == 0) the NP A operands
       const int g = st / 3, kh = st - 3 * g;
@@ -237,8 +233,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_units_kernel(const WgUnitsP
 #pragma unroll
           for (int e = 0; e < LPM; ++e) ld1(st + 1, bs ^ 1, m * LPM + e);
         }
-        // ... and the step's DMA pieces behind its 2nd, 8th, ... MFMA
-        if (m % 6 == 1 && st * DMA_PER_STEP + m / 6 < PPW && m / 6 < DMA_PER_STEP) issue_piece(st * DMA_PER_STEP + m / 6, sb, lb, buf ^ 1);
+        // ... and the next chunk's DMA pieces in the FIRST HALF of the phase, evenly spaced, so that they have landed when it ends
+        {
+          constexpr int STRIDE = (NST * NM / 2) / PPW > 0 ? (NST * NM / 2) / PPW : 1;
+          const int slot = st * NM + m;
+          if (slot % STRIDE == 0 && slot / STRIDE < PPW) issue_piece(slot / STRIDE, sb, lb, buf ^ 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -316,4 +316,216 @@ extern "C" int tbg_conv2d_wgrad_units(const tbg_wgrad_desc *d, const void *SU, c
   p.CS = d->CS; p.CL = d->CL; p.st_t = d->st_t; p.st_l = d->st_l; p.st_s = d->st_s; p.alpha = d->alpha;
   p.dW = dW; p.ws = workspace; p.addw = addw; p.addq = addq; p.gamma = gamma; p.ksplit = u.ksplit;
   return planes == 3 ? launch_wgrad_units<3>(u, p, tbg_stream(stream), nullptr) : launch_wgrad_units<1>(u, p, tbg_stream(stream), nullptr);
+}
+
+// ============================================================================================
+// forward / data-gradient convolution from a unit tensor (3x3, stride 1, pad 1)
+// ============================================================================================
+// y[b,m,Y,X] = epilogue( sum_{t=(kh,kw), c} XU[b,c,Y-1+kh,X-1+kw] * Wp[t'][c][m] ): the implicit GEMM of conv_fprop_kernel (M =
+// output channels, N = pixels, K = taps x channels, packed filter tbg_weight_pack_x3 / _bf16, same MFMA term pairing and the same
+// fused epilogue), with EVERY operand byte arriving by LDS-DMA: the filter slice as before, and the halo tile straight from the
+// unit tensor (the x * s modulation, the split / rounding and the zero padding were paid once by the producer) -- no staging
+// registers, no VALU pass, no clamps.  That frees the kernel to be ONE 512-thread block per CU (8 waves, 2 per SIMD; tile =
+// 64 WTM output channels x 8 rows x 32 pixels) with BOTH tiles double-buffered in LDS (x3: 2 x 70 KB): the DMA of chunk k+1 is
+// issued piece by piece behind the MFMAs of chunk k, one barrier per chunk, and the two waves of a SIMD cover each other's
+// operand reads.  (conv_fprop_kernel runs two 256-thread blocks per CU with single buffers: its filter DMA wait and its split +
+// store pass are exposed, 25 % of the large layers -- DESIGN 4.1b.)
+struct ConvUnitsP {
+  const char *XU, *Wf;
+  long long x_plane, w_plane;  // 16-byte units per plane
+  float *y;
+  int B, C8, M, H, W, ldw;
+  int tilesU, tilesV, dot_slots;
+  int wtap[9];
+  EpiK e;
+};
+
+template <int NP, int WTM>
+__global__ __launch_bounds__(512, 2) void conv_units_fprop_kernel(const ConvUnitsP p) {
+  constexpr int WGN = 4, WTN = 2, BM = 2 * WTM * 32;
+  constexpr int CKU = NP == 3 ? 1 : 2;       // channel units per chunk (x3: 8 channels x 3 planes; bf16: 16 channels)
+  constexpr int HALO = 10 * 34;
+  constexpr int A_UNITS = NP * 9 * CKU * BM, X_UNITS = NP * CKU * HALO;
+  constexpr int NPIECE = (A_UNITS + X_UNITS + 63) / 64, BUF = NPIECE * 64, PPW = (NPIECE + 7) / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][BUF] units
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, half = lane >> 5;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+
+  const int tn = blockIdx.x;
+  const int tv = tn % p.tilesV, t2 = tn / p.tilesV;
+  const int tu = t2 % p.tilesU, b = t2 / p.tilesU;
+  const int m0 = blockIdx.y * BM, y0 = tu * 8, x0 = tv * 32;
+  const int Hp = p.H + 2, Wp = p.W + 2;
+
+  // ---- DMA descriptors of this wave's pieces (piece q = wave + 8 k): the per-lane source ADDRESS for chunk 0 (registers:
+  // the descriptor must not be re-derived from kernel arguments inside the K loop -- a vector load there puts an
+  // s_waitcnt vmcnt(0) in front of the next piece, i.e. behind every piece still in flight).  The filter region is a whole
+  // number of pieces, so a piece belongs to one tensor and its per-chunk address step is wave-uniform.  Slots past the halo
+  // region (the last piece's tail) re-fetch the halo's last unit.
+  static_assert(A_UNITS % 64 == 0, "a DMA piece never straddles the filter / halo regions");
+  const char *dsrc[PPW];
+  const char *const xu = p.XU, *const wf = p.Wf;
+#pragma unroll
+  for (int k = 0; k < PPW; ++k) {
+    const int q = min(wave + 8 * k, NPIECE - 1);  // (a slot past the buffer re-issues the wave's previous piece ... or the last)
+    const int n = q * 64 + lane;
+    if (n < A_UNITS) {  // As[plane][tap][unit][BM]
+      const int row = n / BM, m = n - row * BM;
+      const int u = row % CKU, t = (row / CKU) % 9, pl = row / (9 * CKU);
+      dsrc[k] = wf + ((pl * p.w_plane + (long long)(p.wtap[t] * p.C8 + u) * p.ldw + m0 + m) << 4);
+    } else {            // Xs[plane][unit][10][34]
+      const int m2 = min(n - A_UNITS, X_UNITS - 1);
+      const int row = m2 / HALO, pos = m2 - row * HALO;
+      const int u = row % CKU, pl = row / CKU;
+      const int r = pos / 34, c = pos - r * 34;
+      dsrc[k] = xu + ((pl * p.x_plane + (long long)((b * p.C8 + u) * Hp + y0 + r) * Wp + x0 + c) << 4);
+    }
+  }
+  const long long a_step = (long long)CKU * p.ldw * 16, x_step = (long long)CKU * Hp * Wp * 16;  // bytes per chunk
+  auto issue_piece = [&](int k, int kc, int buf) {
+    const int q = min(__builtin_amdgcn_readfirstlane(wave) + 8 * k, NPIECE - 1);
+    const long long step = q * 64 < A_UNITS ? a_step : x_step;  // wave-uniform
+    dma16(dsrc[k] + kc * step, lds0 + (unsigned)((buf * BUF + q * 64) * 16));
+  };
+
+  // ---- operand addressing (bytes inside a buffer)
+  const int a_lane = (wm * (WTM * 32) + (lane & 31)) * 16;
+  int b_lane[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) b_lane[j] = A_UNITS * 16 + ((wn * WTN + j) * 34 + (lane & 31)) * 16;
+  // x3: half-wave h supplies K half h of each MFMA:  A (hi | mid) x B hi,  A (hi | mid) x B mid,  A (hi | lo) x B (lo | hi)
+  // bf16: half-wave h holds channel unit h of the chunk
+  constexpr int A_PL = 9 * CKU * BM * 16, X_PL = CKU * HALO * 16;
+  const int aX = NP == 3 ? half * A_PL : half * BM * 16, aY = 2 * half * A_PL;
+  const int bZ = 2 * (1 - half) * X_PL, bH = NP == 3 ? 0 : half * HALO * 16;
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = p.C8 / CKU;
+#pragma unroll
+  for (int k = 0; k < PPW; ++k) issue_piece(k, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int kn = kc + 1 < nchunks ? kc + 1 : kc;  // (the last chunk re-fetches itself: no branch in the loop body)
+    const char *Ab = smem + (size_t)buf * BUF * 16 + a_lane;
+    const char *Xb = smem + (size_t)buf * BUF * 16;
+    constexpr int NA = NP == 3 ? 2 * WTM : WTM, NB = NP == 3 ? 3 * WTN : WTN, NL = NA + NB;
+    constexpr int NM = (NP == 3 ? 3 : 1) * WTM * WTN;  // MFMAs per tap
+    bf16x8 av[2][NA], bw[2][NB];
+    auto ld1 = [&](int t, int bs, int idx) {  // operand idx of tap t: the A tiles (x3: aX then aY per tile), then the B tiles
+      const int kh = t / 3, kw = t - 3 * kh;
+      if (idx < NA) {
+        const int i = NP == 3 ? idx >> 1 : idx;
+        const int plane_off = NP == 3 ? ((idx & 1) ? aY : aX) : aX;
+        av[bs][idx] = *reinterpret_cast<const bf16x8 *>(Ab + t * CKU * BM * 16 + plane_off + i * 32 * 16);
+      } else if (idx < NL) {
+        const int e = idx - NA;
+        const int j = NP == 3 ? e / 3 : e, w = NP == 3 ? e - 3 * j : 0;
+        const int plane_off = NP == 3 ? (w == 0 ? 0 : w == 1 ? X_PL : bZ) : bH;
+        bw[bs][e] = *reinterpret_cast<const bf16x8 *>(Xb + b_lane[j] + (kh * 34 + kw) * 16 + plane_off);
+      }
+    };
+#pragma unroll
+    for (int idx = 0; idx < NL; ++idx) ld1(0, 0, idx);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int bs = t & 1;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm) {
+        // x3, smallest terms first: (hi|lo)x(lo|hi), then (hi|mid) x mid, then (hi|mid) x hi
+        const int grp = mm / (WTM * WTN), ij = mm - grp * (WTM * WTN);
+        const int i = ij / WTN, j = ij - i * WTN;
+        if constexpr (NP == 3) {
+          const int ai = 2 * i + (grp == 0 ? 1 : 0), bi = 3 * j + (grp == 0 ? 2 : grp == 1 ? 1 : 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[bs][ai], bw[bs][bi], acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[bs][i], bw[bs][j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < 9) {  // behind this MFMA: operand loads of the next tap
+          constexpr int LPM = (NL + NM - 1) / NM;
+#pragma unroll
+          for (int e = 0; e < LPM; ++e) ld1(t + 1, bs ^ 1, mm * LPM + e);
+        }
+        // the next chunk's DMA pieces go out in the FIRST HALF of the phase, evenly spaced behind MFMAs, so that they have landed
+        // when the phase ends: a piece issued under the last tap would be waited for in full at the barrier
+        {
+          constexpr int STRIDE = (9 * NM / 2) / PPW > 0 ? (9 * NM / 2) / PPW : 1;
+          const int slot = t * NM + mm;
+          if (slot % STRIDE == 0 && slot / STRIDE < PPW) issue_piece(slot / STRIDE, kn, buf ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  int e_pix[WTN], e_b[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    e_pix[j] = (y0 + wn * WTN + j) * p.W + x0 + (lane & 31);
+    e_b[j] = b;
+  }
+  conv_epilogue<WTM, WTN, 4>(acc, p.e, p.y, nullptr, p.M, p.H * p.W, m0 + wm * WTM * 32, lane, e_pix, e_b, true, b, p.dot_slots,
+                             (tu * p.tilesV + tv) * WGN + wn);
+}
+
+static bool conv_units_ok(const tbg_conv_desc *d, int planes) {
+  const int cku = planes == 3 ? 8 : 16;
+  return !d->transposed && d->KH == 3 && d->KW == 3 && d->sy == 1 && d->sx == 1 && d->py == 1 && d->px == 1 &&
+         d->Hout == d->Hin && d->Wout == d->Win && (d->Hin % 8) == 0 && (d->Win % 32) == 0 && (d->C % cku) == 0 &&
+         (d->M % 64) == 0 && d->ksplit == 1 && d->ldw >= d->M;
+}
+
+extern "C" int tbg_conv2d_units_dot_slots(const tbg_conv_desc *d, int planes) {
+  if (!d || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  if (!conv_units_ok(d, planes)) return TBG_EUNSUPPORTED;
+  return (d->Hin / 8) * (d->Win / 32) * 4;
+}
+
+template <int NP, int WTM>
+static int launch_conv_units(ConvUnitsP &p, hipStream_t st) {
+  constexpr int BM = 2 * WTM * 32, CKU = NP == 3 ? 1 : 2;
+  constexpr int NPIECE = (NP * 9 * CKU * BM + NP * CKU * 340 + 63) / 64;
+  const size_t lds = (size_t)2 * NPIECE * 64 * 16;
+  auto kern = conv_units_fprop_kernel<NP, WTM>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return TBG_EHIP;
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tilesU * p.tilesV, p.M / BM), dim3(512), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_conv2d_units(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
+                                const tbg_epilogue *epi, void *stream) {
+  if (!d || !XU || !w || !y || (planes != 1 && planes != 3) || !epi_valid(epi)) return TBG_EINVAL;
+  if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1) return TBG_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(XU) | reinterpret_cast<uintptr_t>(w)) & 15) != 0) return TBG_EINVAL;
+  if (!conv_units_ok(d, planes)) return TBG_EUNSUPPORTED;
+  if ((double)d->B * d->M * d->Hout * d->Wout > 2147483647.0) return TBG_ERANGE;
+  ConvUnitsP p{};
+  p.XU = reinterpret_cast<const char *>(XU); p.Wf = reinterpret_cast<const char *>(w);
+  p.x_plane = units_per_plane(d->B, d->C, d->Hin, d->Win);
+  p.C8 = d->C / 8;
+  p.w_plane = (long long)9 * p.C8 * d->ldw;
+  if (p.x_plane * planes > 2147483647LL / 2 || p.w_plane * planes > 2147483647LL / 2) return TBG_ERANGE;
+  p.y = y; p.B = d->B; p.M = d->M; p.H = d->Hin; p.W = d->Win; p.ldw = d->ldw;
+  p.tilesU = d->Hin / 8; p.tilesV = d->Win / 32;
+  p.dot_slots = p.tilesU * p.tilesV * 4;
+  for (int t = 0; t < 9; ++t) p.wtap[t] = d->flip ? 8 - t : t;
+  p.e = make_epi(epi);
+  hipStream_t st = tbg_stream(stream);
+  if (d->M % 128 == 0) return planes == 3 ? launch_conv_units<3, 2>(p, st) : launch_conv_units<1, 2>(p, st);
+  return planes == 3 ? launch_conv_units<3, 1>(p, st) : launch_conv_units<1, 1>(p, st);
 }

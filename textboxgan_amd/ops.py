@@ -395,6 +395,38 @@ def units_pack(x: torch.Tensor, scale: Optional[torch.Tensor] = None, planes: Op
     return UnitTensor(U, B, Cc, H, W, planes)
 
 
+def conv_units_ok(C_in, M, H, W, KH, KW, stride, pad, transposed, planes) -> bool:
+    """geometry of tbg_conv2d_units (3x3 stride-1 pad-1 layers in whole 8 x 32-pixel tiles and 64-channel tiles)"""
+    return (KH == 3 and KW == 3 and tuple(stride) == (1, 1) and tuple(pad) == (1, 1) and not transposed and H % 8 == 0 and
+            W % 32 == 0 and M % 64 == 0 and C_in % (8 if planes == 3 else 16) == 0)
+
+
+def conv2d_units_raw(XU: UnitTensor, w: "PackedFilter", M: int, flip=False, epi: Optional[N.Epilogue] = None, dot=None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 stride-1 pad-1 convolution of the activation behind the unit tensor XU (its scale already inside) with a packed
+    filter of the matching format; fp32 NCHW output through the fused epilogue.  dot = (aux, out) as in conv2d_raw."""
+    assert w.fmt == (FMT_X3 if XU.planes == 3 else FMT_BF16) and w.C == XU.C and w.M >= M and w.T == 9
+    B, H, W = XU.B, XU.H, XU.W
+    d = N.ConvDesc(B, XU.C, M, H, W, H, W, 3, 3, 1, 1, 1, 1, 0, int(flip), w.M, 1)
+    epi = N.epilogue() if epi is None else epi
+    partial = None
+    if dot is not None:
+        slots = N.lib().tbg_conv2d_units_dot_slots(C.byref(d), XU.planes)
+        N.check(min(slots, 0), "tbg_conv2d_units_dot_slots")
+        partial = torch.empty((B, M, slots), device=XU.data.device, dtype=torch.float32)
+        epi = N.Epilogue.from_buffer_copy(epi)
+        epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(partial)
+    y = torch.empty((B, M, H, W), device=XU.data.device, dtype=torch.float32) if out is None else out
+    _flops = 2.0 * B * M * XU.C * 9 * H * W
+    N.check(PROFILE.launch(f"conv_units_fprop_kernel<{XU.planes}, {2 if M % 128 == 0 else 1}>", _flops, lambda: N.lib().tbg_conv2d_units(
+        C.byref(d), N.ptr(XU.data), XU.planes, N.ptr(w.data), N.ptr(y), C.byref(epi), N.stream()),
+        f"conv_units[B={B} C={XU.C} M={M} {H}x{W}]", 2.0 * XU.data.numel() + 4.0 * y.numel() + 2.0 * XU.planes * 9 * XU.C * M),
+        "tbg_conv2d_units")
+    if partial is not None:
+        torch.sum(partial, dim=2, out=dot[1].view(B, M))
+    return y
+
+
 def wgrad_units_ok(CS, CL, Hs, Ws, Hl, Wl, KH, KW, stride, pad) -> bool:
     """geometry of tbg_conv2d_wgrad_units (3x3 stride-1 pad-1 layers with whole 2 x 32-pixel chunks and 64-channel tiles)"""
     return (KH == 3 and KW == 3 and tuple(stride) == (1, 1) and tuple(pad) == (1, 1) and (Hl, Wl) == (Hs, Ws) and Ws % 32 == 0

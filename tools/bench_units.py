@@ -28,3 +28,24 @@ for (C, M, H, W) in [(128, 128, 64, 256), (128, 128, 32, 128), (256, 256, 16, 64
         row += (f"  [{mode}] nchw {t_old:7.1f} us ({fl / t_old / 1e6:6.1f} TF)  units {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF)"
                 f"  pack {t_pack:6.1f} us ({(4 + 2 * planes) * x.numel() / t_pack / 1e6:5.2f} TB/s)")
     print(row, flush=True)
+
+print("--- forward 3x3 s1 (with style scale, demod/noise/bias/lrelu epilogue)")
+from textboxgan_amd import native as N
+for (C, M, H, W, Bx) in [(128, 128, 64, 256, B), (128, 128, 32, 128, B), (128, 128, 32, 128, 2 * B), (64, 64, 64, 256, 2 * B), (256, 256, 16, 64, B),
+                         (256, 256, 16, 64, 2 * B), (512, 512, 8, 32, B)]:
+    x = torch.randn(Bx, C, H, W, device=dev)
+    w = torch.randn(3, 3, C, M, device=dev) / (9 * C) ** 0.5
+    xs, dd = torch.rand(Bx, C, device=dev) + 0.5, torch.rand(Bx, M, device=dev) + 0.5
+    nz, bs, st = torch.randn(Bx, 1, H, W, device=dev), torch.randn(M, device=dev), torch.tensor(0.1, device=dev)
+    fl = 2.0 * Bx * C * M * H * W * 9
+    row = f"B={Bx} {C}->{M} {H}x{W}:"
+    for mode, planes in (("f32x3", 3), ("bf16", 1)):
+        with ops.compute_dtype(mode):
+            pf = ops.pack_filter(w, False, False)
+            epi = lambda: N.epilogue(out_scale=dd, bias=bs, noise=nz, strength=st, act=N.ACT_LRELU)
+            out = torch.empty(Bx, M, H, W, device=dev)
+            t_old = timeit(lambda: ops.conv2d_raw(x, pf, M, 3, 3, (H, W), (1, 1), (1, 1), in_scale=xs, epi=epi(), out=out))
+            XU = ops.units_pack(x, xs, planes=planes)
+            t_new = timeit(lambda: ops.conv2d_units_raw(XU, pf, M, epi=epi(), out=out))
+        row += f"  [{mode}] nchw {t_old:7.1f} us ({fl / t_old / 1e6:6.1f} TF)  units {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF)"
+    print(row, flush=True)
