@@ -285,6 +285,15 @@ int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, const void *w,
 long long tbg_units_bytes(int B, int C, int H, int W, int planes);
 int tbg_units_pack_f32(const float *x, const float *scale, void *U, int B, int C, int H, int W, int planes, void *stream);
 
+/* tbg_bias_act_bwd_f32 as a PRODUCER of a unit tensor: U = units(dpre * alpha * out_scale[b,m]) of `planes` planes for the
+ * [B, M, H, W] map (what the data-gradient and filter-gradient launches of the layer consume), dpre itself (NCHW fp32) only if
+ * dpre_out != NULL, and the partial sums part_db / part_dn / part_dyy as [B, M, tbg_bias_act_bwd_units_chunks(H)] (the caller
+ * reduces the last axis).  Same dpre / sum definitions as tbg_bias_act_bwd_f32. */
+int tbg_bias_act_bwd_units_chunks(int H);
+int tbg_bias_act_bwd_units(const float *dout, const float *out_act, void *U, int planes, float *dpre_out, float *part_db,
+                           float *part_dn, float *part_dyy, int B, int M, int H, int W, const tbg_epilogue *epi,
+                           void *stream);
+
 /* Forward / data-gradient convolution from a unit tensor: tbg_conv2d_x3 (planes = 3) / tbg_conv2d_bf16 (planes = 1) with the
  * input given as the unit tensor XU of x * in_scale (so there is no in_scale argument) -- same descriptor, packed filter
  * (tbg_weight_pack_x3 / tbg_weight_pack_bf16), epilogue (fused dot included: tbg_conv2d_units_dot_slots slots per (b, m)) and

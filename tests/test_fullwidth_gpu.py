@@ -316,6 +316,31 @@ def _run_conv_case(dev, case, seed, arith="f32"):
     return set(log)
 
 
+def _run_units_case(dev, arith, M, seed):
+    """the unit-tensor kernels (csrc/conv_units.hip: producer, all-DMA forward, transposing-read filter gradient) against
+    float64 on the operands they see, in arithmetic `arith` (f32x3 / bf16); returns the instantiations launched."""
+    import torch.nn.functional as F
+    from textboxgan_amd import native as N, ops
+    B, Cc, H, W = 2, 64, 16, 64
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cc, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(3, 3, Cc, M, generator=g, dtype=torch.float64) / math.sqrt(9 * Cc)
+    dy = torch.randn(B, M, H, W, generator=g, dtype=torch.float64)
+    q = (lambda t: t.float().bfloat16().double()) if arith == "bf16" else (lambda t: t.float().double())
+    rel = lambda a, r: float((a.double().cpu() - r).abs().max() / (r.abs().max() + 1e-30))
+    xr, wr = q(x).requires_grad_(True), q(w).requires_grad_(True)
+    ref = F.conv2d(xr, wr.permute(3, 2, 0, 1), padding=1)
+    gx, gw = torch.autograd.grad(ref, (xr, wr), q(dy))
+    with N.record_calls() as log, ops.compute_dtype(arith):
+        xd, wd, dyd = x.float().to(dev), w.float().to(dev), dy.float().to(dev)
+        XU, DU = ops.units_pack(xd), ops.units_pack(dyd)
+        assert rel(ops.conv2d_units_raw(XU, ops.pack_filter(wd, False, False), M), ref.detach()) < 3e-5, ("units fwd", arith, M)
+        assert rel(ops.conv2d_units_raw(DU, ops.pack_filter(wd, True, True), Cc), gx) < 3e-5, ("units dgrad", arith, M)
+        dw = torch.empty(3, 3, Cc, M, device=dev)
+        assert rel(ops.wgrad_units_raw(DU, XU, dw, Cc * M, M, 1, 1.0), gw) < 5e-5, ("units wgrad", arith, M)
+    return set(log)
+
+
 _COVERED = {}
 
 
@@ -331,6 +356,8 @@ def _covered(dev, arith):
             cov |= _run_conv_case(dev, case, 500 + i, arith)
             if arith == "bf16":  # the frozen OCR branch of a bf16 step runs on the f32x3 kernels (training_step.py)
                 cov |= _run_conv_case(dev, case, 500 + i, "f32x3")
+        if arith != "f32":  # the 3x3 stride-1 layers of these arithmetics consume unit tensors
+            cov |= _run_units_case(dev, arith, 128, 700) | _run_units_case(dev, arith, 64, 701)
         for reg in ((False, False), (True, True)):
             cov |= set(_step_vs_oracle(dev, arith, 4, reg)[0])
         _COVERED[arith] = cov

@@ -154,3 +154,27 @@ def test_conv_units_matches_float64_and_the_nchw_kernel(dev, mode, case):
     print(f"\nCONVUNITS {mode} {case}: vs float64 {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}   vs nchw kernel {dns[0]:.1e} {dns[1]:.1e} {dns[2]:.1e}")
     assert max(errs) < 3e-5, errs
     assert max(dns) < 2e-6, dns
+
+
+@pytest.mark.parametrize("planes", [3, 1])
+@pytest.mark.parametrize("shape", [(2, 20, 5, 9), (2, 64, 16, 64), (1, 128, 64, 256)])
+def test_bias_act_bwd_units_equals_bias_act_bwd_then_pack(dev, planes, shape):
+    """the fused producer (tbg_bias_act_bwd_units) against the two launches it replaces: the unit tensor bit for bit, dpre bit
+    for bit, and the partial sums (different chunking) to fp32 summation order."""
+    B, M, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    out = torch.randn(B, M, H, W, generator=g).to(dev)
+    dout = torch.randn(B, M, H, W, generator=g).to(dev)
+    d, noise = (torch.rand(B, M, generator=g) + 0.5).to(dev), torch.randn(B, 1, H, W, generator=g).to(dev)
+    bias, strength = torch.randn(M, generator=g).to(dev), torch.tensor(0.3, device=dev)
+    epi = lambda: N.epilogue(out_scale=d, bias=bias, noise=noise, strength=strength, act=N.ACT_LRELU)
+    dx_ref, dpre_ref, pdb, pdn, pdy = ops.bias_act_bwd_raw(dout, out, epi(), want_dx=True, want_dn=True, want_dyy=True)
+    U_ref = ops.units_pack(dpre_ref, d, planes=planes)
+    DU, dpre, qdb, qdn, qdy = ops.bias_act_bwd_units_raw(dout, out, epi(), planes=planes, want_dpre=True, want_dn=True, want_dyy=True)
+    assert torch.equal(dpre, dpre_ref)
+    assert torch.equal(DU.data.view(torch.int16), U_ref.data.view(torch.int16)), "unit tensor differs from pack(dpre * d)"
+    for a, r in ((qdb, pdb), (qdn, pdn), (qdy, pdy)):
+        a, r = a.sum(2).double().cpu(), r.sum(2).double().cpu()
+        assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max() + 1e-30)
+    DU2, none, _, _, _ = ops.bias_act_bwd_units_raw(dout, out, epi(), planes=planes)
+    assert none is None and torch.equal(DU2.data.view(torch.int16), U_ref.data.view(torch.int16))

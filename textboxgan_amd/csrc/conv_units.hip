@@ -16,6 +16,10 @@
 #include "conv_common.h"
 
 #define UNIT_RING 1
+// TBG_EXP: ablation builds of conv_units_fprop_kernel for tools/exp_units_fprop.sh (where its time goes).  0 = product.
+#ifndef TBG_EXP
+#define TBG_EXP 0
+#endif
 
 static inline long long units_per_plane(int B, int C, int H, int W) {
   return (long long)B * ((C + 7) / 8) * (H + 2 * UNIT_RING) * (W + 2 * UNIT_RING);
@@ -27,35 +31,49 @@ extern "C" long long tbg_units_bytes(int B, int C, int H, int W, int planes) {
 }
 
 // ---- producer of last resort: NCHW fp32 (x optional per-(b,c) scale) -> unit tensor, ring and channel tail included.
-// One lane per unit: 8 channel loads (each coalesced along x across the wave), one 16-byte store per plane.
+// One lane per unit (two units per thread, both load batches in flight together): 8 channel loads (each coalesced along x
+// across the wave), one 16-byte store per plane.
 template <int NP>
 __global__ __launch_bounds__(256) void units_pack_kernel(const float *__restrict__ x, const float *__restrict__ scale,
                                                          bf16x8 *__restrict__ U, int B, int C, int H, int W, long long plane) {
   const int Wp = W + 2, Hp = H + 2, C8 = (C + 7) >> 3;
-  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (n >= plane) return;
-  const int xp = (int)(n % Wp);
-  long long t = n / Wp;
-  const int yp = (int)(t % Hp);
-  t /= Hp;
-  const int cu = (int)(t % C8), b = (int)(t / C8);
-  const bool inside = xp >= 1 && xp <= W && yp >= 1 && yp <= H;
-  float v[8];
   const long long HW = (long long)H * W;
-  const long long g0 = ((long long)b * C + cu * 8) * HW + (long long)(yp - 1) * W + (xp - 1);
+  const long long half = (plane + 1) >> 1;
+  const long long n0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n0 >= half) return;
+  float v[2][8];
+  long long nn[2];
+  bool live[2];
 #pragma unroll
-  for (int cc = 0; cc < 8; ++cc) {
-    const bool ok = inside && cu * 8 + cc < C;
-    float a = x[ok ? g0 + cc * HW : 0];
-    if (scale) a *= scale[ok ? b * C + cu * 8 + cc : 0];
-    v[cc] = ok ? a : 0.f;
+  for (int k = 0; k < 2; ++k) {
+    const long long n = n0 + k * half;
+    nn[k] = n; live[k] = n < plane;
+    const long long nc = live[k] ? n : 0;
+    const int xp = (int)(nc % Wp);
+    long long t = nc / Wp;
+    const int yp = (int)(t % Hp);
+    t /= Hp;
+    const int cu = (int)(t % C8), b = (int)(t / C8);
+    const bool inside = live[k] && xp >= 1 && xp <= W && yp >= 1 && yp <= H;
+    const long long g0 = ((long long)b * C + cu * 8) * HW + (long long)(yp - 1) * W + (xp - 1);
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const bool ok = inside && cu * 8 + cc < C;
+      float a = x[ok ? g0 + cc * HW : 0];
+      if (scale) a *= scale[ok ? b * C + cu * 8 + cc : 0];
+      v[k][cc] = ok ? a : 0.f;
+    }
   }
-  if constexpr (NP == 3) {
-    bf16x8 h, m, l;
-    split3_bf16x8(v, h, m, l);
-    U[n] = h; U[plane + n] = m; U[2 * plane + n] = l;
-  } else {
-    U[n] = pack_bf16x8(v);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (!live[k]) continue;
+    if constexpr (NP == 3) {
+      bf16x8 h, m, l;
+      split3_bf16x8(v[k], h, m, l);
+      U[nn[k]] = h; U[plane + nn[k]] = m; U[2 * plane + nn[k]] = l;
+    } else {
+      U[nn[k]] = pack_bf16x8(v[k]);
+    }
   }
 }
 
@@ -65,13 +83,125 @@ extern "C" int tbg_units_pack_f32(const float *x, const float *scale, void *U, i
   if ((reinterpret_cast<uintptr_t>(U) & 15) != 0) return TBG_EINVAL;
   const long long plane = units_per_plane(B, C, H, W);
   if (plane * 8 > 2147483647LL || (long long)B * C * H * W > 2147483647LL) return TBG_ERANGE;
-  const dim3 grid((unsigned)((plane + 255) / 256));
+  const dim3 grid((unsigned)(((plane + 1) / 2 + 255) / 256));
   if (planes == 3)
     hipLaunchKernelGGL(units_pack_kernel<3>, grid, dim3(256), 0, tbg_stream(stream), x, scale, reinterpret_cast<bf16x8 *>(U), B, C,
                        H, W, plane);
   else
     hipLaunchKernelGGL(units_pack_kernel<1>, grid, dim3(256), 0, tbg_stream(stream), x, scale, reinterpret_cast<bf16x8 *>(U), B, C,
                        H, W, plane);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// ---- fused producer: the backward of bias + noise + LeakyReLU (tbg_bias_act_bwd_f32) writing its result as a UNIT TENSOR.
+//   dpre = dout * (residual_fused ? res_scale : 1) * gain * (out_act > 0 ? 1 : slope)
+//   U    = units(dpre * alpha * out_scale[b,m])        (what the data-gradient and filter-gradient launches consume)
+//   dpre_out (optional, NCHW fp32) and the per-(b, m, row chunk) partial sums part_db / part_dn / part_dyy as that entry.
+// One block = one (b, 8-channel unit) and UB_ROWS rows of the padded plane; one lane = one padded position: 8 + 8 channel loads
+// (each coalesced along x across the wave) + the noise value, one 16-byte store per plane; the 3 x 8 running sums are reduced
+// once per block.  Replaces bias_act_bwd_kernel + units_pack_kernel: 8 + 2 planes bytes per element instead of 12 + 4 + 2 planes.
+#define UB_ROWS 8
+struct BabUnitsP {
+  const float *__restrict__ dout, *__restrict__ out_act;
+  bf16x8 *__restrict__ U;
+  float *dpre_out, *part_db, *part_dn, *part_dyy;
+  int B, M, H, W, nchunks;
+  long long plane;
+  EpiK e;
+};
+
+extern "C" int tbg_bias_act_bwd_units_chunks(int H) { return H < 1 ? 0 : (H + 2 + UB_ROWS - 1) / UB_ROWS; }
+
+template <int NP>
+__global__ __launch_bounds__(256) void bias_act_bwd_units_kernel(const BabUnitsP p) {
+  __shared__ float red[4][24];
+  const int Wp = p.W + 2, Hp = p.H + 2, C8 = (p.M + 7) >> 3, HW = p.H * p.W;
+  const int cu = blockIdx.x % C8, b = blockIdx.x / C8;
+  const int r0 = blockIdx.y * UB_ROWS, r1 = min(r0 + UB_ROWS, Hp);
+  const float str = p.e.noise ? p.e.strength[0] : 0.f;
+  const float gin = p.e.residual ? p.e.res_scale : 1.f;  // residual != NULL only flags "fused residual"
+  const float g_pos = p.e.gain, g_neg = p.e.gain * (p.e.act == TBG_ACT_LRELU ? p.e.slope : 1.f);
+  const float ig_pos = 1.f / g_pos, ig_neg = g_neg != 0.f ? 1.f / g_neg : 0.f;  // slope 0 = ReLU
+  float sc[8], bias[8];
+  bool chok[8];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    const int m = cu * 8 + cc;
+    chok[cc] = m < p.M;
+    sc[cc] = chok[cc] ? p.e.alpha * (p.e.out_scale ? p.e.out_scale[b * p.M + m] : 1.f) : 0.f;
+    bias[cc] = (chok[cc] && p.e.bias) ? p.e.bias[m] * p.e.bias_mul : 0.f;
+  }
+  float s_db[8], s_dn[8], s_dy[8];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) { s_db[cc] = 0.f; s_dn[cc] = 0.f; s_dy[cc] = 0.f; }
+  const size_t g0 = ((size_t)b * p.M + cu * 8) * HW;
+  bf16x8 *Ub = p.U + ((size_t)b * C8 + cu) * Hp * Wp;
+  const int npos = (r1 - r0) * Wp;
+  for (int e = threadIdx.x; e < npos; e += 256) {
+    const int rr = e / Wp, xp = e - rr * Wp, yp = r0 + rr;
+    const bool inside = xp >= 1 && xp <= p.W && yp >= 1 && yp <= p.H;
+    const int pix = inside ? (yp - 1) * p.W + (xp - 1) : 0;
+    float ov[8], dv[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const size_t gi = (inside && chok[cc]) ? g0 + (size_t)cc * HW + pix : 0;
+      ov[cc] = p.out_act[gi];
+      dv[cc] = p.dout[gi];
+    }
+    const float n = (inside && p.e.noise) ? p.e.noise[(size_t)b * HW + pix] : 0.f;
+    float v[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const bool ok = inside && chok[cc];
+      const bool pos = ov[cc] > 0.f;
+      const float dp = ok ? dv[cc] * gin * (pos ? g_pos : g_neg) : 0.f;
+      const float pre = ov[cc] * (pos ? ig_pos : ig_neg);
+      s_db[cc] += dp;
+      s_dn[cc] += dp * n;
+      s_dy[cc] += ok ? dp * (pre - n * str - bias[cc]) : 0.f;
+      v[cc] = dp * sc[cc];
+      if (p.dpre_out && ok) p.dpre_out[g0 + (size_t)cc * HW + pix] = dp;
+    }
+    const size_t u = (size_t)yp * Wp + xp;
+    if constexpr (NP == 3) {
+      bf16x8 h, m, l;
+      split3_bf16x8(v, h, m, l);
+      Ub[u] = h; Ub[p.plane + u] = m; Ub[2 * p.plane + u] = l;
+    } else {
+      Ub[u] = pack_bf16x8(v);
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    const float a = wave_sum(s_db[cc]), c = wave_sum(s_dn[cc]), d = wave_sum(s_dy[cc]);
+    if (lane == 0) { red[wave][cc] = a; red[wave][8 + cc] = c; red[wave][16 + cc] = d; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 24) {
+    const int kind = threadIdx.x >> 3, cc = threadIdx.x & 7, m = cu * 8 + cc;
+    float *dst = kind == 0 ? p.part_db : kind == 1 ? p.part_dn : p.part_dyy;
+    if (dst && m < p.M)
+      dst[((size_t)b * p.M + m) * p.nchunks + blockIdx.y] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+
+extern "C" int tbg_bias_act_bwd_units(const float *dout, const float *out_act, void *U, int planes, float *dpre_out,
+                                      float *part_db, float *part_dn, float *part_dyy, int B, int M, int H, int W,
+                                      const tbg_epilogue *epi, void *stream) {
+  if (!dout || !out_act || !U || B < 1 || M < 1 || H < 1 || W < 1 || !epi || !epi_valid(epi) || (planes != 1 && planes != 3))
+    return TBG_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(U) & 15) != 0) return TBG_EINVAL;
+  if (part_dn && !epi->noise) return TBG_EINVAL;
+  if (epi->gate) return TBG_EINVAL;  // a forward-only epilogue term
+  const long long plane = units_per_plane(B, M, H, W);
+  if (plane * 8 > 2147483647LL || (long long)B * M * H * W > 2147483647LL) return TBG_ERANGE;
+  BabUnitsP p{dout, out_act, reinterpret_cast<bf16x8 *>(U), dpre_out, part_db, part_dn, part_dyy, B, M, H, W,
+              tbg_bias_act_bwd_units_chunks(H), plane, make_epi(epi)};
+  const dim3 grid(B * ((M + 7) / 8), p.nchunks);
+  if (planes == 3) hipLaunchKernelGGL(bias_act_bwd_units_kernel<3>, grid, dim3(256), 0, tbg_stream(stream), p);
+  else hipLaunchKernelGGL(bias_act_bwd_units_kernel<1>, grid, dim3(256), 0, tbg_stream(stream), p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
@@ -340,6 +470,11 @@ struct ConvUnitsP {
   EpiK e;
 };
 
+#if TBG_EXP == 3
+#define FPROP_SCHED_BARRIER()
+#else
+#define FPROP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <int NP, int WTM>
 __global__ __launch_bounds__(512, 2) void conv_units_fprop_kernel(const ConvUnitsP p) {
   constexpr int WGN = 4, WTN = 2, BM = 2 * WTM * 32;
@@ -438,8 +573,8 @@ __global__ __launch_bounds__(512, 2) void conv_units_fprop_kernel(const ConvUnit
     for (int idx = 0; idx < NL; ++idx) ld1(0, 0, idx);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int bs = t & 1;
-      __builtin_amdgcn_sched_barrier(0);
+      const int bs = TBG_EXP == 4 ? 0 : (t & 1);
+      FPROP_SCHED_BARRIER();
 #pragma unroll
       for (int mm = 0; mm < NM; ++mm) {
         // x3, smallest terms first: (hi|lo)x(lo|hi), then (hi|mid) x mid, then (hi|mid) x hi
@@ -451,7 +586,7 @@ __global__ __launch_bounds__(512, 2) void conv_units_fprop_kernel(const ConvUnit
         } else {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[bs][i], bw[bs][j], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < 9) {  // behind this MFMA: operand loads of the next tap
+        if (t + 1 < 9 && TBG_EXP != 4) {  // behind this MFMA: operand loads of the next tap
           constexpr int LPM = (NL + NM - 1) / NM;
 #pragma unroll
           for (int e = 0; e < LPM; ++e) ld1(t + 1, bs ^ 1, mm * LPM + e);
@@ -461,9 +596,9 @@ __global__ __launch_bounds__(512, 2) void conv_units_fprop_kernel(const ConvUnit
         {
           constexpr int STRIDE = (9 * NM / 2) / PPW > 0 ? (9 * NM / 2) / PPW : 1;
           const int slot = t * NM + mm;
-          if (slot % STRIDE == 0 && slot / STRIDE < PPW) issue_piece(slot / STRIDE, kn, buf ^ 1);
+          if (TBG_EXP != 2 && slot % STRIDE == 0 && slot / STRIDE < PPW) issue_piece(slot / STRIDE, kn, buf ^ 1);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        FPROP_SCHED_BARRIER();
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -476,6 +611,17 @@ __global__ __launch_bounds__(512, 2) void conv_units_fprop_kernel(const ConvUnit
   for (int j = 0; j < WTN; ++j) {
     e_pix[j] = (y0 + wn * WTN + j) * p.W + x0 + (lane & 31);
     e_b[j] = b;
+  }
+  if (TBG_EXP == 1) {  // ablation: no epilogue
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    if (sum == 123.f) p.y[0] = sum;
+    return;
   }
   conv_epilogue<WTM, WTN, 4>(acc, p.e, p.y, nullptr, p.M, p.H * p.W, m0 + wm * WTM * 32, lane, e_pix, e_b, true, b, p.dot_slots,
                              (tu * p.tilesV + tv) * WGN + wn);

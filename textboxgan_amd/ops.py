@@ -395,6 +395,26 @@ def units_pack(x: torch.Tensor, scale: Optional[torch.Tensor] = None, planes: Op
     return UnitTensor(U, B, Cc, H, W, planes)
 
 
+def bias_act_bwd_units_raw(dout, out_act, epi: N.Epilogue, planes=None, want_dpre=False, want_db=True, want_dn=False,
+                           want_dyy=False):
+    """bias_act_bwd_raw that writes units(dpre * alpha * out_scale) (tbg_bias_act_bwd_units): returns (DU, dpre | None, pdb, pdn,
+    pdy) with the partial sums as [B, M, row chunks]."""
+    B, M, H, W = dout.shape
+    planes = unit_planes() if planes is None else planes
+    nbytes = N.lib().tbg_units_bytes(B, M, H, W, planes)
+    N.check(min(nbytes, 0), "tbg_units_bytes")
+    U = torch.empty(nbytes // 2, device=dout.device, dtype=torch.bfloat16)
+    nch = N.lib().tbg_bias_act_bwd_units_chunks(H)
+    mk = lambda: torch.empty((B, M, nch), device=dout.device, dtype=torch.float32)
+    dpre = torch.empty_like(dout) if want_dpre else None
+    pdb, pdn, pdy = (mk() if want_db else None), (mk() if want_dn else None), (mk() if want_dyy else None)
+    _nb = 4.0 * dout.numel() * (2 + int(want_dpre)) + nbytes + (4.0 * B * H * W if epi.noise else 0.0)
+    N.check(PROFILE.launch("bias_act_bwd_units_kernel", 0.0, lambda: N.lib().tbg_bias_act_bwd_units(
+        N.ptr(dout), N.ptr(out_act), N.ptr(U), planes, N.ptr(dpre), N.ptr(pdb), N.ptr(pdn), N.ptr(pdy), B, M, H, W, C.byref(epi),
+        N.stream()), nbytes=_nb), "tbg_bias_act_bwd_units")
+    return UnitTensor(U, B, M, H, W, planes), dpre, pdb, pdn, pdy
+
+
 def conv_units_ok(C_in, M, H, W, KH, KW, stride, pad, transposed, planes) -> bool:
     """geometry of tbg_conv2d_units (3x3 stride-1 pad-1 layers in whole 8 x 32-pixel tiles and 64-channel tiles)"""
     return (KH == 3 and KW == 3 and tuple(stride) == (1, 1) and tuple(pad) == (1, 1) and not transposed and H % 8 == 0 and
@@ -985,6 +1005,76 @@ def bias_act_c(y, noise, strength, b):
 # ----------------------------------------------------------------------------------------
 # fused first-order layers
 # ----------------------------------------------------------------------------------------
+USE_UNITS = True         # 3x3 stride-1 layers consume unit tensors (tbg_conv2d_units / tbg_conv2d_wgrad_units) where they apply
+UNITS_MIN_BLOCKS = 200   # tbg_conv2d_units runs ONE 512-thread block per CU: launches of fewer blocks keep the NCHW kernel
+                         # (measured, profiles/r04_units_isolated.txt: 128 blocks 136 vs 145 TFLOP/s, 256 blocks 196 vs 154)
+
+
+def _units_conv(B, C_in, M, H, W) -> bool:
+    """does a 3x3 stride-1 pad-1 convolution C_in -> M on B x H x W take tbg_conv2d_units in the current arithmetic?"""
+    fmt = _FMT[_TLS.compute]
+    if not USE_UNITS or fmt == FMT_F32:
+        return False
+    if not conv_units_ok(C_in, M, H, W, 3, 3, (1, 1), (1, 1), False, unit_planes(fmt)):
+        return False
+    return B * (H // 8) * (W // 32) * (M // (128 if M % 128 == 0 else 64)) >= UNITS_MIN_BLOCKS
+
+
+def _units_wgrad(I, O, H, W) -> bool:
+    fmt = _FMT[_TLS.compute]
+    return USE_UNITS and fmt != FMT_F32 and wgrad_units_ok(O, I, H, W, H, W, 3, 3, (1, 1), (1, 1))
+
+
+def _unit_tensor(data, like: torch.Tensor, planes=None) -> UnitTensor:
+    """re-wrap the flat buffer of a unit tensor saved by a forward pass"""
+    B, Cc, H, W = like.shape
+    return UnitTensor(data, B, Cc, H, W, unit_planes() if planes is None else planes)
+
+
+class _Bwd3x3:
+    """backward launches of a 3x3 stride-1 pad-1 convolution, through unit tensors where they apply: DU = units(dpre * dscale)
+    is written once -- by the fused bias_act backward (from_bias_act) or by the stand-alone producer -- and feeds the data
+    gradient (tbg_conv2d_units on the transposed, flipped pack) AND the filter gradient (tbg_conv2d_wgrad_units, with XU =
+    units(x * x_scale) from the forward pass or packed here); geometries the unit kernels do not take keep the NCHW launches."""
+
+    def __init__(self, B, I, O, H, W, want_dx=True, want_dw=True):
+        self.I, self.O = I, O
+        self.g = _Geom((1, 1), (1, 1), 3, 3, (H, W), (H, W))
+        self.u_dx = want_dx and _units_conv(B, O, I, H, W)
+        self.u_dw = want_dw and _units_wgrad(I, O, H, W)
+        self.units = self.u_dx or self.u_dw
+        # is the NCHW fp32 gradient needed at all?
+        self.need_dpre = (want_dx and not self.u_dx) or (want_dw and not self.u_dw)
+        self.dpre = self.dscale = self.DU = None
+
+    def from_bias_act(self, dout, out_act, epi, dscale, **want):
+        """bias / noise / LeakyReLU backward: returns (pdb, pdn, pdy); epi.out_scale must be dscale (or None)"""
+        self.dscale = dscale
+        if self.units:
+            self.DU, self.dpre, pdb, pdn, pdy = bias_act_bwd_units_raw(dout, out_act, epi, want_dpre=self.need_dpre, **want)
+        else:
+            _, self.dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout, out_act, epi, **want)
+        return pdb, pdn, pdy
+
+    def from_dpre(self, dpre, dscale=None):
+        self.dpre, self.dscale = dpre, dscale
+        if self.units:
+            self.DU = units_pack(dpre, dscale)
+        return self
+
+    def dx(self, w, epi, dot=None, out=None):
+        if self.u_dx:
+            return conv2d_units_raw(self.DU, pack_filter(w, transpose=True, flip=True), self.I, epi=epi, dot=dot, out=out)
+        return _bwd_data_launch(self.dpre, w, self.g, in_scale=self.dscale, epi=epi, dot=dot, out=out)
+
+    def dw(self, x, XU, coef, x_scale=None, add=None):
+        if self.u_dw:
+            XU = units_pack(x, x_scale) if XU is None else XU
+            dw = torch.empty((3, 3, self.I, self.O), device=x.device, dtype=torch.float32)
+            return wgrad_units_raw(self.DU, XU, dw, self.I * self.O, self.O, 1, coef, add=add)
+        return _bwd_weight_launch(x, self.dpre, self.g, self.I, self.O, alpha=coef, x_scale=x_scale, dy_scale=self.dscale, add=add)
+
+
 def _lrelu_epi(**kw):
     return N.epilogue(act=ACT_LRELU, slope=0.2, gain=SQRT2, **kw)
 
@@ -1012,26 +1102,42 @@ class _ModConvFused(torch.autograd.Function):
         x = x.contiguous(); s = s.contiguous()
         d, wsq = demod_coefs_raw(s, w.contiguous(), coef)
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=coef)
-        out = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (x.shape[2], x.shape[3]), (1, 1), (KH // 2, KW // 2),
-                         in_scale=s, epi=epi)
-        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out)
+        xu = None
+        if KH == 3 and _units_conv(x.shape[0], I, O, x.shape[2], x.shape[3]):
+            # x * s written ONCE as a unit tensor: this launch DMAs its halo tiles from it, and the filter gradient of the
+            # backward pass consumes the same tensor (modulated_conv2d.py:94-96: both use exactly this product)
+            XU = units_pack(x, s)
+            out = conv2d_units_raw(XU, pack_filter(w, False, False), O, epi=epi)
+            xu = XU.data
+        else:
+            out = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (x.shape[2], x.shape[3]), (1, 1), (KH // 2, KW // 2),
+                             in_scale=s, epi=epi)
+        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, xu)
         ctx.coef = coef
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
-        x, w, s, d, wsq, noise, strength, b, out = ctx.saved_tensors
+        x, w, s, d, wsq, noise, strength, b, out, xu = ctx.saved_tensors
         KH, KW, I, O = w.shape
         coef = ctx.coef
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
-        _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
         g = _Geom((1, 1), (KH // 2, KW // 2), KH, KW, (x.shape[2], x.shape[3]), (out.shape[2], out.shape[3]))
         ds_conv = torch.empty_like(s)  # every element written (sum of the launch's partial slots)
+        want_dw = ctx.needs_input_grad[1]  # frozen generator (projector.py: only the latent is optimised): no filter gradient
+        if KH == 3:
+            bw = _Bwd3x3(x.shape[0], I, O, x.shape[2], x.shape[3], want_dw=want_dw)
+            pdb, pdn, pdy = bw.from_bias_act(dout.contiguous(), out, epi, d, want_dn=True, want_dyy=True)  # units(dpre * d)
+            dx = bw.dx(w, N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
+            db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)  # (dwsq needs ds_conv)
+            dw = bw.dw(x, _unit_tensor(xu, x) if xu is not None else None, coef, x_scale=s, add=(w, dwsq, -coef * coef)) if want_dw else None
+            return dx, dw, ds, None, dstrength, db
+        _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
         dx = _bwd_data_launch(dpre, w, g, in_scale=d, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
         db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)
         dw = None
-        if ctx.needs_input_grad[1]:  # frozen generator (projector.py: only the latent is optimised): no filter gradient
+        if want_dw:
             dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef, x_scale=s, dy_scale=d, add=(w, dwsq, -coef * coef))
         return dx, dw, ds, None, dstrength, db
 
@@ -1137,8 +1243,15 @@ class _ConvBiasActFused(torch.autograd.Function):
         H, W = x.shape[2], x.shape[3]
         yhw = ((H + 2 * pad[0] - KH) // stride[0] + 1, (W + 2 * pad[1] - KW) // stride[1] + 1)
         epi = N.epilogue(alpha=coef, bias=b, act=act, gain=gain, residual=residual, res_scale=res_scale)
-        out = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, yhw, stride, pad, epi=epi)
-        ctx.save_for_backward(x, w, b, out if act == ACT_LRELU else None)
+        xu = None
+        ctx.s1_3x3 = KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1)
+        if ctx.s1_3x3 and _units_conv(x.shape[0], I, O, H, W):
+            XU = units_pack(x)  # written once: this launch's halo tiles and the backward pass's filter gradient read it
+            out = conv2d_units_raw(XU, pack_filter(w, False, False), O, epi=epi)
+            xu = XU.data
+        else:
+            out = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, yhw, stride, pad, epi=epi)
+        ctx.save_for_backward(x, w, b, out if act == ACT_LRELU else None, xu)
         ctx.cfgv = (stride, pad, act, res_scale, coef, residual is not None, yhw)
         ctx.role = role
         ctx.gain = gain
@@ -1147,7 +1260,7 @@ class _ConvBiasActFused(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
-        x, w, b, out = ctx.saved_tensors
+        x, w, b, out, xu = ctx.saved_tensors
         stride, pad, act, res_scale, coef, has_res, yhw = ctx.cfgv
         KH, KW, I, O = w.shape
         dout = dout.contiguous()
@@ -1157,10 +1270,17 @@ class _ConvBiasActFused(torch.autograd.Function):
             dout_f, x_f, out_f = dout, x, out
             dout, x, out = dout[:h], x[:h], (out[:h] if out is not None else None)
         dres = None
+        prune_w = FLAGS.skip_d_wgrad and ctx.role in ("d", "d_image")
+        want_dx = ctx.needs_input_grad[0] and not (FLAGS.skip_image_grad and ctx.role == "d_image")
+        bw = _Bwd3x3(dout.shape[0], I, O, x.shape[2], x.shape[3], want_dx=want_dx, want_dw=not prune_w) if ctx.s1_3x3 else None
         if act == ACT_LRELU:
             assert not has_res
-            _, dpre, pdb, _, _ = bias_act_bwd_raw(dout, out, N.epilogue(act=ACT_LRELU, slope=0.2, gain=ctx.gain, bias=b),
-                                                  want_db=b is not None)
+            epi_b = N.epilogue(act=ACT_LRELU, slope=0.2, gain=ctx.gain, bias=b)
+            if bw is not None:  # (writes units(dpre) for the launches below; the NCHW dpre only if one of them needs it)
+                pdb, _, _ = bw.from_bias_act(dout, out, epi_b, None, want_db=b is not None)
+                dpre = bw.dpre
+            else:
+                _, dpre, pdb, _, _ = bias_act_bwd_raw(dout, out, epi_b, want_db=b is not None)
             db = pdb.sum(dim=(0, 2)) if b is not None else None
         elif has_res and res_scale == 1.0:  # (the sum's scale folded into both branches: the gradient passes through as it is)
             dpre = dout
@@ -1177,7 +1297,8 @@ class _ConvBiasActFused(torch.autograd.Function):
         g = _Geom(stride, pad, KH, KW, (x.shape[2], x.shape[3]), yhw)
         dx = None
         thin = KH == 1 and KW == 1 and I <= 4 and stride == (1, 1)  # fromRGB: streaming kernels, not MFMA tiles
-        prune_w = FLAGS.skip_d_wgrad and ctx.role in ("d", "d_image")
+        if bw is not None and act != ACT_LRELU:
+            bw.from_dpre(dpre.contiguous())
         if ctx.needs_input_grad[0] and not (FLAGS.skip_image_grad and ctx.role == "d_image"):
             dx_out = None
             if h:
@@ -1185,6 +1306,8 @@ class _ConvBiasActFused(torch.autograd.Function):
                 dx_out = dx[:h]
             if thin:  # d(image)[b,c,p] = coef * sum_o w[c,o] dpre[b,o,p]
                 r = rgb_project_raw(dpre, w.reshape(I, O).t().contiguous(), I, None, None, None, coef, out=dx_out)
+            elif bw is not None:
+                r = bw.dx(w, N.epilogue(alpha=coef), out=dx_out)
             else:
                 r = _bwd_data_launch(dpre, w, g, alpha=coef, out=dx_out)
             dx = dx if h else r
@@ -1193,6 +1316,8 @@ class _ConvBiasActFused(torch.autograd.Function):
             if thin:  # G[b,o,c] = sum_p dpre[b,o,p] x[b,c,p]
                 _, G = rgb_backproject_raw(dpre, x, None, None, 1.0, want_dx=False, want_G=True)
                 dw = (coef * G.sum(dim=0).t()).reshape(w.shape).contiguous()
+            elif bw is not None:
+                dw = bw.dw(x, _unit_tensor(xu, x) if (xu is not None and not h) else None, coef)
             else:
                 dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef)
         else:
