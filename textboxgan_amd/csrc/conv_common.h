@@ -55,6 +55,17 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // name-only mode (name != NULL): write the instantiation the descriptor selects (rocprofv3 spelling) and launch nothing
 struct NameOut { char *buf; int n; int *dot_slots; int *blocks; };
 
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to the lane-linear LDS range starting at the
+// wave-uniform byte address `lds_base` (M0).  Inline assembly ON PURPOSE: hipcc's waitcnt pass treats a
+// __builtin_amdgcn_global_load_lds in flight as a pending write to ALL of LDS and puts s_waitcnt vmcnt(0) in front of every
+// later LDS read -- including the operand reads of the OTHER buffer, which serialises the DMA with the MFMA phase it is
+// meant to hide under (seen in the ISA of this kernel's builtin form, and in conv.hip's split-filter pipeline).
+// The kernel orders the pieces itself: s_waitcnt vmcnt(0) + s_barrier before a buffer is read.
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
+}
+
+
 // ---- fused epilogue of the implicit-GEMM convolution kernels (tbg.h tbg_epilogue), for a wave that holds WTM x WTN 32x32 MFMA
 // accumulator tiles: rows = output channels mrow0 + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column (lane & 31) of tile j =
 // the output pixel e_pix[j] (offset inside the [Hout*Wout] plane, -1: not an output) of sample e_b[j].  slab != NULL: store-only

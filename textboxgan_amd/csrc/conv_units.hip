@@ -101,7 +101,7 @@ extern "C" int tbg_units_pack_f32(const float *x, const float *scale, void *U, i
 // One block = one (b, 8-channel unit) and UB_ROWS rows of the padded plane; one lane = one padded position: 8 + 8 channel loads
 // (each coalesced along x across the wave) + the noise value, one 16-byte store per plane; the 3 x 8 running sums are reduced
 // once per block.  Replaces bias_act_bwd_kernel + units_pack_kernel: 8 + 2 planes bytes per element instead of 12 + 4 + 2 planes.
-#define UB_ROWS 8
+#define UB_ROWS 24
 struct BabUnitsP {
   const float *__restrict__ dout, *__restrict__ out_act;
   bf16x8 *__restrict__ U;
@@ -230,16 +230,6 @@ struct WgUnitsP {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to the lane-linear LDS range starting at the
-// wave-uniform byte address `lds_base` (M0).  Inline assembly ON PURPOSE: hipcc's waitcnt pass treats a
-// __builtin_amdgcn_global_load_lds in flight as a pending write to ALL of LDS and puts s_waitcnt vmcnt(0) in front of every
-// later LDS read -- including the operand reads of the OTHER buffer, which serialises the DMA with the MFMA phase it is
-// meant to hide under (seen in the ISA of this kernel's builtin form, and in conv.hip's split-filter pipeline).
-// The kernel orders the pieces itself: s_waitcnt vmcnt(0) + s_barrier before a buffer is read.
-__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
-}
 
 template <int NP>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_units_kernel(const WgUnitsP p) {

@@ -1,0 +1,18 @@
+"""N graph-replayed plain steps (f32x3, B=16) for `rocprofv3 --kernel-trace --stats`: python tools/trace_graph_step.py <USE_UNITS 0|1> [steps]
+(per-kernel time UNDER GRAPH REPLAY -- the eager roofline pass does not see cache / clock effects between kernels)"""
+import sys; sys.path.insert(0, '.')
+import torch
+from textboxgan_amd import ops
+from textboxgan_amd.config import Config
+from textboxgan_amd.training_step import build_trainer_state
+from bench import synthetic_batch, bench_init_
+ops.USE_UNITS = bool(int(sys.argv[1]))
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device('cuda:0')
+cfg = Config(batch_size_per_gpu=16)
+b = synthetic_batch(cfg, dev, 1234)
+st = build_trainer_state(cfg, dev, seed=0, use_graphs=True, compute_dtype="f32x3"); bench_init_(st)
+ts = st["training_step"]
+args = (b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False, 1e-4)
+for _ in range(4 + n): ts.dist_train_step(*args)
+torch.cuda.synchronize()
