@@ -205,7 +205,7 @@ def _call_key(name, a):
     return name
 
 
-_NOT_COMPUTE = ("tbg_version", "tbg_strerror", "tbg_crc32c", "_kernel_name", "_bytes", "_floats", "_chunks")
+_NOT_COMPUTE = ("tbg_version", "tbg_strerror", "tbg_crc32c", "_kernel_name", "_bytes", "_floats", "_chunks", "_dot_slots", "_blocks")  # queries: no device work
 
 
 class _LibProxy:

@@ -1,5 +1,5 @@
 """A/B of a host-side knob on the SAME box: graph-replayed plain step (f32x3, B=16), alternating settings.
-usage: python tools/ab_step.py <ops attribute> <value A> <value B> [rounds]"""
+usage: python tools/ab_step.py <ops attribute> <value A> <value B> [rounds] [dtype] [batch]"""
 import sys; sys.path.insert(0, '.')
 import torch, time
 from textboxgan_amd import ops
@@ -9,13 +9,14 @@ from bench import synthetic_batch, bench_init_
 dev = torch.device('cuda:0')
 attr, va, vb = sys.argv[1], eval(sys.argv[2]), eval(sys.argv[3])
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-cfg = Config(batch_size_per_gpu=16)
+dtype = sys.argv[5] if len(sys.argv) > 5 else "f32x3"
+cfg = Config(batch_size_per_gpu=int(sys.argv[6]) if len(sys.argv) > 6 else 16)
 b = synthetic_batch(cfg, dev, 1234)
 res = {repr(va): [], repr(vb): []}
 for r in range(rounds):
     for v in (va, vb):
         setattr(ops, attr, v)
-        st = build_trainer_state(cfg, dev, seed=0, use_graphs=True, compute_dtype="f32x3"); bench_init_(st)
+        st = build_trainer_state(cfg, dev, seed=0, use_graphs=True, compute_dtype=dtype); bench_init_(st)
         ts = st["training_step"]
         args = (b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False, 1e-4)
         for _ in range(4): ts.dist_train_step(*args)
