@@ -4,7 +4,7 @@
 # Every --pmc pass is its own rocprofv3 run without any trace domain.   usage: tools/pmc_report.sh TAG
 TAG=${1:-rXX}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-CMD="python bench.py --roofline-only --steps 2 --warmup 1"
+CMD="python bench.py --roofline-only --steps 2 --warmup 1 $BENCH_ARGS"   # BENCH_ARGS="--dtype bf16": the configs[2] pass
 cd /tmp && export TMPDIR=/tmp
 (cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rep_${TAG}_trace -o t -- $CMD > /tmp/rep_${TAG}_trace.log 2>&1)
 i=0
@@ -29,7 +29,8 @@ def per(k, c):
     n = cnt[(k, c)]
     return acc[k][c] / n if n else float("nan")
 print("# command: rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES}")
-print("#          -- python bench.py --roofline-only --steps 2 --warmup 1      (4 separate runs; MI355X, gfx950)")
+import os
+print("#          -- python bench.py --roofline-only --steps 2 --warmup 1 " + os.environ.get("BENCH_ARGS", "") + "     (4 separate runs; MI355X, gfx950)")
 print("# hbm_MB/launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB / 1024  (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half of wide coalesced reads;")
 print("#                 uncalibrated for narrow accesses -> read GB/s as an upper estimate); GB/s = hbm bytes / average kernel duration; roof 8000 GB/s (6300 achievable)")
 print("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs): share of SIMD cycles with the fp32 MFMA pipe busy")

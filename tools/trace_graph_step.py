@@ -1,4 +1,4 @@
-"""N graph-replayed plain steps (f32x3, B=16) for `rocprofv3 --kernel-trace --stats`: python tools/trace_graph_step.py <USE_UNITS 0|1> [steps]
+"""N graph-replayed plain steps (f32x3, B=16) for `rocprofv3 --kernel-trace --stats`: python tools/trace_graph_step.py <USE_UNITS 0|1> [steps] [plain|pl|r1]
 (per-kernel time UNDER GRAPH REPLAY -- the eager roofline pass does not see cache / clock effects between kernels)"""
 import sys; sys.path.insert(0, '.')
 import torch
@@ -13,6 +13,7 @@ cfg = Config(batch_size_per_gpu=16)
 b = synthetic_batch(cfg, dev, 1234)
 st = build_trainer_state(cfg, dev, seed=0, use_graphs=True, compute_dtype="f32x3"); bench_init_(st)
 ts = st["training_step"]
-args = (b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False, 1e-4)
+REG = sys.argv[3] if len(sys.argv) > 3 else "plain"
+args = (b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], REG == "r1", REG in ("pl", "r1"), 1e-4)
 for _ in range(4 + n): ts.dist_train_step(*args)
 torch.cuda.synchronize()
