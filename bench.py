@@ -313,9 +313,9 @@ def cycle_value(step_ms, batch):
 
 WORKLOAD_ARITH = {
     "f32": "fp32, exact v_mfma_f32_32x32x2_f32 contractions",
-    "f32x3": "fp32 tensors; forward / data-gradient contractions as 3xbf16 split operands, 6 products, fp32 accumulate "
-             "(tbg_conv2d_x3: fp32-grade error, passes every fp32 parity test at the fp32 tolerances); filter gradients on "
-             "exact v_mfma_f32_32x32x2_f32",
+    "f32x3": "fp32 tensors; every MFMA contraction (forward, data gradient, filter gradient) as 3xbf16 split operands, 6 products, "
+             "fp32 accumulate (tbg_conv2d_x3 / tbg_conv2d_units: fp32-grade error, passes every fp32 parity test at the fp32 "
+             "tolerances); the large 3x3 stride-1 layers read their operands from unit tensors (tbg.h) written once per tensor",
     "bf16": "bf16 MFMA operands / fp32 accumulate / fp32 master weights + Adam",
 }
 
