@@ -491,8 +491,24 @@ def training_step(state: dict, cfg, real_images, ocr_images, input_words, ocr_la
 # ----------------------------------------------------------------------------------------
 # synthetic inputs + injected randomness
 # ----------------------------------------------------------------------------------------
+# the two vocabularies of the reference (config/char_tokens.py:4-9) and the Keras Tokenizer rule (:12-17: char_level, no
+# lower-casing, "<OOV>" = index 1, fitted characters 2.. in order of first appearance) restated here, independent of the product's
+# host code: main ids are (token - 1) (utils/utils.py:66-85: pad / OOV -> 0, characters 1..69), ASTER labels keep the token
+# (utils/utils.py:87-105: pad / OOV = 1 = the recogniser's end-of-sequence class, characters 2..95)
+_MAIN_CHARS = "0123456789abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ-'.!?,\""
+_ASTER_CHARS = "0123456789abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~"
+
+
+def main_to_aster_labels(input_words: np.ndarray) -> np.ndarray:
+    """main-vocabulary ids (0 = pad, i = i-th character of the main vector) -> ASTER labels (1 = pad / EOS)."""
+    table = np.ones(len(_MAIN_CHARS) + 1, dtype=np.int32)
+    for i, ch in enumerate(_MAIN_CHARS):
+        j = _ASTER_CHARS.find(ch)
+        table[i + 1] = j + 2 if j >= 0 else 1
+    return table[np.asarray(input_words)]
+
+
 def make_batch(cfg, seed=1234, rank=0):
-    from textboxgan_amd.char_tokens import main_to_aster_labels  # host logic only (no device code)
     g = np.random.default_rng(seed + rank)
     B = cfg.batch_size_per_gpu
     L = g.integers(1, cfg.max_char_number + 1, size=B)

@@ -298,3 +298,17 @@ def test_projector_oracle_known_answers():
         xn, yn = x / x.norm(dim=1, keepdim=True), y / y.norm(dim=1, keepdim=True)
         manual += float((((xn - yn) ** 2) * P[f"lins.{i}.kernel"].reshape(1, -1, 1, 1)).sum(dim=1).mean())
     assert abs(manual - float(RP.lpips(P, a, b))) < 1e-10
+
+
+def test_oracle_label_table_is_independent_and_equals_the_products():
+    """oracle/ref_model restates the two vocabularies and the Keras Tokenizer rule itself (config/char_tokens.py:4-17); the
+    product's host table (textboxgan_amd/char_tokens.py) must agree on every id, and the oracle must not import the product."""
+    import inspect
+    import numpy as np
+    from oracle import ref_model as M
+    from textboxgan_amd import char_tokens as CT
+    ids = np.arange(0, 70, dtype=np.int32)[None]
+    assert np.array_equal(M.main_to_aster_labels(ids), CT.main_to_aster_labels(ids))
+    assert M._MAIN_CHARS == CT.MAIN_CHAR_VECTOR and M._ASTER_CHARS == CT.ASTER_CHAR_VECTOR and len(M._ASTER_CHARS) == 94
+    assert M.main_to_aster_labels(np.array([[0, 1, 11, 69]])).tolist() == [[1, 2, 12, 65]]  # pad, '0', 'a', '"' by hand
+    assert "textboxgan_amd" not in inspect.getsource(M)
