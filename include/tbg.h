@@ -300,6 +300,10 @@ int tbg_bias_act_bwd_units(const float *dout, const float *out_act, void *U, int
  * fp32 NCHW output.  Geometry: 3x3, stride 1, pad 1, not transposed, Hin % 8 == 0, Win % 32 == 0, M % 64 == 0, C % 8 == 0
  * (planes = 1: C % 16 == 0), ksplit == 1 -- TBG_EUNSUPPORTED otherwise (the caller keeps the NCHW entry for those). */
 int tbg_conv2d_units_dot_slots(const tbg_conv_desc *d, int planes);
+/* blocks of the launch and output channels per block (128, or 64 where 128-channel tiles would leave half the CUs without a
+ * block): what a caller needs to decide between this entry and tbg_conv2d_x3 / _bf16 for a small layer */
+int tbg_conv2d_units_blocks(const tbg_conv_desc *d, int planes);
+int tbg_conv2d_units_tile_channels(const tbg_conv_desc *d, int planes);
 int tbg_conv2d_units(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
                      const tbg_epilogue *epi, void *stream);
 

@@ -624,6 +624,30 @@ static bool conv_units_ok(const tbg_conv_desc *d, int planes) {
          (d->M % 64) == 0 && d->ksplit == 1 && d->ldw >= d->M;
 }
 
+// tile height in output channels: 128 (WTM = 2) where the layer has them, unless that leaves half the chip idle (ONE block per CU:
+// fewer than UNITS_FULL blocks) while 64-channel tiles fill it -- the 256-channel 16x64 layers at B = 16: 128 -> 256 blocks
+#ifndef UNITS_FULL  // (-DUNITS_FULL=0: always the 128-channel tile -- tools/ab_lib.py)
+#define UNITS_FULL 200
+#endif
+static int units_wtm(const tbg_conv_desc *d) {
+  if (d->M % 128 != 0) return 1;
+  const long long b2 = (long long)d->B * (d->Hin / 8) * (d->Win / 32) * (d->M / 128);
+  return (b2 < UNITS_FULL && 2 * b2 >= UNITS_FULL) ? 1 : 2;
+}
+
+extern "C" int tbg_conv2d_units_blocks(const tbg_conv_desc *d, int planes) {
+  if (!d || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  if (!conv_units_ok(d, planes)) return TBG_EUNSUPPORTED;
+  const long long n = (long long)d->B * (d->Hin / 8) * (d->Win / 32) * (d->M / (64 * units_wtm(d)));
+  return n > 2147483647LL ? TBG_ERANGE : (int)n;
+}
+
+extern "C" int tbg_conv2d_units_tile_channels(const tbg_conv_desc *d, int planes) {
+  if (!d || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  if (!conv_units_ok(d, planes)) return TBG_EUNSUPPORTED;
+  return 64 * units_wtm(d);
+}
+
 extern "C" int tbg_conv2d_units_dot_slots(const tbg_conv_desc *d, int planes) {
   if (!d || (planes != 1 && planes != 3)) return TBG_EINVAL;
   if (!conv_units_ok(d, planes)) return TBG_EUNSUPPORTED;
@@ -662,6 +686,6 @@ extern "C" int tbg_conv2d_units(const tbg_conv_desc *d, const void *XU, int plan
   for (int t = 0; t < 9; ++t) p.wtap[t] = d->flip ? 8 - t : t;
   p.e = make_epi(epi);
   hipStream_t st = tbg_stream(stream);
-  if (d->M % 128 == 0) return planes == 3 ? launch_conv_units<3, 2>(p, st) : launch_conv_units<1, 2>(p, st);
+  if (units_wtm(d) == 2) return planes == 3 ? launch_conv_units<3, 2>(p, st) : launch_conv_units<1, 2>(p, st);
   return planes == 3 ? launch_conv_units<3, 1>(p, st) : launch_conv_units<1, 1>(p, st);
 }

@@ -1017,7 +1017,9 @@ def _units_conv(B, C_in, M, H, W) -> bool:
         return False
     if not conv_units_ok(C_in, M, H, W, 3, 3, (1, 1), (1, 1), False, unit_planes(fmt)):
         return False
-    return B * (H // 8) * (W // 32) * (M // (128 if M % 128 == 0 else 64)) >= UNITS_MIN_BLOCKS
+    # the tile choice (128- or 64-channel blocks) belongs to the library: ask it for the block count
+    d = N.ConvDesc(B, C_in, M, H, W, H, W, 3, 3, 1, 1, 1, 1, 0, 0, M, 1)
+    return N.lib().tbg_conv2d_units_blocks(C.byref(d), unit_planes(fmt)) >= UNITS_MIN_BLOCKS
 
 
 def _units_wgrad(I, O, H, W) -> bool:
