@@ -307,6 +307,23 @@ int tbg_conv2d_units_tile_channels(const tbg_conv_desc *d, int planes);
 int tbg_conv2d_units(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
                      const tbg_epilogue *epi, void *stream);
 
+/* PHASE unit tensors and the stride-2 convolution that reads them (csrc/conv_units_s2.hip).  The input t [B, C, Hin, Win] of a 3x3 /
+ * stride-2 / pad-0 convolution with Ho x Wo outputs (conv_downsample_2d's strided convolution after its blur,
+ * upfirdn_2d_v2.py:106-113; the data gradient of upsample_conv_2d's transposed convolution, :65-103), de-interleaved by parity:
+ *     P[plane][b][c / 8][2 (Y & 1) + (X & 1)][Y >> 1][X >> 1][c % 8] = t[b][c][Y][X]      (Ho + 1) x (Wo + 1) units per phase,
+ * zero where t has no element, planes as above.  tbg_units_pack_s2_f32 is the stand-alone producer (scale as tbg_units_pack_f32).
+ * tbg_conv2d_units_s2: tbg_conv2d_x3 / _bf16 on such a tensor -- same descriptor (Hin, Win = the dimensions of t), packed filter
+ * and epilogue; geometry 3x3, stride 2, pad 0, Hout % 8 == 0, Wout % 32 == 0, M % 64 == 0, C % 8 == 0 (planes = 1: C % 16 == 0),
+ * ksplit == 1 -- TBG_EUNSUPPORTED otherwise. */
+long long tbg_units_s2_bytes(int B, int C, int Ho, int Wo, int planes);
+int tbg_units_pack_s2_f32(const float *x, const float *scale, void *U, int B, int C, int Hin, int Win, int Ho, int Wo, int planes,
+                          void *stream);
+int tbg_conv2d_units_s2_blocks(const tbg_conv_desc *d, int planes);
+int tbg_conv2d_units_s2_tile_channels(const tbg_conv_desc *d, int planes);
+int tbg_conv2d_units_s2_dot_slots(const tbg_conv_desc *d, int planes);
+int tbg_conv2d_units_s2(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
+                        const tbg_epilogue *epi, void *stream);
+
 /* Filter gradient from unit tensors: tbg_conv2d_wgrad_ex_f32's result (same descriptor, dW strides, alpha, addw / addq /
  * gamma) with S and L given as unit tensors SU (of [B,CS,Hs,Ws]) and LU (of [B,CL,Hl,Wl]) of `planes` planes each (their
  * scales already inside).  planes = 3: f32x3 arithmetic (six products per tap, fp32 accumulate); planes = 1: bf16 operands.

@@ -1,0 +1,105 @@
+"""-m gpu: PHASE unit tensors (tbg.h; csrc/conv_units_s2.hip) -- the stand-alone producer against its definition and the stride-2
+convolution that reads them against float64 at the bar of the NCHW stride-2 kernels (tests/test_x3_gpu.py, test_bf16_gpu.py) and
+against those kernels themselves."""
+import math
+
+import pytest
+import torch
+
+from textboxgan_amd import native as N, ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64)
+
+
+def _rel(a, r):
+    return float((a.double().cpu() - r).abs().max() / (r.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("planes", [3, 1])
+@pytest.mark.parametrize("shape", [(2, 20, 17, 65), (1, 64, 18, 66), (3, 130, 5, 9)])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_units_pack_s2_is_the_definition(dev, planes, shape, scaled):
+    """P[pl][b][c/8][2 (Y&1) + (X&1)][Y>>1][X>>1][c%8] = t[b][c][Y][X]: planes = 3 sums EXACTLY to the fp32 product, planes = 1 is
+    its RNE bf16; positions t does not have and the channel tail are zero; every unit is written."""
+    B, C, Hin, Win = shape
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(B, C, Hin, Win, generator=g) * torch.exp(3 * torch.randn(B, C, Hin, Win, generator=g))).to(dev)
+    s = (torch.rand(B, C, generator=g) + 0.5).to(dev) if scaled else None
+    P = ops.units_pack_s2(x, s, planes=planes)
+    Hq, Wq, C8 = P.Ho + 1, P.Wo + 1, (C + 7) // 8
+    assert P.data.numel() * 2 == N.lib().tbg_units_s2_bytes(B, C, P.Ho, P.Wo, planes)
+    got = P.data.float().double().reshape(planes, B, C8, 2, 2, Hq, Wq, 8)
+    assert torch.isfinite(got).all()
+    v = (x * s[:, :, None, None]) if scaled else x
+    exp = torch.zeros(B, C8 * 8, 2 * Hq, 2 * Wq, device=dev, dtype=torch.float32)
+    exp[:, :C, :Hin, :Win] = v
+    exp = exp.reshape(B, C8, 8, Hq, 2, Wq, 2).permute(0, 1, 4, 6, 3, 5, 2)  # [B, C8, py, px, i, j, 8]
+    if planes == 3:
+        assert torch.equal(got.sum(0), exp.double())
+    assert torch.equal(got[0], exp.bfloat16().double())
+
+
+CONV_S2 = [(2, 64, 64, 17, 65), (2, 128, 128, 18, 66), (3, 64, 192, 33, 129), (1, 256, 256, 34, 130), (2, 64, 128, 66, 258)]
+
+
+@pytest.mark.parametrize("mode", ["f32x3", "bf16"])
+@pytest.mark.parametrize("case", CONV_S2, ids=[str(c) for c in CONV_S2])
+def test_conv_units_s2_matches_float64_and_the_nchw_kernel(dev, mode, case):
+    """tbg_conv2d_units_s2 (phase tiles by LDS-DMA, two stages per channel chunk) with the full fused epilogue, and -- as the data
+    gradient of the up-convolution -- with the transposed pack, out_scale and the fused dot product: against float64 on the operands
+    the kernels see at the NCHW kernels' bar, and against the NCHW stride-2 kernel of the same arithmetic (same products; the
+    taps are summed in another order, so fp32 rounding differs)."""
+    import torch.nn.functional as F
+    B, C, M, Hin, Win = case
+    if mode == "bf16" and C % 16:
+        pytest.skip("bf16 units need whole 16-channel chunks")
+    planes = 3 if mode == "f32x3" else 1
+    Ho, Wo = (Hin - 3) // 2 + 1, (Win - 3) // 2 + 1
+    x, w = _rnd(B, C, Hin, Win, seed=1), _rnd(3, 3, C, M, seed=2) / math.sqrt(9 * C)
+    s, dmod = _rnd(B, C, seed=3).abs() + 0.5, _rnd(B, M, seed=4).abs() + 0.5
+    bias = _rnd(M, seed=6) * 0.2
+    f = lambda t: t.float().to(dev).contiguous()
+    xd, wd, sd, dd, bd = f(x), f(w), f(s), f(dmod), f(bias)
+    xs = xd * sd[:, :, None, None]
+    w_ref = wd.double().cpu()
+    if mode == "bf16":
+        xs, w_ref = xs.bfloat16().float(), wd.bfloat16().double().cpu()
+    with ops.compute_dtype(mode):
+        assert ops.conv_units_s2_ok(C, M, Hin, Win, planes)
+        XP = ops.units_pack_s2(xd, sd, planes=planes)
+        pf = ops.pack_filter(wd, False, False)
+        epi = lambda: N.epilogue(out_scale=dd, bias=bd, alpha=0.9, act=N.ACT_LRELU)
+        y = torch.full((B, M, Ho, Wo), float("nan"), device=dev)
+        ops.conv2d_units_s2_raw(XP, pf, M, epi=epi(), out=y)
+        y_nchw = ops.conv2d_raw(xd, pf, M, 3, 3, (Ho, Wo), (2, 2), (0, 0), in_scale=sd, epi=epi(), allow_split=False)
+        pre = 0.9 * F.conv2d(xs.double().cpu(), w_ref.permute(3, 2, 0, 1), stride=2) * dd.double().cpu()[:, :, None, None]
+        ref = F.leaky_relu(pre + bd.double().cpu()[None, :, None, None], 0.2) * math.sqrt(2.0)
+        errs = [_rel(y, ref)]
+        dns = [float((y - y_nchw).abs().max() / y_nchw.abs().max())]
+        # data gradient of a transposed convolution M -> C (the up-convolution's backward): transposed + flipped pack of ITS filter
+        wt = f(_rnd(3, 3, M, C, seed=9) / math.sqrt(9 * M))      # the up-convolution's filter [kh, kw, in = M, out = C]
+        aux = f(_rnd(B, M, Ho, Wo, seed=8))
+        pft = ops.pack_filter(wt, True, True)
+        dot_u, dot_n = torch.empty(B, M, device=dev), torch.empty(B, M, device=dev)
+        dx = ops.conv2d_units_s2_raw(XP, pft, M, epi=N.epilogue(out_scale=dd, alpha=0.7), dot=(aux, dot_u))
+        dx_n = ops.conv2d_raw(xd, pft, M, 3, 3, (Ho, Wo), (2, 2), (0, 0), in_scale=sd, epi=N.epilogue(out_scale=dd, alpha=0.7),
+                              dot=(aux, dot_n), allow_split=False)
+        errs += [0.0, 0.0]
+        dns += [float((dx - dx_n).abs().max() / dx_n.abs().max()), float((dot_u - dot_n).abs().max() / dot_n.abs().max())]
+    print(f"\nCONVS2 {mode} {case}: vs float64 {errs[0]:.2e}   vs nchw kernel {dns[0]:.1e} {dns[1]:.1e} {dns[2]:.1e}")
+    assert max(errs) < 3e-5, errs
+    assert max(dns) < 5e-6, dns
+
+
+def test_conv_units_s2_refuses_other_geometries(dev):
+    import ctypes as C
+    for d in (N.ConvDesc(2, 64, 64, 16, 64, 16, 64, 3, 3, 1, 1, 1, 1, 0, 0, 64, 1),     # stride 1
+              N.ConvDesc(2, 64, 64, 17, 33, 8, 16, 3, 3, 2, 2, 0, 0, 0, 0, 64, 1),      # 16-pixel rows
+              N.ConvDesc(2, 64, 72, 17, 65, 8, 32, 3, 3, 2, 2, 0, 0, 0, 0, 72, 1),      # partial channel tile
+              N.ConvDesc(2, 64, 64, 17, 65, 8, 32, 3, 3, 2, 2, 0, 0, 0, 0, 64, 2)):     # split K
+        assert N.lib().tbg_conv2d_units_s2_blocks(C.byref(d), 3) == -4  # TBG_EUNSUPPORTED

@@ -1,0 +1,332 @@
+// Stride-2 3x3 convolutions (conv_downsample_2d's strided convolution, upfirdn_2d_v2.py:106-113; the data gradient of the
+// up-convolution, :65-103) from PHASE unit tensors: the input t[B][C][Hin][Win] of a 3x3 / stride-2 / pad-0 convolution with
+// Ho x Wo outputs, stored de-interleaved by row / column parity
+//     P[plane][b][c / 8][ph = 2 py + px][i][j][c % 8] = t[b][c][2 i + py][2 j + px]      bf16 (planes as tbg.h "unit tensors"),
+//     i in [0, Ho], j in [0, Wo]  (Hq = Ho + 1 rows of Wq = Wo + 1 units per phase), zero where t has no element.
+// Tap (kh, kw) of output (y, x) reads t[2y + kh][2x + kw] = P[kh & 1][kw & 1][y + (kh >> 1)][x + (kw >> 1)]: inside a phase plane
+// the stride is gone -- a tap shift is a unit-stride address offset, exactly as in conv_units.hip -- so the halo tiles go
+// HBM -> LDS by DMA with no staging pass (the NCHW stride-2 kernels stage a 5 x 65 halo per 64 outputs on the VALU, split it
+// three ways in f32x3 and de-interleave it on the way: 0.20-0.27 of the roof).
+#include <type_traits>
+
+#include "conv_common.h"
+
+static inline long long s2_units_per_plane(int B, int C, int Ho, int Wo) {
+  return (long long)B * ((C + 7) / 8) * 4 * (Ho + 1) * (Wo + 1);
+}
+
+extern "C" long long tbg_units_s2_bytes(int B, int C, int Ho, int Wo, int planes) {
+  if (B < 1 || C < 1 || Ho < 1 || Wo < 1 || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  return s2_units_per_plane(B, C, Ho, Wo) * planes * 16;
+}
+
+// ---- stand-alone producer: NCHW fp32 (x optional per-(b,c) scale) -> phase unit tensor.  One lane per INPUT position of the
+// padded domain (2 Hq x 2 Wq, x fastest: the 8 channel loads are coalesced along x; the stores of a wave alternate between two
+// phase planes, each a contiguous run of units).
+template <int NP>
+__global__ __launch_bounds__(256) void units_pack_s2_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                            bf16x8 *__restrict__ U, int B, int C, int Hin, int Win, int Hq,
+                                                            int Wq, long long plane) {
+  const int C8 = (C + 7) >> 3, W2 = 2 * Wq, H2 = 2 * Hq;
+  const long long HW = (long long)Hin * Win;
+  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= plane) return;
+  const int X = (int)(n % W2);
+  long long t = n / W2;
+  const int Y = (int)(t % H2);
+  t /= H2;
+  const int cu = (int)(t % C8), b = (int)(t / C8);
+  const bool inside = Y < Hin && X < Win;
+  const long long g0 = ((long long)b * C + cu * 8) * HW + (long long)Y * Win + X;
+  float v[8];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    const bool ok = inside && cu * 8 + cc < C;
+    float a = x[ok ? g0 + cc * HW : 0];
+    if (scale) a *= scale[ok ? b * C + cu * 8 + cc : 0];
+    v[cc] = ok ? a : 0.f;
+  }
+  const long long u = ((((long long)b * C8 + cu) * 4 + (Y & 1) * 2 + (X & 1)) * Hq + (Y >> 1)) * Wq + (X >> 1);
+  if constexpr (NP == 3) {
+    bf16x8 h, m, l;
+    split3_bf16x8(v, h, m, l);
+    U[u] = h; U[plane + u] = m; U[2 * plane + u] = l;
+  } else {
+    U[u] = pack_bf16x8(v);
+  }
+}
+
+extern "C" int tbg_units_pack_s2_f32(const float *x, const float *scale, void *U, int B, int C, int Hin, int Win, int Ho, int Wo,
+                                     int planes, void *stream) {
+  if (!x || !U || B < 1 || C < 1 || Hin < 3 || Win < 3 || Ho < 1 || Wo < 1 || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(U) & 15) != 0) return TBG_EINVAL;
+  if (Ho != (Hin - 3) / 2 + 1 || Wo != (Win - 3) / 2 + 1) return TBG_EINVAL;
+  const long long plane = s2_units_per_plane(B, C, Ho, Wo);
+  if (plane * 8 > 2147483647LL || (long long)B * C * Hin * Win > 2147483647LL) return TBG_ERANGE;
+  const dim3 grid((unsigned)((plane + 255) / 256));
+  if (planes == 3)
+    hipLaunchKernelGGL(units_pack_s2_kernel<3>, grid, dim3(256), 0, tbg_stream(stream), x, scale, reinterpret_cast<bf16x8 *>(U), B, C,
+                       Hin, Win, Ho + 1, Wo + 1, plane);
+  else
+    hipLaunchKernelGGL(units_pack_s2_kernel<1>, grid, dim3(256), 0, tbg_stream(stream), x, scale, reinterpret_cast<bf16x8 *>(U), B, C,
+                       Hin, Win, Ho + 1, Wo + 1, plane);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// ============================================================================================
+// forward convolution (3x3, stride 2, pad 0) from a phase unit tensor
+// ============================================================================================
+// The structure of conv_units_fprop_kernel (conv_units.hip): implicit GEMM (M = output channels, N = 8 x 32 output pixels, K =
+// taps x channels), packed filter, f32x3 term pairing, fused epilogue, ONE 512-thread block per CU, every operand byte by
+// LDS-DMA, two LDS buffers.  What differs: a channel chunk is contracted in TWO STAGES, each with its own buffer --
+//     stage 0: phases (0,0) + (1,1), taps (0,0) (0,2) (2,0) (2,2) | (1,1)      5 taps, 2 phase tiles of 9 x 34 positions
+//     stage 1: phases (0,1) + (1,0), taps (0,1) (2,1) | (1,0) (1,2)            4 taps, 2 phase tiles
+// (all four phase tiles and nine filter taps of a chunk at once are 114 KB in f32x3: no double buffer; split this way the two
+// buffers are 60 + 54 KB and the DMA of one stage runs under the MFMAs of the other: 16 B per matrix cycle and CU against 10 of
+// the stride-1 kernel -- the phase tiles are 3.6x the bytes of a stride-1 halo for the same MFMA work).
+struct ConvS2P {
+  const char *XU, *Wf;
+  long long x_plane, w_plane;  // 16-byte units per plane
+  float *y;
+  int B, C8, M, Ho, Wo, Hq, Wq, ldw, flip;
+  int tilesU, tilesV, dot_slots;
+  EpiK e;
+};
+
+// stage tables: tap t = 3 kh + kw of a stage's tap slot, its phase slot in the stage's buffer, and its (row, column) offset
+// inside the phase tile  (stage 0: t = 0 2 6 8 | 4;  stage 1: t = 1 7 | 3 5)
+constexpr int s2_tap(int st, int ts) { return st == 0 ? (ts == 0 ? 0 : ts == 1 ? 2 : ts == 2 ? 6 : ts == 3 ? 8 : 4) : (ts == 0 ? 1 : ts == 1 ? 7 : ts == 2 ? 3 : 5); }
+constexpr int s2_slot(int st, int ts) { return st == 0 ? (ts == 4 ? 1 : 0) : (ts >= 2 ? 1 : 0); }
+constexpr int s2_roff(int st, int ts) { return st == 0 ? ((ts == 2 || ts == 3) ? 1 : 0) : (ts == 1 ? 1 : 0); }
+constexpr int s2_coff(int st, int ts) { return st == 0 ? ((ts == 1 || ts == 3) ? 1 : 0) : (ts == 3 ? 1 : 0); }
+
+template <int NP, int WTM>
+struct S2Cfg {
+  static constexpr int BM = 2 * WTM * 32, CKU = NP == 3 ? 1 : 2;
+  static constexpr int XS = 9 * 34;                       // positions of one phase tile (9 rows, pitch 34)
+  static constexpr int X_UNITS = NP * CKU * 2 * XS;       // Xs[plane][unit][slot][XS]
+  static constexpr int NT0 = 5, NT1 = 4;
+  static constexpr int A0 = NP * NT0 * CKU * BM, A1 = NP * NT1 * CKU * BM;  // As[plane][tap slot][unit][BM]
+  static constexpr int NPIECE0 = (A0 + X_UNITS + 63) / 64, NPIECE1 = (A1 + X_UNITS + 63) / 64;
+  static constexpr int BUF0 = NPIECE0 * 64, BUF1 = NPIECE1 * 64;
+  static constexpr int PPW0 = (NPIECE0 + 7) / 8, PPW1 = (NPIECE1 + 7) / 8;
+  static_assert(A0 % 64 == 0 && A1 % 64 == 0, "a DMA piece never straddles the filter / phase-tile regions");
+};
+
+template <int NP, int WTM>
+__global__ __launch_bounds__(512, 2) void conv_units_s2_fprop_kernel(const ConvS2P p) {
+  using Cf = S2Cfg<NP, WTM>;
+  constexpr int WTN = 2, BM = Cf::BM, CKU = Cf::CKU, XS = Cf::XS, X_UNITS = Cf::X_UNITS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [BUF0 | BUF1] units
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, half = lane >> 5;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+
+  const int tn = blockIdx.x;
+  const int tv = tn % p.tilesV, t2 = tn / p.tilesV;
+  const int tu = t2 % p.tilesU, b = t2 / p.tilesU;
+  const int m0 = blockIdx.y * BM, y0 = tu * 8, x0 = tv * 32;
+
+  // ---- DMA descriptors (registers, as conv_units_fprop_kernel): per-lane source address at chunk 0 of every piece this wave
+  // issues in stage 0 / stage 1 (piece q = wave + 8 k)
+  const char *dsrc0[Cf::PPW0], *dsrc1[Cf::PPW1];
+  const char *const xu = p.XU, *const wf = p.Wf;
+  auto describe = [&](int st, int q) -> const char * {
+    const int NT = st == 0 ? Cf::NT0 : Cf::NT1, A_UNITS = st == 0 ? Cf::A0 : Cf::A1;
+    const int n = q * 64 + lane;
+    if (n < A_UNITS) {
+      const int row = n / BM, m = n - row * BM;
+      const int u = row % CKU, ts = (row / CKU) % NT, pl = row / (NT * CKU);
+      const int t = s2_tap(st, ts);
+      const int tw = p.flip ? 8 - t : t;
+      return wf + ((pl * p.w_plane + (long long)(tw * p.C8 + u) * p.ldw + m0 + m) << 4);
+    }
+    const int m2 = min(n - A_UNITS, X_UNITS - 1);
+    const int row = m2 / XS, pos = m2 - row * XS;
+    const int slot = row & 1, u = (row >> 1) % CKU, pl = (row >> 1) / CKU;
+    const int ph = st == 0 ? (slot == 0 ? 0 : 3) : (slot == 0 ? 1 : 2);
+    const int r = pos / 34, c = min(pos - r * 34, 32);  // (pitch slot 33 is never read: it re-fetches column 32)
+    return xu + ((pl * p.x_plane + ((((long long)(b * p.C8 + u)) * 4 + ph) * p.Hq + y0 + r) * p.Wq + x0 + c) << 4);
+  };
+#pragma unroll
+  for (int k = 0; k < Cf::PPW0; ++k) dsrc0[k] = describe(0, min(wave + 8 * k, Cf::NPIECE0 - 1));
+#pragma unroll
+  for (int k = 0; k < Cf::PPW1; ++k) dsrc1[k] = describe(1, min(wave + 8 * k, Cf::NPIECE1 - 1));
+  const long long a_step = (long long)CKU * p.ldw * 16, x_step = (long long)CKU * 4 * p.Hq * p.Wq * 16;  // bytes per chunk
+  auto issue0 = [&](int k, int kc) {
+    const int q = min(__builtin_amdgcn_readfirstlane(wave) + 8 * k, Cf::NPIECE0 - 1);
+    dma16(dsrc0[k] + kc * (q * 64 < Cf::A0 ? a_step : x_step), lds0 + (unsigned)(q * 64 * 16));
+  };
+  auto issue1 = [&](int k, int kc) {
+    const int q = min(__builtin_amdgcn_readfirstlane(wave) + 8 * k, Cf::NPIECE1 - 1);
+    dma16(dsrc1[k] + kc * (q * 64 < Cf::A1 ? a_step : x_step), lds0 + (unsigned)((Cf::BUF0 + q * 64) * 16));
+  };
+
+  // ---- operand addressing (bytes inside a stage's buffer)
+  const int a_lane = (wm * (WTM * 32) + (lane & 31)) * 16;
+  int b_lane[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) b_lane[j] = ((wn * WTN + j) * 34 + (lane & 31)) * 16;
+  constexpr int X_PL = CKU * 2 * XS * 16;
+  const int bZ = 2 * (1 - half) * X_PL, bH = NP == 3 ? 0 : half * 2 * XS * 16;
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // one stage: NT taps of MFMAs from this stage's buffer; behind them the operand reads of the next tap and the DMA pieces of
+  // the NEXT stage (chunk kc_next) into the other buffer
+  auto run_stage = [&](auto stc, int kc_next) {
+    constexpr int ST = decltype(stc)::value;
+    constexpr int NT = ST == 0 ? Cf::NT0 : Cf::NT1, A_UNITS = ST == 0 ? Cf::A0 : Cf::A1;
+    constexpr int PPW_NEXT = ST == 0 ? Cf::PPW1 : Cf::PPW0;
+    constexpr int A_PL = NT * CKU * BM * 16;
+    const int aX = NP == 3 ? half * A_PL : half * BM * 16, aY = 2 * half * A_PL;
+    const char *Ab = smem + (size_t)(ST == 0 ? 0 : Cf::BUF0) * 16 + a_lane;
+    const char *Xb = smem + (size_t)((ST == 0 ? 0 : Cf::BUF0) + A_UNITS) * 16;
+    constexpr int NA = NP == 3 ? 2 * WTM : WTM, NB = NP == 3 ? 3 * WTN : WTN, NL = NA + NB;
+    constexpr int NM = (NP == 3 ? 3 : 1) * WTM * WTN;  // MFMAs per tap
+    bf16x8 av[2][NA], bw[2][NB];
+    auto ld1 = [&](int ts, int bs, int idx) {
+      if (idx < NA) {
+        const int i = NP == 3 ? idx >> 1 : idx;
+        const int plane_off = NP == 3 ? ((idx & 1) ? aY : aX) : aX;
+        av[bs][idx] = *reinterpret_cast<const bf16x8 *>(Ab + ts * CKU * BM * 16 + plane_off + i * 32 * 16);
+      } else if (idx < NL) {
+        const int e = idx - NA;
+        const int j = NP == 3 ? e / 3 : e, w = NP == 3 ? e - 3 * j : 0;
+        const int plane_off = NP == 3 ? (w == 0 ? 0 : w == 1 ? X_PL : bZ) : bH;
+        bw[bs][e] = *reinterpret_cast<const bf16x8 *>(Xb + b_lane[j] + (s2_slot(ST, ts) * XS + s2_roff(ST, ts) * 34 + s2_coff(ST, ts)) * 16 +
+                                                      plane_off);
+      }
+    };
+#pragma unroll
+    for (int idx = 0; idx < NL; ++idx) ld1(0, 0, idx);
+#pragma unroll
+    for (int ts = 0; ts < NT; ++ts) {
+      const int bs = ts & 1;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm) {
+        const int grp = mm / (WTM * WTN), ij = mm - grp * (WTM * WTN);
+        const int i = ij / WTN, j = ij - i * WTN;
+        if constexpr (NP == 3) {  // smallest terms first: (hi|lo)x(lo|hi), then (hi|mid) x mid, then (hi|mid) x hi
+          const int ai = 2 * i + (grp == 0 ? 1 : 0), bi = 3 * j + (grp == 0 ? 2 : grp == 1 ? 1 : 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[bs][ai], bw[bs][bi], acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[bs][i], bw[bs][j], acc[i][j], 0, 0, 0);
+        }
+        if (ts + 1 < NT) {
+          constexpr int LPM = (NL + NM - 1) / NM;
+#pragma unroll
+          for (int e = 0; e < LPM; ++e) ld1(ts + 1, bs ^ 1, mm * LPM + e);
+        }
+        {
+          constexpr int STRIDE = (NT * NM / 2) / PPW_NEXT > 0 ? (NT * NM / 2) / PPW_NEXT : 1;
+          static_assert(NT * NM >= PPW_NEXT, "every piece of the next stage has an MFMA to hide behind");
+          const int slot = ts * NM + mm;
+          if (slot % STRIDE == 0 && slot / STRIDE < PPW_NEXT) {
+            if constexpr (ST == 0) issue1(slot / STRIDE, kc_next); else issue0(slot / STRIDE, kc_next);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage's tiles have landed
+    __syncthreads();                                   // ... for every wave, and every wave is done with this buffer
+  };
+
+  const int nchunks = p.C8 / CKU;
+#pragma unroll
+  for (int k = 0; k < Cf::PPW0; ++k) issue0(k, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kc = 0; kc < nchunks; ++kc) {
+    run_stage(std::integral_constant<int, 0>{}, kc);
+    run_stage(std::integral_constant<int, 1>{}, kc + 1 < nchunks ? kc + 1 : kc);  // (the last chunk re-fetches itself: no branch)
+  }
+
+  int e_pix[WTN], e_b[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    e_pix[j] = (y0 + wn * WTN + j) * p.Wo + x0 + (lane & 31);
+    e_b[j] = b;
+  }
+  conv_epilogue<WTM, WTN, 4>(acc, p.e, p.y, nullptr, p.M, p.Ho * p.Wo, m0 + wm * WTM * 32, lane, e_pix, e_b, true, b, p.dot_slots,
+                             (tu * p.tilesV + tv) * 4 + wn);
+}
+
+static bool conv_units_s2_ok(const tbg_conv_desc *d, int planes) {
+  const int cku = planes == 3 ? 8 : 16;
+  return !d->transposed && d->KH == 3 && d->KW == 3 && d->sy == 2 && d->sx == 2 && d->py == 0 && d->px == 0 && d->Hin >= 3 &&
+         d->Win >= 3 && d->Hout == (d->Hin - 3) / 2 + 1 && d->Wout == (d->Win - 3) / 2 + 1 && (d->Hout % 8) == 0 &&
+         (d->Wout % 32) == 0 && (d->C % cku) == 0 && (d->M % 64) == 0 && d->ksplit == 1 && d->ldw >= d->M;
+}
+
+#ifndef UNITS_FULL
+#define UNITS_FULL 200
+#endif
+static int units_s2_wtm(const tbg_conv_desc *d) {  // (the rule of conv_units.hip units_wtm)
+  if (d->M % 128 != 0) return 1;
+  const long long b2 = (long long)d->B * (d->Hout / 8) * (d->Wout / 32) * (d->M / 128);
+  return (b2 < UNITS_FULL && 2 * b2 >= UNITS_FULL) ? 1 : 2;
+}
+
+extern "C" int tbg_conv2d_units_s2_blocks(const tbg_conv_desc *d, int planes) {
+  if (!d || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  if (!conv_units_s2_ok(d, planes)) return TBG_EUNSUPPORTED;
+  const long long n = (long long)d->B * (d->Hout / 8) * (d->Wout / 32) * (d->M / (64 * units_s2_wtm(d)));
+  return n > 2147483647LL ? TBG_ERANGE : (int)n;
+}
+
+extern "C" int tbg_conv2d_units_s2_tile_channels(const tbg_conv_desc *d, int planes) {
+  if (!d || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  if (!conv_units_s2_ok(d, planes)) return TBG_EUNSUPPORTED;
+  return 64 * units_s2_wtm(d);
+}
+
+extern "C" int tbg_conv2d_units_s2_dot_slots(const tbg_conv_desc *d, int planes) {
+  if (!d || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  if (!conv_units_s2_ok(d, planes)) return TBG_EUNSUPPORTED;
+  return (d->Hout / 8) * (d->Wout / 32) * 4;
+}
+
+template <int NP, int WTM>
+static int launch_conv_units_s2(ConvS2P &p, hipStream_t st) {
+  using Cf = S2Cfg<NP, WTM>;
+  const size_t lds = (size_t)(Cf::BUF0 + Cf::BUF1) * 16;
+  auto kern = conv_units_s2_fprop_kernel<NP, WTM>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return TBG_EHIP;
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tilesU * p.tilesV, p.M / Cf::BM), dim3(512), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_conv2d_units_s2(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
+                                   const tbg_epilogue *epi, void *stream) {
+  if (!d || !XU || !w || !y || (planes != 1 && planes != 3) || !epi_valid(epi)) return TBG_EINVAL;
+  if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1) return TBG_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(XU) | reinterpret_cast<uintptr_t>(w)) & 15) != 0) return TBG_EINVAL;
+  if (!conv_units_s2_ok(d, planes)) return TBG_EUNSUPPORTED;
+  if ((double)d->B * d->M * d->Hout * d->Wout > 2147483647.0) return TBG_ERANGE;
+  ConvS2P p{};
+  p.XU = reinterpret_cast<const char *>(XU); p.Wf = reinterpret_cast<const char *>(w);
+  p.x_plane = s2_units_per_plane(d->B, d->C, d->Hout, d->Wout);
+  p.C8 = d->C / 8;
+  p.w_plane = (long long)9 * p.C8 * d->ldw;
+  if (p.x_plane * planes > 2147483647LL / 2 || p.w_plane * planes > 2147483647LL / 2) return TBG_ERANGE;
+  p.y = y; p.B = d->B; p.M = d->M; p.Ho = d->Hout; p.Wo = d->Wout; p.Hq = d->Hout + 1; p.Wq = d->Wout + 1; p.ldw = d->ldw;
+  p.flip = d->flip;
+  p.tilesU = d->Hout / 8; p.tilesV = d->Wout / 32;
+  p.dot_slots = p.tilesU * p.tilesV * 4;
+  p.e = make_epi(epi);
+  hipStream_t st = tbg_stream(stream);
+  if (units_s2_wtm(d) == 2) return planes == 3 ? launch_conv_units_s2<3, 2>(p, st) : launch_conv_units_s2<1, 2>(p, st);
+  return planes == 3 ? launch_conv_units_s2<3, 1>(p, st) : launch_conv_units_s2<1, 1>(p, st);
+}

@@ -438,10 +438,72 @@ def conv2d_units_raw(XU: UnitTensor, w: "PackedFilter", M: int, flip=False, epi:
         epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(partial)
     y = torch.empty((B, M, H, W), device=XU.data.device, dtype=torch.float32) if out is None else out
     _flops = 2.0 * B * M * XU.C * 9 * H * W
-    N.check(PROFILE.launch(f"conv_units_fprop_kernel<{XU.planes}, {2 if M % 128 == 0 else 1}>", _flops, lambda: N.lib().tbg_conv2d_units(
+    _wtm = N.lib().tbg_conv2d_units_tile_channels(C.byref(d), XU.planes) // 64
+    N.check(PROFILE.launch(f"conv_units_fprop_kernel<{XU.planes}, {_wtm}>", _flops, lambda: N.lib().tbg_conv2d_units(
         C.byref(d), N.ptr(XU.data), XU.planes, N.ptr(w.data), N.ptr(y), C.byref(epi), N.stream()),
         f"conv_units[B={B} C={XU.C} M={M} {H}x{W}]", 2.0 * XU.data.numel() + 4.0 * y.numel() + 2.0 * XU.planes * 9 * XU.C * M),
         "tbg_conv2d_units")
+    if partial is not None:
+        torch.sum(partial, dim=2, out=dot[1].view(B, M))
+    return y
+
+
+class PhaseUnitTensor(NamedTuple):
+    """the input t [B,C,Hin,Win] of a 3x3 stride-2 pad-0 convolution with Ho x Wo outputs, de-interleaved by parity (tbg.h "PHASE
+    unit tensors"): P[planes][B][ceil(C/8)][4][Ho+1][Wo+1][8] bf16 -- inside a phase plane the stride is gone."""
+    data: torch.Tensor  # flat bf16
+    B: int
+    C: int
+    Hin: int
+    Win: int
+    Ho: int
+    Wo: int
+    planes: int
+
+
+def units_pack_s2(x: torch.Tensor, scale: Optional[torch.Tensor] = None, planes: Optional[int] = None) -> PhaseUnitTensor:
+    """x [B,C,Hin,Win] fp32 (x scale[b,c]) -> its phase unit tensor (stand-alone producer)."""
+    B, Cc, Hin, Win = x.shape
+    Ho, Wo = (Hin - 3) // 2 + 1, (Win - 3) // 2 + 1
+    planes = unit_planes() if planes is None else planes
+    nbytes = N.lib().tbg_units_s2_bytes(B, Cc, Ho, Wo, planes)
+    N.check(min(nbytes, 0), "tbg_units_s2_bytes")
+    U = torch.empty(nbytes // 2, device=x.device, dtype=torch.bfloat16)
+    N.check(PROFILE.launch("units_pack_s2_kernel", 0.0, lambda: N.lib().tbg_units_pack_s2_f32(
+        N.ptr(x), N.ptr(scale), N.ptr(U), B, Cc, Hin, Win, Ho, Wo, planes, N.stream()), nbytes=4.0 * x.numel() + nbytes),
+        "tbg_units_pack_s2")
+    return PhaseUnitTensor(U, B, Cc, Hin, Win, Ho, Wo, planes)
+
+
+def conv_units_s2_ok(C_in, M, Hin, Win, planes) -> bool:
+    """geometry of tbg_conv2d_units_s2 (3x3 stride-2 pad-0 layers with whole 8 x 32-pixel output tiles and 64-channel tiles)"""
+    Ho, Wo = (Hin - 3) // 2 + 1, (Win - 3) // 2 + 1
+    return Hin >= 3 and Win >= 3 and Ho % 8 == 0 and Wo % 32 == 0 and M % 64 == 0 and C_in % (8 if planes == 3 else 16) == 0
+
+
+def conv2d_units_s2_raw(XP: PhaseUnitTensor, w: "PackedFilter", M: int, flip=False, epi: Optional[N.Epilogue] = None, dot=None,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 stride-2 pad-0 convolution of the tensor behind the phase unit tensor XP with a packed filter of the matching format;
+    fp32 NCHW output through the fused epilogue.  dot = (aux, out) as in conv2d_raw."""
+    assert w.fmt == (FMT_X3 if XP.planes == 3 else FMT_BF16) and w.C == XP.C and w.M >= M and w.T == 9
+    B, Ho, Wo = XP.B, XP.Ho, XP.Wo
+    d = N.ConvDesc(B, XP.C, M, XP.Hin, XP.Win, Ho, Wo, 3, 3, 2, 2, 0, 0, 0, int(flip), w.M, 1)
+    epi = N.epilogue() if epi is None else epi
+    partial = None
+    if dot is not None:
+        slots = N.lib().tbg_conv2d_units_s2_dot_slots(C.byref(d), XP.planes)
+        N.check(min(slots, 0), "tbg_conv2d_units_s2_dot_slots")
+        partial = torch.empty((B, M, slots), device=XP.data.device, dtype=torch.float32)
+        epi = N.Epilogue.from_buffer_copy(epi)
+        epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(partial)
+    y = torch.empty((B, M, Ho, Wo), device=XP.data.device, dtype=torch.float32) if out is None else out
+    _flops = 2.0 * B * M * XP.C * 9 * Ho * Wo
+    _wtm = N.lib().tbg_conv2d_units_s2_tile_channels(C.byref(d), XP.planes) // 64
+    N.check(min(_wtm, 0), "tbg_conv2d_units_s2_tile_channels")
+    N.check(PROFILE.launch(f"conv_units_s2_fprop_kernel<{XP.planes}, {_wtm}>", _flops, lambda: N.lib().tbg_conv2d_units_s2(
+        C.byref(d), N.ptr(XP.data), XP.planes, N.ptr(w.data), N.ptr(y), C.byref(epi), N.stream()),
+        f"conv_units_s2[B={B} C={XP.C} M={M} {XP.Hin}x{XP.Win}->{Ho}x{Wo}]",
+        2.0 * XP.data.numel() + 4.0 * y.numel() + 2.0 * XP.planes * 9 * XP.C * M), "tbg_conv2d_units_s2")
     if partial is not None:
         torch.sum(partial, dim=2, out=dot[1].view(B, M))
     return y

@@ -1,0 +1,39 @@
+"""isolated timings of the phase-unit stride-2 kernels against the NCHW stride-2 kernels they replace:
+python tools/bench_units_s2.py [B]"""
+import sys, torch
+sys.path.insert(0, ".")
+from textboxgan_amd import ops, native as N
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+print("--- forward 3x3 s2 (D: blur output -> conv_1 with bias + lrelu; G: data gradient of the up-convolution with out_scale + dot)")
+for (C, M, Hin, Win, Bx) in [(128, 128, 65, 257, B), (64, 128, 66, 258, 2 * B), (128, 256, 33, 129, B), (128, 256, 34, 130, 2 * B),
+                             (256, 512, 18, 66, 2 * B), (256, 256, 17, 65, B)]:
+    Ho, Wo = (Hin - 3) // 2 + 1, (Win - 3) // 2 + 1
+    x = torch.randn(Bx, C, Hin, Win, device=dev)
+    w = torch.randn(3, 3, C, M, device=dev) / (9 * C) ** 0.5
+    bs = torch.randn(M, device=dev)
+    fl = 2.0 * Bx * C * M * Ho * Wo * 9
+    row = f"B={Bx} {C}->{M} {Hin}x{Win}:"
+    for mode, planes in (("f32x3", 3), ("bf16", 1)):
+        with ops.compute_dtype(mode):
+            pf = ops.pack_filter(w, False, False)
+            epi = lambda: N.epilogue(bias=bs, act=N.ACT_LRELU)
+            out = torch.empty(Bx, M, Ho, Wo, device=dev)
+            t_old = timeit(lambda: ops.conv2d_raw(x, pf, M, 3, 3, (Ho, Wo), (2, 2), (0, 0), epi=epi(), out=out))
+            t_pack = timeit(lambda: ops.units_pack_s2(x, planes=planes))
+            XP = ops.units_pack_s2(x, planes=planes)
+            d = N.ConvDesc(Bx, C, M, Hin, Win, Ho, Wo, 3, 3, 2, 2, 0, 0, 0, 0, M, 1)
+            import ctypes
+            nb = N.lib().tbg_conv2d_units_s2_blocks(ctypes.byref(d), planes)
+            t_new = timeit(lambda: ops.conv2d_units_s2_raw(XP, pf, M, epi=epi(), out=out))
+        row += (f"  [{mode}] nchw {t_old:7.1f} us ({fl / t_old / 1e6:6.1f} TF)  units {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF, {nb} blocks)"
+                f"  pack {t_pack:6.1f} us")
+    print(row, flush=True)
