@@ -324,6 +324,13 @@ int tbg_conv2d_units_s2_dot_slots(const tbg_conv_desc *d, int planes);
 int tbg_conv2d_units_s2(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
                         const tbg_epilogue *epi, void *stream);
 
+/* Filter gradient of that stride-2 convolution from unit tensors: S (the tensor on the Ho x Wo output grid) as a stride-1 unit
+ * tensor, L (the input-grid tensor t) as a PHASE unit tensor; result, strides, alpha and the additive term as
+ * tbg_conv2d_wgrad_units.  Geometry: 3x3, stride 2, pad 0, Ws % 32 == 0, CS % 128 == 0, CL % 64 == 0 -- TBG_EUNSUPPORTED otherwise. */
+long long tbg_conv2d_wgrad_units_s2_workspace_bytes(const tbg_wgrad_desc *d);
+int tbg_conv2d_wgrad_units_s2(const tbg_wgrad_desc *d, const void *SU, const void *LU, int planes, float *dW, const float *addw,
+                              const float *addq, float gamma, float *workspace, long long workspace_bytes, void *stream);
+
 /* Filter gradient from unit tensors: tbg_conv2d_wgrad_ex_f32's result (same descriptor, dW strides, alpha, addw / addq /
  * gamma) with S and L given as unit tensors SU (of [B,CS,Hs,Ws]) and LU (of [B,CL,Hl,Wl]) of `planes` planes each (their
  * scales already inside).  planes = 3: f32x3 arithmetic (six products per tap, fp32 accumulate); planes = 1: bf16 operands.

@@ -103,3 +103,44 @@ def test_conv_units_s2_refuses_other_geometries(dev):
               N.ConvDesc(2, 64, 72, 17, 65, 8, 32, 3, 3, 2, 2, 0, 0, 0, 0, 72, 1),      # partial channel tile
               N.ConvDesc(2, 64, 64, 17, 65, 8, 32, 3, 3, 2, 2, 0, 0, 0, 0, 64, 2)):     # split K
         assert N.lib().tbg_conv2d_units_s2_blocks(C.byref(d), 3) == -4  # TBG_EUNSUPPORTED
+
+
+WG_S2 = [(2, 128, 64, 17, 65), (2, 128, 128, 18, 66), (3, 256, 64, 9, 65), (1, 128, 64, 66, 258), (4, 256, 128, 33, 129)]
+
+
+@pytest.mark.parametrize("planes", [3, 1])
+@pytest.mark.parametrize("case", WG_S2, ids=[str(c) for c in WG_S2])
+def test_wgrad_units_s2_matches_float64(dev, planes, case):
+    """tbg_conv2d_wgrad_units_s2 (8-wave 128 x 64 blocks, phase tiles by LDS-DMA, transposing operand reads) with both operands
+    scaled and the fused additive term, against float64 on the operands the kernels see.  planes = 3: the fp32 bar of
+    conv_wgrad_x3_kernel (3e-5) and not worse than 2x the exact fp32 kernel; planes = 1: float64 on the bf16-rounded operands."""
+    import torch.nn.functional as F
+    B, CS, CL, Hl, Wl = case
+    Hs, Ws = (Hl - 3) // 2 + 1, (Wl - 3) // 2 + 1
+    x, dy = _rnd(B, CL, Hl, Wl, seed=40), _rnd(B, CS, Hs, Ws, seed=41)
+    xs, ds = _rnd(B, CL, seed=42).abs() + 0.5, _rnd(B, CS, seed=43).abs() + 0.5
+    addw, addq = _rnd(3, 3, CL, CS, seed=44), _rnd(CL, CS, seed=45)
+    f32 = lambda t: t.float().double()
+    xr = (f32(x) * f32(xs)[:, :, None, None]).float()
+    dyr = (f32(dy) * f32(ds)[:, :, None, None]).float()
+    if planes == 1:
+        xr, dyr = xr.bfloat16().float(), dyr.bfloat16().float()
+    w = torch.zeros(3, 3, CL, CS, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xr.double(), w.permute(3, 2, 0, 1), stride=2), w, dyr.double())
+    ref = 0.7 * ref + 0.3 * f32(addw) * f32(addq)[None, None]
+    f = lambda t: t.float().to(dev).contiguous()
+    assert ops.wgrad_units_s2_ok(CS, CL, Hs, Ws, Hl, Wl)
+    SU, LP = ops.units_pack(f(dy), f(ds), planes=planes), ops.units_pack_s2(f(x), f(xs), planes=planes)
+    dw = torch.full((3, 3, CL, CS), float("nan"), device=dev)
+    ops.wgrad_units_s2_raw(SU, LP, dw, CL * CS, CS, 1, 0.7, add=(f(addw), f(addq), 0.3))
+    err = _rel(dw, ref)
+    if planes == 3:
+        g = ops._Geom((2, 2), (0, 0), 3, 3, (Hl, Wl), (Hs, Ws))
+        with ops.compute_dtype("f32"):
+            dw32 = ops._bwd_weight_launch(f(x), f(dy), g, CL, CS, alpha=0.7, x_scale=f(xs), dy_scale=f(ds), add=(f(addw), f(addq), 0.3))
+        e32 = _rel(dw32, ref)
+        print(f"\nWGS2 {case}: f32 {e32:.3e}  units x3 {err:.3e}")
+        assert err < 3e-5 and err <= max(2.0 * e32, 1e-6), (err, e32)
+    else:
+        print(f"\nWGS2 bf16 {case}: {err:.3e}")
+        assert err < 3e-5, err

@@ -330,3 +330,252 @@ extern "C" int tbg_conv2d_units_s2(const tbg_conv_desc *d, const void *XU, int p
   if (units_s2_wtm(d) == 2) return planes == 3 ? launch_conv_units_s2<3, 2>(p, st) : launch_conv_units_s2<1, 2>(p, st);
   return planes == 3 ? launch_conv_units_s2<3, 1>(p, st) : launch_conv_units_s2<1, 1>(p, st);
 }
+
+// ============================================================================================
+// filter gradient of the 3x3 stride-2 pad-0 convolution from unit tensors
+// ============================================================================================
+// dW[t][cl][cs] = sum_{b,y,x} S[b,cs,y,x] * t_in[b,cl,2y+kh,2x+kw]   with S (the gradient on the Ho x Wo output grid) as a
+// stride-1 unit tensor (conv_units.hip: ring of one zero unit) and t_in as a PHASE unit tensor, so that every tap is a
+// unit-stride shifted read of one phase plane and the contraction over PIXELS runs on transposing LDS reads exactly as in
+// conv_wgrad_units_kernel.  What the stride costs is operand traffic: per 32 output pixels the four phase tiles are 3 x the
+// bytes of a stride-1 halo -- a 64 x 64-channel block of 4 waves would need 28 B of LDS-DMA per matrix cycle and CU (the
+// stride-1 kernel: 11.6; the pipe sustains < 20).  Hence:
+//   * block = 128 S-channels x 64 L-channels, EIGHT waves (2 per SIMD; wave = 32 x 32 x 9 taps = 144 accumulator registers):
+//     the phase tiles feed twice the MFMAs -- 16 B per matrix cycle;
+//   * K chunk = ONE output row x 32 pixels, contracted in the two stages of conv_units_s2_fprop_kernel (phases (0,0)+(1,1): 5
+//     taps; (0,1)+(1,0): 4 taps), each stage's L tiles in its own buffer (x3: 41 KB each), the S tile (x3: 27 KB) double-buffered:
+//     the L tiles of stage 1 and the S tile of the next chunk arrive under the MFMAs of stage 0, the L tiles of the next chunk's
+//     stage 0 under stage 1;
+//   * the partial tiles are written in the 64 x 64 layout of the 4-wave kernels (waves 0-3 / 4-7 = S-channels 0-63 / 64-127), so
+//     the shared reduce kernels sum them.
+// LDS rows: S [plane][16 units][S_ROW = 36] (32 used), L [plane][8 units][L_ROW = 108]: slot 0 = 2 rows x 34 positions of the
+// stage's first phase, slot 1 (at 68) = 1 row x 34 of its second (pitches = 4 / 12 mod 16: the four channel units a transposing
+// read touches fall on disjoint banks).
+struct WgS2P {
+  const char *SU, *LU;
+  long long s_plane, l_plane;  // units per plane
+  int CS8, CL8, Hps, Wps, Hq, Wq;
+  int Ho, tilesV, nchunks, ksplit;
+  float *ws;
+};
+
+template <int NP>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_units_s2_kernel(const WgS2P p) {
+  constexpr int S_ROW = 36, L_ROW = 108, NT = 9;
+  constexpr int S_UNITS = NP * 16 * S_ROW, L_RAW = NP * 8 * L_ROW;
+  static_assert(S_UNITS % 64 == 0, "the S tile is a whole number of DMA pieces");
+  constexpr int S_PIECES = S_UNITS / 64, L_PIECES = (L_RAW + 63) / 64, LBUF = L_PIECES * 64;
+  constexpr int PPW_A = (L_PIECES + S_PIECES + 7) / 8;  // issued during stage 0: L of stage 1 (this chunk) + S of the next chunk
+  constexpr int PPW_B = (L_PIECES + 7) / 8;             // issued during stage 1: L of stage 0 (next chunk)
+  constexpr int NQ = NP == 3 ? 6 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // units: [S0][S1][L stage 0][L stage 1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sgrp = wave >> 1, wl = wave & 1;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+  constexpr int OFF_L0 = 2 * S_UNITS, OFF_L1 = 2 * S_UNITS + LBUF;
+
+  // ---- DMA descriptors: per-lane source OFFSET (units, relative to the chunk base of its tensor) of every piece this wave issues
+  // (32-bit: the tensors hold < 2^31 bytes per plane set, checked on the host)
+  auto l_off = [&](int st, int q) -> int {  // piece q of a stage's L buffer
+    const int n = min(q * 64 + lane, L_RAW - 1);
+    const int row = n / L_ROW, pos = n - row * L_ROW;
+    const int pl = row >> 3, lu = row & 7;
+    const int slot = pos >= 68 ? 1 : 0, ps = min(pos - 68 * slot, slot ? 33 : 67);
+    const int r = ps / 34, c = min(ps - r * 34, 32);
+    const int ph = st == 0 ? (slot == 0 ? 0 : 3) : (slot == 0 ? 1 : 2);
+    return (int)(pl * p.l_plane) + ((lu * 4 + ph) * p.Hq + r) * p.Wq + c;
+  };
+  auto s_off = [&](int q) -> int {
+    const int n = q * 64 + lane;
+    const int row = n / S_ROW, pix = min(n - row * S_ROW, 31);
+    const int pl = row >> 4, su = row & 15;
+    return (int)(pl * p.s_plane) + su * p.Hps * p.Wps + pix;
+  };
+  int offA[PPW_A], offB[PPW_B];
+#pragma unroll
+  for (int k = 0; k < PPW_A; ++k) {
+    const int q = min(wave + 8 * k, L_PIECES + S_PIECES - 1);
+    offA[k] = q < L_PIECES ? l_off(1, q) : s_off(q - L_PIECES);
+  }
+#pragma unroll
+  for (int k = 0; k < PPW_B; ++k) offB[k] = l_off(0, min(wave + 8 * k, L_PIECES - 1));
+  const char *const su_ = p.SU, *const lu_ = p.LU;
+  const int cs8 = blockIdx.x * 16, cl8 = blockIdx.y * 8;
+
+  auto chunk_bases = [&](int chunk, int &sb, int &lb) {
+    const int tv = chunk % p.tilesV;
+    const int t2 = chunk / p.tilesV;
+    const int y = t2 % p.Ho, b = t2 / p.Ho;
+    sb = ((b * p.CS8 + cs8) * p.Hps + y + 1) * p.Wps + tv * 32 + 1;  // interior starts at (1, 1)
+    lb = ((b * p.CL8 + cl8) * 4 * p.Hq + y) * p.Wq + tv * 32;
+  };
+  // pieces of stage 0's issue list: q < L_PIECES -> L buffer of stage 1 (chunk lb), else S buffer `sbuf` (chunk sb_next)
+  auto issueA = [&](int k, int lb, int sb_next, int sbuf) {
+    const int q = min(__builtin_amdgcn_readfirstlane(wave) + 8 * k, L_PIECES + S_PIECES - 1);
+    if (q < L_PIECES) dma16(lu_ + ((long long)(lb + offA[k]) << 4), lds0 + (unsigned)((OFF_L1 + q * 64) * 16));
+    else dma16(su_ + ((long long)(sb_next + offA[k]) << 4), lds0 + (unsigned)((sbuf * S_UNITS + (q - L_PIECES) * 64) * 16));
+  };
+  auto issueB = [&](int k, int lb_next) {
+    const int q = min(__builtin_amdgcn_readfirstlane(wave) + 8 * k, L_PIECES - 1);
+    dma16(lu_ + ((long long)(lb_next + offB[k]) << 4), lds0 + (unsigned)((OFF_L0 + q * 64) * 16));
+  };
+
+  // ---- operand addressing (conv_wgrad_units_kernel: lane i of a 16-lane group supplies the address of (pixel i / 4, channels
+  // 4 (i % 4) .. + 3) and receives channel i at the 4 pixels; two reads = 8 consecutive pixels of one channel)
+  const int i16 = lane & 15, grp = lane >> 4;
+  const int jj = i16 >> 2, cq = i16 & 3, chblk = grp & 1, khalf = grp >> 1;
+  const int a_lane = ((sgrp * 4 + chblk * 2 + (cq >> 1)) * S_ROW + 8 * khalf + jj) * 16 + (cq & 1) * 8;
+  const int b_lane = ((wl * 4 + chblk * 2 + (cq >> 1)) * L_ROW + 8 * khalf + jj) * 16 + (cq & 1) * 8;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto rd = [&](const char *ptr) -> bf16x8 {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(ptr));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(ptr + 64));
+    return __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+  };
+
+  // one stage of one chunk: steps (16-pixel group g, tap slot ts), NQ x 1 MFMAs each; behind them the operand reads of the next
+  // step and this stage's DMA issue list
+  auto run_stage = [&](auto stc, int sbuf, auto &&issue) {
+    constexpr int ST = decltype(stc)::value;
+    constexpr int NTS = ST == 0 ? 5 : 4, NS = 2 * NTS, PPW = ST == 0 ? PPW_A : PPW_B;
+    const char *Ab = smem + (size_t)sbuf * S_UNITS * 16 + a_lane;
+    const char *Bb = smem + (size_t)(ST == 0 ? OFF_L0 : OFF_L1) * 16 + b_lane;
+    bf16x8 a[2][NP], bv[2][NP];
+    auto ld = [&](int s, int idx) {  // operand idx of step s: the NP B planes, then (first tap of a group) the NP A planes
+      const int g = s / NTS, ts = s - g * NTS;
+      if (idx < NP)
+        bv[s & 1][idx] = rd(Bb + (idx * 8 * L_ROW + s2_slot(ST, ts) * 68 + s2_roff(ST, ts) * 34 + 16 * g + s2_coff(ST, ts)) * 16);
+      else if (ts == 0 && idx < 2 * NP)
+        a[g][idx - NP] = rd(Ab + ((idx - NP) * 16 * S_ROW + 16 * g) * 16);
+    };
+#pragma unroll
+    for (int idx = 0; idx < 2 * NP; ++idx) ld(0, idx);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int g = s / NTS, ts = s - g * NTS, t = s2_tap(ST, ts);
+      __builtin_amdgcn_sched_barrier(0);
+      // six partial products per tap, smallest first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int m = 0; m < NQ; ++m) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][NP == 3 ? PA[m] : 0], bv[s & 1][NP == 3 ? PB[m] : 0], acc[t], 0, 0, 0);
+        if (s + 1 < NS) {
+          constexpr int LPM = (2 * NP + NQ - 1) / NQ;
+#pragma unroll
+          for (int e = 0; e < LPM; ++e) ld(s + 1, m * LPM + e);
+        }
+        {
+          constexpr int STRIDE = (NS * NQ / 2) / PPW > 0 ? (NS * NQ / 2) / PPW : 1;
+          static_assert(NS * NQ >= PPW, "every DMA piece has an MFMA to hide behind");
+          const int slot = s * NQ + m;
+          if (slot % STRIDE == 0 && slot / STRIDE < PPW) issue(slot / STRIDE);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  int chunk = blockIdx.z;
+  int sb = 0, lb = 0, sbn = 0, lbn = 0;
+  if (chunk < p.nchunks) {  // prologue: S tile and stage-0 L tiles of the first chunk
+    chunk_bases(chunk, sb, lb);
+#pragma unroll
+    for (int k = 0; k < PPW_B; ++k) issueB(k, lb);
+#pragma unroll
+    for (int k = 0; k < PPW_A; ++k) {
+      const int q = min(__builtin_amdgcn_readfirstlane(wave) + 8 * k, L_PIECES + S_PIECES - 1);
+      if (q >= L_PIECES) dma16(su_ + ((long long)(sb + offA[k]) << 4), lds0 + (unsigned)(((q - L_PIECES) * 64) * 16));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int sbuf = 0;
+  for (; chunk < p.nchunks; chunk += p.ksplit) {
+    chunk_bases(chunk + p.ksplit < p.nchunks ? chunk + p.ksplit : chunk, sbn, lbn);  // (the last chunk re-fetches itself)
+    run_stage(std::integral_constant<int, 0>{}, sbuf, [&](int k) { issueA(k, lb, sbn, sbuf ^ 1); });
+    run_stage(std::integral_constant<int, 1>{}, sbuf, [&](int k) { issueB(k, lbn); });
+    sb = sbn; lb = lbn;
+    sbuf ^= 1;
+  }
+
+  // partial tile, in the 64 x 64 layout of the 4-wave kernels
+  const int tile = sgrp >> 1, tid4 = ((sgrp & 1) * 2 + wl) * 64 + lane;
+  const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * (2 * gridDim.x) + 2 * blockIdx.x + tile;
+  float *wsp = p.ws + blk * (size_t)(NT * 16 * 256);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r16 = 0; r16 < 16; ++r16) wsp[(t * 16 + r16) * 256 + tid4] = acc[t][r16];
+}
+
+static bool wgrad_units_s2_ok(const tbg_wgrad_desc *d) {
+  return d->KH == 3 && d->KW == 3 && d->sy == 2 && d->sx == 2 && d->py == 0 && d->px == 0 && d->Hl >= 3 && d->Wl >= 3 &&
+         d->Hs == (d->Hl - 3) / 2 + 1 && d->Ws == (d->Wl - 3) / 2 + 1 && (d->Ws % 32) == 0 && (d->CS % 128) == 0 && (d->CL % 64) == 0;
+}
+
+static int wgrad_units_s2_ksplit(const tbg_wgrad_desc *d) {
+  const int tiles = (d->CS / 128) * (d->CL / 64);
+  const int nchunks = d->B * d->Hs * (d->Ws / 32);
+  return wgrad_ksplit(tiles, nchunks, 256);  // one block per CU
+}
+
+extern "C" long long tbg_conv2d_wgrad_units_s2_workspace_bytes(const tbg_wgrad_desc *d) {
+  if (!d || d->B < 1 || d->CS < 1 || d->CL < 1 || d->Hs < 1 || d->Ws < 1) return TBG_EINVAL;
+  if (!wgrad_units_s2_ok(d)) return TBG_EUNSUPPORTED;
+  return (long long)wgrad_units_s2_ksplit(d) * (d->CS / 64) * (d->CL / 64) * 9 * 16 * 256 * (long long)sizeof(float);
+}
+
+template <int NP>
+static int launch_wgrad_units_s2(WgS2P &u, WgradP &p, hipStream_t st) {
+  constexpr int S_UNITS = NP * 16 * 36, LBUF = ((NP * 8 * 108 + 63) / 64) * 64;
+  const size_t lds = (size_t)(2 * S_UNITS + 2 * LBUF) * 16;
+  auto kern = conv_wgrad_units_s2_kernel<NP>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return TBG_EHIP;
+  const int tx = p.CS / 64, ty = p.CL / 64;
+  hipLaunchKernelGGL(kern, dim3(p.CS / 128, ty, u.ksplit), dim3(512), lds, st, u);
+  TBG_LAUNCH_CHECK();
+  if (tx * ty * 9 >= 256)
+    hipLaunchKernelGGL((conv_wgrad_reduce_kernel<2, 2, 9>), dim3(tx, ty, 9), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_reduce_wide_kernel<2, 2, 9>), dim3(tx, ty, 9 * 16), dim3(256), 0, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_conv2d_wgrad_units_s2(const tbg_wgrad_desc *d, const void *SU, const void *LU, int planes, float *dW,
+                                         const float *addw, const float *addq, float gamma, float *workspace,
+                                         long long workspace_bytes, void *stream) {
+  if (!d || !SU || !LU || !dW || !workspace || ((addw == nullptr) != (addq == nullptr)) || (planes != 1 && planes != 3))
+    return TBG_EINVAL;
+  if (d->B < 1 || d->CS < 1 || d->CL < 1 || d->Hs < 1 || d->Ws < 1 || d->Hl < 1 || d->Wl < 1) return TBG_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(SU) | reinterpret_cast<uintptr_t>(LU)) & 15) != 0) return TBG_EINVAL;
+  if (!wgrad_units_s2_ok(d)) return TBG_EUNSUPPORTED;
+  const long long s_plane = (long long)d->B * (d->CS / 8) * (d->Hs + 2) * (d->Ws + 2);
+  const long long l_plane = s2_units_per_plane(d->B, d->CL, d->Hs, d->Ws);
+  if (s_plane * planes > 2147483647LL / 16 || l_plane * planes > 2147483647LL / 16) return TBG_ERANGE;  // 32-bit unit offsets
+  WgS2P u{};
+  u.SU = reinterpret_cast<const char *>(SU); u.LU = reinterpret_cast<const char *>(LU);
+  u.s_plane = s_plane; u.l_plane = l_plane;
+  u.CS8 = d->CS / 8; u.CL8 = d->CL / 8;
+  u.Hps = d->Hs + 2; u.Wps = d->Ws + 2; u.Hq = d->Hs + 1; u.Wq = d->Ws + 1;
+  u.Ho = d->Hs; u.tilesV = d->Ws / 32;
+  u.nchunks = d->B * d->Hs * u.tilesV;
+  u.ksplit = wgrad_units_s2_ksplit(d);
+  u.ws = workspace;
+  if ((long long)u.ksplit * (d->CS / 64) * (d->CL / 64) * 9 * 16 * 256 * (long long)sizeof(float) > workspace_bytes) return TBG_EINVAL;
+  WgradP p{};  // what the reduce kernels read
+  p.CS = d->CS; p.CL = d->CL; p.st_t = d->st_t; p.st_l = d->st_l; p.st_s = d->st_s; p.alpha = d->alpha;
+  p.dW = dW; p.ws = workspace; p.addw = addw; p.addq = addq; p.gamma = gamma; p.ksplit = u.ksplit;
+  return planes == 3 ? launch_wgrad_units_s2<3>(u, p, tbg_stream(stream)) : launch_wgrad_units_s2<1>(u, p, tbg_stream(stream));
+}

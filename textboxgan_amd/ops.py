@@ -534,6 +534,30 @@ def wgrad_units_raw(SU: UnitTensor, LU: UnitTensor, out: torch.Tensor, st_t: int
     return out
 
 
+def wgrad_units_s2_ok(CS, CL, Hs, Ws, Hl, Wl) -> bool:
+    """geometry of tbg_conv2d_wgrad_units_s2 (3x3 stride-2 pad-0 layers with whole 32-pixel output rows, 128 S- / 64 L-channel tiles)"""
+    return Hl >= 3 and Wl >= 3 and Hs == (Hl - 3) // 2 + 1 and Ws == (Wl - 3) // 2 + 1 and Ws % 32 == 0 and CS % 128 == 0 and CL % 64 == 0
+
+
+def wgrad_units_s2_raw(SU: UnitTensor, LP: PhaseUnitTensor, out: torch.Tensor, st_t: int, st_l: int, st_s: int, alpha: float,
+                       out_offset: int = 0, add=None):
+    """filter gradient of a 3x3 stride-2 pad-0 convolution from the unit tensor of S (output-grid tensor, scale inside) and the
+    phase unit tensor of L (input-grid tensor, scale inside).  Overwrites ``out`` like wgrad_raw."""
+    assert SU.planes == LP.planes and SU.B == LP.B and (SU.H, SU.W) == (LP.Ho, LP.Wo)
+    d = N.WgradDesc(SU.B, SU.C, LP.C, SU.H, SU.W, LP.Hin, LP.Win, 3, 3, 2, 2, 0, 0, st_t, st_l, st_s, alpha)
+    nbytes = N.lib().tbg_conv2d_wgrad_units_s2_workspace_bytes(C.byref(d))
+    N.check(min(nbytes, 0), "tbg_conv2d_wgrad_units_s2_workspace_bytes")
+    ws = _workspace(out.device, nbytes)
+    addw, addq, gamma = add if add is not None else (None, None, 0.0)
+    _flops = 2.0 * SU.B * SU.C * LP.C * SU.H * SU.W * 9
+    N.check(PROFILE.launch(f"conv_wgrad_units_s2_kernel<{SU.planes}>", _flops, lambda: N.lib().tbg_conv2d_wgrad_units_s2(
+        C.byref(d), N.ptr(SU.data), N.ptr(LP.data), SU.planes, N.ptr(out) + 4 * out_offset,
+        (N.ptr(addw) + 4 * out_offset) if addw is not None else None, N.ptr(addq), gamma, N.ptr(ws), ws.numel() * 4, N.stream()),
+        f"wgrad_units_s2[B={SU.B} CS={SU.C} CL={LP.C} {SU.H}x{SU.W}]",
+        2.0 * (SU.data.numel() + LP.data.numel()) + 36.0 * SU.C * LP.C), "tbg_conv2d_wgrad_units_s2")
+    return out
+
+
 HAVE_WGRAD_X3 = True  # tbg_conv2d_wgrad_x3 (falls back to the exact fp32 kernel inside the library for the small geometries)
 
 

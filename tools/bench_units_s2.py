@@ -37,3 +37,20 @@ for (C, M, Hin, Win, Bx) in [(128, 128, 65, 257, B), (64, 128, 66, 258, 2 * B), 
         row += (f"  [{mode}] nchw {t_old:7.1f} us ({fl / t_old / 1e6:6.1f} TF)  units {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF, {nb} blocks)"
                 f"  pack {t_pack:6.1f} us")
     print(row, flush=True)
+print("--- filter gradient 3x3 s2 (S = gradient on the output grid, scaled; L = the strided convolution's input)")
+for (CS, CL, Hl, Wl, Bx) in [(128, 128, 65, 257, B), (128, 64, 66, 258, 2 * B), (256, 128, 33, 129, B), (256, 128, 34, 130, 2 * B),
+                             (512, 256, 18, 66, 2 * B), (256, 256, 17, 65, B)]:
+    Hs, Ws = (Hl - 3) // 2 + 1, (Wl - 3) // 2 + 1
+    x, dy = torch.randn(Bx, CL, Hl, Wl, device=dev), torch.randn(Bx, CS, Hs, Ws, device=dev)
+    ds = torch.rand(Bx, CS, device=dev) + 0.5
+    dw = torch.empty(3, 3, CL, CS, device=dev)
+    g = ops._Geom((2, 2), (0, 0), 3, 3, (Hl, Wl), (Hs, Ws))
+    fl = 2.0 * Bx * CS * CL * Hs * Ws * 9
+    row = f"B={Bx} CS={CS} CL={CL} L={Hl}x{Wl}:"
+    for mode, planes in (("f32x3", 3), ("bf16", 1)):
+        with ops.compute_dtype(mode):
+            t_old = timeit(lambda: ops._bwd_weight_launch(x, dy, g, CL, CS, alpha=1.0, dy_scale=ds))
+        SU, LP = ops.units_pack(dy, ds, planes=planes), ops.units_pack_s2(x, planes=planes)
+        t_new = timeit(lambda: ops.wgrad_units_s2_raw(SU, LP, dw, CL * CS, CS, 1, 1.0))
+        row += f"  [{mode}] nchw {t_old:7.1f} us ({fl / t_old / 1e6:6.1f} TF)  units {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF)"
+    print(row, flush=True)
