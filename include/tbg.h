@@ -316,6 +316,11 @@ int tbg_conv2d_units(const tbg_conv_desc *d, const void *XU, int planes, const v
  * and epilogue; geometry 3x3, stride 2, pad 0, Hout % 8 == 0, Wout % 32 == 0, M % 64 == 0, C % 8 == 0 (planes = 1: C % 16 == 0),
  * ksplit == 1 -- TBG_EUNSUPPORTED otherwise. */
 long long tbg_units_s2_bytes(int B, int C, int Ho, int Wo, int planes);
+/* fused producer: t = upfirdn2d(x, kx (x) ky, up = down = 1, pad) * in_scale[b*C + c] written as the PHASE unit tensor of t (the
+ * blur in front of conv_downsample_2d's strided convolution; the blur's adjoint in upsample_conv_2d's backward pass):
+ * tbg_units_pack_s2_f32 of tbg_upfirdn2d_sep_f32's output (to single fp32 roundings), without the fp32 tensor in between.  Filters of <= 4 x 4 taps. */
+int tbg_upfirdn2d_units_s2_f32(const float *x, const float *kx, const float *ky, void *U, int B, int C, int inH, int inW, int kH,
+                               int kW, int padx0, int padx1, int pady0, int pady1, const float *in_scale, int planes, void *stream);
 int tbg_units_pack_s2_f32(const float *x, const float *scale, void *U, int B, int C, int Hin, int Win, int Ho, int Wo, int planes,
                           void *stream);
 int tbg_conv2d_units_s2_blocks(const tbg_conv_desc *d, int planes);

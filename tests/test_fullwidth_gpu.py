@@ -341,6 +341,35 @@ def _run_units_case(dev, arith, M, seed):
     return set(log)
 
 
+def _run_units_s2_case(dev, arith, M, seed):
+    """the phase-unit kernels (csrc/conv_units_s2.hip: fused FIR producer, all-DMA stride-2 convolution, 8-wave filter gradient)
+    against float64 on the operands they see, in arithmetic `arith` (f32x3 / bf16); returns the instantiations launched."""
+    import torch.nn.functional as F
+    from textboxgan_amd import native as N, ops
+    B, Cc, H, W = 2, 64, 16, 64
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cc, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(3, 3, Cc, M, generator=g, dtype=torch.float64) / math.sqrt(9 * Cc)
+    dy = torch.randn(B, M, H // 2, W // 2, generator=g, dtype=torch.float64)
+    q = (lambda t: t.float().bfloat16().double()) if arith == "bf16" else (lambda t: t.float().double())
+    rel = lambda a, r: float((a.double().cpu() - r).abs().max() / (r.abs().max() + 1e-30))
+    with N.record_calls() as log, ops.compute_dtype(arith):
+        xd, wd, dyd = x.float().to(dev), w.float().to(dev), dy.float().to(dev)
+        k = ops.fir_kernel(dev, 1.0)
+        t = ops.upfirdn2d_raw(xd, k, pad=(2, 3, 2, 3))            # the blurred tensor (the NCHW FIR: oracle-compared elsewhere)
+        TP = ops.upfirdn2d_units_s2(xd, k, pad=(2, 3, 2, 3))      # ... and its phase unit tensor from the fused producer
+        dpk = (TP.data.float() - ops.units_pack_s2(t).data.float()).abs().max()  # same arithmetic, single fp32 roundings apart
+        assert float(dpk) <= 2.0 ** -7 * float(t.abs().max()), ("fir units", arith, float(dpk))
+        tr, wr = q(t.double().cpu()).requires_grad_(True), q(w).requires_grad_(True)
+        ref = F.conv2d(tr, wr.permute(3, 2, 0, 1), stride=2)
+        (gw,) = torch.autograd.grad(ref, (wr,), q(dy))
+        assert rel(ops.conv2d_units_s2_raw(TP, ops.pack_filter(wd, False, False), M), ref.detach()) < 3e-5, ("units s2 fwd", arith, M)
+        if M % 128 == 0:
+            dw = torch.empty(3, 3, Cc, M, device=dev)
+            assert rel(ops.wgrad_units_s2_raw(ops.units_pack(dyd), TP, dw, Cc * M, M, 1, 1.0), gw) < 5e-5, ("units s2 wgrad", arith, M)
+    return set(log)
+
+
 _COVERED = {}
 
 
@@ -358,6 +387,7 @@ def _covered(dev, arith):
                 cov |= _run_conv_case(dev, case, 500 + i, "f32x3")
         if arith != "f32":  # the 3x3 stride-1 layers of these arithmetics consume unit tensors
             cov |= _run_units_case(dev, arith, 128, 700) | _run_units_case(dev, arith, 64, 701)
+            cov |= _run_units_s2_case(dev, arith, 128, 702) | _run_units_s2_case(dev, arith, 64, 703)
         for reg in ((False, False), (True, True)):
             cov |= set(_step_vs_oracle(dev, arith, 4, reg)[0])
         _COVERED[arith] = cov

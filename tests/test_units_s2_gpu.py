@@ -144,3 +144,88 @@ def test_wgrad_units_s2_matches_float64(dev, planes, case):
     else:
         print(f"\nWGS2 bf16 {case}: {err:.3e}")
         assert err < 3e-5, err
+
+
+@pytest.mark.parametrize("planes", [3, 1])
+@pytest.mark.parametrize("case", [(2, 20, 16, 64, (2, 3, 2, 3), False), (2, 64, 16, 64, (2, 2, 2, 2), True),
+                                  (1, 128, 64, 256, (2, 3, 2, 3), False), (3, 16, 5, 9, (2, 2, 2, 2), True)], ids=str)
+def test_fir_units_s2_equals_fir_then_pack(dev, planes, case):
+    """the fused producer (tbg_upfirdn2d_units_s2_f32: blur -> phase unit tensor) against the two launches it replaces (to single fp32 roundings)
+    -- the D blocks' blur (pad 2,3: 64x256 -> 66x258) and the up-convolution's backward blur (pad 2,2 with the demodulation scale:
+    -> 65x257, whose odd size leaves the last row / column of two phases empty)."""
+    B, C, H, W, pad, scaled = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    s = (torch.rand(B, C, generator=g) + 0.5).to(dev) if scaled else None
+    k = ops.fir_kernel(dev, 4.0 if scaled else 1.0)
+    t = ops.upfirdn2d_raw(x, k, pad=pad, in_scale=s.reshape(-1) if scaled else None)
+    ref = ops.units_pack_s2(t, planes=planes)
+    P = ops.upfirdn2d_units_s2(x, k, pad=pad, in_scale=s.reshape(-1) if scaled else None, planes=planes)
+    assert (P.Hin, P.Win, P.Ho, P.Wo) == (ref.Hin, ref.Win, ref.Ho, ref.Wo)
+    # the value behind every unit against the two-launch form: the same arithmetic (horizontal pass, vertical pass, scale) in
+    # another kernel -- the compiler contracts a few multiply-adds differently, so single fp32 roundings differ (both forms sit at
+    # the same 1e-7 of float64): planes = 3 reconstructs fp32 exactly, planes = 1 may land on the other side of a bf16 boundary
+    Hq, Wq, C8 = P.Ho + 1, P.Wo + 1, (C + 7) // 8
+    val = lambda U: U.data.float().double().reshape(planes, B, C8, 2, 2, Hq, Wq, 8).sum(0)
+    got, exp = val(P), val(ref)
+    assert torch.equal(got == 0, exp == 0), "padding / channel tail"
+    # (a rounding of an intermediate is relative to the tensor's scale, not to a result that cancelled; one bf16 ulp is up to
+    # 2^-7 of the value)
+    bad = (got - exp).abs() > (0.0 if planes == 3 else 2.0 ** -7) * exp.abs() + 2.0 ** -21 * float(exp.abs().max())
+    assert not bool(bad.any()), (int(bad.sum()), float((got - exp).abs().max()))
+    assert float(((got != exp).double().mean())) < (0.5 if planes == 3 else 5e-3), "more than rounding-level cases differ"
+
+
+@pytest.mark.parametrize("mode", ["f32x3", "bf16"])
+def test_blur_conv_s2_fused_equals_the_nchw_layers(dev, mode, monkeypatch):
+    """ops._BlurConvS2Fused (FIR -> phase units -> strided convolution; backward: units(dpre) -> filter gradient from unit tensors)
+    against the two launches + NCHW backward it replaces (ops.upfirdn2d + ops.conv_bias_act_fused): output, input gradient,
+    filter gradient and bias gradient at the kernels' own agreement (same products, other summation orders)."""
+    monkeypatch.setattr(ops, "UNITS_MIN_BLOCKS", 1)
+    B, I, O, H, W = 2, 64, 128, 32, 128
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, I, H, W, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(3, 3, I, O, generator=g)).to(dev).requires_grad_(True)
+    b = (0.1 * torch.randn(O, generator=g)).to(dev).requires_grad_(True)
+    dout = torch.randn(B, O, H // 2, W // 2, generator=g).to(dev)
+    with ops.compute_dtype(mode):
+        assert ops.blur_conv_s2_units(B, I, O, H, W)
+        k = ops.fir_kernel(dev, 1.0)
+        y0 = ops.conv_bias_act_fused(ops.upfirdn2d(x, k, pad=(2, 3, 2, 3)), w, b, stride=(2, 2), out_mul=0.7)
+        g0 = torch.autograd.grad(y0, (x, w, b), dout)
+        y1 = ops.blur_conv_s2_fused(x, w, b, out_mul=0.7)
+        g1 = torch.autograd.grad(y1, (x, w, b), dout)
+    # bf16: the two FIR kernels differ by single fp32 roundings, which moves a few elements of the blurred tensor to the neighbouring
+    # bf16 value (2^-8 relative on one of 576 products)
+    tol = 5e-6 if mode == "f32x3" else 3e-4
+    rel = lambda a, r: float((a - r).abs().max() / r.abs().max())
+    errs = [rel(y1, y0)] + [rel(a, r) for a, r in zip(g1, g0)]
+    print(f"\nBLURCONV {mode}: y {errs[0]:.1e} dx {errs[1]:.1e} dw {errs[2]:.1e} db {errs[3]:.1e}")
+    assert max(errs) < tol, errs
+
+
+@pytest.mark.parametrize("mode", ["f32x3", "bf16"])
+def test_modconv_up_backward_through_phase_units_equals_the_nchw_path(dev, mode, monkeypatch):
+    """ops._ModConvUpFused's backward with the blur^T output as a phase unit tensor (data gradient = tbg_conv2d_units_s2 with the
+    fused style dot, filter gradient = tbg_conv2d_wgrad_units_s2 with the demodulation term) against its NCHW launches."""
+    monkeypatch.setattr(ops, "UNITS_MIN_BLOCKS", 1)
+    B, I, O, H, W = 2, 128, 64, 16, 64
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, I, H, W, generator=g).to(dev).requires_grad_(True)
+    w = torch.randn(3, 3, I, O, generator=g).to(dev).requires_grad_(True)
+    s = (torch.rand(B, I, generator=g) + 0.5).to(dev).requires_grad_(True)
+    noise = torch.randn(B, 1, 2 * H, 2 * W, generator=g).to(dev)
+    strength = torch.tensor(0.2, device=dev, requires_grad=True)
+    b = (0.1 * torch.randn(O, generator=g)).to(dev).requires_grad_(True)
+    dout = torch.randn(B, O, 2 * H, 2 * W, generator=g).to(dev)
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(ops, "USE_UNITS_S2", on)
+        with ops.compute_dtype(mode):
+            y = ops.modconv_up_fused(x, w, s, noise, strength, b)
+            res.append((y,) + torch.autograd.grad(y, (x, w, s, strength, b), dout))
+    rel = lambda a, r: float((a - r).abs().max() / (r.abs().max() + 1e-30))
+    errs = [rel(a, r) for a, r in zip(res[1], res[0])]
+    print(f"\nMODCONVUP {mode}: " + " ".join(f"{e:.1e}" for e in errs))
+    tol = 5e-6 if mode == "f32x3" else 3e-4  # (bf16: see test_blur_conv_s2_fused_equals_the_nchw_layers)
+    assert errs[0] == 0.0 and max(errs) < tol, errs

@@ -74,6 +74,159 @@ extern "C" int tbg_units_pack_s2_f32(const float *x, const float *scale, void *U
   return TBG_OK;
 }
 
+// ---- fused producer: the FIR pass in front of a stride-2 convolution (conv_downsample_2d's blur, upfirdn_2d_v2.py:106-113; the
+// blur's adjoint in the backward pass of upsample_conv_2d, :204-209) writing its result t = upfirdn2d(x, k, pad) * in_scale as a
+// PHASE unit tensor -- the fp32 NCHW tensor between the blur and the strided convolution / its filter gradient never exists.
+// up = down = 1, separable filter of <= 4 x 4 taps (the model's [1,3,3,1] x [1,3,3,1]): same arithmetic as
+// upfirdn2d_tile_kernel<1,1,1,1,..,SEP> (horizontal pass over the window rows, then the vertical pass, then the scale), so the
+// result is tbg_units_pack_s2_f32 of that kernel's output up to single fp32 roundings (the compiler contracts a few multiply-adds
+// differently in the two kernels; both sit at the same distance from float64).
+// A unit needs 8 channels of one pixel in one lane, the FIR wants a lane to own a patch of ONE plane (its window rows are 16-byte
+// loads, coalesced along x): the block (256 lanes = 8 channels x 32 lanes, tile = 8 rows x 64 columns of t) computes per plane --
+// lane = 4 rows x 4 columns, a 7 x 8 window as fourteen 16-byte loads (the patch of upfirdn2d_tile_kernel), lanes whose patch lies
+// outside t load nothing -- into a 16 KB LDS tile, and after one barrier every lane gathers the 8 channels of TWO pixels and stores
+// their units (per plane): the stores of a half-wave are one 512-byte run of a phase plane row.
+struct FirS2P {
+  const float *x, *kx, *ky, *in_scale;
+  bf16x8 *U;
+  int B, C, inH, inW, Ht, Wt, kH, kW, padx0, pady0, Hq, Wq, tilesX, tilesY;
+  long long plane;
+};
+
+typedef float f32x4u2 __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int NP>
+__global__ __launch_bounds__(256) void fir_units_s2_kernel(const FirS2P p) {
+  constexpr int TR = 8, TC = 64, PITCH = TC + 1;
+  __shared__ float tile[8][TR][PITCH];
+  const int tid = threadIdx.x;
+  const int C8 = (p.C + 7) >> 3;
+  int bid = blockIdx.x;
+  const int tx = bid % p.tilesX; bid /= p.tilesX;
+  const int ty = bid % p.tilesY; bid /= p.tilesY;
+  const int cu = bid % C8, b = bid / C8;
+  {
+    const int cc = tid >> 5, l = tid & 31;
+    const int c = cu * 8 + cc;
+    const int ly = 4 * (l >> 4), lx = 4 * (l & 15);
+    const int Y0 = ty * TR + ly, X0 = tx * TC + lx;
+    float out[4][4];
+#pragma unroll
+    for (int ny = 0; ny < 4; ++ny)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) out[ny][n] = 0.f;
+    if (c < p.C && Y0 < p.Ht && X0 < p.Wt) {
+      float kfx[4], kfy[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        kfx[j] = j < p.kW ? p.kx[p.kW - 1 - j] : 0.f;
+        kfy[j] = j < p.kH ? p.ky[p.kH - 1 - j] : 0.f;
+      }
+      const int iy0 = Y0 - p.pady0, ix0 = X0 - p.padx0;
+      const long long plane_off = ((long long)b * p.C + c) * p.inH * p.inW;
+      const long long n_total = (long long)p.B * p.C * p.inH * p.inW;
+      const float *xin = p.x + plane_off;
+      const int iy_lo = min(max(iy0, 0), p.inH - 1), iy_hi = min(max(iy0 + 6, 0), p.inH - 1);
+      const bool safe = plane_off + (long long)iy_lo * p.inW + ix0 >= 0 && plane_off + (long long)iy_hi * p.inW + ix0 + 8 <= n_total;
+      float w[7][8];
+      if (safe) {
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+          const float *src = xin + (long long)min(max(iy0 + m, 0), p.inH - 1) * p.inW + ix0;
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            const f32x4u2 t = *reinterpret_cast<const f32x4u2 *>(src + 4 * v);
+            w[m][4 * v] = t.x; w[m][4 * v + 1] = t.y; w[m][4 * v + 2] = t.z; w[m][4 * v + 3] = t.w;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+          const float *row = xin + (size_t)min(max(iy0 + m, 0), p.inH - 1) * p.inW;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[m][e] = row[min(max(ix0 + e, 0), p.inW - 1)];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 7; ++m) {
+        const bool row_ok = iy0 + m >= 0 && iy0 + m < p.inH;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[m][e] = (row_ok && e < 7 && ix0 + e >= 0 && ix0 + e < p.inW) ? w[m][e] : 0.f;
+      }
+      float h[7][4];
+#pragma unroll
+      for (int m = 0; m < 7; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          float a = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a += w[m][n + t] * kfx[t];
+          h[m][n] = a;
+        }
+      const float isc = p.in_scale ? p.in_scale[b * p.C + c] : 1.f;
+#pragma unroll
+      for (int ny = 0; ny < 4; ++ny)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          float a = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a += h[ny + t][n] * kfy[t];
+          out[ny][n] = (Y0 + ny < p.Ht && X0 + n < p.Wt) ? a * isc : 0.f;
+        }
+    }
+#pragma unroll
+    for (int ny = 0; ny < 4; ++ny)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) tile[cc][ly + ny][lx + n] = out[ny][n];
+  }
+  __syncthreads();
+  // the two pixels of this lane: idx = tid, tid + 256 of [phase 4][row 4][column 32] of the tile's phase planes
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + 256 * q;
+    const int ph = idx >> 7, il = (idx >> 5) & 3, jl = idx & 31;
+    const int i = ty * (TR / 2) + il, j = tx * (TC / 2) + jl;
+    if (i >= p.Hq || j >= p.Wq) continue;
+    float v[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) v[cc] = tile[cc][2 * il + (ph >> 1)][2 * jl + (ph & 1)];
+    const long long u = ((((long long)b * C8 + cu) * 4 + ph) * p.Hq + i) * p.Wq + j;
+    if constexpr (NP == 3) {
+      bf16x8 hh, mm, ll;
+      split3_bf16x8(v, hh, mm, ll);
+      p.U[u] = hh; p.U[p.plane + u] = mm; p.U[2 * p.plane + u] = ll;
+    } else {
+      p.U[u] = pack_bf16x8(v);
+    }
+  }
+}
+
+extern "C" int tbg_upfirdn2d_units_s2_f32(const float *x, const float *kx, const float *ky, void *U, int B, int C, int inH, int inW,
+                                          int kH, int kW, int padx0, int padx1, int pady0, int pady1, const float *in_scale,
+                                          int planes, void *stream) {
+  if (!x || !kx || !ky || !U || B < 1 || C < 1 || inH < 1 || inW < 1 || kH < 1 || kW < 1 || kH > 4 || kW > 4 ||
+      (planes != 1 && planes != 3))
+    return TBG_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(U) & 15) != 0) return TBG_EINVAL;
+  const int Ht = inH + pady0 + pady1 - kH + 1, Wt = inW + padx0 + padx1 - kW + 1;
+  if (Ht < 3 || Wt < 3) return TBG_EINVAL;
+  const int Ho = (Ht - 3) / 2 + 1, Wo = (Wt - 3) / 2 + 1;
+  const long long plane = s2_units_per_plane(B, C, Ho, Wo);
+  if (plane * 8 > 2147483647LL || (long long)B * C * inH * inW > 2147483647LL) return TBG_ERANGE;
+  FirS2P p{};
+  p.x = x; p.kx = kx; p.ky = ky; p.in_scale = in_scale; p.U = reinterpret_cast<bf16x8 *>(U);
+  p.B = B; p.C = C; p.inH = inH; p.inW = inW; p.Ht = Ht; p.Wt = Wt; p.kH = kH; p.kW = kW; p.padx0 = padx0; p.pady0 = pady0;
+  p.Hq = Ho + 1; p.Wq = Wo + 1; p.tilesX = (2 * p.Wq + 63) / 64; p.tilesY = (2 * p.Hq + 7) / 8;
+  p.plane = plane;
+  const long long nblk = (long long)B * ((C + 7) / 8) * p.tilesX * p.tilesY;
+  if (nblk > 2147483647LL) return TBG_ERANGE;
+  const dim3 grid((unsigned)nblk);
+  if (planes == 3) hipLaunchKernelGGL(fir_units_s2_kernel<3>, grid, dim3(256), 0, tbg_stream(stream), p);
+  else hipLaunchKernelGGL(fir_units_s2_kernel<1>, grid, dim3(256), 0, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
 // ============================================================================================
 // forward convolution (3x3, stride 2, pad 0) from a phase unit tensor
 // ============================================================================================

@@ -364,8 +364,14 @@ class DiscriminatorBlock(nn.Module):
         xd = ops.upfirdn2d(x, k, down=(2, sh), pad=(1, 2, 1, 2), role=role)
         if mode == "fused":
             t = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1), role="d")
+            fold = ops.FOLD_RES_SCALE and ops.compute_mode() != "bf16"
+            if sh == 2 and ops.blur_conv_s2_units(t.shape[0], t.shape[1], self.conv_1.w.shape[3], t.shape[2], t.shape[3]):
+                # blur + strided convolution with the blurred tensor as a phase unit tensor only (ops._BlurConvS2Fused)
+                u = ops.blur_conv_s2_fused(t, self.conv_1.w, self.apply_bias_act_1.b, role="d", out_mul=rs if fold else 1.0)
+                return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=1.0 if fold else rs,
+                                               role="d", out_mul=rs if fold else 1.0)
             tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3), role="d")  # conv_downsample_2d, upfirdn_2d_v2.py:106-113
-            if ops.FOLD_RES_SCALE and ops.compute_mode() != "bf16":
+            if fold:
                 # (u + skip) / sqrt(2) with the factor folded into u's lrelu gain and the skip conv's scale: the sum and its
                 # gradient need no scaling pass (13 elementwise passes over block-sized tensors per step otherwise).
                 # fp32-grade arithmetics only: the full-width step's G-gradient error against the oracle is unchanged there

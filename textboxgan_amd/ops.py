@@ -475,6 +475,26 @@ def units_pack_s2(x: torch.Tensor, scale: Optional[torch.Tensor] = None, planes:
     return PhaseUnitTensor(U, B, Cc, Hin, Win, Ho, Wo, planes)
 
 
+def upfirdn2d_units_s2(x: torch.Tensor, k: torch.Tensor, pad=(0, 0, 0, 0), in_scale: Optional[torch.Tensor] = None,
+                       planes: Optional[int] = None) -> PhaseUnitTensor:
+    """the phase unit tensor of upfirdn2d_raw(x, k, pad=pad, in_scale=in_scale) (k: one of fir_kernel's separable filters) in one
+    launch -- the FIR pass in front of a stride-2 convolution as the PRODUCER of that convolution's operand."""
+    B, Cc, H, W = x.shape
+    kH, kW = k.shape
+    sep = _sep_factors(k)
+    assert sep is not None, "the fused producer takes the model's separable filters (fir_kernel)"
+    Ht, Wt = H + pad[2] + pad[3] - kH + 1, W + pad[0] + pad[1] - kW + 1
+    Ho, Wo = (Ht - 3) // 2 + 1, (Wt - 3) // 2 + 1
+    planes = unit_planes() if planes is None else planes
+    nbytes = N.lib().tbg_units_s2_bytes(B, Cc, Ho, Wo, planes)
+    N.check(min(nbytes, 0), "tbg_units_s2_bytes")
+    U = torch.empty(nbytes // 2, device=x.device, dtype=torch.bfloat16)
+    N.check(PROFILE.launch("fir_units_s2_kernel", 0.0, lambda: N.lib().tbg_upfirdn2d_units_s2_f32(
+        N.ptr(x), N.ptr(sep[0]), N.ptr(sep[1]), N.ptr(U), B, Cc, H, W, kH, kW, pad[0], pad[1], pad[2], pad[3], N.ptr(in_scale),
+        planes, N.stream()), nbytes=4.0 * x.numel() + nbytes), "tbg_upfirdn2d_units_s2")
+    return PhaseUnitTensor(U, B, Cc, Ht, Wt, Ho, Wo, planes)
+
+
 def conv_units_s2_ok(C_in, M, Hin, Win, planes) -> bool:
     """geometry of tbg_conv2d_units_s2 (3x3 stride-2 pad-0 layers with whole 8 x 32-pixel output tiles and 64-channel tiles)"""
     Ho, Wo = (Hin - 3) // 2 + 1, (Win - 3) // 2 + 1
@@ -1113,6 +1133,25 @@ def _units_wgrad(I, O, H, W) -> bool:
     return USE_UNITS and fmt != FMT_F32 and wgrad_units_ok(O, I, H, W, H, W, 3, 3, (1, 1), (1, 1))
 
 
+USE_UNITS_S2 = True      # blur + 3x3 stride-2 layers (and the up-convolution's backward) through phase unit tensors where both the
+                         # strided convolution AND its filter gradient take them (the fp32 tensor between blur and convolution is then
+                         # never written)
+
+
+def _units_s2(B, C_in, M, Ht, Wt) -> bool:
+    """does a 3x3 stride-2 pad-0 convolution C_in -> M of a B x Ht x Wt tensor take the phase-unit kernels (forward / data-gradient
+    form tbg_conv2d_units_s2 AND the filter gradient tbg_conv2d_wgrad_units_s2) in the current arithmetic?"""
+    fmt = _FMT[_TLS.compute]
+    if not (USE_UNITS and USE_UNITS_S2) or fmt == FMT_F32 or Ht < 3 or Wt < 3:
+        return False
+    planes = unit_planes(fmt)
+    Ho, Wo = (Ht - 3) // 2 + 1, (Wt - 3) // 2 + 1
+    if not conv_units_s2_ok(C_in, M, Ht, Wt, planes) or not wgrad_units_s2_ok(M, C_in, Ho, Wo, Ht, Wt):
+        return False
+    d = N.ConvDesc(B, C_in, M, Ht, Wt, Ho, Wo, 3, 3, 2, 2, 0, 0, 0, 0, M, 1)
+    return N.lib().tbg_conv2d_units_s2_blocks(C.byref(d), planes) >= UNITS_MIN_BLOCKS
+
+
 def _unit_tensor(data, like: torch.Tensor, planes=None) -> UnitTensor:
     """re-wrap the flat buffer of a unit tensor saved by a forward pass"""
     B, Cc, H, W = like.shape
@@ -1262,19 +1301,31 @@ class _ModConvUpFused(torch.autograd.Function):
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
         _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
         k = fir_kernel(x.device, gain=4.0)  # symmetric: flipped == itself
-        dy_up = upfirdn2d_raw(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))  # [B,O,2H+1,2W+1]
         wt = pack_filter(w, transpose=True, flip=True)
         ds_conv = torch.empty_like(s)  # every element written (sum of the launch's partial slots)
-        dx = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0),
-                        epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
+        T = KH * KW
+        # the data gradient is a 3x3 stride-2 convolution O -> I of dy_up = blur^T(dpre * d) [B,O,2H+1,2W+1], the filter gradient
+        # contracts dy_up with x * s: where the phase-unit kernels take the layer, the blur writes dy_up ONCE as a phase unit tensor
+        # (no fp32 dy_up) and both launches DMA their tiles from it
+        s2 = KH == 3 and _units_s2(x.shape[0], O, I, 2 * H + 1, 2 * W + 1)
+        if s2:
+            DYP = upfirdn2d_units_s2(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))
+            dx = conv2d_units_s2_raw(DYP, wt, I, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
+        else:
+            dy_up = upfirdn2d_raw(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))  # [B,O,2H+1,2W+1]
+            dx = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0),
+                            epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
         db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            T = KH * KW
             # dW_t[t][i][o] = sum x*s . dy_up shifted;  w = flip(w_t)  -> write tap t at T-1-t
-            wgrad_raw(x, dy_up, KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O,
-                      add=(w, dwsq, -coef * coef))
+            if s2:
+                wgrad_units_s2_raw(units_pack(x, s), DYP, dw, -I * O, 1, O, coef, out_offset=(T - 1) * I * O,
+                                   add=(w, dwsq, -coef * coef))
+            else:
+                wgrad_raw(x, dy_up, KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O,
+                          add=(w, dwsq, -coef * coef))
         return dx, dw, ds, None, dstrength, db
 
 
@@ -1411,6 +1462,78 @@ class _ConvBiasActFused(torch.autograd.Function):
         else:
             db = None
         return dx, dw, db, dres, None, None, None, None, None, None
+
+
+class _BlurConvS2Fused(torch.autograd.Function):
+    """out = lrelu(coef * conv_s2(blur(x), w) + b) * gain: conv_downsample_2d (upfirdn_2d_v2.py:106-113: FIR with pad (2,3), then the
+    3x3 stride-2 convolution) + bias_act.py:25-34, with the blurred tensor existing ONLY as a phase unit tensor: the FIR launch is
+    the producer (tbg_upfirdn2d_units_s2_f32), the strided convolution and -- in the backward pass -- its filter gradient DMA their
+    tiles from it (tbg_conv2d_units_s2 / tbg_conv2d_wgrad_units_s2).  The data gradient keeps the NCHW transposed kernel + the
+    FIR's adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, role, out_mul):
+        KH, KW, I, O = w.shape
+        coef = 1.0 / math.sqrt(KH * KW * I)
+        gain = SQRT2 * out_mul
+        x = x.contiguous()
+        k = fir_kernel(x.device, 1.0)
+        TP = upfirdn2d_units_s2(x, k, pad=(2, 3, 2, 3))
+        out = conv2d_units_s2_raw(TP, pack_filter(w, False, False), O, epi=N.epilogue(alpha=coef, bias=b, act=ACT_LRELU, gain=gain))
+        ctx.save_for_backward(w, b, out, TP.data)
+        ctx.meta = (tuple(x.shape), tuple(TP[1:]), coef, gain, role)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        w, b, out, tp = ctx.saved_tensors
+        xshape, tpm, coef, gain, role = ctx.meta
+        B, I, H, W = xshape
+        O = w.shape[3]
+        _, _, Ht, Wt, Ho, Wo, _ = tpm
+        dout = dout.contiguous()
+        h = _half(role, B)
+        if h:  # G-loss pass over [fake; real]: only the leading h samples carry a gradient (FLAGS.d_first_half)
+            assert FLAGS.skip_d_wgrad, "the first-half mode belongs to the pass that skips the discriminator's filter gradients"
+            dout, out = dout[:h], out[:h]
+        prune_w = FLAGS.skip_d_wgrad and role in ("d", "d_image")
+        want_dx = ctx.needs_input_grad[0]
+        epi_b = N.epilogue(act=ACT_LRELU, slope=0.2, gain=gain, bias=b)
+        DU = None
+        if not prune_w:  # units(dpre) for the filter gradient; the NCHW dpre only if the data gradient is wanted
+            DU, dpre, pdb, _, _ = bias_act_bwd_units_raw(dout, out, epi_b, want_dpre=want_dx, want_db=b is not None)
+        else:
+            _, dpre, pdb, _, _ = bias_act_bwd_raw(dout, out, epi_b, want_db=b is not None)
+        db = pdb.sum(dim=(0, 2)) if b is not None else None
+        dx = None
+        if want_dx:
+            g = _Geom((2, 2), (0, 0), 3, 3, (Ht, Wt), (Ho, Wo))
+            dtb = _bwd_data_launch(dpre, w, g, alpha=coef)  # d(blurred tensor) [h | B, I, Ht, Wt]
+            k = fir_kernel(dout.device, 1.0)
+            gpad = (4 - 2 - 1, W - Wt + 2, 4 - 2 - 1, H - Ht + 2)  # upfirdn_2d_v2.py:204-209 for up = down = 1, pad (2, 3)
+            if h:
+                dx = _tail_empty(xshape, dout.device)
+                upfirdn2d_raw(dtb, _flipped_fir(k), pad=gpad, out=dx[:h])
+            else:
+                dx = upfirdn2d_raw(dtb, _flipped_fir(k), pad=gpad)
+        dw = None
+        if not prune_w:
+            dw = torch.empty_like(w)
+            wgrad_units_s2_raw(DU, PhaseUnitTensor(tp, *tpm), dw, I * O, O, 1, coef)
+        else:
+            db = None
+        return dx, dw, db, None, None
+
+
+def blur_conv_s2_units(B, I, O, H, W) -> bool:
+    """does DiscriminatorBlock's blur (pad 2,3) + 3x3 stride-2 convolution I -> O of a B x H x W map take _BlurConvS2Fused?"""
+    return _units_s2(B, I, O, H + 2, W + 2)
+
+
+def blur_conv_s2_fused(x, w, b, role=None, out_mul=1.0):
+    """lrelu(conv_downsample_2d(x, w) + b) * sqrt2 * out_mul through phase unit tensors (see blur_conv_s2_units)."""
+    return _BlurConvS2Fused.apply(x, w, b, role, out_mul)
 
 
 def modconv_fused(x, w, s, noise, strength, b):

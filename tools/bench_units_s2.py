@@ -54,3 +54,18 @@ for (CS, CL, Hl, Wl, Bx) in [(128, 128, 65, 257, B), (128, 64, 66, 258, 2 * B), 
         t_new = timeit(lambda: ops.wgrad_units_s2_raw(SU, LP, dw, CL * CS, CS, 1, 1.0))
         row += f"  [{mode}] nchw {t_old:7.1f} us ({fl / t_old / 1e6:6.1f} TF)  units {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF)"
     print(row, flush=True)
+print("--- producers: FIR (NCHW) + stand-alone phase pack vs the fused FIR -> phase units")
+for (C, H, W, Bx, pad, gain) in [(128, 64, 256, B, (2, 2, 2, 2), 4.0), (64, 64, 256, 2 * B, (2, 3, 2, 3), 1.0), (128, 32, 128, 2 * B, (2, 3, 2, 3), 1.0),
+                                 (256, 16, 64, 2 * B, (2, 3, 2, 3), 1.0)]:
+    x = torch.randn(Bx, C, H, W, device=dev)
+    sc = torch.rand(Bx * C, device=dev) + 0.5
+    k = ops.fir_kernel(dev, gain)
+    row = f"B={Bx} C={C} {H}x{W} pad={pad}:"
+    t_fir = timeit(lambda: ops.upfirdn2d_raw(x, k, pad=pad, in_scale=sc))
+    t = ops.upfirdn2d_raw(x, k, pad=pad, in_scale=sc)
+    for planes in (3, 1):
+        t_pack = timeit(lambda: ops.units_pack_s2(t, planes=planes))
+        t_fused = timeit(lambda: ops.upfirdn2d_units_s2(x, k, pad=pad, in_scale=sc, planes=planes))
+        nb = 4.0 * x.numel() + 2.0 * planes * t.numel()
+        row += f"  [planes={planes}] fir {t_fir:6.1f} + pack {t_pack:6.1f} us   fused {t_fused:6.1f} us ({nb / t_fused / 1e6:5.2f} TB/s)"
+    print(row, flush=True)
