@@ -329,6 +329,14 @@ int tbg_conv2d_units_s2_dot_slots(const tbg_conv_desc *d, int planes);
 int tbg_conv2d_units_s2(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
                         const tbg_epilogue *epi, void *stream);
 
+/* The stride-2 TRANSPOSED 3x3 convolution (upsample_conv_2d's transposed convolution, upfirdn_2d_v2.py:65-103; the data gradient
+ * of the strided convolution above) from the stride-1 unit tensor XU of its input [B, C, Hin, Win] (scale inside): the transposed
+ * form of tbg_conv2d_x3 / _bf16 -- same descriptor (transposed = 1, stride 2, pad 0, Hout in {2 Hin + 1, 2 Hin + 2}, likewise
+ * Wout), packed filter and flip; y = alpha * result, fp32 NCHW (store-only).  M % 64 == 0, C % 8 == 0 (planes = 1: C % 16 == 0),
+ * ksplit == 1 -- TBG_EUNSUPPORTED otherwise. */
+int tbg_conv2d_units_t2_blocks(const tbg_conv_desc *d, int planes);
+int tbg_conv2d_units_t2(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y, float alpha, void *stream);
+
 /* Filter gradient of that stride-2 convolution from unit tensors: S (the tensor on the Ho x Wo output grid) as a stride-1 unit
  * tensor, L (the input-grid tensor t) as a PHASE unit tensor; result, strides, alpha and the additive term as
  * tbg_conv2d_wgrad_units.  Geometry: 3x3, stride 2, pad 0, Ws % 32 == 0, CS % 128 == 0, CL % 64 == 0 -- TBG_EUNSUPPORTED otherwise. */

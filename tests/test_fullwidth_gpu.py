@@ -362,11 +362,13 @@ def _run_units_s2_case(dev, arith, M, seed):
         assert float(dpk) <= 2.0 ** -7 * float(t.abs().max()), ("fir units", arith, float(dpk))
         tr, wr = q(t.double().cpu()).requires_grad_(True), q(w).requires_grad_(True)
         ref = F.conv2d(tr, wr.permute(3, 2, 0, 1), stride=2)
-        (gw,) = torch.autograd.grad(ref, (wr,), q(dy))
+        gw, gt = torch.autograd.grad(ref, (wr, tr), q(dy))  # filter gradient; data gradient (a transposed convolution of dy)
         assert rel(ops.conv2d_units_s2_raw(TP, ops.pack_filter(wd, False, False), M), ref.detach()) < 3e-5, ("units s2 fwd", arith, M)
         if M % 128 == 0:
             dw = torch.empty(3, 3, Cc, M, device=dev)
             assert rel(ops.wgrad_units_s2_raw(ops.units_pack(dyd), TP, dw, Cc * M, M, 1, 1.0), gw) < 5e-5, ("units s2 wgrad", arith, M)
+        got = ops.conv2d_units_t2_raw(ops.units_pack(dyd), ops.pack_filter(wd, True, False), Cc, (H + 2, W + 2))
+        assert rel(got, gt) < 3e-5, ("units t2", arith, M)
     return set(log)
 
 

@@ -193,8 +193,12 @@ def test_blur_conv_s2_fused_equals_the_nchw_layers(dev, mode, monkeypatch):
         k = ops.fir_kernel(dev, 1.0)
         y0 = ops.conv_bias_act_fused(ops.upfirdn2d(x, k, pad=(2, 3, 2, 3)), w, b, stride=(2, 2), out_mul=0.7)
         g0 = torch.autograd.grad(y0, (x, w, b), dout)
-        y1 = ops.blur_conv_s2_fused(x, w, b, out_mul=0.7)
-        g1 = torch.autograd.grad(y1, (x, w, b), dout)
+        for t2 in (False, True):  # the data gradient through the NCHW transposed kernel, then through tbg_conv2d_units_t2
+            monkeypatch.setattr(ops, "USE_UNITS_T2", t2)
+            y1 = ops.blur_conv_s2_fused(x, w, b, out_mul=0.7)
+            g1 = torch.autograd.grad(y1, (x, w, b), dout)
+            if not t2:
+                assert float((g1[0] - g0[0]).abs().max()) / float(g0[0].abs().max()) < (5e-6 if mode == "f32x3" else 3e-4)
     # bf16: the two FIR kernels differ by single fp32 roundings, which moves a few elements of the blurred tensor to the neighbouring
     # bf16 value (2^-8 relative on one of 576 products)
     tol = 5e-6 if mode == "f32x3" else 3e-4
@@ -219,8 +223,9 @@ def test_modconv_up_backward_through_phase_units_equals_the_nchw_path(dev, mode,
     b = (0.1 * torch.randn(O, generator=g)).to(dev).requires_grad_(True)
     dout = torch.randn(B, O, 2 * H, 2 * W, generator=g).to(dev)
     res = []
-    for on in (False, True):
+    for on in (False, True):  # NCHW launches, then every stride-2 launch of the layer from unit tensors
         monkeypatch.setattr(ops, "USE_UNITS_S2", on)
+        monkeypatch.setattr(ops, "USE_UNITS_T2", on)
         with ops.compute_dtype(mode):
             y = ops.modconv_up_fused(x, w, s, noise, strength, b)
             res.append((y,) + torch.autograd.grad(y, (x, w, s, strength, b), dout))
@@ -228,4 +233,51 @@ def test_modconv_up_backward_through_phase_units_equals_the_nchw_path(dev, mode,
     errs = [rel(a, r) for a, r in zip(res[1], res[0])]
     print(f"\nMODCONVUP {mode}: " + " ".join(f"{e:.1e}" for e in errs))
     tol = 5e-6 if mode == "f32x3" else 3e-4  # (bf16: see test_blur_conv_s2_fused_equals_the_nchw_layers)
-    assert errs[0] == 0.0 and max(errs) < tol, errs
+    assert max(errs) < tol, errs
+
+
+CONV_T2 = [(2, 64, 64, 8, 32, 1), (2, 128, 128, 16, 64, 2), (3, 64, 192, 5, 9, 1), (1, 256, 64, 32, 128, 2), (2, 64, 128, 33, 20, 1)]
+
+
+@pytest.mark.parametrize("mode", ["f32x3", "bf16"])
+@pytest.mark.parametrize("case", CONV_T2, ids=[str(c) for c in CONV_T2])
+def test_conv_units_t2_matches_float64_and_the_nchw_kernel(dev, mode, case):
+    """tbg_conv2d_units_t2 (merged-class transposed convolution over a FLAT tiling of the padded unit tensor) as the
+    up-convolution's forward (flip, output 2H+1) and as the strided convolution's data gradient (transposed pack, output 2H+2):
+    against float64 on the operands the kernels see and against the NCHW transposed kernels; every output element written."""
+    import torch.nn.functional as F
+    B, C, M, H, W, extra = case
+    if mode == "bf16" and C % 16:
+        pytest.skip("bf16 units need whole 16-channel chunks")
+    planes = 3 if mode == "f32x3" else 1
+    Hout, Wout = 2 * H + extra, 2 * W + extra
+    x, w = _rnd(B, C, H, W, seed=1), _rnd(3, 3, C, M, seed=2) / math.sqrt(9 * C)
+    s = _rnd(B, C, seed=3).abs() + 0.5
+    f = lambda t: t.float().to(dev).contiguous()
+    xd, wd, sd = f(x), f(w), f(s)
+    xs = xd * sd[:, :, None, None]
+    w_ref = wd.double().cpu()
+    if mode == "bf16":
+        xs, w_ref = xs.bfloat16().float(), wd.bfloat16().double().cpu()
+    with ops.compute_dtype(mode):
+        assert ops.conv_units_t2_ok(C, M, planes)
+        XU = ops.units_pack(xd, sd, planes=planes)
+        # (1) the up-convolution's forward: conv_transpose with flip(w) = correlation form; ops passes flip=True on the plain pack
+        pf = ops.pack_filter(wd, False, False)
+        y = torch.full((B, M, Hout, Wout), float("nan"), device=dev)
+        ops.conv2d_units_t2_raw(XU, pf, M, (Hout, Wout), flip=True, alpha=0.8, out=y)
+        y_n = ops.conv2d_raw(xd, pf, M, 3, 3, (Hout, Wout), (2, 2), (0, 0), transposed=True, flip=True, in_scale=sd,
+                             epi=N.epilogue(alpha=0.8), allow_split=False)
+        ref = 0.8 * F.conv_transpose2d(xs.double().cpu(), torch.flip(w_ref, (0, 1)).permute(2, 3, 0, 1), stride=2)
+        refp = torch.zeros(B, M, Hout, Wout, dtype=torch.float64)
+        refp[:, :, :2 * H + 1, :2 * W + 1] = ref
+        assert torch.isfinite(y).all()
+        e1, d1 = _rel(y, refp), float((y - y_n).abs().max() / y_n.abs().max())
+        # (2) the data gradient of a strided convolution M' = C -> its input channels: transposed pack, no flip
+        wt = f(_rnd(3, 3, M, C, seed=9) / math.sqrt(9 * M))  # the strided convolution's filter [kh, kw, in = M, out = C]
+        pft = ops.pack_filter(wt, True, False)
+        g = ops.conv2d_units_t2_raw(XU, pft, M, (Hout, Wout), flip=False, alpha=1.0)
+        g_n = ops.conv2d_raw(xd, pft, M, 3, 3, (Hout, Wout), (2, 2), (0, 0), transposed=True, in_scale=sd, allow_split=False)
+        d2 = float((g - g_n).abs().max() / g_n.abs().max())
+    print(f"\nCONVT2 {mode} {case}: vs float64 {e1:.2e}   vs nchw kernel {d1:.1e} {d2:.1e}")
+    assert e1 < 3e-5 and max(d1, d2) < 5e-6, (e1, d1, d2)

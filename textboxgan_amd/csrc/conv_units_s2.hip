@@ -732,3 +732,223 @@ extern "C" int tbg_conv2d_wgrad_units_s2(const tbg_wgrad_desc *d, const void *SU
   p.dW = dW; p.ws = workspace; p.addw = addw; p.addq = addq; p.gamma = gamma; p.ksplit = u.ksplit;
   return planes == 3 ? launch_wgrad_units_s2<3>(u, p, tbg_stream(stream)) : launch_wgrad_units_s2<1>(u, p, tbg_stream(stream));
 }
+
+// ============================================================================================
+// transposed convolution (3x3, stride 2) from a stride-1 unit tensor: the up-convolution's forward, the strided convolution's
+// data gradient
+// ============================================================================================
+// y[b,m,2u+kh,2v+kw] += x[b,c,u,v] w[kh,kw,c,m] in the MERGED-class form of conv_fprop_kernel<..,TM>: grid position (u, v) owns the
+// four outputs (2u + cy, 2v + cx), tap (kh, kw) accumulates into class (kh & 1, kw & 1) reading x[u - (kh == 2), v - (kw == 2)] --
+// nine taps, four accumulator sets, one staged tile.  The class grids are (H + 1) x (W + 1) (33 x 129 for a 32 x 128 map): 8 x 32
+// tiles pad that to 40 x 160 (+46 %; the NCHW kernel's 4 x 32 tiles: +35 %).  Here the grid is tiled FLAT: a tile is 256
+// consecutive positions q = (u + 1) Wp + (v + 1) of the PADDED unit tensor (row pitch Wp = W + 2, u in [0, H], v in [-1, W]; the
+// v = -1 column is a dummy position whose outputs are masked), so that
+//   * the four operands of a position are q, q - 1, q - Wp, q - Wp - 1: two contiguous runs of 257 units per channel unit and
+//     plane -- the simplest DMA there is; the padding (row u = H, column v = W, the row above u = 0) IS the zero ring;
+//   * a tap shift is again a unit-stride LDS offset (run select + one unit);
+//   * (H + 1) Wp positions per image in tiles of 256: 33 x 130 = 4290 -> 17 tiles (+5 %).
+// Block = 64 output channels x 256 positions, 8 waves (wave = 32 channels x 64 positions x 4 classes = 128 accumulator
+// registers), both tiles double-buffered, everything else as conv_units_fprop_kernel.  Store-only epilogue (alpha * acc), scattered
+// by class.
+struct ConvT2P {
+  const char *XU, *Wf;
+  long long x_plane, w_plane;  // 16-byte units per plane
+  float *y;
+  int B, C8, M, H, W, Hp, Wp, Hout, Wout, ldw, flip, tilesQ;
+  float alpha;
+};
+
+template <int NP>
+struct T2Cfg {
+  static constexpr int BM = 64, CKU = NP == 3 ? 1 : 2, RUNP = 260;
+  static constexpr int A_UNITS = NP * 9 * CKU * BM, X_UNITS = NP * CKU * 2 * RUNP;
+  static constexpr int NPIECE = (A_UNITS + X_UNITS + 63) / 64, BUF = NPIECE * 64, PPW = (NPIECE + 7) / 8;
+  static_assert(A_UNITS % 64 == 0, "a DMA piece never straddles the filter / run regions");
+};
+
+template <int NP>
+__global__ __launch_bounds__(512, 2) void conv_units_t2_kernel(const ConvT2P p) {
+  using Cf = T2Cfg<NP>;
+  constexpr int WTN = 2, BM = Cf::BM, CKU = Cf::CKU, RUNP = Cf::RUNP, A_UNITS = Cf::A_UNITS, X_UNITS = Cf::X_UNITS;
+  constexpr int NPIECE = Cf::NPIECE, BUF = Cf::BUF, PPW = Cf::PPW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][BUF] units
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, half = lane >> 5;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+
+  const int tq = blockIdx.x % p.tilesQ, b = blockIdx.x / p.tilesQ;
+  const int m0 = blockIdx.y * BM;
+  const int q0 = p.Wp + tq * 256, qmax = p.Hp * p.Wp - 1;
+
+  const char *dsrc[PPW];
+  const char *const xu = p.XU, *const wf = p.Wf;
+#pragma unroll
+  for (int k = 0; k < PPW; ++k) {
+    const int n = min(wave + 8 * k, NPIECE - 1) * 64 + lane;
+    if (n < A_UNITS) {  // As[plane][tap][unit][BM]
+      const int row = n / BM, m = n - row * BM;
+      const int u = row % CKU, t = (row / CKU) % 9, pl = row / (9 * CKU);
+      dsrc[k] = wf + ((pl * p.w_plane + (long long)((p.flip ? 8 - t : t) * p.C8 + u) * p.ldw + m0 + m) << 4);
+    } else {            // Xs[plane][unit][run][RUNP]: run 0 = units q0 - 1 .., run 1 = the same one padded row up
+      const int m2 = min(n - A_UNITS, X_UNITS - 1);
+      const int row = m2 / RUNP, pos = min(m2 - row * RUNP, 256);
+      const int run = row & 1, u = (row >> 1) % CKU, pl = (row >> 1) / CKU;
+      const int q = min(max(q0 - 1 + pos - run * p.Wp, 0), qmax);
+      dsrc[k] = xu + ((pl * p.x_plane + (long long)(b * p.C8 + u) * p.Hp * p.Wp + q) << 4);
+    }
+  }
+  const long long a_step = (long long)CKU * p.ldw * 16, x_step = (long long)CKU * p.Hp * p.Wp * 16;  // bytes per chunk
+  auto issue_piece = [&](int k, int kc, int buf) {
+    const int q = min(__builtin_amdgcn_readfirstlane(wave) + 8 * k, NPIECE - 1);
+    const long long step = q * 64 < A_UNITS ? a_step : x_step;  // wave-uniform
+    dma16(dsrc[k] + kc * step, lds0 + (unsigned)((buf * BUF + q * 64) * 16));
+  };
+
+  const int a_lane = (wm * 32 + (lane & 31)) * 16;
+  int b_lane[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) b_lane[j] = A_UNITS * 16 + (1 + wn * 64 + j * 32 + (lane & 31)) * 16;
+  constexpr int A_PL = 9 * CKU * BM * 16, X_PL = CKU * 2 * RUNP * 16;
+  const int aX = NP == 3 ? half * A_PL : half * BM * 16, aY = 2 * half * A_PL;
+  const int bZ = 2 * (1 - half) * X_PL, bH = NP == 3 ? 0 : half * 2 * RUNP * 16;
+
+  f32x16 acc[4][WTN];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+
+  const int nchunks = p.C8 / CKU;
+#pragma unroll
+  for (int k = 0; k < PPW; ++k) issue_piece(k, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int kn = kc + 1 < nchunks ? kc + 1 : kc;  // (the last chunk re-fetches itself: no branch in the loop body)
+    const char *Ab = smem + (size_t)buf * BUF * 16 + a_lane;
+    const char *Xb = smem + (size_t)buf * BUF * 16;
+    constexpr int NA = NP == 3 ? 2 : 1, NB = NP == 3 ? 3 * WTN : WTN, NL = NA + NB;
+    constexpr int NM = (NP == 3 ? 3 : 1) * WTN;  // MFMAs per tap
+    bf16x8 av[2][NA], bw[2][NB];
+    auto ld1 = [&](int t, int bs, int idx) {
+      const int kh = t / 3, kw = t - 3 * kh;
+      if (idx < NA) {
+        const int plane_off = NP == 3 ? ((idx & 1) ? aY : aX) : aX;
+        av[bs][idx] = *reinterpret_cast<const bf16x8 *>(Ab + t * CKU * BM * 16 + plane_off);
+      } else if (idx < NL) {
+        const int e = idx - NA;
+        const int j = NP == 3 ? e / 3 : e, w = NP == 3 ? e - 3 * j : 0;
+        const int plane_off = NP == 3 ? (w == 0 ? 0 : w == 1 ? X_PL : bZ) : bH;
+        bw[bs][e] = *reinterpret_cast<const bf16x8 *>(Xb + b_lane[j] + ((kh == 2 ? RUNP : 0) - (kw == 2 ? 1 : 0)) * 16 + plane_off);
+      }
+    };
+#pragma unroll
+    for (int idx = 0; idx < NL; ++idx) ld1(0, 0, idx);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int bs = t & 1, kh = t / 3, kw = t - 3 * kh, c = (kh & 1) * 2 + (kw & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm) {
+        const int grp = mm / WTN, j = mm - grp * WTN;
+        if constexpr (NP == 3) {  // smallest terms first: (hi|lo)x(lo|hi), then (hi|mid) x mid, then (hi|mid) x hi
+          const int ai = grp == 0 ? 1 : 0, bi = 3 * j + (grp == 0 ? 2 : grp == 1 ? 1 : 0);
+          acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[bs][ai], bw[bs][bi], acc[c][j], 0, 0, 0);
+        } else {
+          acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[bs][0], bw[bs][j], acc[c][j], 0, 0, 0);
+        }
+        if (t + 1 < 9) {
+          constexpr int LPM = (NL + NM - 1) / NM;
+#pragma unroll
+          for (int e = 0; e < LPM; ++e) ld1(t + 1, bs ^ 1, mm * LPM + e);
+        }
+        {
+          constexpr int STRIDE = (9 * NM / 2) / PPW > 0 ? (9 * NM / 2) / PPW : 1;
+          static_assert(9 * NM >= PPW, "every DMA piece has an MFMA to hide behind");
+          const int slot = t * NM + mm;
+          if (slot % STRIDE == 0 && slot / STRIDE < PPW) issue_piece(slot / STRIDE, kn, buf ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- store-only epilogue: position q -> (u, v); class (cy, cx) -> output (2u + cy, 2v + cx).  The two column classes of a
+  // position are neighbours in memory: one 8-byte store (rows are only 4-byte aligned: 257-float rows), and the 32 positions of a
+  // half-wave make one contiguous 256-byte run per output row and channel
+  typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+  const float alpha = p.alpha;
+  const int HWout = p.Hout * p.Wout;
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    const int q = q0 + wn * 64 + j * 32 + (lane & 31);
+    const int row = q / p.Wp, v = q - row * p.Wp - 1, u = row - 1;
+    const bool okp = v >= 0 && u <= p.H;
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy) {
+      const int Y = 2 * u + cy, X = 2 * v;
+      const bool ok0 = okp && Y < p.Hout && X < p.Wout, ok1 = ok0 && X + 1 < p.Wout;
+      float *yb = p.y + (size_t)b * p.M * HWout + (size_t)(ok0 ? Y * p.Wout + X : 0);
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int m = m0 + wm * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
+        const float v0 = acc[2 * cy][j][r16] * alpha, v1 = acc[2 * cy + 1][j][r16] * alpha;
+        if (ok1) *reinterpret_cast<f32x2u *>(yb + (size_t)m * HWout) = f32x2u{v0, v1};
+        else if (ok0) yb[(size_t)m * HWout] = v0;
+      }
+    }
+  }
+}
+
+static bool conv_units_t2_ok(const tbg_conv_desc *d, int planes) {
+  const int cku = planes == 3 ? 8 : 16;
+  return d->transposed && d->KH == 3 && d->KW == 3 && d->sy == 2 && d->sx == 2 && d->py == 0 && d->px == 0 &&
+         d->Hout >= 2 * d->Hin + 1 && d->Hout <= 2 * d->Hin + 2 && d->Wout >= 2 * d->Win + 1 && d->Wout <= 2 * d->Win + 2 &&
+         (d->C % cku) == 0 && (d->M % 64) == 0 && d->ksplit == 1 && d->ldw >= d->M;
+}
+
+extern "C" int tbg_conv2d_units_t2_blocks(const tbg_conv_desc *d, int planes) {
+  if (!d || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  if (!conv_units_t2_ok(d, planes)) return TBG_EUNSUPPORTED;
+  const long long n = (long long)d->B * (((long long)(d->Hin + 1) * (d->Win + 2) + 255) / 256) * (d->M / 64);
+  return n > 2147483647LL ? TBG_ERANGE : (int)n;
+}
+
+template <int NP>
+static int launch_conv_units_t2(ConvT2P &p, hipStream_t st) {
+  using Cf = T2Cfg<NP>;
+  const size_t lds = (size_t)2 * Cf::BUF * 16;
+  auto kern = conv_units_t2_kernel<NP>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return TBG_EHIP;
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tilesQ, p.M / Cf::BM), dim3(512), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_conv2d_units_t2(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y, float alpha,
+                                   void *stream) {
+  if (!d || !XU || !w || !y || (planes != 1 && planes != 3)) return TBG_EINVAL;
+  if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1) return TBG_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(XU) | reinterpret_cast<uintptr_t>(w)) & 15) != 0) return TBG_EINVAL;
+  if (!conv_units_t2_ok(d, planes)) return TBG_EUNSUPPORTED;
+  if ((double)d->B * d->M * d->Hout * d->Wout > 2147483647.0) return TBG_ERANGE;
+  ConvT2P p{};
+  p.XU = reinterpret_cast<const char *>(XU); p.Wf = reinterpret_cast<const char *>(w);
+  p.C8 = d->C / 8;
+  p.Hp = d->Hin + 2; p.Wp = d->Win + 2;
+  p.x_plane = (long long)d->B * p.C8 * p.Hp * p.Wp;
+  p.w_plane = (long long)9 * p.C8 * d->ldw;
+  if (p.x_plane * planes > 2147483647LL / 2 || p.w_plane * planes > 2147483647LL / 2) return TBG_ERANGE;
+  p.y = y; p.B = d->B; p.M = d->M; p.H = d->Hin; p.W = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.ldw = d->ldw;
+  p.flip = d->flip; p.alpha = alpha;
+  p.tilesQ = ((d->Hin + 1) * p.Wp + 255) / 256;
+  hipStream_t st = tbg_stream(stream);
+  return planes == 3 ? launch_conv_units_t2<3>(p, st) : launch_conv_units_t2<1>(p, st);
+}

@@ -24,7 +24,7 @@ EXPORTS = [
     "tbg_conv2d_wgrad_f32", "tbg_conv2d_wgrad_ex_f32", "tbg_conv2d_wgrad_workspace_bytes", "tbg_weight_pack_f32", "tbg_weight_pack_floats", "tbg_conv2d_kernel_name", "tbg_conv2d_f32_variant", "tbg_conv2d_bf16_variant", "tbg_conv2d_wgrad_kernel_name", "tbg_weight_pack_bf16_bytes", "tbg_weight_pack_bf16", "tbg_weight_pack_multi", "tbg_modconv_bwd_smalls_f32", "tbg_torgb_bwd_smalls_f32", "tbg_minibatch_std_fwd_f32", "tbg_minibatch_std_bwd_f32", "tbg_dense_fwd_f32", "tbg_dense_bwd_f32", "tbg_dense_multi_fwd_f32", "tbg_dense_multi_bwd_f32", "tbg_conv2d_bf16", "tbg_conv2d_bf16_kernel_name", "tbg_conv2d_wgrad_bf16", "tbg_conv2d_wgrad_bf16_kernel_name", "tbg_lstm_step_fwd_f32", "tbg_lstm_step_bwd_f32", "tbg_attn_ctx_fwd_f32", "tbg_attn_ctx_bwd_f32", "tbg_bias_act_fwd_f32", "tbg_slab_epilogue_f32", "tbg_bias_act_bwd_chunks",
     "tbg_upfirdn2d_kernel_name", "tbg_upfirdn2d_f16", "tbg_weight_pack_x3_bytes", "tbg_weight_pack_x3", "tbg_conv2d_x3", "tbg_conv2d_x3_kernel_name", "tbg_conv2d_x3_variant", "tbg_conv2d_wgrad_x3", "tbg_conv2d_wgrad_x3_kernel_name", "tbg_conv2d_dot_slots", "tbg_conv2d_blocks", "tbg_units_bytes", "tbg_units_pack_f32",
     "tbg_conv2d_wgrad_units", "tbg_conv2d_wgrad_units_workspace_bytes", "tbg_conv2d_units", "tbg_conv2d_units_dot_slots", "tbg_conv2d_units_blocks", "tbg_conv2d_units_tile_channels", "tbg_bias_act_bwd_units", "tbg_bias_act_bwd_units_chunks",
-    "tbg_units_s2_bytes", "tbg_units_pack_s2_f32", "tbg_upfirdn2d_units_s2_f32", "tbg_conv2d_units_s2_blocks", "tbg_conv2d_units_s2_tile_channels", "tbg_conv2d_units_s2_dot_slots", "tbg_conv2d_units_s2", "tbg_conv2d_wgrad_units_s2_workspace_bytes", "tbg_conv2d_wgrad_units_s2",
+    "tbg_units_s2_bytes", "tbg_units_pack_s2_f32", "tbg_upfirdn2d_units_s2_f32", "tbg_conv2d_units_s2_blocks", "tbg_conv2d_units_s2_tile_channels", "tbg_conv2d_units_s2_dot_slots", "tbg_conv2d_units_s2", "tbg_conv2d_wgrad_units_s2_workspace_bytes", "tbg_conv2d_wgrad_units_s2", "tbg_conv2d_units_t2_blocks", "tbg_conv2d_units_t2",
     "tbg_bias_act_bwd_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_rgb_backproject_chunks", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -134,6 +134,8 @@ def lib():
         l.tbg_conv2d_units_s2_tile_channels.argtypes = [C.POINTER(ConvDesc), ci]
         l.tbg_conv2d_units_s2_dot_slots.argtypes = [C.POINTER(ConvDesc), ci]
         l.tbg_conv2d_units_s2.argtypes = [C.POINTER(ConvDesc), vp, ci, vp, vp, C.POINTER(Epilogue), vp]
+        l.tbg_conv2d_units_t2_blocks.argtypes = [C.POINTER(ConvDesc), ci]
+        l.tbg_conv2d_units_t2.argtypes = [C.POINTER(ConvDesc), vp, ci, vp, vp, cf, vp]
         l.tbg_conv2d_wgrad_units_s2_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
         l.tbg_conv2d_wgrad_units_s2_workspace_bytes.restype = C.c_longlong
         l.tbg_conv2d_wgrad_units_s2.argtypes = [C.POINTER(WgradDesc), vp, vp, ci, vp, vp, vp, cf, vp, ll, vp]
@@ -203,6 +205,8 @@ def _call_key(name, a):
             return f"fir_units_s2_kernel<{a[15]}>"
         if name == "tbg_units_pack_s2_f32":   # x scale U B C Hin Win Ho Wo planes stream
             return f"units_pack_s2_kernel<{a[9]}>"
+        if name == "tbg_conv2d_units_t2":
+            return f"conv_units_t2_kernel<{a[2]}>"
         if name == "tbg_conv2d_wgrad_units_s2":
             return f"conv_wgrad_units_s2_kernel<{a[3]}>"
         if name == "tbg_conv2d_wgrad_units":  # d SU LU planes ...

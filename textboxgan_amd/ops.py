@@ -554,6 +554,28 @@ def wgrad_units_raw(SU: UnitTensor, LU: UnitTensor, out: torch.Tensor, st_t: int
     return out
 
 
+def conv_units_t2_ok(C_in, M, planes) -> bool:
+    """geometry of tbg_conv2d_units_t2 (3x3 stride-2 transposed convolutions in 64-channel tiles)"""
+    return M % 64 == 0 and C_in % (8 if planes == 3 else 16) == 0
+
+
+def conv2d_units_t2_raw(XU: UnitTensor, w: "PackedFilter", M: int, out_hw, flip=False, alpha=1.0,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """alpha * the 3x3 stride-2 transposed convolution of the activation behind the unit tensor XU (its scale inside) with a
+    packed filter of the matching format; out_hw in {2H + 1, 2H + 2} x {2W + 1, 2W + 2}; fp32 NCHW."""
+    assert w.fmt == (FMT_X3 if XU.planes == 3 else FMT_BF16) and w.C == XU.C and w.M >= M and w.T == 9
+    B, H, W = XU.B, XU.H, XU.W
+    Hout, Wout = out_hw
+    d = N.ConvDesc(B, XU.C, M, H, W, Hout, Wout, 3, 3, 2, 2, 0, 0, 1, int(flip), w.M, 1)
+    y = torch.empty((B, M, Hout, Wout), device=XU.data.device, dtype=torch.float32) if out is None else out
+    _flops = 2.0 * B * M * XU.C * 9 * H * W
+    N.check(PROFILE.launch(f"conv_units_t2_kernel<{XU.planes}>", _flops, lambda: N.lib().tbg_conv2d_units_t2(
+        C.byref(d), N.ptr(XU.data), XU.planes, N.ptr(w.data), N.ptr(y), alpha, N.stream()),
+        f"conv_units_t2[B={B} C={XU.C} M={M} {H}x{W}->{Hout}x{Wout}]",
+        2.0 * XU.data.numel() + 4.0 * y.numel() + 2.0 * XU.planes * 9 * XU.C * M), "tbg_conv2d_units_t2")
+    return y
+
+
 def wgrad_units_s2_ok(CS, CL, Hs, Ws, Hl, Wl) -> bool:
     """geometry of tbg_conv2d_wgrad_units_s2 (3x3 stride-2 pad-0 layers with whole 32-pixel output rows, 128 S- / 64 L-channel tiles)"""
     return Hl >= 3 and Wl >= 3 and Hs == (Hl - 3) // 2 + 1 and Ws == (Wl - 3) // 2 + 1 and Ws % 32 == 0 and CS % 128 == 0 and CL % 64 == 0
@@ -1152,6 +1174,18 @@ def _units_s2(B, C_in, M, Ht, Wt) -> bool:
     return N.lib().tbg_conv2d_units_s2_blocks(C.byref(d), planes) >= UNITS_MIN_BLOCKS
 
 
+USE_UNITS_T2 = True      # 3x3 stride-2 TRANSPOSED convolutions (up-convolution forward, data gradient of the strided layers) from unit tensors
+
+
+def _units_t2(B, C_in, M, H, W, Hout, Wout) -> bool:
+    """does the 3x3 stride-2 transposed convolution C_in -> M of a B x H x W map take tbg_conv2d_units_t2 in the current arithmetic?"""
+    fmt = _FMT[_TLS.compute]
+    if not (USE_UNITS and USE_UNITS_T2) or fmt == FMT_F32 or not conv_units_t2_ok(C_in, M, unit_planes(fmt)):
+        return False
+    d = N.ConvDesc(B, C_in, M, H, W, Hout, Wout, 3, 3, 2, 2, 0, 0, 1, 0, M, 1)
+    return N.lib().tbg_conv2d_units_t2_blocks(C.byref(d), unit_planes(fmt)) >= UNITS_MIN_BLOCKS
+
+
 def _unit_tensor(data, like: torch.Tensor, planes=None) -> UnitTensor:
     """re-wrap the flat buffer of a unit tensor saved by a forward pass"""
     B, Cc, H, W = like.shape
@@ -1282,19 +1316,27 @@ class _ModConvUpFused(torch.autograd.Function):
         x = x.contiguous(); s = s.contiguous()
         d, wsq = demod_coefs_raw(s, w.contiguous(), coef)
         H, W = x.shape[2], x.shape[3]
-        y_up = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True,
-                          flip=True, in_scale=s, epi=N.epilogue(alpha=coef))
+        xu = None
+        if KH == 3 and _units_t2(x.shape[0], I, O, H, W, 2 * H + 1, 2 * W + 1):
+            # x * s written ONCE as a unit tensor: the transposed convolution DMAs its tiles from it, and the filter gradient of the
+            # backward pass contracts the same tensor with the blur^T phase tensor
+            XU = units_pack(x, s)
+            y_up = conv2d_units_t2_raw(XU, pack_filter(w, False, False), O, (2 * H + 1, 2 * W + 1), flip=True, alpha=coef)
+            xu = XU.data
+        else:
+            y_up = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True,
+                              flip=True, in_scale=s, epi=N.epilogue(alpha=coef))
         k = fir_kernel(x.device, gain=4.0)
         epi = _lrelu_epi(out_scale=d.reshape(-1), bias=b, noise=noise, strength=strength, alpha=1.0)
         out = upfirdn2d_raw(y_up, k, pad=(1, 1, 1, 1), epi=epi)
-        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out)
+        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, xu)
         ctx.coef = coef
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
-        x, w, s, d, wsq, noise, strength, b, out = ctx.saved_tensors
+        x, w, s, d, wsq, noise, strength, b, out, xu = ctx.saved_tensors
         KH, KW, I, O = w.shape
         coef = ctx.coef
         H, W = x.shape[2], x.shape[3]
@@ -1321,7 +1363,8 @@ class _ModConvUpFused(torch.autograd.Function):
             dw = torch.empty_like(w)
             # dW_t[t][i][o] = sum x*s . dy_up shifted;  w = flip(w_t)  -> write tap t at T-1-t
             if s2:
-                wgrad_units_s2_raw(units_pack(x, s), DYP, dw, -I * O, 1, O, coef, out_offset=(T - 1) * I * O,
+                wgrad_units_s2_raw(_unit_tensor(xu, x) if xu is not None else units_pack(x, s), DYP, dw, -I * O, 1, O, coef,
+                                   out_offset=(T - 1) * I * O,
                                    add=(w, dwsq, -coef * coef))
             else:
                 wgrad_raw(x, dy_up, KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O,
@@ -1501,15 +1544,21 @@ class _BlurConvS2Fused(torch.autograd.Function):
         want_dx = ctx.needs_input_grad[0]
         epi_b = N.epilogue(act=ACT_LRELU, slope=0.2, gain=gain, bias=b)
         DU = None
-        if not prune_w:  # units(dpre) for the filter gradient; the NCHW dpre only if the data gradient is wanted
-            DU, dpre, pdb, _, _ = bias_act_bwd_units_raw(dout, out, epi_b, want_dpre=want_dx, want_db=b is not None)
+        # the data gradient (a transposed convolution O -> I of dpre) reads units(dpre) too where tbg_conv2d_units_t2 takes it: the
+        # NCHW dpre is then never written
+        t2 = want_dx and _units_t2(dout.shape[0], O, I, Ho, Wo, Ht, Wt)
+        if not prune_w or t2:  # units(dpre) for the filter gradient / the unit-tensor data gradient
+            DU, dpre, pdb, _, _ = bias_act_bwd_units_raw(dout, out, epi_b, want_dpre=want_dx and not t2, want_db=b is not None)
         else:
             _, dpre, pdb, _, _ = bias_act_bwd_raw(dout, out, epi_b, want_db=b is not None)
         db = pdb.sum(dim=(0, 2)) if b is not None else None
         dx = None
         if want_dx:
             g = _Geom((2, 2), (0, 0), 3, 3, (Ht, Wt), (Ho, Wo))
-            dtb = _bwd_data_launch(dpre, w, g, alpha=coef)  # d(blurred tensor) [h | B, I, Ht, Wt]
+            if t2:
+                dtb = conv2d_units_t2_raw(DU, pack_filter(w, transpose=True, flip=False), I, (Ht, Wt), flip=False, alpha=coef)
+            else:
+                dtb = _bwd_data_launch(dpre, w, g, alpha=coef)  # d(blurred tensor) [h | B, I, Ht, Wt]
             k = fir_kernel(dout.device, 1.0)
             gpad = (4 - 2 - 1, W - Wt + 2, 4 - 2 - 1, H - Ht + 2)  # upfirdn_2d_v2.py:204-209 for up = down = 1, pad (2, 3)
             if h:

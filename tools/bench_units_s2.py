@@ -69,3 +69,24 @@ for (C, H, W, Bx, pad, gain) in [(128, 64, 256, B, (2, 2, 2, 2), 4.0), (64, 64, 
         nb = 4.0 * x.numel() + 2.0 * planes * t.numel()
         row += f"  [planes={planes}] fir {t_fir:6.1f} + pack {t_pack:6.1f} us   fused {t_fused:6.1f} us ({nb / t_fused / 1e6:5.2f} TB/s)"
     print(row, flush=True)
+print("--- transposed 3x3 s2 (G: up-convolution forward; D: data gradient of the strided convolution)")
+for (C, M, H, W, Bx, extra) in [(128, 128, 32, 128, B, 1), (128, 64, 32, 128, 2 * B, 2), (128, 64, 32, 128, B, 2), (256, 128, 16, 64, B, 1),
+                                (256, 128, 16, 64, 2 * B, 2), (512, 256, 8, 32, 2 * B, 2)]:
+    x = torch.randn(Bx, C, H, W, device=dev)
+    w = torch.randn(3, 3, C, M, device=dev) / (9 * C) ** 0.5
+    xs = torch.rand(Bx, C, device=dev) + 0.5
+    fl = 2.0 * Bx * C * M * H * W * 9
+    hw = (2 * H + extra, 2 * W + extra)
+    row = f"B={Bx} {C}->{M} {H}x{W}->{hw[0]}x{hw[1]}:"
+    for mode, planes in (("f32x3", 3), ("bf16", 1)):
+        with ops.compute_dtype(mode):
+            pf = ops.pack_filter(w, False, False)
+            out = torch.empty(Bx, M, *hw, device=dev)
+            t_old = timeit(lambda: ops.conv2d_raw(x, pf, M, 3, 3, hw, (2, 2), (0, 0), transposed=True, flip=True, in_scale=xs, out=out))
+            XU = ops.units_pack(x, xs, planes=planes)
+            import ctypes
+            d = N.ConvDesc(Bx, C, M, H, W, hw[0], hw[1], 3, 3, 2, 2, 0, 0, 1, 1, M, 1)
+            nb = N.lib().tbg_conv2d_units_t2_blocks(ctypes.byref(d), planes)
+            t_new = timeit(lambda: ops.conv2d_units_t2_raw(XU, pf, M, hw, flip=True, out=out))
+        row += f"  [{mode}] nchw {t_old:7.1f} us ({fl / t_old / 1e6:6.1f} TF)  units {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF, {nb} blocks)"
+    print(row, flush=True)
