@@ -440,6 +440,20 @@ int tbg_bias_act_bwd_f32(const float *dout, const float *out_act, float *dx, flo
                          float *part_db, float *part_dn, float *part_dyy, int B, int M, int HW,
                          const tbg_epilogue *epi, void *stream);
 
+/* Second-order pieces of the regularised passes (path-length term training_step.py:300-347, R1 :349-373): the inner gradient of a
+ * fused layer out = act(d * L_w(s * x) + noise * strength + b) is a function (dx, ds, dd) of (dout, x, w, s, d) whose own gradient
+ * is made of the convolution launches above plus two per-plane elementwise forms (nchunks = tbg_bias_act_bwd_chunks(HW)):
+ *   tbg_axpby_planes_f32:  y[pl][i] = sa[pl] * a[pl][i] + sb[pl] * b[pl][i]   (sa / sb NULL = 1; b NULL = no second term; y NULL =
+ *                          sums only);  part[pl][chunk] = sum_i c[pl][i] * a[pl][i]  when part != NULL.
+ *   tbg_bias_act_bwd2_f32: with m = act'(out_act) * gain, d = alpha * out_scale[pl], yd = pre(out_act) - noise * strength - bias:
+ *                          g_dout = m * (d * c + gdd[pl] * yd / d)  (gdd NULL = 0);  part[pl][chunk] = sum_i dout * m * c.
+ * Replaces, in the reference's terms, the second tf.gradients pass through x*s -> conv -> *d -> noise/bias/lrelu
+ * (modulated_conv2d.py:94-96,119-121; noise.py:12-22; bias_act.py:25-34). */
+int tbg_axpby_planes_f32(const float *a, const float *sa, const float *b, const float *sb, const float *c, float *y,
+                         float *part, int planes, int HW, void *stream);
+int tbg_bias_act_bwd2_f32(const float *c, const float *out_act, const float *dout, const float *gdd, float *g_dout,
+                          float *part, int B, int M, int HW, const tbg_epilogue *epi, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Small-tensor tails of the layer gradients: one launch each instead of a chain of tiny reductions / GEMMs.
  * tbg_modconv_bwd_smalls_f32 (modulated_conv2d.py:78-82, activation-scaling form), from the partial sums of

@@ -273,6 +273,125 @@ extern "C" int tbg_bias_act_bwd_f32(const float *dout, const float *out_act, flo
 }
 
 // ============================================================================================
+// second-order pieces of the regularised passes (path length: training_step.py:300-347, R1: :349-373).  The inner gradient
+// of a fused layer out = act(d * L_w(s * x) + noise * strength + b) is itself a function (dx, ds, dd) of (dout, x, w, s, d);
+// its gradient needs two per-plane elementwise forms besides the convolution launches:
+//   tbg_axpby_planes_f32:   y = sa[plane] * a + sb[plane] * b   (+ part[plane][chunk] = sum_i c * a)
+//       u   = s * gdx + gds * x            (the operand of the forward map in the second-order pass)
+//       g_x = gds * r + s * r2             and   sum_p gdx * r   (d/ds of dx = s * r)
+//   tbg_bias_act_bwd2_f32:  with m = act'(out) * gain, p = dout * m, d = out_scale[plane], yd = pre(out) - noise*strength - b (= d * yc):
+//       g_dout = m * (d * c + gdd[plane] * yd / d),   part[plane][chunk] = sum_i p * c        (d/dd of dx, ds via c = L_w(u))
+// Both use the chunking of tbg_bias_act_bwd_f32 (tbg_bias_act_bwd_chunks(HW) partial sums per plane).
+// ============================================================================================
+struct AxpbyP {
+  const float *a, *sa, *b, *sb, *c;
+  float *y, *part;
+  int planes, HW, nchunks;
+};
+
+__global__ __launch_bounds__(256) void axpby_planes_kernel(const AxpbyP p) {
+  __shared__ float red[4];
+  const int plane = blockIdx.x;
+  const int p0 = blockIdx.y * BA_CHUNK;
+  const int p1 = min(p0 + BA_CHUNK, p.HW);
+  const float fa = p.sa ? p.sa[plane] : 1.f, fb = p.sb ? p.sb[plane] : 1.f;
+  const float *a = p.a + (size_t)plane * p.HW;
+  const float *b = p.b ? p.b + (size_t)plane * p.HW : nullptr;
+  const float *c = p.c ? p.c + (size_t)plane * p.HW : nullptr;
+  float *y = p.y ? p.y + (size_t)plane * p.HW : nullptr;
+  float acc = 0.f;
+  if ((p.HW & 3) == 0) {
+#pragma unroll 4
+    for (int i = p0 + threadIdx.x * 4; i < p1; i += 1024) {
+      const float4 a4 = *reinterpret_cast<const float4 *>(a + i);
+      const float4 b4 = b ? *reinterpret_cast<const float4 *>(b + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c) {
+        const float4 c4 = *reinterpret_cast<const float4 *>(c + i);
+        acc += c4.x * a4.x + c4.y * a4.y + c4.z * a4.z + c4.w * a4.w;
+      }
+      if (y) *reinterpret_cast<float4 *>(y + i) = make_float4(fa * a4.x + fb * b4.x, fa * a4.y + fb * b4.y,
+                                                               fa * a4.z + fb * b4.z, fa * a4.w + fb * b4.w);
+    }
+  } else {
+    for (int i = p0 + threadIdx.x; i < p1; i += 256) {
+      const float av = a[i];
+      if (c) acc += c[i] * av;
+      if (y) y[i] = fa * av + fb * (b ? b[i] : 0.f);
+    }
+  }
+  if (p.part) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) p.part[(size_t)plane * p.nchunks + blockIdx.y] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+extern "C" int tbg_axpby_planes_f32(const float *a, const float *sa, const float *b, const float *sb, const float *c, float *y,
+                                    float *part, int planes, int HW, void *stream) {
+  if (!a || planes < 1 || HW < 1 || (!y && !part) || (part && !c) || (sb && !b)) return TBG_EINVAL;
+  if ((double)planes * HW > 2147483647.0) return TBG_ERANGE;
+  if ((HW & 3) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)y) & 15) != 0)) return TBG_EINVAL;
+  AxpbyP p{a, sa, b, sb, c, y, part, planes, HW, tbg_bias_act_bwd_chunks(HW)};
+  hipLaunchKernelGGL(axpby_planes_kernel, dim3(planes, p.nchunks), dim3(256), 0, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+struct BiasActBwd2P {
+  const float *c, *out_act, *dout, *gdd;
+  float *g_dout, *part;
+  int B, M, HW, nchunks;
+  EpiK e;
+};
+
+__global__ __launch_bounds__(256) void bias_act_bwd2_kernel(const BiasActBwd2P p) {
+  __shared__ float red[4];
+  const int plane = blockIdx.x;
+  const int b = plane / p.M, m = plane - b * p.M;
+  const int p0 = blockIdx.y * BA_CHUNK;
+  const int p1 = min(p0 + BA_CHUNK, p.HW);
+  const float d = p.e.alpha * (p.e.out_scale ? p.e.out_scale[plane] : 1.f);
+  const float gq = p.gdd ? p.gdd[plane] / d : 0.f;  // gdd * (yd / d)
+  const float bias = p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f;
+  const float str = p.e.noise ? p.e.strength[0] : 0.f;
+  const float g_pos = p.e.gain, g_neg = p.e.gain * (p.e.act == TBG_ACT_LRELU ? p.e.slope : 1.f);
+  const float ig_pos = 1.f / g_pos, ig_neg = g_neg != 0.f ? 1.f / g_neg : 0.f;
+  const float *cc = p.c + (size_t)plane * p.HW;
+  const float *oa = p.out_act + (size_t)plane * p.HW;
+  const float *dout = p.dout ? p.dout + (size_t)plane * p.HW : nullptr;
+  const float *nz = p.e.noise ? p.e.noise + (size_t)b * p.HW : nullptr;
+  float *go = p.g_dout + (size_t)plane * p.HW;
+  float acc = 0.f;
+  for (int i = p0 + threadIdx.x; i < p1; i += 256) {
+    const float o = oa[i];
+    const bool pos = o > 0.f;
+    const float mk = pos ? g_pos : g_neg;
+    const float cv = cc[i];
+    const float yd = o * (pos ? ig_pos : ig_neg) - (nz ? nz[i] * str : 0.f) - bias;
+    go[i] = mk * (d * cv + gq * yd);
+    if (dout) acc += dout[i] * mk * cv;
+  }
+  if (p.part) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) p.part[(size_t)plane * p.nchunks + blockIdx.y] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+extern "C" int tbg_bias_act_bwd2_f32(const float *c, const float *out_act, const float *dout, const float *gdd, float *g_dout,
+                                     float *part, int B, int M, int HW, const tbg_epilogue *epi, void *stream) {
+  if (!c || !out_act || !g_dout || B < 1 || M < 1 || HW < 1 || !epi || !epi_valid(epi) || (part && !dout)) return TBG_EINVAL;
+  if ((double)B * M * HW > 2147483647.0) return TBG_ERANGE;
+  if (epi->gate || epi->residual) return TBG_EINVAL;
+  BiasActBwd2P p{c, out_act, dout, gdd, g_dout, part, B, M, HW, tbg_bias_act_bwd_chunks(HW), make_epi(epi)};
+  hipLaunchKernelGGL(bias_act_bwd2_kernel, dim3(B * M, p.nchunks), dim3(256), 0, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// ============================================================================================
 // filter packing for the MFMA convolutions: HWIO parameter [T][I][O] -> Wp[T][C/4][M][4]
 //   transpose = 0: C = I (reduction), M = O  -- forward correlation
 //   transpose = 1: C = O, M = I              -- data gradient (the transposed filter); flip reverses the taps

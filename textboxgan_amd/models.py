@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, ops2
 from .config import Config
 from .native import ACT_LINEAR, ACT_LRELU, SQRT2
 
@@ -209,6 +209,8 @@ class ToRGB(nn.Module):
         s = self.conv.style(style, mode) if s is None else s
         if mode == "fused":
             return ops.torgb_fused(x, self.conv.w, s, self.apply_bias.b, skip, colmask, mask_cw)
+        if x.is_cuda and colmask is None and ops2.USE_FUSED2:  # twice-differentiable fused node (path-length pass)
+            return ops2.torgb2(x, self.conv.w, s, self.apply_bias.b, skip)
         y = self.apply_bias(self.conv.conv_composable(x, s, None))
         y = y if skip is None else skip + y
         if colmask is not None:
@@ -235,6 +237,8 @@ class SynthesisBlock(nn.Module):
             if mode == "fused":
                 fn = ops.modconv_up_fused if conv.up else ops.modconv_fused
                 x = fn(x, conv.w, s, noise, nz.noise_strength, ba.b)
+            elif x.is_cuda and ops2.USE_FUSED2:  # twice-differentiable fused layer: two autograd nodes with hand-written gradients
+                x = ops2.mod_layer2(x, conv.w, s, conv.demod(s, mode), noise, nz.noise_strength, ba.b, up=conv.up)
             else:  # any-order path: one launch for noise + bias + lrelu (ops.bias_act_c), gradients again primitives
                 x = ops.bias_act_c(conv.conv_composable(x, s, conv.demod(s, mode)), noise, nz.noise_strength, ba.b)
         return x

@@ -1,0 +1,273 @@
+"""Fused layers that can be differentiated TWICE: the synthesis layers of the path-length pass (training_step.py:300-347).
+
+The path-length term differentiates THROUGH a gradient, so its generator pass cannot use the once-differentiable fused
+layers of ``ops``.  Rounds 1-3 ran it on composable primitives (x*s -> conv -> *d -> noise/bias/lrelu as four launches whose
+gradients are again primitives): correct to any order, but every scale is a full elementwise pass and the second backward
+walks ~25 small nodes per layer (profiles/r04_i_launch_sources_pl_step.txt: 237 launches in _ScaleChBackward alone).
+
+Here every layer is TWO autograd nodes with hand-written gradients:
+
+  A  out = act(d * L_w(s * x) + noise * strength + b)                 (modulated_conv2d.py:66-122, noise.py:12-22, bias_act.py:25-34)
+       L_w = coef * conv3x3 (SAME), or coef * FIR(convT_s2) for the up-sampling layer (upfirdn_2d_v2.py:65-103); the
+       demodulation d [B,O] is an INPUT (a few tiny tensor ops outside, differentiable by the framework).
+  B  (dx, ds, dd) = grad of A with respect to (x, s, d) for a cotangent dout -- the node A's backward returns when the
+       gradient itself is being recorded (create_graph=True).  With m = act'(out), p = dout * m, r = L_w^T(d * p):
+           dx = s * r,   ds = sum_p x * r,   dd = sum_p p * yc          (yc = L_w(s * x), recovered from out)
+     and B's own backward, for cotangents (gdx, gds, gdd), with u = s * gdx + gds * x, c = L_w(u), r2 = L_w^T(gdd * p):
+           g_dout = m * (d * c + gdd * yc)            g_d = sum_p p * c
+           g_x    = gds * r + s * r2                   g_s = sum_p gdx * r + sum_p x * r2
+           g_w    = W(u, d * p) + W(s * x, gdd * p)    (W = the filter gradient of L_w)
+     (every map is multilinear in its arguments except the LeakyReLU mask, whose derivative is zero almost everywhere).
+
+Launches: A forward 1-2, B forward 3-4, B backward 9-11 (two convolutions, two filter gradients, three elementwise passes:
+tbg_axpby_planes_f32 x2, tbg_bias_act_bwd2_f32), A backward (first order) 3-4 -- against ~4 / ~8 / ~25 / ~8 before.
+
+toRGB (to_rgb.py:28-33: 1x1 modulated convolution to 3 channels without demodulation, + bias + skip) gets the same pair on the
+streaming kernels tbg_rgb_project_f32 / tbg_rgb_backproject_f32."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import native as N
+from . import ops
+from .ops import (ACT_LRELU, FLAGS, _Geom, _bwd_data_launch, _bwd_weight_launch, _lrelu_epi, bias_act_bwd_raw,
+                  bias_act_fwd_raw, conv2d_raw, fir_kernel, pack_filter, rgb_backproject_raw, rgb_project_raw,
+                  torgb_bwd_smalls_raw, upfirdn2d_raw, wgrad_raw)
+
+
+USE_FUSED2 = True  # measurement aid (tools/ab_step.py): False = the composable primitives of rounds 1-3
+
+
+# ----------------------------------------------------------------------------------------
+# raw launches
+# ----------------------------------------------------------------------------------------
+def axpby_planes_raw(a, sa, b=None, sb=None, c=None, want_y=True):
+    """y = sa[plane] * a + sb[plane] * b over [B, C, H, W] planes (sa / sb [B, C] or None = 1); with c: also sum_p c * a -> [B, C]."""
+    B, Cc = a.shape[0], a.shape[1]
+    HW = a.numel() // (B * Cc)
+    nch = N.lib().tbg_bias_act_bwd_chunks(HW)
+    y = torch.empty_like(a) if want_y else None
+    part = torch.empty((B, Cc, nch), device=a.device, dtype=torch.float32) if c is not None else None
+    N.check(ops.PROFILE.launch("axpby_planes_kernel", 0.0, lambda: N.lib().tbg_axpby_planes_f32(
+        N.ptr(a), N.ptr(sa), N.ptr(b), N.ptr(sb), N.ptr(c), N.ptr(y), N.ptr(part), B * Cc, HW, N.stream()),
+        nbytes=4.0 * a.numel() * (1 + int(b is not None) + int(c is not None) + int(want_y))), "tbg_axpby_planes")
+    dot = None if part is None else (part.sum(dim=2) if nch > 1 else part[:, :, 0])
+    return y, dot
+
+
+def bias_act_bwd2_raw(c, out_act, dout, gdd, epi: N.Epilogue):
+    """g_dout = m * (d * c + gdd * yd / d) and sum_p dout * m * c -> [B, M]   (see tbg.h)."""
+    B, M = c.shape[0], c.shape[1]
+    HW = c.numel() // (B * M)
+    nch = N.lib().tbg_bias_act_bwd_chunks(HW)
+    g = torch.empty_like(c)
+    part = torch.empty((B, M, nch), device=c.device, dtype=torch.float32)
+    N.check(ops.PROFILE.launch("bias_act_bwd2_kernel", 0.0, lambda: N.lib().tbg_bias_act_bwd2_f32(
+        N.ptr(c), N.ptr(out_act), N.ptr(dout), N.ptr(gdd), N.ptr(g), N.ptr(part), B, M, HW, C.byref(epi), N.stream()),
+        nbytes=4.0 * c.numel() * 4), "tbg_bias_act_bwd2")
+    return g, (part.sum(dim=2) if nch > 1 else part[:, :, 0])
+
+
+# ----------------------------------------------------------------------------------------
+# the linear map L_w of a layer, its adjoint and its filter gradient as launches
+# ----------------------------------------------------------------------------------------
+class _Lin:
+    """L_w = coef * conv (k x k, stride 1, SAME) or, up=True, FIR_4(coef * convT_s2(., flip w)) (gain-4 [1,3,3,1] blur, pad 1)."""
+
+    def __init__(self, w, up, xhw):
+        self.KH, self.KW, self.I, self.O = w.shape
+        self.up = bool(up)
+        self.coef = 1.0 / math.sqrt(self.KH * self.KW * self.I)
+        self.H, self.W = xhw
+        if self.up:
+            assert self.KH == 3 and self.KW == 3
+            self.yhw = (2 * self.H, 2 * self.W)
+        else:
+            self.yhw = (self.H, self.W)
+            self.g = _Geom((1, 1), (self.KH // 2, self.KW // 2), self.KH, self.KW, xhw, xhw)
+
+    def fwd(self, x, w, in_scale, act=False, **kw):
+        """act(out_scale * L_w(in_scale * x) + noise * strength + bias); kw: out_scale, bias, noise, strength."""
+        mk = (lambda **k: _lrelu_epi(**k)) if act else (lambda **k: N.epilogue(**k))
+        if not self.up:
+            return conv2d_raw(x, pack_filter(w, False, False), self.O, self.KH, self.KW, self.yhw, (1, 1),
+                              (self.KH // 2, self.KW // 2), in_scale=in_scale, epi=mk(alpha=self.coef, **kw))
+        H, W = self.H, self.W
+        y_up = conv2d_raw(x, pack_filter(w, False, False), self.O, 3, 3, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True,
+                          flip=True, in_scale=in_scale, epi=N.epilogue(alpha=self.coef))
+        if kw.get("out_scale") is not None:
+            kw["out_scale"] = kw["out_scale"].reshape(-1)
+        return upfirdn2d_raw(y_up, fir_kernel(x.device, gain=4.0), pad=(1, 1, 1, 1), epi=mk(alpha=1.0, **kw))
+
+    def adj(self, y, w, in_scale, out_scale=None, dot=None):
+        """(out_scale * L_w^T(in_scale * y), aux); dot = (t, out [B, I]): out = sum_p t * L_w^T(in_scale * y) (before out_scale).
+        aux: the blurred gradient FIR^T(in_scale * y) of the up layer (its filter gradient contracts exactly that tensor)."""
+        epi = N.epilogue(alpha=self.coef, out_scale=out_scale)
+        if not self.up:
+            return _bwd_data_launch(y, w, self.g, in_scale=in_scale, epi=epi, dot=dot), None
+        dy_up = upfirdn2d_raw(y, fir_kernel(y.device, gain=4.0), pad=(2, 2, 2, 2),
+                              in_scale=None if in_scale is None else in_scale.reshape(-1))  # symmetric taps: flipped == itself
+        r = conv2d_raw(dy_up, pack_filter(w, transpose=True, flip=True), self.I, 3, 3, (self.H, self.W), (2, 2), (0, 0),
+                       epi=epi, dot=dot)
+        return r, dy_up
+
+    def wgrad(self, x, w, y, x_scale, y_scale, aux=None):
+        """d<L_w(x_scale * x), y_scale * y>/dw; aux = FIR^T(y_scale * y) if the caller has it (up layer)."""
+        if not self.up:
+            return _bwd_weight_launch(x, y, self.g, self.I, self.O, alpha=self.coef, x_scale=x_scale, dy_scale=y_scale)
+        if aux is None:
+            aux = upfirdn2d_raw(y, fir_kernel(y.device, gain=4.0), pad=(2, 2, 2, 2),
+                                in_scale=None if y_scale is None else y_scale.reshape(-1))
+        dw = torch.empty_like(w)
+        T, I, O = 9, self.I, self.O
+        # dW_t[t][i][o] = sum (x * x_scale) . aux shifted;  w = flip(w_t)  ->  tap t is written at T-1-t
+        wgrad_raw(x, aux, 3, 3, (2, 2), (0, 0), dw, -I * O, 1, O, self.coef, s_scale=x_scale, out_offset=(T - 1) * I * O)
+        return dw
+
+
+def _act_epi(d, noise, strength, b):
+    return _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
+
+
+# ----------------------------------------------------------------------------------------
+# modulated convolution + noise + bias + LeakyReLU
+# ----------------------------------------------------------------------------------------
+class _ModLayer2(torch.autograd.Function):
+    """A: out = lrelu(d * L_w(s * x) + noise * strength + b) * sqrt2, d [B,O] given."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, d, noise, strength, b, up):
+        x, w, s, d = x.contiguous(), w.contiguous(), s.contiguous(), d.contiguous()
+        assert x.shape[0] == s.shape[0] == d.shape[0] and s.shape[1] == w.shape[2] and d.shape[1] == w.shape[3]
+        L = _Lin(w, up, (x.shape[2], x.shape[3]))
+        out = L.fwd(x, w, s, act=True, out_scale=d, bias=b, noise=noise, strength=strength)
+        ctx.save_for_backward(x, w, s, d, noise, strength, b, out)
+        ctx.up = up
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, s, d, noise, strength, b, out = ctx.saved_tensors
+        dout = dout.contiguous()
+        if torch.is_grad_enabled():  # the gradient is being recorded (path-length pass): a node that can be differentiated again
+            assert FLAGS.no_filter_grads, "the recorded gradient of a twice-differentiable layer ends at the activations / styles"
+            dx, ds, dd = _ModLayer2Bwd.apply(dout, out, x, w, s, d, noise, strength, b, ctx.up)
+            return dx, None, ds, dd, None, None, None, None
+        L = _Lin(w, ctx.up, (x.shape[2], x.shape[3]))
+        _, p, pdb, pdn, pdy = bias_act_bwd_raw(dout, out, _act_epi(d, noise, strength, b), want_dn=noise is not None, want_dyy=True)
+        ds = torch.empty_like(s)
+        dx, aux = L.adj(p, w, d, out_scale=s, dot=(x, ds))
+        dd = pdy.sum(dim=2) / d
+        db = pdb.sum(dim=(0, 2)) if ctx.needs_input_grad[6] else None
+        dstrength = pdn.sum() if (noise is not None and ctx.needs_input_grad[5]) else None
+        dw = L.wgrad(x, w, p, s, d, aux) if (ctx.needs_input_grad[1] and not FLAGS.no_filter_grads) else None
+        return dx, dw, ds, dd, None, dstrength, db, None
+
+
+class _ModLayer2Bwd(torch.autograd.Function):
+    """B: (dx, ds, dd) of A for the cotangent dout (see the module docstring); once more differentiable."""
+
+    @staticmethod
+    def forward(ctx, dout, out, x, w, s, d, noise, strength, b, up):
+        L = _Lin(w, up, (x.shape[2], x.shape[3]))
+        dout = dout.contiguous()
+        _, p, _, _, pdy = bias_act_bwd_raw(dout, out, _act_epi(d, noise, strength, b), want_db=False, want_dyy=True)
+        ds = torch.empty_like(s)
+        r, aux = L.adj(p, w, d, dot=(x, ds))
+        dx = bias_act_fwd_raw(r, N.epilogue(out_scale=s))
+        dd = pdy.sum(dim=2) / d
+        ctx.save_for_backward(dout, out, x, w, s, d, noise, strength, b, p, r, aux)
+        ctx.up = up
+        return dx, ds, dd
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gdx, gds, gdd):
+        dout, out, x, w, s, d, noise, strength, b, p, r, aux = ctx.saved_tensors
+        L = _Lin(w, ctx.up, (x.shape[2], x.shape[3]))
+        gdx, gds, gdd = gdx.contiguous(), gds.contiguous(), gdd.contiguous()
+        u, _ = axpby_planes_raw(gdx, s, x, gds)                      # u = s * gdx + gds * x
+        c = L.fwd(u, w, None)                                        # c = L_w(u)
+        g_dout, g_d = bias_act_bwd2_raw(c, out, dout, gdd, _act_epi(d, noise, strength, b))
+        xr2 = torch.empty_like(s)
+        r2, aux2 = L.adj(p, w, gdd, dot=(x, xr2))                    # r2 = L_w^T(gdd * p), xr2 = sum_p x * r2
+        g_x, gr = axpby_planes_raw(r, gds, r2, s, c=gdx)             # g_x = gds * r + s * r2, gr = sum_p gdx * r
+        g_s = gr + xr2
+        g_w = None
+        if ctx.needs_input_grad[3]:
+            g_w = L.wgrad(u, w, p, None, d, aux) + L.wgrad(x, w, p, s, gdd, aux2)
+        return g_dout, None, g_x, g_w, g_s, g_d, None, None, None, None
+
+
+def mod_layer2(x, w, s, d, noise, strength, b, up=False):
+    """lrelu(d * L_w(s * x) + noise * strength + b) * sqrt2, differentiable twice (d: the demodulation coefficients [B, O])."""
+    return _ModLayer2.apply(x, w, s, d, noise, strength, b, bool(up))
+
+
+# ----------------------------------------------------------------------------------------
+# toRGB: y = coef * conv1x1(s * x, w) + b (+ skip)
+# ----------------------------------------------------------------------------------------
+class _ToRGB2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, s, b, skip):
+        _, _, I, O = w.shape
+        x, s = x.contiguous(), s.contiguous()
+        ctx.coef = 1.0 / math.sqrt(I)
+        y = rgb_project_raw(x, w, O, s, b, None if skip is None else skip.contiguous(), ctx.coef)
+        ctx.save_for_backward(x, w, s)
+        ctx.has_skip = skip is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, s = ctx.saved_tensors
+        dy = dy.contiguous()
+        dskip = dy if ctx.has_skip else None
+        if torch.is_grad_enabled():
+            assert FLAGS.no_filter_grads
+            dx, ds = _ToRGB2Bwd.apply(dy, x, w, s)
+            return dx, None, ds, None, dskip
+        _, _, I, O = w.shape
+        dx, G = rgb_backproject_raw(x, dy, w, s, ctx.coef)
+        ds, dw = torgb_bwd_smalls_raw(G.contiguous(), w.reshape(I, O), s, ctx.coef)
+        db = dy.sum(dim=(0, 2, 3)) if ctx.needs_input_grad[3] else None
+        return dx, dw.reshape(w.shape), ds, db, dskip
+
+
+class _ToRGB2Bwd(torch.autograd.Function):
+    """dx = coef * s * sum_o w[c,o] dy[o];  ds = coef * sum_o w[c,o] G[b,c,o],  G = sum_p x[c] dy[o]."""
+
+    @staticmethod
+    def forward(ctx, dy, x, w, s):
+        _, _, I, O = w.shape
+        coef = 1.0 / math.sqrt(I)
+        dx, G = rgb_backproject_raw(x, dy, w, s, coef)
+        G = G.contiguous()
+        ds, _ = torgb_bwd_smalls_raw(G, w.reshape(I, O), s, coef)
+        ctx.save_for_backward(dy, x, w, s, G)
+        ctx.coef = coef
+        return dx, ds
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gdx, gds):
+        dy, x, w, s, G = ctx.saved_tensors
+        _, _, I, O = w.shape
+        coef, w2 = ctx.coef, w.reshape(I, O)
+        gdx, gds = gdx.contiguous(), gds.contiguous()
+        # g_dy = coef * sum_c w[c,o] (s gdx + gds x): two projections, the second adds the first
+        t = rgb_project_raw(gdx, w, O, s, None, None, coef)
+        g_dy = rgb_project_raw(x, w, O, gds, None, t, coef)
+        g_x, _ = rgb_backproject_raw(x, dy, w, gds, coef, want_dx=True, want_G=False)       # gds * r
+        _, G2 = rgb_backproject_raw(gdx, dy, w, None, coef, want_dx=False, want_G=True)     # sum_p gdx[c] dy[o]
+        g_s, dw_a = torgb_bwd_smalls_raw(G2.contiguous(), w2, s, coef)      # coef sum_o G2 w ; coef sum_b G2 s
+        _, dw_b = torgb_bwd_smalls_raw(G, w2, gds, coef)                    #                   coef sum_b G gds
+        return g_dy, g_x, (dw_a + dw_b).reshape(w.shape), g_s
+
+
+def torgb2(x, w, s, b, skip=None):
+    """coef * conv1x1(s * x, w) + b (+ skip), differentiable twice."""
+    return _ToRGB2.apply(x, w, s, b, skip)

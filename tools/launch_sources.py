@@ -26,7 +26,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     ts.dist_train_step(*args)
     torch.cuda.synchronize()
 
-by_src = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])
+by_src = collections.defaultdict(lambda: [0, 0.0, collections.Counter(), collections.Counter()])
 n_k = 0
 for e in prof.events():
     ks = getattr(e, "kernels", None)
@@ -46,13 +46,14 @@ for e in prof.events():
     src = src or "fwd " + top.name
     for k in ks:
         rec = by_src[src]
-        rec[0] += 1; rec[1] += k.duration; rec[2][k.name.replace("void ", "").replace("at::native::", "")[:90]] += 1
+        kn = k.name.replace("void ", "").replace("at::native::", "")[:90]
+        rec[0] += 1; rec[1] += k.duration; rec[2][kn] += 1; rec[3][kn] += k.duration
         n_k += 1
 tot = sum(r[1] for r in by_src.values())
 print(f"{n_k} launches, {tot/1e3:.2f} ms of kernel time in one eager step ({DTYPE}, B={BATCH}{', no OCR' if NOOCR else ''}, {REG})")
 print("--- by launch count")
-for src, (n, us, names) in sorted(by_src.items(), key=lambda kv: -kv[1][0])[:70]:
+for src, (n, us, names, durs) in sorted(by_src.items(), key=lambda kv: -kv[1][0])[:70]:
     print(f"{n:5d} launches {us/1e3:7.3f} ms avg {us/n:6.1f} us  {src[:70]}")
     if n >= 20:
-        for nm, c in names.most_common(12):
-            print(f"          {c:4d}x {nm}")
+        for nm, c in names.most_common(16):
+            print(f"          {c:4d}x {durs[nm]/1e3:7.3f} ms  {nm}")
