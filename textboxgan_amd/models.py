@@ -230,15 +230,16 @@ class SynthesisBlock(nn.Module):
         self.apply_noise_1 = Noise()
         self.apply_bias_act_1 = BiasAct(fmaps, 1.0, "lrelu")
 
-    def forward(self, x, w0, w1, noise0, noise1, mode="fused", s0=None, s1=None):
-        for conv, nz, ba, style, noise, s in ((self.conv_0, self.apply_noise_0, self.apply_bias_act_0, w0, noise0, s0),
-                                              (self.conv_1, self.apply_noise_1, self.apply_bias_act_1, w1, noise1, s1)):
+    def forward(self, x, w0, w1, noise0, noise1, mode="fused", s0=None, s1=None, d0=None, d1=None):
+        for conv, nz, ba, style, noise, s, d in ((self.conv_0, self.apply_noise_0, self.apply_bias_act_0, w0, noise0, s0, d0),
+                                                 (self.conv_1, self.apply_noise_1, self.apply_bias_act_1, w1, noise1, s1, d1)):
             s = conv.style(style, mode) if s is None else s
             if mode == "fused":
                 fn = ops.modconv_up_fused if conv.up else ops.modconv_fused
                 x = fn(x, conv.w, s, noise, nz.noise_strength, ba.b)
             elif x.is_cuda and ops2.USE_FUSED2:  # twice-differentiable fused layer: two autograd nodes with hand-written gradients
-                x = ops2.mod_layer2(x, conv.w, s, conv.demod(s, mode), noise, nz.noise_strength, ba.b, up=conv.up)
+                x = ops2.mod_layer2(x, conv.w, s, conv.demod(s, mode) if d is None else d, noise, nz.noise_strength, ba.b,
+                                    up=conv.up)
             else:  # any-order path: one launch for noise + bias + lrelu (ops.bias_act_c), gradients again primitives
                 x = ops.bias_act_c(conv.conv_composable(x, s, conv.demod(s, mode)), noise, nz.noise_strength, ba.b)
         return x
@@ -282,9 +283,22 @@ class Synthesis(nn.Module):
             s_tr[0] = ss[0]
             for i in range(nb):
                 s_c0[i], s_c1[i], s_tr[i + 1] = ss[1 + 3 * i], ss[2 + 3 * i], ss[3 + 3 * i]
+        d_c0, d_c1 = [None] * nb, [None] * nb
+        if mode != "fused" and x.is_cuda and ops2.USE_FUSED2:  # twice-differentiable pass: all affines / demodulations batched
+            convs = [self.initial_torgb.conv] + [c for b, t in zip(self.synth_blocks, self.torgbs)
+                                                  for c in (b.conv_0, b.conv_1, t.conv)]
+            rows = [0] + [r for i in range(nb) for r in (3 * i, 3 * i + 1, 3 * i + 2)]
+            dl = [1 + 3 * i + j for i in range(nb) for j in (0, 1)]
+            ss, dd = ops2.synthesis_styles(style, rows, [c.mod_dense.w for c in convs], [c.mod_bias.b for c in convs],
+                                           _coef(convs[0].mod_dense.w.shape), dl, [convs[l].w for l in dl])
+            s_tr[0] = ss[0]
+            for i in range(nb):
+                s_c0[i], s_c1[i], s_tr[i + 1] = ss[1 + 3 * i], ss[2 + 3 * i], ss[3 + 3 * i]
+                d_c0[i], d_c1[i] = dd[1 + 3 * i], dd[2 + 3 * i]
         y = self.initial_torgb(x, ws[0], None, mode, s=s_tr[0])
         for i, (block, torgb) in enumerate(zip(self.synth_blocks, self.torgbs)):
-            x = block(x, ws[3 * i], ws[3 * i + 1], noises[2 * i], noises[2 * i + 1], mode, s0=s_c0[i], s1=s_c1[i])
+            x = block(x, ws[3 * i], ws[3 * i + 1], noises[2 * i], noises[2 * i + 1], mode, s0=s_c0[i], s1=s_c1[i],
+                      d0=d_c0[i], d1=d_c1[i])
             y = ops.upfirdn2d(y, k_up, up=(2, 2), pad=(2, 1, 2, 1))  # upsample_2d, :152
             last = i == nb - 1
             y = torgb(x, ws[3 * i + 2], y, mode, s=s_tr[i + 1], colmask=colmask if last else None, mask_cw=mask_cw if last else 0)

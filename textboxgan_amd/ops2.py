@@ -140,7 +140,7 @@ class _ModLayer2(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, s, d, noise, strength, b, up):
-        x, w, s, d = x.contiguous(), w.contiguous(), s.contiguous(), d.contiguous()
+        assert x.is_contiguous() and w.is_contiguous() and s.is_contiguous() and d.is_contiguous()
         assert x.shape[0] == s.shape[0] == d.shape[0] and s.shape[1] == w.shape[2] and d.shape[1] == w.shape[3]
         L = _Lin(w, up, (x.shape[2], x.shape[3]))
         out = L.fwd(x, w, s, act=True, out_scale=d, bias=b, noise=noise, strength=strength)
@@ -204,7 +204,9 @@ class _ModLayer2Bwd(torch.autograd.Function):
 
 def mod_layer2(x, w, s, d, noise, strength, b, up=False):
     """lrelu(d * L_w(s * x) + noise * strength + b) * sqrt2, differentiable twice (d: the demodulation coefficients [B, O])."""
-    return _ModLayer2.apply(x, w, s, d, noise, strength, b, bool(up))
+    # contiguous copies are taken HERE, as recorded operations: a copy made inside forward() would be saved as a constant and cut
+    # s / d out of the graph of the recorded gradient
+    return _ModLayer2.apply(x.contiguous(), w.contiguous(), s.contiguous(), d.contiguous(), noise, strength, b, bool(up))
 
 
 # ----------------------------------------------------------------------------------------
@@ -214,9 +216,9 @@ class _ToRGB2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, s, b, skip):
         _, _, I, O = w.shape
-        x, s = x.contiguous(), s.contiguous()
+        assert x.is_contiguous() and s.is_contiguous()
         ctx.coef = 1.0 / math.sqrt(I)
-        y = rgb_project_raw(x, w, O, s, b, None if skip is None else skip.contiguous(), ctx.coef)
+        y = rgb_project_raw(x, w, O, s, b, skip, ctx.coef)
         ctx.save_for_backward(x, w, s)
         ctx.has_skip = skip is not None
         return y
@@ -270,4 +272,76 @@ class _ToRGB2Bwd(torch.autograd.Function):
 
 def torgb2(x, w, s, b, skip=None):
     """coef * conv1x1(s * x, w) + b (+ skip), differentiable twice."""
-    return _ToRGB2.apply(x, w, s, b, skip)
+    return _ToRGB2.apply(x.contiguous(), w.contiguous(), s.contiguous(), b, None if skip is None else skip.contiguous())
+
+
+# ----------------------------------------------------------------------------------------
+# style affines and demodulation coefficients of ALL layers in a handful of batched tensor ops (differentiable to any order by
+# the framework).  Per layer they are four to six tiny launches forward and several times that in each derivative
+# (profiles/r04_j_launch_sources_pl_step.txt: ~600 launches, ~3 ms of a path-length step in Pow / Mm / Addmm / Mul / Rsqrt nodes).
+# ----------------------------------------------------------------------------------------
+class _PadStack(torch.autograd.Function):
+    """[L, R, width] <- the parameter tensors t_l ([R, n_l] or [n_l]) side by side, zero padded to ``width`` columns.  The
+    parameters are never on the path of a recorded gradient (that path runs from the styles), so first order suffices."""
+
+    @staticmethod
+    def forward(ctx, width, *ts):
+        R = ts[0].shape[0] if ts[0].dim() == 2 else 1
+        out = ts[0].new_zeros((len(ts), R, width))
+        for l, t in enumerate(ts):
+            out[l, :, :t.shape[-1]].copy_(t.reshape(R, -1))
+        ctx.shapes = [tuple(t.shape) for t in ts]
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        return (None, *[g[l, :, :shp[-1]].reshape(shp) for l, shp in enumerate(ctx.shapes)])
+
+
+class _Wsq(torch.autograd.Function):
+    """wsq[i,o] = coef^2 sum_taps w[.,.,i,o]^2   (the demodulation's filter norms, modulated_conv2d.py:78-82)."""
+
+    @staticmethod
+    def forward(ctx, w):
+        KH, KW, I, O = w.shape
+        ctx.c2 = 1.0 / (KH * KW * I)
+        ctx.save_for_backward(w)
+        return (w * w).sum(dim=(0, 1)).mul_(ctx.c2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        return w * (g * (2.0 * ctx.c2))
+
+
+_IDX = {}
+
+
+def _index(device, values):
+    """constant index vector, one per (device, values) for the life of the process (a host-to-device copy is not capturable)."""
+    key = (device, tuple(int(v) for v in values))
+    if key not in _IDX:
+        _IDX[key] = torch.tensor(key[1], device=device, dtype=torch.long)
+    return _IDX[key]
+
+
+def synthesis_styles(style, rows, mod_ws, mod_bs, coef, demod_layers, conv_ws):
+    """s_l = coef * style[:, rows[l]] @ mod_ws[l] + mod_bs[l] + 1 for every layer l (modulated_conv2d.py:74-76) and, for the layers
+    listed in demod_layers, d_l = rsqrt(s_l^2 @ wsq_l + 1e-8) with wsq_l from conv_ws (:78-82).  -> (list of s_l, {l: d_l})."""
+    K = style.shape[2]
+    width = max(max(w.shape[1] for w in mod_ws), max(w.shape[3] for w in conv_ws))
+    Wp = _PadStack.apply(width, *mod_ws)                      # [L, K, width]
+    bp = _PadStack.apply(width, *mod_bs)                      # [L, 1, width]
+    xr = style.index_select(1, _index(style.device, rows)).transpose(0, 1)           # [L, B, K]
+    S = torch.baddbmm(bp + 1.0, xr, Wp, alpha=float(coef))    # [L, B, width]; padded columns = 1
+    Sl = S.unbind(0)
+    ss = [Sl[l][:, :w.shape[1]] for l, w in enumerate(mod_ws)]
+    WSQ = _PadStack.apply(width, *[torch.nn.functional.pad(_Wsq.apply(w), (0, 0, 0, width - w.shape[2])) if w.shape[2] < width
+                                   else _Wsq.apply(w) for w in conv_ws])    # [Ld, width, width], zero rows past I_l
+    Sd = S.index_select(0, _index(style.device, demod_layers))
+    D = torch.rsqrt(torch.bmm(Sd.square(), WSQ) + 1e-8)       # padded columns: 1e4, never read
+    Dl = D.unbind(0)
+    ds = {l: Dl[j][:, :conv_ws[j].shape[3]] for j, l in enumerate(demod_layers)}
+    return ss, ds
