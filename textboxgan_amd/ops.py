@@ -1114,9 +1114,10 @@ class _BiasActC(torch.autograd.Function):
         out, noise = ctx.saved_tensors
         dpre = _MaskMul.apply(dout, out)
         dstrength = None
-        if noise is not None and ctx.needs_input_grad[2]:
+        params = not FLAGS.no_filter_grads  # a recorded inner gradient (R1 / path length) ends at the activations: no parameter sums
+        if noise is not None and ctx.needs_input_grad[2] and params:
             dstrength = (dpre.sum(dim=1, keepdim=True) * noise).sum()
-        db = dpre.sum(dim=(0, 2, 3)) if ctx.needs_input_grad[3] else None
+        db = dpre.sum(dim=(0, 2, 3)) if (ctx.needs_input_grad[3] and params) else None
         return (dpre if ctx.needs_input_grad[0] else None), None, dstrength, db
 
 

@@ -57,3 +57,14 @@ for src, (n, us, names, durs) in sorted(by_src.items(), key=lambda kv: -kv[1][0]
     if n >= 20:
         for nm, c in names.most_common(16):
             print(f"          {c:4d}x {durs[nm]/1e3:7.3f} ms  {nm}")
+# where the framework's glue launches come from (all sources, not only the top names of each)
+import os, re
+pat = re.compile(os.environ.get("LS_GREP", "Memcpy|CUDAFunctor_add|reduce_kernel|FillFunctor|MulFunctor|direct_copy"))
+print("--- glue launches by (kernel, source)")
+rows = []
+for src, (n, us, names, durs) in by_src.items():
+    for nm, c in names.items():
+        if pat.search(nm):
+            rows.append((durs[nm], c, nm[:60], src[:60]))
+for us, c, nm, src in sorted(rows, reverse=True)[:60]:
+    print(f"{c:5d}x {us/1e3:7.3f} ms  {nm:60s} <- {src}")
