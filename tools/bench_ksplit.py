@@ -14,6 +14,7 @@ shapes = [  # C, M, Hin, Win, Hout, Wout, stride
     (256, 256, 16, 64, 16, 64, None), (128, 128, 16, 64, 16, 64, None), (128, 128, 32, 128, 32, 128, None),
 ]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+_scope = ops.compute_dtype(sys.argv[2] if len(sys.argv) > 2 else "f32"); _scope.__enter__()
 for C, M, Hin, Win, Hout, Wout, st in shapes:
     x = torch.randn(B, C, Hin, Win, device=dev); w = ops.pack_filter(torch.randn(9, C, M, device=dev), False, False)
     row = []
