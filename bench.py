@@ -106,7 +106,8 @@ def cpu_baseline(batch_size=4, warmup=1, steps=3, threads=None):
         cfg = Config(batch_size_per_gpu=batch_size)
         st = M.make_state(cfg, 0, bench_init=True)
         batch, rand = M.make_batch(cfg), M.make_rand(cfg, with_pl=False)
-        ocr = AsterLikeOCR(max_steps=cfg.max_char_number)
+        from oracle.ref_ocr import OcrOracle  # the oracle's own network code; the product module only supplies the frozen weights
+        ocr = OcrOracle(AsterLikeOCR(max_steps=cfg.max_char_number).state_dict(), max_steps=cfg.max_char_number, dtype=torch.float32)
         args = (batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"], False, False, 1e-4)
         for _ in range(warmup):  # oneDNN primitive creation
             M.training_step(st, cfg, *args, rand, ocr.serve)

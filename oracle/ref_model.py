@@ -508,6 +508,32 @@ def main_to_aster_labels(input_words: np.ndarray) -> np.ndarray:
     return table[np.asarray(input_words)]
 
 
+def _tokens(text: str, chars: str):
+    """Keras Tokenizer(char_level=True, lower=False, oov_token="<OOV>") fitted on ``chars`` (config/char_tokens.py:12-17):
+    "<OOV>" = 1, the fitted characters 2.. in order of first appearance (every character occurs once)."""
+    return [chars.find(ch) + 2 if chars.find(ch) >= 0 else 1 for ch in text]
+
+
+def _pad_post(seqs, maxlen: int, value: int) -> np.ndarray:
+    """keras pad_sequences(maxlen, value, padding="post") with its DEFAULT truncating="pre": a longer sequence keeps its LAST
+    maxlen tokens (utils/utils.py:80-85,102-105 pass no truncating argument)."""
+    out = np.full((len(seqs), maxlen), value, dtype=np.int32)
+    for r, q in enumerate(seqs):
+        q = q[len(q) - maxlen:] if len(q) > maxlen else q
+        out[r, : len(q)] = q
+    return out
+
+
+def string_to_main_int_sequence(words, max_char_number=8) -> np.ndarray:
+    """utils/utils.py:66-85: main-vocabulary tokens, padded with 1, minus 1 (pad / OOV -> 0, characters 1..69)."""
+    return _pad_post([_tokens(w, _MAIN_CHARS) for w in words], max_char_number, 1) - 1
+
+
+def string_to_aster_int_sequence(words, max_char_number=8) -> np.ndarray:
+    """utils/utils.py:87-105: ASTER-vocabulary tokens, padded with 1 (= the recogniser's end-of-sequence class)."""
+    return _pad_post([_tokens(w, _ASTER_CHARS) for w in words], max_char_number, 1)
+
+
 def make_batch(cfg, seed=1234, rank=0):
     g = np.random.default_rng(seed + rank)
     B = cfg.batch_size_per_gpu

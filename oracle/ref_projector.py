@@ -75,19 +75,19 @@ def compute_w_latent(G, cfg, z_latent):
     return std, mean.clone()
 
 
-def project(G, LP, cfg, text: str, target_image_nhwc, ocr_serve: Callable, rand: dict, num_steps: int, total_steps=1000):
+def project(G, LP, cfg, text: str, target_image_nhwc, ocr_serve: Callable, rand: dict, num_steps: int, total_steps=1000,
+            return_grads=False):
     """projector.py:122-182 + :230-273 for ``num_steps`` steps with injected randomness
     (rand: z_latent [n,512], w_noise [steps][1,512] unit normals, noises [steps][10 maps])."""
-    from textboxgan_amd.char_tokens import string_to_aster_int_sequence, string_to_main_int_sequence
-    words = torch.from_numpy(string_to_main_int_sequence([text], cfg.max_char_number))
-    ocr_label = torch.from_numpy(string_to_aster_int_sequence([text], cfg.max_char_number))
+    words = torch.from_numpy(M.string_to_main_int_sequence([text], cfg.max_char_number))
+    ocr_label = torch.from_numpy(M.string_to_aster_int_sequence([text], cfg.max_char_number))
     image_width = cfg.char_width * len(text)
     w_std, w_var = compute_w_latent(G, cfg, rand["z_latent"])
     word_encoded = M.word_encoder(G, cfg, words, None)
     ns = M.n_style(cfg)
     b1, b2, eps = 0.9, 0.999, 1e-7  # tf.keras.optimizers.Adam() defaults
     m, v = torch.zeros_like(w_var), torch.zeros_like(w_var)
-    losses = []
+    losses, grads = [], []
     for step in range(1, num_steps + 1):
         t = step / total_steps
         lr = get_lr(t)
@@ -101,9 +101,10 @@ def project(G, LP, cfg, text: str, target_image_nhwc, ocr_serve: Callable, rand:
         gen = (gen.clamp(-1.0, 1.0) + 1.0) * 127.5
         loss = lpips(LP, target_image_nhwc, gen) + 0.1 * ocr_loss
         (g,) = torch.autograd.grad(loss, [w])
+        grads.append(g.detach().clone())
         m = b1 * m + (1 - b1) * g
         v = b2 * v + (1 - b2) * g * g
         lr_t = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
         w_var = w_var - lr_t * m / (v.sqrt() + eps)
         losses.append(float(loss))
-    return w_var, losses
+    return (w_var, losses, grads) if return_grads else (w_var, losses)

@@ -23,6 +23,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+def ocr_oracle(max_steps=8, dtype=None, **kw):
+    """the oracle's OWN implementation of the frozen OCR network (oracle/ref_ocr.py), loaded with the frozen synthetic weights of
+    the product's network as DATA (a state_dict, as a checkpoint would be handed to two implementations).  float64 by default."""
+    import torch
+    from oracle.ref_ocr import OcrOracle
+    from textboxgan_amd.aster import AsterLikeOCR
+    return OcrOracle(AsterLikeOCR(max_steps=max_steps, **kw).state_dict(), max_steps=max_steps,
+                     dtype=torch.float64 if dtype is None else dtype)
+
+
 @pytest.fixture
 def arith(request):
     """arithmetic of the MFMA contractions for this test (ops.compute_dtype scope): "f32" unless parametrised."""

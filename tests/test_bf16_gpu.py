@@ -226,7 +226,7 @@ def _todev(rand, dev):
 
 def test_training_step_bf16_vs_fp32_oracle_small(dev):
     """whole step (r1 + pl) in bf16 mode against the fp32 CPU oracle: stated bf16 tolerances (module docstring)."""
-    from textboxgan_amd.aster import AsterLikeOCR
+    from conftest import ocr_oracle
     from textboxgan_amd.training_step import build_trainer_state
     cfg = small_config(4)
     st = M.make_state(cfg, seed=0, bench_init=True)
@@ -235,7 +235,7 @@ def test_training_step_bf16_vs_fp32_oracle_small(dev):
     prod["generator"].load_state_dict({k: v.clone() for k, v in st["G"].items()})
     prod["discriminator"].load_state_dict({k: v.clone() for k, v in st["D"].items()})
     ts = prod["training_step"]
-    ocr_cpu = AsterLikeOCR(max_steps=cfg.max_char_number)
+    ocr_cpu = ocr_oracle(cfg.max_char_number)
     ref_losses, ref_grads = M.training_step(st, cfg, batch["real_images"], batch["ocr_images"], batch["input_words"],
                                             batch["ocr_labels"], True, True, 1e-4, rand, ocr_cpu.serve, return_grads=True)
     b = {k: v.to(dev) for k, v in batch.items()}

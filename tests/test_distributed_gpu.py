@@ -103,11 +103,11 @@ def _grad_worker(rank, world, port, backend, q, full_width=False):
 def _exchange_vs_oracle(backend, full_width=False, world=2):
     import torch.multiprocessing as mp
     from oracle import ref_model as M
-    from textboxgan_amd.aster import AsterLikeOCR
+    from conftest import ocr_oracle
     from textboxgan_amd.config import small_config
     cfg = _cfg(full_width, world)
     assert cfg.batch_size == 4 * world  # config/config.py:140-141: the losses are divided by the GLOBAL batch
-    ocr = AsterLikeOCR(max_steps=cfg.max_char_number)
+    ocr = ocr_oracle(cfg.max_char_number)
     sums, loss_sum = None, None
     for rank in range(world):  # the oracle, replica by replica, from the same initial weights
         st = M.make_state(cfg, seed=0, bench_init=True)

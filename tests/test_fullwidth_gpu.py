@@ -105,12 +105,12 @@ def _oracle_step(B, reg):
     shared by every arithmetic that is compared with it."""
     key = (B, reg)
     if key not in _ORACLE_STEPS:
-        from textboxgan_amd.aster import AsterLikeOCR
+        from conftest import ocr_oracle
         cfg = Config(batch_size_per_gpu=B)
         batch, rand = M.make_batch(cfg), M.make_rand(cfg, seed=99)
         st = M.make_state(cfg, seed=0, bench_init=True)
         init = {k: {n: v.clone() for n, v in st[k].items()} for k in ("G", "D")}
-        ocr_cpu = AsterLikeOCR(max_steps=cfg.max_char_number)
+        ocr_cpu = ocr_oracle(cfg.max_char_number)
         prev = torch.get_num_threads()
         if B >= 16:  # the per-sample pieces over-subscribe oneDNN on a 256-thread host (44 s / step against ~13 s)
             torch.set_num_threads(min(prev, 16))

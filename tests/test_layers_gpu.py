@@ -174,12 +174,12 @@ def test_frozen_bilstm_layer(dev, dims):
 
 
 def test_frozen_attn_decoder(dev):
-    """one-node attention decoder (HIP attention context + LSTM-cell launches) vs the torch definition in float64:
-    logits and d/d(encoder output) for a gradient that reaches every step."""
-    from textboxgan_amd.aster import AsterLikeOCR, AsterLikeOCRHip
-    ref = AsterLikeOCR().double()
+    """one-node attention decoder (HIP attention context + LSTM-cell launches) vs the oracle's decoder loop (oracle/ref_ocr.py,
+    float64, the same frozen weights): logits and d/d(encoder output) for a gradient that reaches every step."""
+    from oracle.ref_ocr import OcrOracle
+    from textboxgan_amd.aster import AsterLikeOCRHip
     hip = AsterLikeOCRHip().to(dev)
-    hip.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    ref = OcrOracle(hip.state_dict(), max_steps=hip.max_steps, dtype=torch.float64)
     enc = (rnd(5, 25, 512, seed=41) * 0.5).requires_grad_(True)
     lg = ref._decode(enc)
     dl = rnd(*lg.shape, seed=42)
@@ -350,22 +350,40 @@ def test_generator_hello_known_answer_geometry(dev):
 
 
 @arith_modes
-def test_ocr_hip_matches_torch_definition(dev):
-    """AsterLikeOCRHip (convs on the MFMA kernel) == AsterLikeOCR (plain torch, CPU): logits and d/dimage."""
+def test_ocr_hip_matches_oracle_network(dev):
+    """AsterInferer(AsterLikeOCRHip) -- MFMA convolutions with folded BatchNorm, lstm_step / attn_ctx kernels, hand-written
+    backward -- against the ORACLE's restatement of the wrapper (ref_model.ocr_convert_inputs / ocr_call, per sample as
+    aster_inferer.py:28-37) and of the network (oracle/ref_ocr.py: no code shared with the product; float64; the product
+    network's frozen weights handed over as data): logits and d(CE)/d(image)."""
+    from oracle.ref_ocr import OcrOracle
     from textboxgan_amd.aster import AsterInferer, AsterLikeOCRHip
-    ref = AsterInferer()
+    from textboxgan_amd.config import Config
+    cfg = Config()
     hip = AsterInferer(model=AsterLikeOCRHip()).to(dev)
     x = (rnd(4, 3, 64, 256, seed=31) * 0.5).float()
     labels = torch.tensor([[5, 6, 1, 1, 1, 1, 1, 1], [2, 3, 4, 5, 6, 7, 8, 9], [7, 1, 1, 1, 1, 1, 1, 1], [3, 4, 5, 6, 1, 1, 1, 1]])
-    outs = []
-    for o, d in ((ref, "cpu"), (hip, dev)):
-        xx = x.to(d).requires_grad_(True)
-        lg = o(o.convert_inputs(xx, labels.to(d)))
-        ce = torch.nn.functional.cross_entropy(lg.reshape(-1, lg.shape[-1]), labels.reshape(-1).to(d), reduction="sum")
-        (g,) = torch.autograd.grad(ce, xx)
-        outs.append((lg, g))
-    assert rel_err(outs[1][0], outs[0][0]) < 1e-3
-    assert rel_err(outs[1][1], outs[0][1]) < 5e-3
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        orc = OcrOracle(hip.model.state_dict(), max_steps=8, dtype=dt)
+        xr = x.to(dt).requires_grad_(True)
+        lg_ref = M.ocr_call(M.ocr_convert_inputs(xr, labels, cfg), orc.serve, 8)
+        ce = torch.nn.functional.cross_entropy(lg_ref.reshape(-1, lg_ref.shape[-1]), labels.reshape(-1), reduction="sum")
+        ref[dt] = (lg_ref, torch.autograd.grad(ce, xr)[0])
+    xx = x.to(dev).requires_grad_(True)
+    lg = hip(hip.convert_inputs(xx, labels.to(dev)))
+    ce = torch.nn.functional.cross_entropy(lg.reshape(-1, lg.shape[-1]), labels.reshape(-1).to(dev), reduction="sum")
+    (g,) = torch.autograd.grad(ce, xx)
+    # logits: against the float64 oracle (measured 2e-5)
+    assert rel_err(lg, ref[torch.float64][0]) < 1e-4
+    # d(CE)/d(image): the third sample is a one-character word -- its 32-pixel crop is stretched x8 to 256 columns
+    # (aster_inferer.py:166-187), which hands the localisation network's max-pools EXACT ties between neighbouring pixels.  A
+    # tie's subgradient is a choice: every fp32 evaluation sees the tie and takes the first index, float64 sees the two
+    # candidates 1e-17 apart and follows the rounding -- a discrete event worth 1e-2 of the maximum on 230 pixels of that
+    # sample (the oracle's OWN fp32 evaluation differs from its float64 one by exactly that: 1.0e-2 max, 3.0e-3 relative L2).
+    # So: element-wise against the oracle evaluated in fp32 (same ties, still no shared code) at the old bar, and relative L2
+    # against float64.
+    assert rel_err(g, ref[torch.float32][1]) < 5e-3
+    assert l2_err(g, ref[torch.float64][1]) < 5e-3
 
 
 @arith_modes

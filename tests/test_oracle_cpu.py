@@ -225,9 +225,9 @@ def test_golden_upfirdn_and_modconv_and_networks():
 
 
 def test_training_step_oracle_runs_and_is_deterministic():
-    from textboxgan_amd.aster import AsterLikeOCR
+    from conftest import ocr_oracle
     cfg = small_config(2)
-    ocr = AsterLikeOCR(max_steps=cfg.max_char_number)  # the stand-in network behind its serving signature
+    ocr = ocr_oracle(cfg.max_char_number)  # oracle/ref_ocr.py: the stand-in network behind its serving signature
     outs = []
     for _ in range(2):
         st = M.make_state(cfg, 0, bench_init=True)
@@ -312,3 +312,41 @@ def test_oracle_label_table_is_independent_and_equals_the_products():
     assert M._MAIN_CHARS == CT.MAIN_CHAR_VECTOR and M._ASTER_CHARS == CT.ASTER_CHAR_VECTOR and len(M._ASTER_CHARS) == 94
     assert M.main_to_aster_labels(np.array([[0, 1, 11, 69]])).tolist() == [[1, 2, 12, 65]]  # pad, '0', 'a', '"' by hand
     assert "textboxgan_amd" not in inspect.getsource(M)
+
+
+def test_ocr_oracle_equals_the_product_torch_module_in_float64():
+    """oracle/ref_ocr.py (explicit recurrences, un-folded BatchNorm, own TPS constants) and the product's torch module
+    (nn.LSTM / nn.LSTMCell / nn.Conv2d + BatchNorm2d; the weight-import and CPU-definition side of textboxgan_amd.aster) are two
+    independent statements of one function: with the same weights they agree to float64 rounding, forward (both predictors, the
+    dynamic decode lengths) and d/d(image)."""
+    from oracle.ref_ocr import OcrOracle
+    from textboxgan_amd.aster import AsterLikeOCR
+    net = AsterLikeOCR(max_steps=8, backward_predictor=True).double()
+    orc = OcrOracle(net.state_dict(), max_steps=8, dtype=torch.float64)
+    img = (torch.rand(2, 3, 64, 256, dtype=torch.float64, generator=torch.Generator().manual_seed(5)) * 2 - 1).requires_grad_(True)
+    a, b = net(img), orc(img)
+    assert float((a - b).abs().max()) < 1e-12
+    (ga,), (gb,) = torch.autograd.grad(a.square().sum(), img), torch.autograd.grad(b.square().sum(), img)
+    assert float((ga - gb).norm() / ga.norm()) < 1e-9
+    x = img[:1].detach().permute(0, 2, 3, 1)
+    sa, sb = net.serve(x), orc.serve(x)
+    assert set(sa) == set(sb) == {"forward_logits", "backward_logits"}
+    for k in sa:
+        assert sa[k].shape == sb[k].shape and float((sa[k] - sb[k]).abs().max()) < 1e-12
+
+
+def test_tokenisers_product_vs_oracle_and_known_answer():
+    """utils/utils.py:66-105 + config/char_tokens.py:4-17: the product's host tokenisers against the oracle's own restatement, and
+    the hand-derived literal of SURVEY 8(c) ("Hello"); long words keep their LAST max_char_number characters (Keras pad_sequences'
+    default truncating="pre"), unknown characters map to the pad / OOV id."""
+    from textboxgan_amd import char_tokens as T
+    assert M.string_to_main_int_sequence(["Hello"]).tolist() == [[44, 15, 22, 22, 25, 0, 0, 0]]
+    assert M.string_to_aster_int_sequence(["Hello"]).tolist() == [[45, 16, 23, 23, 26, 1, 1, 1]]
+    ws = ["Hello", "GAN", "abcdefghij", "x~y", "", "12345678", "a\n", "\"quoted\"", "Zz-'.!?,"]
+    np.testing.assert_array_equal(M.string_to_main_int_sequence(ws), T.string_to_main_int_sequence(ws))
+    np.testing.assert_array_equal(M.string_to_aster_int_sequence(ws), T.string_to_aster_int_sequence(ws))
+    assert M.string_to_main_int_sequence(["abcdefghij"]).tolist() == [[13, 14, 15, 16, 17, 18, 19, 20]]  # "cdefghij"
+    import inspect
+    from oracle import ref_model, ref_ocr, ref_ops, ref_projector
+    for mod in (ref_model, ref_ocr, ref_ops, ref_projector):  # the oracle stands on its own: no product import anywhere
+        assert "import textboxgan_amd" not in inspect.getsource(mod) and "from textboxgan_amd" not in inspect.getsource(mod)

@@ -154,6 +154,7 @@ class Projector:
         self.beta_1, self.beta_2, self.epsilon = 0.9, 0.999, 1e-7
         self._m = self._v = None
         self._t = 0
+        self.grad_log = None  # set to [] to record the latent gradient of every step (parity tests)
 
     def _get_lr(self, t: float) -> float:
         """projector.py:65-83."""
@@ -196,6 +197,8 @@ class Projector:
         p_loss = self.get_perceptual_loss(generated, target_image)
         loss = p_loss + self.ocr_loss_factor * ocr_loss
         (g,) = torch.autograd.grad(loss, [w])
+        if self.grad_log is not None:  # parity tests: the latent gradient of every step (gradient parity x optimiser parity)
+            self.grad_log.append(g.detach().clone())
         with torch.no_grad():
             if self._m is None:
                 self._m, self._v = torch.zeros_like(g), torch.zeros_like(g)
