@@ -9,7 +9,7 @@
 //   ds[b,i]   = ds_conv[b,i] - s[b,i] * sum_o t[b,o] wsq[i,o]   (gradient of the style scale, incl. the demod term)
 //   dwsq[i,o] = sum_b s[b,i]^2 t[b,o]                           (enters dW through tbg_conv2d_wgrad_ex_f32's addq)
 //   db[o]     = sum_{b,ch} pdb[b,o,ch];   dstrength = sum pdn
-// grid: ceil(I / 16) blocks own 16 input channels each (all b, all o) + one last block for db / dstrength.
+// grid: ceil(I / MS_IT) blocks own MS_IT input channels each (all b, all o) + ceil(O / 256) blocks for db / dstrength.
 // ---------------------------------------------------------------------------------------------------------------
 struct ModSmallP {
   const float *pdb, *pdn, *pdy, *d, *s, *wsq, *ds_conv;
@@ -17,7 +17,7 @@ struct ModSmallP {
   int B, I, O, nch;
 };
 
-#define MS_IT 4  // input channels per block: 128 blocks at I = 512 (the first version's 16 gave 33 blocks and 30 us)
+#define MS_IT 2  // input channels per block: 256 blocks at I = 512 (16: 33 blocks, 30 us; 4: 12.6 us; 2: 11.3 us at B = 16, 16.2 vs 20.8 at B = 32 -- the per-block LDS dot chains scale with it, tools/bench_smalls.py)
 
 __global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -26,15 +26,20 @@ __global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP
   if ((int)blockIdx.x >= nI) {  // ---- bias / noise-strength gradients: blocks nI .. nI + ceil(O/256) - 1
     __shared__ float red[4];
     const int o = ((int)blockIdx.x - nI) * 256 + tid;
-    if (o < p.O) {  // four samples per trip: independent load chains (a single chain was one round trip per element)
-      float a4[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int b = 0; b < p.B; b += 4)
+    if (o < p.O) {  // sixteen samples per trip: independent load chains (a single chain was one round trip per element)
+      float a16[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a16[u] = 0.f;
+      for (int b = 0; b < p.B; b += 16)
         for (int c = 0; c < p.nch; ++c) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (b + u < p.B) a4[u] += p.pdb[((size_t)(b + u) * p.O + o) * p.nch + c];
+          for (int u = 0; u < 16; ++u)
+            if (b + u < p.B) a16[u] += p.pdb[((size_t)(b + u) * p.O + o) * p.nch + c];
         }
-      p.db[o] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+      float a = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a += a16[u];
+      p.db[o] = a;
     }
     if ((int)blockIdx.x == nI && p.pdn) {
       float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -57,23 +62,37 @@ __global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP
   float *s2 = wq + MS_IT * p.O;           // [B][MS_IT]
   float *part = s2 + p.B * MS_IT;         // [B][MS_IT][4] partial dots
   const int i0 = blockIdx.x * MS_IT;
-  {  // t[b,o]: four (b,o) entries per trip, their partial-sum loads in flight together (the one-entry-per-trip loop was a
-     // chain of B*O/256 dependent round trips -- most of this kernel's 29 us)
+  {  // t[b,o]: TU (b,o) entries per trip with ALL their partial-sum loads in flight together: every block re-derives the whole
+     // [B, O] table, and one entry per trip was a chain of B*O/256 dependent round trips (most of the first version's 29 us;
+     // four per trip: 15 us at B = 16, 26 us at B = 32; sixteen per trip: the table is 2 - 4 trips)
+    constexpr int TU = 16;
     const int BO = p.B * p.O;
-    for (int e0 = tid; e0 < BO; e0 += 256 * 4) {
-      float a4[4] = {0.f, 0.f, 0.f, 0.f}, dv[4];
-      int ee[4];
+    for (int e0 = tid; e0 < BO; e0 += 256 * TU) {
+      float a[TU], dv[TU];
+      int ee[TU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) ee[u] = min(e0 + 256 * u, BO - 1);
+      for (int u = 0; u < TU; ++u) { ee[u] = min(e0 + 256 * u, BO - 1); a[u] = 0.f; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) dv[u] = p.d[ee[u]];
-      for (int c = 0; c < p.nch; ++c) {
+      for (int u = 0; u < TU; ++u) dv[u] = p.d[ee[u]];
+      if (p.nch <= 4) {  // (the step's chunk counts: 1 - 3) every load of the trip issued before the first use
+        float v[TU][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a4[u] += p.pdy[(size_t)ee[u] * p.nch + c];
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[u][c] = p.pdy[(size_t)ee[u] * p.nch + min(c, p.nch - 1)];
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a[u] += c < p.nch ? v[u][c] : 0.f;
+      } else {
+        for (int c = 0; c < p.nch; ++c) {
+#pragma unroll
+          for (int u = 0; u < TU; ++u) a[u] += p.pdy[(size_t)ee[u] * p.nch + c];
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (e0 + 256 * u < BO) t[e0 + 256 * u] = a4[u] * dv[u] * dv[u];
+      for (int u = 0; u < TU; ++u)
+        if (e0 + 256 * u < BO) t[e0 + 256 * u] = a[u] * dv[u] * dv[u];
     }
   }
   for (int e0 = tid; e0 < MS_IT * p.O; e0 += 256 * 8) {  // 8 loads in flight per lane
@@ -100,9 +119,18 @@ __global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP
     const int q = e & 3, pair = e >> 2;
     const int b = pair / MS_IT, ii = pair - b * MS_IT;
     const float *tb = t + b * p.O, *wr = wq + ii * p.O;
-    float a = 0.f;
-    for (int o = q; o < p.O; o += 4) a += tb[o] * wr[o];
-    part[e] = a;
+    // eight LDS read pairs in flight per trip, four accumulators (a single chain was one LDS round trip per term: 128 of them)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int o = q;
+    for (; o + 28 < p.O; o += 32) {
+      float tv[8], wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { tv[u] = tb[o + 4 * u]; wv[u] = wr[o + 4 * u]; }
+      a0 += tv[0] * wv[0] + tv[4] * wv[4]; a1 += tv[1] * wv[1] + tv[5] * wv[5];
+      a2 += tv[2] * wv[2] + tv[6] * wv[6]; a3 += tv[3] * wv[3] + tv[7] * wv[7];
+    }
+    for (; o < p.O; o += 4) a0 += tb[o] * wr[o];
+    part[e] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
   for (int pair = tid; pair < p.B * MS_IT; pair += 256) {
@@ -116,12 +144,20 @@ __global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP
   for (int e = tid; e < MS_IT * p.O; e += 256) {  // dwsq
     const int ii = e / p.O, o = e - ii * p.O;
     if (i0 + ii < p.I) {
-      float a = 0.f;
-      for (int b = 0; b < p.B; ++b) {
-        const float sv = s2[b * MS_IT + ii];
-        a += sv * sv * t[b * p.O + o];
+      float a0 = 0.f, a1 = 0.f;
+      int b = 0;
+      for (; b + 8 <= p.B; b += 8) {  // eight LDS read pairs in flight per trip
+        float sv[8], tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { sv[u] = s2[(b + u) * MS_IT + ii]; tv[u] = t[(b + u) * p.O + o]; }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { a0 += sv[u] * sv[u] * tv[u]; a1 += sv[u + 1] * sv[u + 1] * tv[u + 1]; }
       }
-      p.dwsq[(size_t)(i0 + ii) * p.O + o] = a;
+      for (; b < p.B; ++b) {
+        const float sv = s2[b * MS_IT + ii];
+        a0 += sv * sv * t[b * p.O + o];
+      }
+      p.dwsq[(size_t)(i0 + ii) * p.O + o] = a0 + a1;
     }
   }
 }
