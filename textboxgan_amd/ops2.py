@@ -13,14 +13,18 @@ Here every layer is TWO autograd nodes with hand-written gradients:
   B  (dx, ds, dd) = grad of A with respect to (x, s, d) for a cotangent dout -- the node A's backward returns when the
        gradient itself is being recorded (create_graph=True).  With m = act'(out), p = dout * m, r = L_w^T(d * p):
            dx = s * r,   ds = sum_p x * r,   dd = sum_p p * yc          (yc = L_w(s * x), recovered from out)
-     and B's own backward, for cotangents (gdx, gds, gdd), with u = s * gdx + gds * x, c = L_w(u), r2 = L_w^T(gdd * p):
-           g_dout = m * (d * c + gdd * yc)            g_d = sum_p p * c
-           g_x    = gds * r + s * r2                   g_s = sum_p gdx * r + sum_p x * r2
-           g_w    = W(u, d * p) + W(s * x, gdd * p)    (W = the filter gradient of L_w)
-     (every map is multilinear in its arguments except the LeakyReLU mask, whose derivative is zero almost everywhere).
+     and B's own backward, for cotangents (gdx, gds, gdd), with u = s * gdx + gds * x, c = L_w(u):
+           g_dout = m * (d * c + gdd * yc)            g_d = sum_p p * c - gdd * dd / d
+           g_x    = gds * r                            g_s = sum_p gdx * r
+           g_w    = W(u, d * p)                        g_out = (gdd / d) * dout       (W = the filter gradient of L_w)
+     -- the dd term is differentiated through ``out`` (yc = (act^-1(out) - noise * strength - b) / d): node A's backward, which
+     runs later in the same pass with g_out in its cotangent, delivers s * L_w^T(gdd * p), sum_p x * L_w^T(gdd * p) and
+     W(s * x, gdd * p) inside the launches it issues anyway (see _ModLayer2Bwd); every other map is multilinear in its
+     arguments except the LeakyReLU mask, whose derivative is zero almost everywhere.
 
-Launches: A forward 1-2, B forward 3-4, B backward 9-11 (two convolutions, two filter gradients, three elementwise passes:
-tbg_axpby_planes_f32 x2, tbg_bias_act_bwd2_f32), A backward (first order) 3-4 -- against ~4 / ~8 / ~25 / ~8 before.
+Launches: A forward 1-2, B forward 3-4, B backward 6-8 (ONE convolution, ONE filter gradient, four elementwise passes:
+tbg_axpby_planes_f32 x2, tbg_bias_act_bwd2_f32, one per-plane scale), A backward (first order) 3-4 -- against ~4 / ~8 / ~25 / ~8
+on the composable primitives.
 
 toRGB (to_rgb.py:28-33: 1x1 modulated convolution to 3 channels without demodulation, + bias + skip) gets the same pair on the
 streaming kernels tbg_rgb_project_f32 / tbg_rgb_backproject_f32."""
@@ -168,38 +172,48 @@ class _ModLayer2(torch.autograd.Function):
 
 
 class _ModLayer2Bwd(torch.autograd.Function):
-    """B: (dx, ds, dd) of A for the cotangent dout (see the module docstring); once more differentiable."""
+    """B: (dx, ds, dd) of A for the cotangent dout (see the module docstring); once more differentiable.
+
+    dd = sum_p p * yc is differentiated THROUGH ``out``: yc = (act^-1(out) - noise * strength - b) / d, so
+    d<gdd, dd>/d(out) = (gdd / d) * dout (the mask cancels: act^-1' = 1 / act') and node A's own backward -- which runs later in
+    the same pass with that tensor added to its cotangent -- delivers the x, s and w parts of the term (s * L^T(gdd * p),
+    sum_p x * L^T(gdd * p), W(s * x, gdd * p)) inside the convolution and filter-gradient launches it issues anyway; what it adds
+    beyond them (its dd, db, dstrength see the extra cotangent too) is exactly minus the DIRECT derivatives of yc with respect
+    to d, b and strength, returned here.  One convolution and one filter gradient per layer less than forming those parts here."""
 
     @staticmethod
     def forward(ctx, dout, out, x, w, s, d, noise, strength, b, up):
         L = _Lin(w, up, (x.shape[2], x.shape[3]))
         dout = dout.contiguous()
-        _, p, _, _, pdy = bias_act_bwd_raw(dout, out, _act_epi(d, noise, strength, b), want_db=False, want_dyy=True)
+        _, p, pdb, pdn, pdy = bias_act_bwd_raw(dout, out, _act_epi(d, noise, strength, b), want_db=True, want_dn=noise is not None,
+                                               want_dyy=True)
         ds = torch.empty_like(s)
         r, aux = L.adj(p, w, d, dot=(x, ds))
         dx = bias_act_fwd_raw(r, N.epilogue(out_scale=s))
         dd = pdy.sum(dim=2) / d
-        ctx.save_for_backward(dout, out, x, w, s, d, noise, strength, b, p, r, aux)
+        sp = pdb.sum(dim=2)                                  # sum_p p        [B, O]
+        sn = pdn.sum(dim=2) if noise is not None else None   # sum_p p * n    [B, O]
+        ctx.save_for_backward(dout, out, x, w, s, d, noise, strength, b, p, r, aux, dd, sp, sn)
         ctx.up = up
         return dx, ds, dd
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gdx, gds, gdd):
-        dout, out, x, w, s, d, noise, strength, b, p, r, aux = ctx.saved_tensors
+        dout, out, x, w, s, d, noise, strength, b, p, r, aux, dd, sp, sn = ctx.saved_tensors
         L = _Lin(w, ctx.up, (x.shape[2], x.shape[3]))
         gdx, gds, gdd = gdx.contiguous(), gds.contiguous(), gdd.contiguous()
         u, _ = axpby_planes_raw(gdx, s, x, gds)                      # u = s * gdx + gds * x
         c = L.fwd(u, w, None)                                        # c = L_w(u)
-        g_dout, g_d = bias_act_bwd2_raw(c, out, dout, gdd, _act_epi(d, noise, strength, b))
-        xr2 = torch.empty_like(s)
-        r2, aux2 = L.adj(p, w, gdd, dot=(x, xr2))                    # r2 = L_w^T(gdd * p), xr2 = sum_p x * r2
-        g_x, gr = axpby_planes_raw(r, gds, r2, s, c=gdx)             # g_x = gds * r + s * r2, gr = sum_p gdx * r
-        g_s = gr + xr2
-        g_w = None
-        if ctx.needs_input_grad[3]:
-            g_w = L.wgrad(u, w, p, None, d, aux) + L.wgrad(x, w, p, s, gdd, aux2)
-        return g_dout, None, g_x, g_w, g_s, g_d, None, None, None, None
+        g_dout, pc = bias_act_bwd2_raw(c, out, dout, gdd, _act_epi(d, noise, strength, b))   # m * (d * c + gdd * yc), sum_p p * c
+        gq = (gdd / d).contiguous()
+        g_out = bias_act_fwd_raw(dout, N.epilogue(out_scale=gq))     # (gdd / d) * dout: the dd term, routed through node A
+        g_x, gr = axpby_planes_raw(r, gds, None, None, c=gdx)        # g_x = gds * r, gr = sum_p gdx * r
+        g_d = pc - gq * dd                                           # (- gdd * dd / d: the direct d-dependence of yc)
+        g_b = -(gq * sp).sum(dim=0) if (b is not None and ctx.needs_input_grad[8]) else None
+        g_str = -(gq * sn).sum() if (sn is not None and ctx.needs_input_grad[7]) else None
+        g_w = L.wgrad(u, w, p, None, d, aux) if ctx.needs_input_grad[3] else None
+        return g_dout, g_out, g_x, g_w, gr, g_d, None, g_str, g_b, None
 
 
 def mod_layer2(x, w, s, d, noise, strength, b, up=False):
