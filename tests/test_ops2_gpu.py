@@ -103,3 +103,58 @@ def test_torgb2_first_and_second_order(dev, shape):
     grads = torch.autograd.grad(loss, (xd, wd, mwd, mbd, bd, styled))
     for name, a, e in zip(("x", "w", "mod_w", "mod_b", "bias", "style"), grads, grads_ref):
         assert l2_err(a, e) < 3e-4, (name, l2_err(a, e))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (3, 8, 16, 64), (2, 4, 96, 128)], ids=["ragged", "small", "two-chunks"])
+def test_second_order_elementwise_entries_c_abi(dev, shape):
+    """tbg_axpby_planes_f32 / tbg_bias_act_bwd2_f32 called through the C ABI: values against their float64 definitions (tbg.h),
+    scalar (HW % 4 != 0) and 16-byte paths, one and several partial-sum chunks; bad calls return negative codes, never launch."""
+    import ctypes as C
+    from textboxgan_amd import native as N
+    L = N.lib()
+    B, M, H, W = shape
+    HW = H * W
+    nch = L.tbg_bias_act_bwd_chunks(HW)
+    f = lambda t: t.float().to(dev).contiguous()
+    a, b_, c = rnd(B, M, H, W, seed=1), rnd(B, M, H, W, seed=2), rnd(B, M, H, W, seed=3)
+    sa, sb = rnd(B, M, seed=4), rnd(B, M, seed=5)
+    ad, bd, cd, sad, sbd = f(a), f(b_), f(c), f(sa), f(sb)
+    y = torch.empty_like(ad)
+    part = torch.empty(B, M, nch, device=dev)
+    assert L.tbg_axpby_planes_f32(N.ptr(ad), N.ptr(sad), N.ptr(bd), N.ptr(sbd), N.ptr(cd), N.ptr(y), N.ptr(part), B * M, HW,
+                                  N.stream()) == 0
+    assert l2_err(y, sa[:, :, None, None] * a + sb[:, :, None, None] * b_) < 1e-6
+    assert l2_err(part.sum(dim=2), (c * a).sum(dim=(2, 3))) < 1e-5
+    y2 = torch.empty_like(ad)  # no scales, no second operand
+    assert L.tbg_axpby_planes_f32(N.ptr(ad), None, None, None, None, N.ptr(y2), None, B * M, HW, N.stream()) == 0
+    assert torch.equal(y2, ad)
+    EINVAL = -1
+    assert L.tbg_axpby_planes_f32(None, None, None, None, None, N.ptr(y), None, B * M, HW, N.stream()) == EINVAL
+    assert L.tbg_axpby_planes_f32(N.ptr(ad), None, None, None, None, None, None, B * M, HW, N.stream()) == EINVAL       # nothing to write
+    assert L.tbg_axpby_planes_f32(N.ptr(ad), None, None, None, None, N.ptr(y), N.ptr(part), B * M, HW, N.stream()) == EINVAL  # sums without c
+    assert L.tbg_axpby_planes_f32(N.ptr(ad), None, None, N.ptr(sbd), None, N.ptr(y), None, B * M, HW, N.stream()) == EINVAL   # scale without b
+    assert L.tbg_axpby_planes_f32(N.ptr(ad), None, None, None, None, N.ptr(y), None, 0, HW, N.stream()) == EINVAL
+
+    # bias_act_bwd2: out = lrelu(d * yc + noise * strength + b) * sqrt2 built in float64
+    yc, noise, bias = rnd(B, M, H, W, seed=6), rnd(B, 1, H, W, seed=7), rnd(M, seed=8) * 0.3
+    d, gdd, strength = rnd(B, M, seed=9).abs() + 0.5, rnd(B, M, seed=10), torch.tensor(0.4, dtype=torch.float64)
+    pre = d[:, :, None, None] * yc + noise * strength + bias[None, :, None, None]
+    out = torch.where(pre > 0, pre, 0.2 * pre) * math.sqrt(2.0)
+    m = torch.where(pre > 0, 1.0, 0.2).double() * math.sqrt(2.0)
+    cc, dout = rnd(B, M, H, W, seed=11), rnd(B, M, H, W, seed=12)
+    g_ref = m * (d[:, :, None, None] * cc + gdd[:, :, None, None] * yc)
+    pc_ref = (dout * m * cc).sum(dim=(2, 3))
+    keep = (f(d), f(bias), f(noise), f(strength))  # (the epilogue holds raw pointers)
+    epi = N.epilogue(out_scale=keep[0], bias=keep[1], noise=keep[2], strength=keep[3], act=N.ACT_LRELU, slope=0.2)
+    ccd, outd, doutd, gddd = f(cc), f(out), f(dout), f(gdd)
+    g = torch.empty_like(ccd)
+    assert L.tbg_bias_act_bwd2_f32(N.ptr(ccd), N.ptr(outd), N.ptr(doutd), N.ptr(gddd), N.ptr(g), N.ptr(part), B, M, HW,
+                                   C.byref(epi), N.stream()) == 0
+    assert l2_err(g, g_ref) < 2e-6 and l2_err(part.sum(dim=2), pc_ref) < 1e-5
+    assert L.tbg_bias_act_bwd2_f32(None, N.ptr(outd), N.ptr(doutd), None, N.ptr(g), None, B, M, HW, C.byref(epi), N.stream()) == EINVAL
+    assert L.tbg_bias_act_bwd2_f32(N.ptr(ccd), N.ptr(outd), None, None, N.ptr(g), N.ptr(part), B, M, HW, C.byref(epi),
+                                   N.stream()) == EINVAL  # sums need dout
+    assert L.tbg_bias_act_bwd2_f32(N.ptr(ccd), N.ptr(outd), N.ptr(doutd), None, N.ptr(g), None, B, M, HW, None, N.stream()) == EINVAL
+    res = N.epilogue(residual=ccd)
+    assert L.tbg_bias_act_bwd2_f32(N.ptr(ccd), N.ptr(outd), N.ptr(doutd), None, N.ptr(g), None, B, M, HW, C.byref(res),
+                                   N.stream()) == EINVAL  # a fused residual is not part of this form
