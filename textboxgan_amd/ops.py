@@ -1487,12 +1487,19 @@ class _ConvBiasActFused(torch.autograd.Function):
             if h:
                 dx = _tail_empty(x_f.shape, x_f.device)
                 dx_out = dx[:h]
+            # gradient of ANOTHER consumer of x, added by this launch's epilogue instead of by an elementwise pass of the autograd
+            # engine (_ConvBiasActSkipFused: the discriminator block's skip branch)
+            xres = getattr(ctx, "dx_residual", None)
+            if xres is not None:
+                assert not thin
+                xres = xres[:h] if h else xres
+            epi_dx = N.epilogue(alpha=coef, residual=xres)
             if thin:  # d(image)[b,c,p] = coef * sum_o w[c,o] dpre[b,o,p]
                 r = rgb_project_raw(dpre, w.reshape(I, O).t().contiguous(), I, None, None, None, coef, out=dx_out)
             elif bw is not None:
-                r = bw.dx(w, N.epilogue(alpha=coef), out=dx_out)
+                r = bw.dx(w, epi_dx, out=dx_out)
             else:
-                r = _bwd_data_launch(dpre, w, g, alpha=coef, out=dx_out)
+                r = _bwd_data_launch(dpre, w, g, epi=epi_dx, out=dx_out)
             dx = dx if h else r
         dw = None
         if not prune_w:
@@ -1506,6 +1513,50 @@ class _ConvBiasActFused(torch.autograd.Function):
         else:
             db = None
         return dx, dw, db, dres, None, None, None, None, None, None
+
+
+class _ConvBiasActSkipFused(torch.autograd.Function):
+    """(t, xd) = (lrelu(coef * conv3x3(x, w) + b) * sqrt2,  FIR-decimate(x)): the two consumers of a DiscriminatorBlock's input
+    (discriminator.py:68-84: conv_0 and the skip branch's blur + strided 1x1 convolution, whose blur is evaluated at the strided
+    sites only) as ONE node, so that d(x) = conv^T(dt) + FIR^T(dxd) is formed by the data-gradient launch's epilogue (residual =
+    FIR^T(dxd)) instead of two activation-sized tensors and an add of the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, k, down, fpad, role):
+        out = _ConvBiasActFused.forward(ctx, x, w, b, None, (1, 1), (1, 1), ACT_LRELU, 1.0, role)  # (saves its tensors on ctx)
+        ctx.fir = (k, tuple(down), tuple(fpad))
+        return out, upfirdn2d_raw(x.contiguous(), k, (1, 1), down, fpad)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dt, dxd):
+        x = ctx.saved_tensors[0]
+        k, down, pad = ctx.fir
+        inH, inW = x.shape[2], x.shape[3]
+        kH, kW = k.shape
+        outW = (inW + pad[0] + pad[1] - kW) // down[0] + 1
+        outH = (inH + pad[2] + pad[3] - kH) // down[1] + 1
+        gpad = (kW - pad[0] - 1, inW - outW * down[0] + pad[0], kH - pad[2] - 1, inH - outH * down[1] + pad[2])  # upfirdn_2d_v2.py:204-209
+        h = _half(ctx.role, dxd.shape[0])
+        if h:  # first-order pass over the leading samples only: the rest of the tensor is never read
+            dxs = _tail_empty(tuple(x.shape), x.device)
+            upfirdn2d_raw(dxd.contiguous()[:h], _flipped_fir(k), down, (1, 1), gpad, out=dxs[:h])
+        else:
+            dxs = upfirdn2d_raw(dxd.contiguous(), _flipped_fir(k), down, (1, 1), gpad)
+        ctx.dx_residual = dxs
+        try:
+            dx, dw, db = _ConvBiasActFused.backward(ctx, dt)[:3]
+        finally:
+            ctx.dx_residual = None
+        return dx, dw, db, None, None, None, None
+
+
+def conv_bias_act_skip_fused(x, w, b, k, down, fpad, role=None):
+    """(lrelu(coef * conv3x3(x, w) + b) * sqrt2, upfirdn2d(x, k, down=down, pad=fpad)) with one gradient launch chain for x."""
+    return _ConvBiasActSkipFused.apply(x, w, b, k, tuple(down), tuple(fpad), role)
+
+
+FUSE_SKIP_GRAD = True  # measurement aid (tools/ab_step.py): False = two nodes and the autograd engine's add
 
 
 class _BlurConvS2Fused(torch.autograd.Function):
