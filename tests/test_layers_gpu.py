@@ -442,3 +442,37 @@ def test_hip_path_reproduces_committed_golden_fixtures(dev):
     chk = torch.tensor([float(img.sum()), float(img.abs().sum()), float(img.square().sum())])
     assert rel_err(chk, torch.from_numpy(n["image_checksum"])) < 1e-4
     assert rel_err(sc, torch.from_numpy(n["scores"])) < 1e-3
+
+
+@arith_modes
+def test_discriminator_block_fused_skip_gradient_equals_two_nodes(dev):
+    """ops._ConvBiasActSkipFused (conv_0 and the skip FIR of a DiscriminatorBlock as one node: the input gradient conv^T(dt) +
+    FIR^T(dxd) formed by the data-gradient launch's epilogue) against the two-node form with the autograd engine's add --
+    scores, every parameter gradient and d/d(image), on the whole batch and in the G-loss pass's first-half mode
+    (FLAGS.d_first_half: only the leading samples are differentiated, discriminator.py:68-84)."""
+    from textboxgan_amd import ops
+    from textboxgan_amd.models import Discriminator
+    cfg = small_config(4)
+    torch.manual_seed(3)
+    D = Discriminator(cfg).to(dev)
+    img = (torch.randn(8, 3, cfg.char_height, cfg.image_width, device=dev) * 0.5)
+    res = {}
+    for fused in (True, False):
+        ops.FUSE_SKIP_GRAD = fused
+        try:
+            with ops.STATE_LOCK, ops.filter_cache():
+                x = img.clone().requires_grad_(True)
+                sc = D(x, parts=2)
+                g_full = torch.autograd.grad(sc.square().sum(), [x] + list(D.parameters()), retain_graph=True)
+                ops.FLAGS.skip_d_wgrad, ops.FLAGS.d_first_half = True, 4
+                try:
+                    (g_half,) = torch.autograd.grad(sc[:4].sum(), x)
+                finally:
+                    ops.FLAGS.skip_d_wgrad, ops.FLAGS.d_first_half = False, 0
+            res[fused] = (sc.detach(), [g.detach() for g in g_full], g_half[:4].detach())
+        finally:
+            ops.FUSE_SKIP_GRAD = True
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert l2_err(a, b) < 1e-6
+    assert l2_err(res[True][2], res[False][2]) < 1e-6
