@@ -260,12 +260,8 @@ HEADLINE_ARITH = "f32x3"  # arithmetic of the default (BASELINE configs[1]) line
 
 
 def graph_mode(ts):
-    """how the step actually ran: "single" (one HIP graph per step variant), "split" (per-gradient-set graphs with the
-    all-reduces between them), "two-phase" (gradient graph | blocking exchange | update graph) or "eager"."""
-    if not ts.use_graphs or not ts._graphs:
-        return "eager"
-    n = max(len(g[0]) for g in ts._graphs.values())
-    return "single" if n == 1 else "two-phase" if n == 2 else "split"
+    """TrainingStep.graph_mode: "single" | "split" | "two-phase" | "eager"."""
+    return ts.graph_mode
 
 
 def timed_loop(state, batch, steps, warmup, world):

@@ -196,3 +196,62 @@ def test_bench_launcher_two_ranks_gloo_smoke(dev):
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["scaling"] == "weak" and rec["value"] > 0
+
+
+def _forced_exchange_worker(port, q):
+    """one process, backend nccl (= RCCL), world size 1, TBG_FORCE_EXCHANGE=1: the split-graph step with its collectives
+    against the plain single-graph step from the same seed."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TBG_FORCE_EXCHANGE="1")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from oracle import ref_model as M
+    from textboxgan_amd.config import small_config
+    from textboxgan_amd.training_step import build_trainer_state
+    cfg = small_config(4, num_replicas=1)
+    b = {k: v.to(dev) for k, v in M.make_batch(cfg, seed=1234, rank=0).items()}
+    # caller protocol of train.py:178-208 over one lazy-regularisation cycle boundary: plain, PL, PL+R1 variants all replay
+    sched = [(False, False)] * 3 + [(False, True)] * 3 + [(True, True)] * 3
+
+    def run(forced):
+        os.environ["TBG_FORCE_EXCHANGE"] = "1" if forced else "0"
+        st = build_trainer_state(cfg, dev, seed=0, use_graphs=True)
+        ts = st["training_step"]
+        assert ts.distributed == forced and bool(ts.d_cuts) == forced
+        torch.manual_seed(77)
+        losses = []
+        for do_r1, do_pl in sched:
+            l = ts.dist_train_step(b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], do_r1, do_pl, 1e-4)
+            losses.append([float(x) for x in l[0]] + [float(x) for x in l[1]] + [float(l[2])])
+        torch.cuda.synchronize()
+        return (ts.graph_mode, ts.capture_error, losses, st["generator"]._flat.flat.clone(), st["discriminator"]._flat.flat.clone(),
+                float(st["pl_mean"]))
+
+    mode_f, err_f, loss_f, g_f, d_f, pl_f = run(True)
+    mode_p, err_p, loss_p, g_p, d_p, pl_p = run(False)
+    q.put(dict(mode_forced=mode_f, err_forced=err_f, mode_plain=mode_p, err_plain=err_p, losses_equal=loss_f == loss_p,
+               loss_forced=loss_f[-1], loss_plain=loss_p[-1], g_equal=bool(torch.equal(g_f, g_p)), d_equal=bool(torch.equal(d_f, d_p)),
+               g_maxdiff=float((g_f - g_p).abs().max()), d_maxdiff=float((d_f - d_p).abs().max()), pl_equal=pl_f == pl_p))
+    dist.destroy_process_group()
+
+
+def test_forced_exchange_rccl_split_graphs_equal_the_plain_step(dev):
+    """TBG_FORCE_EXCHANGE=1 with backend "nccl" at world size 1: GradExchange is active, so the step is captured as SPLIT HIP
+    graphs sharing one pool -- [forward + g-pass] [ocr-pass] [D stage 0..2] [3 x Adam] -- and ncclAllReduce (RCCL) is issued
+    between their replays for every gradient slice (the bucketed D exchange included), for the plain, PL and PL+R1 variants:
+    the call pattern of the first multi-GPU run (reference training_step.py:91-136,233-235, config/config.py:140-141) on the
+    one GPU this suite has.  A 1-rank SUM is the identity, so everything the step touches -- seven losses per step, pl_mean, and
+    every generator / discriminator weight after nine steps -- must be BIT-identical to the non-distributed single-graph step
+    from the same seed; the capture must not have been lost (graph_mode "split", no capture_error)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_exchange_worker, args=(_free_port(), q))
+    p.start()
+    r = q.get(timeout=900)
+    p.join(timeout=120)
+    assert r["mode_forced"] == "split" and r["err_forced"] is None, r
+    assert r["mode_plain"] == "single" and r["err_plain"] is None, r
+    assert r["losses_equal"] and r["pl_equal"], r
+    assert r["g_equal"] and r["d_equal"], r

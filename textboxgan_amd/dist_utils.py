@@ -10,6 +10,7 @@ corresponding Adam update.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -19,7 +20,13 @@ import torch.distributed as dist
 class GradExchange:
     def __init__(self, process_group=None):
         self.pg = process_group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        up = dist.is_available() and dist.is_initialized()
+        # TBG_FORCE_EXCHANGE=1: run the whole exchange path (bucketed D backward, split-graph capture, one collective per
+        # gradient slice) at world size 1 as well.  A 1-rank SUM all-reduce is the identity, so the step's results must be
+        # bit-identical to the non-distributed step -- which is how a single-GPU box can execute ncclAllReduce between the
+        # replays of HIP graphs that share a pool before the first multi-GPU run does (tests/test_distributed_gpu.py).
+        forced = up and os.environ.get("TBG_FORCE_EXCHANGE", "0") == "1"
+        self.active = up and (dist.get_world_size(process_group) > 1 or forced)
         self._pending: List = []
         self.muted = False  # measurement aid (bench.py dist_record): skip the gradient collectives, keep every launch
 

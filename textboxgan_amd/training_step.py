@@ -154,6 +154,15 @@ class TrainingStep:
             gen_losses, disc_losses, ocr_loss = tuple(r[0:3]), tuple(r[3:6]), r[6]
         return gen_losses, disc_losses, ocr_loss
 
+    @property
+    def graph_mode(self) -> str:
+        """how the step actually ran: "single" (one HIP graph per step variant), "split" (per-gradient-set graphs with the
+        all-reduces between them), "two-phase" (gradient graph | blocking exchange | update graph) or "eager"."""
+        if not self.use_graphs or not self._graphs:
+            return "eager"
+        n = max(len(g[0]) for g in self._graphs.values())
+        return "single" if n == 1 else "two-phase" if n == 2 else "split"
+
     def _count_step(self):
         for o in (self.g_optimizer, self.ocr_optimizer, self.d_optimizer):
             o._iterations += 1
