@@ -552,8 +552,11 @@ def main():
         out["value_16step"] = cycle_value(sm, args.batch)
         out["value"] = out["value_16step"]
         out["ms_per_step"] = round((14 * sm["plain"] + sm["pl"] + sm["pl_r1"]) / 16, 3)
-        out["value_basis"] = ("aligned 16-step cycle from step_ms (plain x6, pl x3, pl_r1 x3 timed steps); value_window = "
-                              "images * steps / wall time of the --steps window")
+        out["value_basis"] = ("value and ms_per_step are the average of ONE ALIGNED 16-STEP CYCLE (14 plain + 1 PL + 1 PL+R1) built "
+                              "from step_ms (plain x6, pl x3, pl_r1 x3 separately timed steps) -- NOT window / steps: steps * "
+                              "ms_per_step is not a wall interval.  The wall-clock figure of the --steps window (barrier + "
+                              "synchronize on both sides, images * steps / wall time) is value_window / ms_per_step_window, and "
+                              "steps * ms_per_step_window is that interval")
         out["conv_tflops_vs_step_time"] = round(out["value"] * CONV_GFLOP_PER_IMAGE / 1e3, 2)
     else:
         dr = dist_record(state, batch, world, backend)

@@ -301,7 +301,7 @@ def test_discriminator_joint_pass_matches_two_oracle_calls(dev):
 
 
 @arith_modes
-@pytest.mark.parametrize("mode", ["fused", "composable"])
+@pytest.mark.parametrize("mode", ["fused", "composable", "fused2"])
 @pytest.mark.parametrize("training", [True, False])
 def test_generator_matches_oracle(dev, mode, training):
     from textboxgan_amd.models import Generator

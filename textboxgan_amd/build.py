@@ -2,6 +2,7 @@
 (custom_ops.py:109-213) -- but ahead of time, one shared library, C ABI, no framework headers."""
 from __future__ import annotations
 
+import fcntl
 import hashlib
 import os
 import subprocess
@@ -29,14 +30,34 @@ def _digest() -> str:
 def build_native(force: bool = False, verbose: bool = True) -> str:
     stamp = LIB + ".sha256"
     dig = _digest()
-    if (not force and os.path.exists(LIB) and os.path.exists(HOST_LIB) and os.path.exists(stamp)
-            and open(stamp).read().strip() == dig):
+
+    def fresh():
+        return (os.path.exists(LIB) and os.path.exists(HOST_LIB) and os.path.exists(stamp)
+                and open(stamp).read().strip() == dig)
+
+    if not force and fresh():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # one object per translation unit, compiled in parallel and cached by content (sources + headers + flags) under
-    # csrc/.obj (git-ignored): editing one kernel file recompiles that file only
     objdir = os.path.join(CSRC, ".obj")
     os.makedirs(objdir, exist_ok=True)
+    # one builder at a time (every rank of a multi-process launch calls this): the others wait here and then find the
+    # library fresh.  Objects and libraries are written to "<name>.tmp.<pid>" and renamed on success, so that a killed
+    # compile can never leave a truncated file under a final name (the role of custom_ops.py's atomic rename, :196-206).
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and fresh():
+            return LIB
+        _build_locked(force, verbose, objdir)
+        with open(stamp + f".tmp.{os.getpid()}", "w") as f:
+            f.write(dig)
+        os.replace(stamp + f".tmp.{os.getpid()}", stamp)
+    return LIB
+
+
+def _build_locked(force: bool, verbose: bool, objdir: str) -> None:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    pid = os.getpid()
+    # one object per translation unit, compiled in parallel and cached by content (sources + headers + flags) under
+    # csrc/.obj (git-ignored): editing one kernel file recompiles that file only
     hdr = hashlib.sha256()
     for name in sorted(os.listdir(CSRC)) + ["../../include/tbg.h"]:
         if name.endswith(".h"):
@@ -53,26 +74,35 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
             for old in os.listdir(objdir):
                 if old.startswith(src + "."):
                     os.remove(os.path.join(objdir, old))
-            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+            tmp = f"{obj}.tmp.{pid}"
+            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", tmp]
             if verbose:
                 print("[tbg build]", " ".join(cmd), flush=True)
-            jobs.append((src, subprocess.Popen(cmd)))
-    for src, job in jobs:
-        if job.wait() != 0:
-            raise subprocess.CalledProcessError(job.returncode, f"hipcc -c {src}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+            jobs.append((src, tmp, obj, subprocess.Popen(cmd)))
+    failed = None
+    for src, tmp, obj, job in jobs:  # every job is waited for, also after a failure (no orphaned compilers)
+        if job.wait() == 0 and failed is None:
+            os.replace(tmp, obj)
+        else:
+            failed = failed or (job.returncode, src)
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    if failed is not None:
+        raise subprocess.CalledProcessError(failed[0], f"hipcc -c {failed[1]}")
+    tmp = f"{LIB}.tmp.{pid}"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
     if verbose:
         print("[tbg build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
     # the host-only helpers once more WITHOUT the HIP runtime (g++): the checkpoint checksum on CPU-only hosts
+    tmp = f"{HOST_LIB}.tmp.{pid}"
     host_cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "c++",
-                os.path.join(CSRC, "host_util.hip"), "-o", HOST_LIB]
+                os.path.join(CSRC, "host_util.hip"), "-o", tmp]
     if verbose:
         print("[tbg build]", " ".join(host_cmd), flush=True)
     subprocess.check_call(host_cmd)
-    with open(stamp, "w") as f:
-        f.write(dig)
-    return LIB
+    os.replace(tmp, HOST_LIB)
 
 
 if __name__ == "__main__":

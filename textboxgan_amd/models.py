@@ -6,8 +6,14 @@ layers/*.py, models/word_encoder.py), and parameters keep the reference's layout
 ``state_dict()`` keys/shapes are the checkpoint layout.  Two execution modes:
 
 * ``mode="fused"``      first-order training/inference path: fused HIP layers (ops.*_fused).
-* ``mode="composable"`` every conv / FIR is a HIP primitive whose backward is again a primitive,
-                        elementwise glue is torch -- gradients of any order (R1, path length).
+* ``mode="composable"`` every conv / FIR / scale / activation is a HIP primitive whose backward is again a
+                        primitive -- gradients of ANY order, with respect to activations AND parameters (R1's
+                        discriminator pass; any caller that records a gradient).
+* ``mode="fused2"``     (generator, device tensors only) the synthesis layers and toRGB as the twice-differentiable
+                        node pairs of ``ops2``: first order like "fused"; a RECORDED gradient (create_graph=True) is
+                        supported with respect to activations / styles / demodulation only and must run under
+                        ``ops.FLAGS.no_filter_grads`` -- exactly the path-length pass (training_step.py:300-347),
+                        which is its one caller.  Anything else that records gradients takes "composable".
 
 Mapping MLP, word encoder and the discriminator's dense head stay PyTorch-ROCm GEMMs
 (BASELINE.json north_star); minibatch-std stays torch (true second-order term for R1).
@@ -209,7 +215,7 @@ class ToRGB(nn.Module):
         s = self.conv.style(style, mode) if s is None else s
         if mode == "fused":
             return ops.torgb_fused(x, self.conv.w, s, self.apply_bias.b, skip, colmask, mask_cw)
-        if x.is_cuda and colmask is None and ops2.USE_FUSED2:  # twice-differentiable fused node (path-length pass)
+        if mode == "fused2" and colmask is None:  # twice-differentiable fused node (path-length pass)
             return ops2.torgb2(x, self.conv.w, s, self.apply_bias.b, skip)
         y = self.apply_bias(self.conv.conv_composable(x, s, None))
         y = y if skip is None else skip + y
@@ -237,7 +243,7 @@ class SynthesisBlock(nn.Module):
             if mode == "fused":
                 fn = ops.modconv_up_fused if conv.up else ops.modconv_fused
                 x = fn(x, conv.w, s, noise, nz.noise_strength, ba.b)
-            elif x.is_cuda and ops2.USE_FUSED2:  # twice-differentiable fused layer: two autograd nodes with hand-written gradients
+            elif mode == "fused2":  # twice-differentiable fused layer: two autograd nodes with hand-written gradients
                 x = ops2.mod_layer2(x, conv.w, s, conv.demod(s, mode) if d is None else d, noise, nz.noise_strength, ba.b,
                                     up=conv.up)
             else:  # any-order path: one launch for noise + bias + lrelu (ops.bias_act_c), gradients again primitives
@@ -284,7 +290,8 @@ class Synthesis(nn.Module):
             for i in range(nb):
                 s_c0[i], s_c1[i], s_tr[i + 1] = ss[1 + 3 * i], ss[2 + 3 * i], ss[3 + 3 * i]
         d_c0, d_c1 = [None] * nb, [None] * nb
-        if mode != "fused" and x.is_cuda and ops2.USE_FUSED2:  # twice-differentiable pass: all affines / demodulations batched
+        if mode == "fused2":  # twice-differentiable pass: all affines / demodulations batched
+            assert x.is_cuda, 'mode="fused2" runs on the HIP kernels (CPU tensors: mode="composable")'
             convs = [self.initial_torgb.conv] + [c for b, t in zip(self.synth_blocks, self.torgbs)
                                                   for c in (b.conv_0, b.conv_1, t.conv)]
             rows = [0] + [r for i in range(nb) for r in (3 * i, 3 * i + 1, 3 * i + 2)]

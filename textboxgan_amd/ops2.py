@@ -157,7 +157,10 @@ class _ModLayer2(torch.autograd.Function):
         x, w, s, d, noise, strength, b, out = ctx.saved_tensors
         dout = dout.contiguous()
         if torch.is_grad_enabled():  # the gradient is being recorded (path-length pass): a node that can be differentiated again
-            assert FLAGS.no_filter_grads, "the recorded gradient of a twice-differentiable layer ends at the activations / styles"
+            if not FLAGS.no_filter_grads:
+                raise RuntimeError('mode="fused2" records gradients with respect to activations / styles only and under '
+                                   'ops.FLAGS.no_filter_grads (the path-length pass); use mode="composable" for any other '
+                                   'recorded gradient')
             dx, ds, dd = _ModLayer2Bwd.apply(dout, out, x, w, s, d, noise, strength, b, ctx.up)
             return dx, None, ds, dd, None, None, None, None
         L = _Lin(w, ctx.up, (x.shape[2], x.shape[3]))
@@ -243,7 +246,8 @@ class _ToRGB2(torch.autograd.Function):
         dy = dy.contiguous()
         dskip = dy if ctx.has_skip else None
         if torch.is_grad_enabled():
-            assert FLAGS.no_filter_grads
+            if not FLAGS.no_filter_grads:
+                raise RuntimeError('mode="fused2" records gradients under ops.FLAGS.no_filter_grads only; use mode="composable"')
             dx, ds = _ToRGB2Bwd.apply(dy, x, w, s)
             return dx, None, ds, None, dskip
         _, _, I, O = w.shape
@@ -337,6 +341,10 @@ def _index(device, values):
     """constant index vector, one per (device, values) for the life of the process (a host-to-device copy is not capturable)."""
     key = (device, tuple(int(v) for v in values))
     if key not in _IDX:
+        # (first use of a path-length variant is an eager warm-up step, TrainingStep._graphed_step; a first use INSIDE a capture
+        # would fail on the copy and leave a process-lifetime tensor in the graph's private pool -- make that loud)
+        assert not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()), \
+            "ops2._index: constant index tensors must be created outside HIP-graph capture (run one eager step first)"
         _IDX[key] = torch.tensor(key[1], device=device, dtype=torch.long)
     return _IDX[key]
 

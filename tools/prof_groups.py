@@ -4,7 +4,11 @@ d, steps = sys.argv[1], float(sys.argv[2])
 rows = list(csv.DictReader(open(glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0])))
 fam = collections.defaultdict(lambda: [0.0, 0])
 def family(n):
-    if "conv_fprop" in n or "conv_tmerge" in n: return "tbg conv_fprop"
+    # unit-tensor families first (their names contain none of the NCHW family substrings, or shadow them)
+    if "conv_wgrad_units" in n: return "tbg conv_wgrad_units (filter gradient from unit tensors)"
+    if "conv_units" in n or "conv_group" in n: return "tbg conv_units (fprop / dgrad / s2 / t2 from unit tensors)"
+    if "units_pack" in n or "fir_units" in n or "bias_act_bwd_units" in n or "units_" in n: return "tbg unit-tensor producers"
+    if "conv_fprop" in n or "conv_tmerge" in n: return "tbg conv_fprop (NCHW operands)"
     if "conv_wgrad" in n: return "tbg conv_wgrad(+reduce)"
     if "upfirdn" in n: return "tbg upfirdn2d"
     if "bias_act" in n: return "tbg bias_act"
@@ -12,7 +16,7 @@ def family(n):
     if "slab_epilogue" in n: return "tbg split-K epilogue"
     if "lstm_step" in n or "attn_ctx" in n: return "tbg OCR recurrent (lstm_step / attn_ctx)"
     if "dense_" in n or "smalls" in n or "mbstd" in n: return "tbg small-tensor kernels (dense / tails / mbstd)"
-    if "weight_pack" in n or "weight_transpose" in n or "demod" in n or "wsq" in n or "adam" in n or "ema_" in n: return "tbg misc (pack/demod/adam/ema)"
+    if "weight_pack" in n or "weight_transpose" in n or "demod" in n or "wsq" in n or "adam" in n or "ema_" in n or "axpby" in n: return "tbg misc (pack/demod/adam/ema)"
     if n.startswith("Cijk") or "gemm" in n.lower(): return "rocBLAS/hipBLASLt GEMM"
     if "LSTM" in n or "miopen" in n.lower() or "MIOpen" in n or "Im2d" in n or "Col2Im" in n or "batched_transpose" in n or "SubTensor" in n or "naive_conv" in n or "ck::" in n: return "MIOpen (LSTM etc.)"
     if "FillFunctor" in n: return "torch fill"
