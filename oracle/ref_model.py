@@ -467,6 +467,8 @@ def training_step(state: dict, cfg, real_images, ocr_images, input_words, ocr_la
     ocr_loss_w = ocr_loss_weight * ocr_loss
 
     grads_g = torch.autograd.grad(reg_g_loss, [G[n] for n in g_names], retain_graph=True, allow_unused=True)
+    # (test aid: the weighted OCR loss's image gradient on its own, so that a lower-precision generator can be checked given it)
+    dfake_ocr = torch.autograd.grad(ocr_loss_w, fake, retain_graph=True)[0] if return_grads else None
     grads_o = torch.autograd.grad(ocr_loss_w, [G[n] for n in o_names], retain_graph=True, allow_unused=True)
     grads_d = torch.autograd.grad(reg_d_loss, [D[n] for n in d_names], allow_unused=True)
 
@@ -484,7 +486,7 @@ def training_step(state: dict, cfg, real_images, ocr_images, input_words, ocr_la
               (ocr_loss_w / ocr_loss_weight).detach())
     if return_grads:
         return losses, dict(g=dict(zip(g_names, grads_g)), ocr=dict(zip(o_names, grads_o)),
-                            d=dict(zip(d_names, grads_d)), fake=fake.detach())
+                            d=dict(zip(d_names, grads_d)), fake=fake.detach(), dfake_ocr=dfake_ocr.detach())
     return losses
 
 

@@ -159,14 +159,12 @@ def _step_vs_oracle(dev, arith, B, reg, tol_override=None):
     cat = lambda names, d: torch.cat([d[n].reshape(-1) for n in names])
     catv = lambda views: torch.cat([v.reshape(-1) for v in views])  # (the flat buffers carry alignment padding)
     if tol["ocr"] is None:
-        # bf16: the OCR-weighted set cannot be compared element-wise.  The recogniser's image gradient is a chaotic function
-        # of the image for this random-weight stand-in (exact-fp32 kernel noise of 1e-7 already becomes 1.2e-3 on this set),
-        # and the bf16 generator's images differ from the oracle's by ~1e-2: measured relative L2 0.9-1.1 with the OCR
-        # network itself at fp32 grade.  What is asserted: the loss (above), finiteness and the set's magnitude.
-        a, e = catv(ts.o_views), cat(onames, ref_grads["ocr"])
-        assert torch.isfinite(a).all()
-        ratio = float(a.double().norm().cpu() / e.double().norm())
-        assert 0.5 < ratio < 2.0, (arith, "ocr set norm ratio", ratio)
+        # bf16: in the COUPLED step the OCR-weighted set cannot be compared element-wise -- the recogniser's image gradient is a
+        # chaotic function of the image for this random-weight stand-in (exact-fp32 kernel noise of 1e-7 already becomes 1.2e-3
+        # on this set) and the bf16 generator's images differ from the oracle's by ~1e-2.  The set is therefore checked
+        # DECOUPLED, element-wise, in test_bf16_ocr_gradient_set_decoupled (recogniser on the oracle's images; generator chain
+        # given the oracle's d(loss)/d(image)); here: the loss (above) and finiteness.
+        assert torch.isfinite(catv(ts.o_views)).all()
         onames = []
     worst = max([(l2_err(v, ref_grads["ocr"][n]), n) for n, v in zip(onames, ts.o_views) if v.numel() > 1] or [(0.0, "-")])
     assert worst[0] < (tol["ocr"] or 1.0), (arith, "ocr", worst)
@@ -219,6 +217,46 @@ def test_training_step_full_width_matches_oracle_bf16(dev, reg):
     losses, every gradient tensor, the three flat gradient sets, pl_mean -- at the bf16 mode-accuracy bars (_TOL_BF16).
     Round 2 compared this mode with the product's own fp32 path only."""
     _step_vs_oracle(dev, "bf16", 4, reg)
+
+
+def test_bf16_ocr_gradient_set_decoupled(dev):
+    """The gradient set ocr_optimizer applies to synthesis + word_encoder (reference training_step.py:201-206, 375-402) in bf16
+    mode, checked ELEMENT-WISE in two decoupled halves (the coupled comparison is meaningless: see _step_vs_oracle):
+      (a) the frozen recogniser + softmax-CE (fp32 grade in every mode) on the ORACLE's fake images: d(w * ocr_loss)/d(fake)
+          against the oracle's, at the fp32 per-tensor bar of that set;
+      (b) the bf16 generator chain GIVEN the oracle's d(w * ocr_loss)/d(fake): every tensor of the set and the flat buffer
+          against the oracle's OCR set at the bf16 bars (per tensor _TOL_BF16["g"], flat _TOL_BF16["flat_o"])."""
+    from textboxgan_amd import ops
+    from textboxgan_amd.training_step import build_trainer_state
+    cfg, batch, rand, init, st, ref_losses, ref_grads = _oracle_step(4, (False, False))
+    prod = build_trainer_state(cfg, dev, seed=0, compute_dtype="bf16")
+    prod["generator"].load_state_dict({k: v.clone() for k, v in init["G"].items()})
+    ts, G = prod["training_step"], prod["generator"]
+    b = {k: v.to(dev) for k, v in batch.items()}
+    w = 1e-4
+    # (a) the step's own OCR branch (TrainingStep._get_ocr_loss under the arithmetic the bf16 step gives it)
+    fake_ref = ref_grads["fake"].to(dev).requires_grad_(True)
+    with ops.STATE_LOCK, ops.filter_cache(), ops.compute_dtype("f32x3"):
+        loss = ts._get_ocr_loss(fake_ref, b["ocr_labels"], b["ocr_images"])
+        (dfake,) = torch.autograd.grad(w * loss, fake_ref)
+    assert abs(float(loss) - float(ref_losses[2])) <= _TOL_F32["loss"] * max(1.0, abs(float(ref_losses[2])))
+    e_a = l2_err(dfake, ref_grads["dfake_ocr"])
+    assert e_a < _TOL_F32["ocr"], ("d(ocr loss)/d(fake) on the oracle's images", e_a)
+    # (b) the generator's ocr-pass in bf16 mode from the oracle's image gradient
+    r = _todev(rand, dev)
+    with ops.STATE_LOCK, ops.filter_cache(), ops.compute_dtype("bf16"):
+        fake = G((b["input_words"], r["z"]), training=True, rand=r, mask_words=b["input_words"])
+        grads = torch.autograd.grad(fake, ts.o_params, grad_outputs=ref_grads["dfake_ocr"].to(dev), allow_unused=True)
+    torch.cuda.synchronize()
+    onames = [n for n in G._flat.names if n.startswith(("synthesis.", "word_encoder."))]
+    assert len(onames) == len(grads)
+    per = sorted(((l2_err(g, ref_grads["ocr"][n]), n) for n, g in zip(onames, grads) if g.numel() > 1), reverse=True)
+    assert per[0][0] < _TOL_BF16["g"], ("o-set per tensor", per[:3])
+    a = torch.cat([g.reshape(-1) for g in grads]).double().cpu()
+    e = torch.cat([ref_grads["ocr"][n].reshape(-1) for n in onames]).double()
+    flat = float((a - e).norm() / e.norm())
+    print(f"bf16 o-set decoupled: dfake {e_a:.3e}; flat {flat:.3e}; worst tensors {per[:3]}")
+    assert flat < _TOL_BF16["flat_o"], ("o-set flat", flat)
 
 
 @pytest.mark.parametrize("arith", ["f32x3", "f32"])
