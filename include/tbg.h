@@ -78,6 +78,15 @@ typedef struct tbg_epilogue {
   float res_scale;
   int act;
   int res_first;
+  /* UNIT SINK (round 5; see "UNIT TENSORS" below): the launch ALSO writes its result as the unit tensor the next
+   * convolution consumes -- units_out = units(out * units_scale[b*M + m]) over the launch's [B, M, Hout, Wout] output, ring of
+   * zero units included (every unit of the tensor is written by the launch; the bits are those of tbg_units_pack_f32(out,
+   * units_scale)).  Served by tbg_conv2d_{f32,bf16,x3} (ksplit == 1), tbg_conv2d_units, tbg_conv2d_units_s2 and
+   * tbg_upfirdn2d_sep_f32 (up = down = 1); M % 8 == 0.  With a sink the fp32 output pointer of those entries may be NULL:
+   * the activation then exists as a unit tensor only.  Other entries return TBG_EINVAL when units_out is set. */
+  void *units_out;            /* bf16 U[units_planes][B][M/8][Hout+2][Wout+2][8], 16-byte aligned, or NULL */
+  const float *units_scale;   /* [B*M] (the NEXT layer's style modulation, modulated_conv2d.py:94-96) or NULL = 1 */
+  int units_planes;           /* 1 (bf16: RNE) | 3 (f32x3: hi | mid | lo) */
 } tbg_epilogue;
 
 /* ------------------------------------------------------------------------------------------
@@ -435,6 +444,11 @@ int tbg_bias_act_bwd_chunks(int HW);
  * ksplit), and the small-plane form of tbg_bias_act_fwd_f32 (nslab = 1): one flat pass. */
 int tbg_slab_epilogue_f32(const float *x, float *y, int B, int M, int HW, int nslab,
                           const tbg_epilogue *epi, void *stream);
+/* The same with a UNIT SINK (epi->units_out required; planes [H, W], M % 8 == 0): y (may be NULL) = epilogue(sum of slabs) as
+ * above AND units_out = units(y * units_scale), ring included -- the second half of a split-K convolution whose result the next
+ * convolution consumes as a unit tensor.  Same sums in the same (slab) order as tbg_slab_epilogue_f32. */
+int tbg_slab_epilogue_units_f32(const float *x, float *y, int B, int M, int H, int W, int nslab,
+                                const tbg_epilogue *epi, void *stream);
 
 int tbg_bias_act_bwd_f32(const float *dout, const float *out_act, float *dx, float *dpre_out,
                          float *part_db, float *part_dn, float *part_dyy, int B, int M, int HW,

@@ -56,9 +56,31 @@ def test_header_symbols_are_exported_by_the_library():
     assert lib.tbg_bias_act_bwd_chunks(0) == 0
 
 
-def test_ctypes_struct_layout_matches_header():
+def test_ctypes_struct_layout_matches_header(tmp_path):
+    """sizes and EVERY field offset of the ctypes mirrors against what a C compiler makes of include/tbg.h (gcc, host only)"""
+    import subprocess
     from textboxgan_amd import native
-    assert ctypes.sizeof(native.Epilogue) == 8 * 8 + 5 * 4 + 2 * 4 + 4  # 8 pointers, 5 floats, 2 ints, tail padding
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"tbg_epilogue": native.Epilogue, "tbg_conv_desc": native.ConvDesc, "tbg_wgrad_desc": native.WgradDesc,
+               "tbg_pack_item": native.PackItem, "tbg_dense_item": native.DenseItem}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tbg.h"', 'int main(void) {']
+    for cname, st in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        c, f, v = ln.split()
+        got[(c, f)] = int(v)
+    for cname, st in structs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert got[(cname, fname)] == getattr(st, fname).offset, (cname, fname)
     assert ctypes.sizeof(native.ConvDesc) == 17 * 4 and ctypes.sizeof(native.WgradDesc) == 17 * 4
 
 

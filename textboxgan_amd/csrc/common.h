@@ -18,6 +18,10 @@ struct EpiK {
   float *dot_out;
   float alpha, bias_mul, slope, gain, res_scale;
   int act, res_first;
+  void *units_out;            // unit sink (tbg.h): units(out * units_scale) beside / instead of the fp32 output
+  const float *units_scale;
+  int units_planes;
+  long long units_plane;      // bytes between two planes of units_out (set by the entry: epi_sink_geometry)
 };
 
 static inline EpiK make_epi(const tbg_epilogue *e) {
@@ -26,9 +30,11 @@ static inline EpiK make_epi(const tbg_epilogue *e) {
     k.out_scale = e->out_scale; k.bias = e->bias; k.noise = e->noise; k.strength = e->strength;
     k.residual = e->residual; k.dot_aux = e->dot_aux; k.gate = e->gate; k.dot_out = e->dot_out; k.alpha = e->alpha; k.bias_mul = e->bias_mul; k.slope = e->slope;
     k.gain = e->gain; k.res_scale = e->res_scale; k.act = e->act; k.res_first = e->res_first;
+    k.units_out = e->units_out; k.units_scale = e->units_scale; k.units_planes = e->units_planes; k.units_plane = 0;
   } else {
     k.out_scale = k.bias = k.noise = k.strength = k.residual = k.dot_aux = k.gate = nullptr; k.dot_out = nullptr;
     k.alpha = 1.f; k.bias_mul = 1.f; k.slope = 1.f; k.gain = 1.f; k.res_scale = 1.f; k.act = TBG_ACT_LINEAR; k.res_first = 0;
+    k.units_out = nullptr; k.units_scale = nullptr; k.units_planes = 0; k.units_plane = 0;
   }
   return k;
 }
@@ -39,7 +45,27 @@ static inline bool epi_valid(const tbg_epilogue *e) {
   if ((e->dot_aux != nullptr) != (e->dot_out != nullptr)) return false;
   if (e->gate && e->dot_aux) return false;
   if (e->act != TBG_ACT_LINEAR && e->act != TBG_ACT_LRELU) return false;
+  if (e->units_out) {
+    if (e->units_planes != 1 && e->units_planes != 3) return false;
+    if ((reinterpret_cast<uintptr_t>(e->units_out) & 15) != 0) return false;
+  } else if (e->units_scale) {
+    return false;
+  }
   return true;
+}
+
+// entries that do not serve a unit sink reject it (tbg.h)
+static inline bool epi_has_sink(const tbg_epilogue *e) { return e && e->units_out; }
+
+// an entry that serves the sink: fix the plane pitch of the [B, M, Hout, Wout] unit tensor (TBG_EINVAL: M % 8 != 0, TBG_ERANGE:
+// more than 2^31 elements)
+static inline int epi_sink_geometry(EpiK &k, int B, int M, int Hout, int Wout) {
+  if (!k.units_out) return TBG_OK;
+  if ((M & 7) != 0) return TBG_EINVAL;
+  const long long units = (long long)B * (M >> 3) * (Hout + 2) * (Wout + 2);
+  if (units * 8 > 2147483647LL) return TBG_ERANGE;
+  k.units_plane = units * 16;
+  return TBG_OK;
 }
 
 // v: accumulator already multiplied by alpha*out_scale by the caller when convenient

@@ -625,7 +625,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
   }
   constexpr int RG = OCC == 4 ? 2 : 4;  // rows per load batch (register budget: the epilogue must not raise the kernel's allocation)
   conv_epilogue<WTM, WTN, RG>(acc[0], p.e, p.y, p.ksplit > 1 ? p.y + (size_t)ks * p.slab : nullptr, p.M, HWout,
-                              m0 + wm * WTM * 32, lane, e_pix, e_b, bg < p.B, bg, p.dot_slots, (tu * ci.tilesV + tv) * WGN + wn);
+                              m0 + wm * WTM * 32, lane, e_pix, e_b, bg < p.B, bg, p.dot_slots, (tu * ci.tilesV + tv) * WGN + wn,
+                              p.Hout, p.Wout);
 }
 
 template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false, bool TM = false, bool X3 = false>
@@ -681,13 +682,14 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
                         const tbg_epilogue *epi, void *stream, const NameOut *name, int mode, int variant, bool force64) {
   const bool bf = mode == 1, x3 = mode == 2;
   if (!d || !epi_valid(epi)) return TBG_EINVAL;
-  if (!name && (!x || !w || !y)) return TBG_EINVAL;
+  if (!name && (!x || !w || (!y && !epi_has_sink(epi)))) return TBG_EINVAL;  // (a unit sink may be the only output)
   if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1 || d->Hout < 1 || d->Wout < 1) return TBG_EINVAL;
   if (d->KH < 1 || d->KW < 1 || d->KH * d->KW > MAXTAPS) return TBG_EUNSUPPORTED;
   if (d->sy < 1 || d->sy > 2 || d->sx < 1 || d->sx > 2) return TBG_EUNSUPPORTED;
   if (d->ldw < d->M || (reinterpret_cast<uintptr_t>(w) & 15) != 0) return TBG_EINVAL;
   if (d->ksplit < 1) return TBG_EINVAL;
-  if (d->ksplit > 1 && epi && (epi->out_scale || epi->bias || epi->noise || epi->residual || epi->dot_aux || epi->gate || epi->act != TBG_ACT_LINEAR))
+  if (d->ksplit > 1 && epi && (epi->out_scale || epi->bias || epi->noise || epi->residual || epi->dot_aux || epi->gate || epi->act != TBG_ACT_LINEAR ||
+                               epi->units_out))
     return TBG_EINVAL;
   if ((double)d->B * d->C * d->Hin * d->Win > 2147483647.0 || (double)d->B * d->M * d->Hout * d->Wout > 2147483647.0)
     return TBG_ERANGE;
@@ -704,11 +706,12 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
   p.B = d->B; p.C = d->C; p.M = d->M; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
   p.ldw = d->ldw;
   p.e = make_epi(epi);
+  if (const int rcs = epi_sink_geometry(p.e, d->B, d->M, d->Hout, d->Wout)) return rcs;
   const int T = d->KH * d->KW;
   p.wplane = T * ((d->C + 7) / 8) * d->ldw * 4;
   // merged form of the stride-2 transposed 3x3 convolution (see the TM template parameter): store-only epilogues
   const bool plain_epi = !epi || (!epi->out_scale && !epi->bias && !epi->noise && !epi->residual && !epi->dot_aux && !epi->gate &&
-                                  epi->act == TBG_ACT_LINEAR && epi->gain == 1.f);
+                                  epi->act == TBG_ACT_LINEAR && epi->gain == 1.f && !epi->units_out);
   // Measured (tools/bench_transposed.py, profiles/r02_transposed_forms.txt): in bf16 the merged form wins on the large maps
   // (216 vs 158 TFLOP/s on 32x128 128->128, 232 vs 124 on the 128->64 data gradient: the per-class form re-stages the halo
   // four times and bf16 launches are staging bound) and loses below ~16k input pixels; in fp32 (MFMA bound) the per-class

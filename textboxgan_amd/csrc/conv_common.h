@@ -75,10 +75,37 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_base) {
 // large launch -- more than the output write itself (a 134 MB fill takes 21 us).
 // Fused dot (e.dot_aux): one image per tile; the partial of this (tile, wave column) goes to its own slot
 // dot_out[(dot_b * M + m) * dot_slots + dot_slot] -- no atomics, the caller sums the slots in a fixed order.
+// Unit sink (e.units_out, tbg.h): the same values, times units_scale[b, m], ALSO leave as the unit tensor the next convolution
+// DMAs its tiles from -- U[plane][b][m/8][1 + Y][1 + X][m % 8] bf16.  The 32x32 MFMA accumulator layout gives a lane 4 CONSECUTIVE
+// channels of one pixel per row group (rows r0 .. r0+3 -> channels m0 + 8 g + 4 (lane >> 5) + 0..3): that is one 8-byte half of a
+// 16-byte unit per plane, the other half-wave writes the other half, 32 lanes cover 32 consecutive pixels -> one 512-byte run per
+// plane and half.  The ring of zero units belongs to the tensor's contract (the consumers read padding, they never clamp): the
+// lane that owns a border pixel also zeroes the ring positions next to it (its own channel half), so every unit of the tensor is
+// written by the launch whatever its tiling.  y may be NULL with a sink (no fp32 output at all).
+template <int NPL>
+__device__ __forceinline__ void sink_store(char *ub, long long plane_bytes, long long off, const float (&v)[4]) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  if constexpr (NPL == 3) {
+    split3_pair(v[0], v[1], h0, m0, l0);
+    split3_pair(v[2], v[3], h1, m1, l1);
+    *reinterpret_cast<u32x2v *>(ub + off) = u32x2v{h0, h1};
+    *reinterpret_cast<u32x2v *>(ub + plane_bytes + off) = u32x2v{m0, m1};
+    *reinterpret_cast<u32x2v *>(ub + 2 * plane_bytes + off) = u32x2v{l0, l1};
+  } else {
+    const f32x2v a = {v[0], v[1]}, b = {v[2], v[3]};
+    h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2p));
+    h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2p));
+    *reinterpret_cast<u32x2v *>(ub + off) = u32x2v{h0, h1};
+  }
+}
+__device__ __forceinline__ void sink_zero(char *ub, long long plane_bytes, int planes, long long off) {
+  for (int pl = 0; pl < planes; ++pl) *reinterpret_cast<u32x2v *>(ub + pl * plane_bytes + off) = u32x2v{0u, 0u};
+}
+
 template <int WTM, int WTN, int RG>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], const EpiK &e, float *y, float *slab, int M_, int HWout,
                                               int mrow0, int lane, const int (&e_pix)[WTN], const int (&e_b)[WTN], bool dot_ok,
-                                              int dot_b, int dot_slots, int dot_slot) {
+                                              int dot_b, int dot_slots, int dot_slot, int Hout = 0, int Wout = 0) {
   const float *const e_os = e.out_scale, *const e_bias = e.bias, *const e_res = e.residual, *const e_aux = e.dot_aux;
   const float *const e_gate = e.gate;
   float *const e_dot = e.dot_out;
@@ -87,7 +114,9 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
   const float str = e.noise ? e.strength[0] : 0.f;
   const bool split = slab != nullptr;
   const bool do_dot = e_aux != nullptr && !split;
-  const bool plain = !e_os && !e_bias && !e.noise && !e_res && !e_aux && !e_gate && !e_lrelu && e_gain == 1.f;
+  char *const e_ub = static_cast<char *>(e.units_out);
+  const bool sink = e_ub != nullptr && !split;
+  const bool plain = !e_os && !e_bias && !e.noise && !e_res && !e_aux && !e_gate && !e_lrelu && e_gain == 1.f && !sink;
   const int M = M_;
   float *const ybase = split ? slab : y;
   float e_nz[WTN];
@@ -104,6 +133,24 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
           if (m < M && e_pix[j] >= 0) ybase[(e_b[j] * M + m) * HWout + e_pix[j]] = acc[i][j][r16] * e_alpha;
       }
     return;
+  }
+  // unit-sink geometry of this lane's pixels: byte offset of pixel j's unit inside plane 0 (channel unit 0), ring flags
+  static_assert(RG == 4 || RG == 2, "a row group is one or half of a 4-channel run");
+  const float *const e_us = e.units_scale;
+  const int s_Hp = Hout + 2, s_Wp = Wout + 2;
+  const long long s_cu = 16LL * s_Hp * s_Wp;     // bytes between two channel units of one sample
+  const long long s_plane = e.units_plane;       // bytes between two planes (hi | mid | lo)
+  const int s_np = e.units_planes;
+  long long s_off[WTN];
+  int s_ring[WTN];  // bit 0: left edge, 1: right edge, 2: top edge, 3: bottom edge (of a live pixel)
+  if (sink) {
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int pix = max(e_pix[j], 0);
+      const int Y = pix / Wout, X = pix - Y * Wout;
+      s_off[j] = (long long)e_b[j] * (M_ >> 3) * s_cu + 16LL * ((Y + 1) * s_Wp + X + 1);
+      s_ring[j] = e_pix[j] < 0 ? 0 : ((X == 0 ? 1 : 0) | (X == Wout - 1 ? 2 : 0) | (Y == 0 ? 4 : 0) | (Y == Hout - 1 ? 8 : 0));
+    }
   }
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
@@ -148,6 +195,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
 #pragma unroll
           for (int j = 0; j < WTN; ++j) axv[q][j] = e_gate[max(idx[q][j], 0)];
       }
+      float uval[RG][WTN];
 #pragma unroll
       for (int q = 0; q < RG; ++q) {
         const int m = mrow[q];
@@ -162,7 +210,8 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
           val = (e_lrelu ? (val > 0.f ? val : val * e_slope) : val) * e_gain;
           if (e_res && !e_rfirst) val = (val + rsv[q][j]) * e_rscale;
           if (e_gate) val = axv[q][j] > 0.f ? val : 0.f;
-          if (okq) y[idx[q][j]] = val;
+          if (okq && y) y[idx[q][j]] = val;
+          if (sink) uval[q][j] = val * (e_us ? e_us[okq ? e_b[j] * M + m : 0] : 1.f);
         }
         if (do_dot) {  // one image per tile (checked on the host): reduce the 32 pixel lanes of each half-wave and store the
           // partial of this (tile, wave column) in its own slot -- no atomics, the caller sums the slots in a fixed order
@@ -170,6 +219,40 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
           for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
           if ((lane & 31) == 0 && m < M && dot_ok)
             e_dot[((size_t)dot_b * M + m) * dot_slots + dot_slot] = dsum;
+        }
+      }
+      if (sink && mrow[0] < M) {  // (M % 8 == 0: a 4-channel run is inside M or outside it as a whole)
+        // this row group's channels mrow[0] .. mrow[0] + RG - 1 sit at byte (mrow[0] & 7) * 2 of unit mrow[0] >> 3
+        const long long cbase = (long long)(mrow[0] >> 3) * s_cu + (mrow[0] & 7) * 2;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+          if (e_pix[j] < 0) continue;
+          const long long off = s_off[j] + cbase;
+          if constexpr (RG == 4) {
+            const float v4[4] = {uval[0][j], uval[1][j], uval[2][j], uval[3][j]};
+            if (s_np == 3) sink_store<3>(e_ub, s_plane, off, v4);
+            else sink_store<1>(e_ub, s_plane, off, v4);
+          } else {
+            for (int pl = 0; pl < s_np; ++pl) {  // RG == 2: a dword (two channels) per plane
+              float r0v = uval[0][j], r1v = uval[1][j];
+              unsigned h, mm, ll;
+              if (s_np == 3) split3_pair(r0v, r1v, h, mm, ll);
+              else { const f32x2v a2 = {r0v, r1v}; h = __builtin_bit_cast(unsigned, __builtin_convertvector(a2, bf16x2p)); mm = ll = 0u; }
+              *reinterpret_cast<unsigned *>(e_ub + pl * s_plane + off) = pl == 0 ? h : pl == 1 ? mm : ll;
+            }
+          }
+          if (s_ring[j]) {  // border pixel: zero this channel run at the ring positions next to it (corners with the column lanes)
+            const int rg = s_ring[j];
+            const long long rowb = 16LL * s_Wp;
+            auto z = [&](long long o) {
+              if constexpr (RG == 4) sink_zero(e_ub, s_plane, s_np, o);
+              else for (int pl = 0; pl < s_np; ++pl) *reinterpret_cast<unsigned *>(e_ub + pl * s_plane + o) = 0u;
+            };
+            if (rg & 1) z(off - 16);
+            if (rg & 2) z(off + 16);
+            if (rg & 4) { z(off - rowb); if (rg & 1) z(off - rowb - 16); if (rg & 2) z(off - rowb + 16); }
+            if (rg & 8) { z(off + rowb); if (rg & 1) z(off + rowb - 16); if (rg & 2) z(off + rowb + 16); }
+          }
         }
       }
     }

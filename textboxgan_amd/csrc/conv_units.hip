@@ -94,6 +94,84 @@ extern "C" int tbg_units_pack_f32(const float *x, const float *scale, void *U, i
   return TBG_OK;
 }
 
+// ---- split-K second half with a unit sink: y = epilogue(sum_s x[s]) (tbg_slab_epilogue_f32) whose result ALSO (or only) leaves
+// as units(y * units_scale).  Split-K layers are the small maps, so one lane per padded position of a (b, channel unit) plane
+// (units_pack_kernel's mapping: ring and channel tail written as zeros by the lane that owns them): 8 channels x nslab loads per
+// lane, slabs summed in slab order (the order of slab_epilogue_kernel: same bits), one 16-byte store per plane.
+struct SlabUnitsP {
+  const float *x;
+  float *y;
+  int B, M, H, W, nslab;
+  long long slab, plane;
+  EpiK e;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void slab_epilogue_units_kernel(const SlabUnitsP p) {
+  const int Wp = p.W + 2, Hp = p.H + 2, C8 = p.M >> 3, HW = p.H * p.W;
+  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= p.plane) return;
+  const int xp = (int)(n % Wp);
+  long long t = n / Wp;
+  const int yp = (int)(t % Hp);
+  t /= Hp;
+  const int cu = (int)(t % C8), b = (int)(t / C8);
+  const bool inside = xp >= 1 && xp <= p.W && yp >= 1 && yp <= p.H;
+  const int pix = inside ? (yp - 1) * p.W + (xp - 1) : 0;
+  float v[8];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) v[cc] = 0.f;
+  if (inside) {
+    const size_t g0 = ((size_t)b * p.M + cu * 8) * HW + pix;
+    for (int s = 0; s < p.nslab; ++s) {
+      float tv[8];
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) tv[cc] = p.x[(size_t)s * p.slab + g0 + (size_t)cc * HW];
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) v[cc] += tv[cc];
+    }
+    const float str = p.e.noise ? p.e.strength[0] : 0.f;
+    const float nz = p.e.noise ? p.e.noise[(size_t)b * HW + pix] * str : 0.f;
+    const bool rf = p.e.residual && p.e.res_first;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int m = cu * 8 + cc, plane = b * p.M + m;
+      const size_t gi = g0 + (size_t)cc * HW;
+      const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[plane] : 1.f);
+      float o = v[cc] * sc + (p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f);
+      if (p.e.noise) o += nz;
+      if (rf) o += p.e.residual[gi];
+      o = epi_act(p.e, o);
+      if (p.e.residual && !rf) o = (o + p.e.residual[gi]) * p.e.res_scale;
+      if (p.e.gate) o = p.e.gate[gi] > 0.f ? o : 0.f;
+      if (p.y) p.y[gi] = o;
+      v[cc] = o * (p.e.units_scale ? p.e.units_scale[plane] : 1.f);
+    }
+  }
+  bf16x8 *U = static_cast<bf16x8 *>(p.e.units_out);
+  if constexpr (NP == 3) {
+    bf16x8 h, m, l;
+    split3_bf16x8(v, h, m, l);
+    U[n] = h; U[p.plane + n] = m; U[2 * p.plane + n] = l;
+  } else {
+    U[n] = pack_bf16x8(v);
+  }
+}
+
+extern "C" int tbg_slab_epilogue_units_f32(const float *x, float *y, int B, int M, int H, int W, int nslab, const tbg_epilogue *epi,
+                                           void *stream) {
+  if (!x || B < 1 || M < 1 || H < 1 || W < 1 || nslab < 1 || !epi || !epi_valid(epi) || epi->dot_aux || !epi->units_out) return TBG_EINVAL;
+  if ((double)B * M * H * W > 2147483647.0) return TBG_ERANGE;
+  SlabUnitsP p{x, y, B, M, H, W, nslab, (long long)B * M * H * W, 0, make_epi(epi)};
+  if (const int rc = epi_sink_geometry(p.e, B, M, H, W)) return rc;
+  p.plane = p.e.units_plane >> 4;
+  const dim3 grid((unsigned)((p.plane + 255) / 256));
+  if (p.e.units_planes == 3) hipLaunchKernelGGL(slab_epilogue_units_kernel<3>, grid, dim3(256), 0, tbg_stream(stream), p);
+  else hipLaunchKernelGGL(slab_epilogue_units_kernel<1>, grid, dim3(256), 0, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
 // ---- fused producer: the backward of bias + noise + LeakyReLU (tbg_bias_act_bwd_f32) writing its result as a UNIT TENSOR.
 //   dpre = dout * (residual_fused ? res_scale : 1) * gain * (out_act > 0 ? 1 : slope)
 //   U    = units(dpre * alpha * out_scale[b,m])        (what the data-gradient and filter-gradient launches consume)
@@ -194,7 +272,7 @@ extern "C" int tbg_bias_act_bwd_units(const float *dout, const float *out_act, v
     return TBG_EINVAL;
   if ((reinterpret_cast<uintptr_t>(U) & 15) != 0) return TBG_EINVAL;
   if (part_dn && !epi->noise) return TBG_EINVAL;
-  if (epi->gate) return TBG_EINVAL;  // a forward-only epilogue term
+  if (epi->gate || epi->units_out) return TBG_EINVAL;  // forward-only epilogue terms
   const long long plane = units_per_plane(B, M, H, W);
   if (plane * 8 > 2147483647LL || (long long)B * M * H * W > 2147483647LL) return TBG_ERANGE;
   BabUnitsP p{dout, out_act, reinterpret_cast<bf16x8 *>(U), dpre_out, part_db, part_dn, part_dyy, B, M, H, W,
@@ -614,7 +692,7 @@ __global__ __launch_bounds__(512, 2) void conv_units_fprop_kernel(const ConvUnit
     return;
   }
   conv_epilogue<WTM, WTN, 4>(acc, p.e, p.y, nullptr, p.M, p.H * p.W, m0 + wm * WTM * 32, lane, e_pix, e_b, true, b, p.dot_slots,
-                             (tu * p.tilesV + tv) * WGN + wn);
+                             (tu * p.tilesV + tv) * WGN + wn, p.H, p.W);
 }
 
 static bool conv_units_ok(const tbg_conv_desc *d, int planes) {
@@ -669,7 +747,7 @@ static int launch_conv_units(ConvUnitsP &p, hipStream_t st) {
 
 extern "C" int tbg_conv2d_units(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
                                 const tbg_epilogue *epi, void *stream) {
-  if (!d || !XU || !w || !y || (planes != 1 && planes != 3) || !epi_valid(epi)) return TBG_EINVAL;
+  if (!d || !XU || !w || (!y && !epi_has_sink(epi)) || (planes != 1 && planes != 3) || !epi_valid(epi)) return TBG_EINVAL;
   if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1) return TBG_EINVAL;
   if (((reinterpret_cast<uintptr_t>(XU) | reinterpret_cast<uintptr_t>(w)) & 15) != 0) return TBG_EINVAL;
   if (!conv_units_ok(d, planes)) return TBG_EUNSUPPORTED;
@@ -685,6 +763,7 @@ extern "C" int tbg_conv2d_units(const tbg_conv_desc *d, const void *XU, int plan
   p.dot_slots = p.tilesU * p.tilesV * 4;
   for (int t = 0; t < 9; ++t) p.wtap[t] = d->flip ? 8 - t : t;
   p.e = make_epi(epi);
+  if (const int rcs = epi_sink_geometry(p.e, d->B, d->M, d->Hin, d->Win)) return rcs;
   hipStream_t st = tbg_stream(stream);
   if (units_wtm(d) == 2) return planes == 3 ? launch_conv_units<3, 2>(p, st) : launch_conv_units<1, 2>(p, st);
   return planes == 3 ? launch_conv_units<3, 1>(p, st) : launch_conv_units<1, 1>(p, st);

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void conv_units_s2_fprop_kernel(const ConvS
     e_b[j] = b;
   }
   conv_epilogue<WTM, WTN, 4>(acc, p.e, p.y, nullptr, p.M, p.Ho * p.Wo, m0 + wm * WTM * 32, lane, e_pix, e_b, true, b, p.dot_slots,
-                             (tu * p.tilesV + tv) * 4 + wn);
+                             (tu * p.tilesV + tv) * 4 + wn, p.Ho, p.Wo);
 }
 
 static bool conv_units_s2_ok(const tbg_conv_desc *d, int planes) {
@@ -463,7 +463,7 @@ static int launch_conv_units_s2(ConvS2P &p, hipStream_t st) {
 
 extern "C" int tbg_conv2d_units_s2(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
                                    const tbg_epilogue *epi, void *stream) {
-  if (!d || !XU || !w || !y || (planes != 1 && planes != 3) || !epi_valid(epi)) return TBG_EINVAL;
+  if (!d || !XU || !w || (!y && !epi_has_sink(epi)) || (planes != 1 && planes != 3) || !epi_valid(epi)) return TBG_EINVAL;
   if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1) return TBG_EINVAL;
   if (((reinterpret_cast<uintptr_t>(XU) | reinterpret_cast<uintptr_t>(w)) & 15) != 0) return TBG_EINVAL;
   if (!conv_units_s2_ok(d, planes)) return TBG_EUNSUPPORTED;
@@ -479,6 +479,7 @@ extern "C" int tbg_conv2d_units_s2(const tbg_conv_desc *d, const void *XU, int p
   p.tilesU = d->Hout / 8; p.tilesV = d->Wout / 32;
   p.dot_slots = p.tilesU * p.tilesV * 4;
   p.e = make_epi(epi);
+  if (const int rcs = epi_sink_geometry(p.e, d->B, d->M, d->Hout, d->Wout)) return rcs;
   hipStream_t st = tbg_stream(stream);
   if (units_s2_wtm(d) == 2) return planes == 3 ? launch_conv_units_s2<3, 2>(p, st) : launch_conv_units_s2<1, 2>(p, st);
   return planes == 3 ? launch_conv_units_s2<3, 1>(p, st) : launch_conv_units_s2<1, 1>(p, st);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const BiasActP p) {
 
 extern "C" int tbg_bias_act_fwd_f32(const float *x, float *y, int B, int M, int HW, const tbg_epilogue *epi,
                                     void *stream) {
-  if (!x || !y || B < 1 || M < 1 || HW < 1 || !epi_valid(epi)) return TBG_EINVAL;
+  if (!x || !y || B < 1 || M < 1 || HW < 1 || !epi_valid(epi) || epi_has_sink(epi)) return TBG_EINVAL;
   if ((double)B * M * HW > 2147483647.0) return TBG_ERANGE;
   if (HW <= 1024 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && !(epi && epi->dot_aux))
     return tbg_slab_epilogue_f32(x, y, B, M, HW, 1, epi, stream);  // small planes: one flat pass
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void slab_epilogue_kernel(const SlabEpiP p) {
 
 extern "C" int tbg_slab_epilogue_f32(const float *x, float *y, int B, int M, int HW, int nslab, const tbg_epilogue *epi,
                                      void *stream) {
-  if (!x || !y || B < 1 || M < 1 || HW < 1 || nslab < 1 || !epi_valid(epi) || (epi && epi->dot_aux)) return TBG_EINVAL;
+  if (!x || !y || B < 1 || M < 1 || HW < 1 || nslab < 1 || !epi_valid(epi) || (epi && epi->dot_aux) || epi_has_sink(epi)) return TBG_EINVAL;
   if ((double)B * M * HW > 2147483647.0) return TBG_ERANGE;
   if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return TBG_EINVAL;
   SlabEpiP p{x, y, B, M, HW, nslab, (long long)B * M * HW, (long long)B * M * HW, make_epi(epi)};
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_small_kernel(const BiasActBw
 extern "C" int tbg_bias_act_bwd_f32(const float *dout, const float *out_act, float *dx, float *dpre_out,
                                     float *part_db, float *part_dn, float *part_dyy, int B, int M, int HW,
                                     const tbg_epilogue *epi, void *stream) {
-  if (!dout || !out_act || B < 1 || M < 1 || HW < 1 || !epi || !epi_valid(epi)) return TBG_EINVAL;
+  if (!dout || !out_act || B < 1 || M < 1 || HW < 1 || !epi || !epi_valid(epi) || epi_has_sink(epi)) return TBG_EINVAL;
   if ((double)B * M * HW > 2147483647.0) return TBG_ERANGE;
   if (part_dn && !epi->noise) return TBG_EINVAL;
   if (epi->gate) return TBG_EINVAL;  // a forward-only epilogue term
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd2_kernel(const BiasActBwd2P p
 
 extern "C" int tbg_bias_act_bwd2_f32(const float *c, const float *out_act, const float *dout, const float *gdd, float *g_dout,
                                      float *part, int B, int M, int HW, const tbg_epilogue *epi, void *stream) {
-  if (!c || !out_act || !g_dout || B < 1 || M < 1 || HW < 1 || !epi || !epi_valid(epi) || (part && !dout)) return TBG_EINVAL;
+  if (!c || !out_act || !g_dout || B < 1 || M < 1 || HW < 1 || !epi || !epi_valid(epi) || epi_has_sink(epi) || (part && !dout)) return TBG_EINVAL;
   if ((double)B * M * HW > 2147483647.0) return TBG_ERANGE;
   if (epi->gate || epi->residual) return TBG_EINVAL;
   BiasActBwd2P p{c, out_act, dout, gdd, g_dout, part, B, M, HW, tbg_bias_act_bwd_chunks(HW), make_epi(epi)};

@@ -25,7 +25,7 @@
 
 #include <hip/hip_fp16.h>
 
-#include "common.h"
+#include "conv_common.h"  // (split3 / bf16 unit helpers of the unit-sink form; includes common.h)
 
 struct UpfirdnP {
   const float *x, *k, *kx, *ky, *in_scale;  // k: 2-D [kH][kW] or NULL; kx/ky: 1-D factors or NULL
@@ -224,6 +224,201 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(const UpfirdnP p) {
   }
 }
 
+// ---- unit-sink form (tbg.h "UNIT SINK"): the model's blur after the up-convolution (upfirdn_2d_v2.py:97-103: FIR, up = down = 1)
+// with the full epilogue, whose result ALSO (or only) leaves as the unit tensor units(out * units_scale) that the next
+// convolution DMAs its tiles from -- the fp32 -> unit pass (tbg_units_pack_f32: read 4 B + write 2 B x planes per element, one
+// launch) disappears.  A unit needs 8 channels of one pixel in one lane while the FIR wants a lane to own a patch of ONE plane
+// (its window rows are 16-byte loads, coalesced along x), so the block (256 lanes = 8 channels x 32 lanes; tile = 8 rows x 64
+// columns of the output) computes per plane exactly as upfirdn2d_tile_kernel<1,1,1,1,0,0,true> does -- same window, same
+// horizontal-then-vertical order, same epilogue expression -- writes the fp32 result (if wanted) straight from registers as
+// 16-byte stores, parks result * units_scale in a 16 KB LDS tile, and after one barrier every lane gathers the 8 channels of two
+// pixels and stores their units; border tiles also write the ring of zero units next to them.
+struct FirUnitsP {
+  const float *x, *kx, *ky, *in_scale;
+  float *y;
+  int B, C, inH, inW, Ht, Wt, kH, kW, padx0, pady0, tilesX, tilesY;
+  EpiK e;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void fir_units_kernel(const FirUnitsP p) {
+  constexpr int TR = 8, TC = 64, PITCH = TC + 1;
+  __shared__ float tile[8][TR][PITCH];
+  const int tid = threadIdx.x;
+  const int C8 = (p.C + 7) >> 3;
+  int bid = blockIdx.x;
+  const int tx = bid % p.tilesX; bid /= p.tilesX;
+  const int ty = bid % p.tilesY; bid /= p.tilesY;
+  const int cu = bid % C8, b = bid / C8;
+  {
+    const int cc = tid >> 5, l = tid & 31;
+    const int c = cu * 8 + cc;
+    const int ly = 4 * (l >> 4), lx = 4 * (l & 15);
+    const int Y0 = ty * TR + ly, X0 = tx * TC + lx;
+    float res[4][4];
+#pragma unroll
+    for (int ny = 0; ny < 4; ++ny)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) res[ny][n] = 0.f;
+    float us = 0.f;
+    if (c < p.C && Y0 < p.Ht && X0 < p.Wt) {
+      float kfx[4], kfy[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        kfx[j] = j < p.kW ? p.kx[p.kW - 1 - j] : 0.f;
+        kfy[j] = j < p.kH ? p.ky[p.kH - 1 - j] : 0.f;
+      }
+      const int iy0 = Y0 - p.pady0, ix0 = X0 - p.padx0;
+      const int plane = b * p.C + c;
+      const long long plane_off = (long long)plane * p.inH * p.inW;
+      const long long n_total = (long long)p.B * p.C * p.inH * p.inW;
+      const float *xin = p.x + plane_off;
+      const int iy_lo = min(max(iy0, 0), p.inH - 1), iy_hi = min(max(iy0 + 6, 0), p.inH - 1);
+      const bool safe = plane_off + (long long)iy_lo * p.inW + ix0 >= 0 && plane_off + (long long)iy_hi * p.inW + ix0 + 8 <= n_total;
+      float w[7][8];
+      if (safe) {
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+          const float *src = xin + (long long)min(max(iy0 + m, 0), p.inH - 1) * p.inW + ix0;
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            const f32x4u t = *reinterpret_cast<const f32x4u *>(src + 4 * v);
+            w[m][4 * v] = t.x; w[m][4 * v + 1] = t.y; w[m][4 * v + 2] = t.z; w[m][4 * v + 3] = t.w;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+          const float *row = xin + (size_t)min(max(iy0 + m, 0), p.inH - 1) * p.inW;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[m][e] = row[min(max(ix0 + e, 0), p.inW - 1)];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 7; ++m) {
+        const bool row_ok = iy0 + m >= 0 && iy0 + m < p.inH;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[m][e] = (row_ok && e < 7 && ix0 + e >= 0 && ix0 + e < p.inW) ? w[m][e] : 0.f;
+      }
+      float h[7][4];
+#pragma unroll
+      for (int m = 0; m < 7; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          float a = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a += w[m][n + t] * kfx[t];
+          h[m][n] = a;
+        }
+      // per-plane terms of the epilogue (upfirdn2d_tile_kernel's expression)
+      const float isc = p.in_scale ? p.in_scale[plane] : 1.f;
+      const float sc = isc * p.e.alpha * (p.e.out_scale ? p.e.out_scale[plane] : 1.f);
+      const float bias = p.e.bias ? p.e.bias[c] * p.e.bias_mul : 0.f;
+      const float str = p.e.noise ? p.e.strength[0] : 0.f;
+      const float *nzp = p.e.noise ? p.e.noise + (size_t)b * p.Ht * p.Wt : nullptr;
+      const bool lrelu = p.e.act == TBG_ACT_LRELU;
+      const float slope = p.e.slope, gain = p.e.gain;
+      us = p.e.units_scale ? p.e.units_scale[plane] : 1.f;
+      const bool full = X0 + 4 <= p.Wt;
+      float *yo = p.y ? p.y + (size_t)plane * p.Ht * p.Wt : nullptr;
+#pragma unroll
+      for (int ny = 0; ny < 4; ++ny) {
+        const int oy = Y0 + ny;
+        if (oy >= p.Ht) break;
+        const size_t off = (size_t)oy * p.Wt + X0;
+        float nz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nzp) {
+          if (full) {
+            const f32x4u t = *reinterpret_cast<const f32x4u *>(nzp + off);
+            nz[0] = t.x; nz[1] = t.y; nz[2] = t.z; nz[3] = t.w;
+          } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+              if (X0 + n < p.Wt) nz[n] = nzp[off + n];
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          float a = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a += h[ny + t][n] * kfy[t];
+          float v = a * sc + nz[n] * str + bias;
+          v = (lrelu ? (v > 0.f ? v : v * slope) : v) * gain;
+          res[ny][n] = X0 + n < p.Wt ? v : 0.f;
+        }
+        if (yo) {
+          if (full) {
+            f32x4u t; t.x = res[ny][0]; t.y = res[ny][1]; t.z = res[ny][2]; t.w = res[ny][3];
+            *reinterpret_cast<f32x4u *>(yo + off) = t;
+          } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+              if (X0 + n < p.Wt) yo[off + n] = res[ny][n];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ny = 0; ny < 4; ++ny)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) tile[cc][ly + ny][lx + n] = res[ny][n] * us;
+  }
+  __syncthreads();
+  const int Hp = p.Ht + 2, Wp = p.Wt + 2;
+  bf16x8 *Ub = static_cast<bf16x8 *>(p.e.units_out) + ((size_t)b * C8 + cu) * Hp * Wp;
+  const size_t plane_units = (size_t)(p.e.units_plane >> 4);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + 256 * q;
+    const int r = idx >> 6, col = idx & 63;
+    const int Y = ty * TR + r, X = tx * TC + col;
+    if (Y >= p.Ht || X >= p.Wt) continue;
+    float v[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) v[cc] = tile[cc][r][col];
+    const size_t u = (size_t)(Y + 1) * Wp + X + 1;
+    if constexpr (NP == 3) {
+      bf16x8 hh, mm, ll;
+      split3_bf16x8(v, hh, mm, ll);
+      Ub[u] = hh; Ub[plane_units + u] = mm; Ub[2 * plane_units + u] = ll;
+    } else {
+      Ub[u] = pack_bf16x8(v);
+    }
+  }
+  // ring positions next to this tile (padded tile = 10 x 66 positions; corners may be written by several blocks: all zeros)
+  const bool edge = ty == 0 || tx == 0 || (ty + 1) * TR >= p.Ht || (tx + 1) * TC >= p.Wt;
+  if (edge) {
+    const u32x4v zero = {0u, 0u, 0u, 0u};
+    for (int pos = tid; pos < (TR + 2) * (TC + 2); pos += 256) {
+      const int pr = pos / (TC + 2), pc = pos - pr * (TC + 2);
+      const int Y = ty * TR - 1 + pr, X = tx * TC - 1 + pc;
+      if (Y > p.Ht || X > p.Wt) continue;
+      if (!(Y == -1 || Y == p.Ht || X == -1 || X == p.Wt)) continue;
+      const size_t u = (size_t)(Y + 1) * Wp + X + 1;
+      for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x4v *>(Ub + pl * plane_units + u) = zero;
+    }
+  }
+}
+
+static int launch_fir_units(const UpfirdnP &q, int padx1, int pady1, float *y, hipStream_t st) {
+  if (q.upx != 1 || q.upy != 1 || q.downx != 1 || q.downy != 1 || q.minor != 1 || q.kH > 4 || q.kW > 4 || !q.kx || !q.ky)
+    return TBG_EUNSUPPORTED;  // the sink rides on the model's separable blur only
+  if (q.M < 1 || q.major % q.M != 0) return TBG_EINVAL;
+  FirUnitsP p{};
+  p.x = q.x; p.kx = q.kx; p.ky = q.ky; p.in_scale = q.in_scale; p.y = y;
+  p.B = q.major / q.M; p.C = q.M; p.inH = q.inH; p.inW = q.inW; p.Ht = q.outH; p.Wt = q.outW; p.kH = q.kH; p.kW = q.kW;
+  p.padx0 = q.padx0; p.pady0 = q.pady0;
+  p.tilesX = (p.Wt + 63) / 64; p.tilesY = (p.Ht + 7) / 8;
+  p.e = q.e;
+  if (const int rc = epi_sink_geometry(p.e, p.B, p.C, p.Ht, p.Wt)) return rc;
+  const long long nblk = (long long)p.B * (p.C / 8) * p.tilesX * p.tilesY;
+  if (nblk > 2147483647LL) return TBG_ERANGE;
+  if (p.e.units_planes == 3) hipLaunchKernelGGL(fir_units_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(fir_units_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
 // General form: one lane per output element; only taps that land on an input sample are visited.
 __global__ __launch_bounds__(256) void upfirdn2d_direct_kernel(const UpfirdnP p) {
   const long long total = (long long)p.major * p.outH * p.outW * p.minor;
@@ -321,8 +516,9 @@ static int upfirdn_fill(UpfirdnP &p, const float *x, float *y, int major, int in
   return TBG_OK;
 }
 
-static int upfirdn_epi(UpfirdnP &p, const float *in_scale, int M, const tbg_epilogue *epi) {
+static int upfirdn_epi(UpfirdnP &p, const float *in_scale, int M, const tbg_epilogue *epi, bool sink_ok = false) {
   if (!epi_valid(epi) || (epi && (epi->residual || epi->dot_aux || epi->gate))) return TBG_EINVAL;
+  if (epi_has_sink(epi) && !sink_ok) return TBG_EINVAL;
   if (epi && (M < 1 || p.major % M != 0)) return TBG_EINVAL;
   p.in_scale = in_scale;
   if (epi) { p.has_epi = 1; p.M = M; p.e = make_epi(epi); }
@@ -359,10 +555,14 @@ extern "C" int tbg_upfirdn2d_sep_f32(const float *x, const float *kx, const floa
                                      const tbg_epilogue *epi, void *stream) {
   UpfirdnP p;
   if (!kx || !ky) return TBG_EINVAL;
-  int rc = upfirdn_fill(p, x, y, major, inH, inW, 1, kH, kW, upx, upy, downx, downy, padx0, padx1, pady0, pady1);
+  const bool sink = epi_has_sink(epi);
+  static float dummy_y;  // (upfirdn_fill checks the pointers for NULL only: a sink may be the only output)
+  int rc = upfirdn_fill(p, x, (sink && !y) ? &dummy_y : y, major, inH, inW, 1, kH, kW, upx, upy, downx, downy, padx0, padx1, pady0,
+                        pady1);
   if (rc != TBG_OK) return rc;
-  if ((rc = upfirdn_epi(p, in_scale, M, epi)) != TBG_OK) return rc;
+  if ((rc = upfirdn_epi(p, in_scale, M, epi, true)) != TBG_OK) return rc;
   p.kx = kx; p.ky = ky;
+  if (sink) return launch_fir_units(p, padx1, pady1, y, tbg_stream(stream));
   return upfirdn_dispatch(p, tbg_stream(stream));
 }
 

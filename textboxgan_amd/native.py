@@ -25,6 +25,7 @@ EXPORTS = [
     "tbg_upfirdn2d_kernel_name", "tbg_upfirdn2d_f16", "tbg_weight_pack_x3_bytes", "tbg_weight_pack_x3", "tbg_conv2d_x3", "tbg_conv2d_x3_kernel_name", "tbg_conv2d_x3_variant", "tbg_conv2d_wgrad_x3", "tbg_conv2d_wgrad_x3_kernel_name", "tbg_conv2d_dot_slots", "tbg_conv2d_blocks", "tbg_units_bytes", "tbg_units_pack_f32",
     "tbg_conv2d_wgrad_units", "tbg_conv2d_wgrad_units_workspace_bytes", "tbg_conv2d_units", "tbg_conv2d_units_dot_slots", "tbg_conv2d_units_blocks", "tbg_conv2d_units_tile_channels", "tbg_bias_act_bwd_units", "tbg_bias_act_bwd_units_chunks",
     "tbg_units_s2_bytes", "tbg_units_pack_s2_f32", "tbg_upfirdn2d_units_s2_f32", "tbg_conv2d_units_s2_blocks", "tbg_conv2d_units_s2_tile_channels", "tbg_conv2d_units_s2_dot_slots", "tbg_conv2d_units_s2", "tbg_conv2d_wgrad_units_s2_workspace_bytes", "tbg_conv2d_wgrad_units_s2", "tbg_conv2d_units_t2_blocks", "tbg_conv2d_units_t2",
+    "tbg_slab_epilogue_units_f32",
     "tbg_bias_act_bwd_f32", "tbg_axpby_planes_f32", "tbg_bias_act_bwd2_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_rgb_backproject_chunks", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -36,7 +37,9 @@ class TbgError(RuntimeError):
 class Epilogue(C.Structure):
     _fields_ = [("out_scale", C.c_void_p), ("bias", C.c_void_p), ("noise", C.c_void_p), ("strength", C.c_void_p),
                 ("residual", C.c_void_p), ("dot_aux", C.c_void_p), ("dot_out", C.c_void_p), ("gate", C.c_void_p), ("alpha", C.c_float), ("bias_mul", C.c_float), ("slope", C.c_float),
-                ("gain", C.c_float), ("res_scale", C.c_float), ("act", C.c_int), ("res_first", C.c_int)]
+                ("gain", C.c_float), ("res_scale", C.c_float), ("act", C.c_int), ("res_first", C.c_int),
+                # unit sink (tbg.h): units(out * units_scale) written beside / instead of the fp32 output
+                ("units_out", C.c_void_p), ("units_scale", C.c_void_p), ("units_planes", C.c_int)]
 
 
 class PackItem(C.Structure):
@@ -154,6 +157,7 @@ def lib():
         l.tbg_conv2d_wgrad_x3_kernel_name.argtypes = [C.POINTER(WgradDesc), C.c_char_p, ci]
         l.tbg_bias_act_fwd_f32.argtypes = [vp, vp, ci, ci, ci, C.POINTER(Epilogue), vp]
         l.tbg_slab_epilogue_f32.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(Epilogue), vp]
+        l.tbg_slab_epilogue_units_f32.argtypes = [vp, vp, ci, ci, ci, ci, ci, C.POINTER(Epilogue), vp]
         l.tbg_bias_act_bwd_f32.argtypes = [vp] * 7 + [ci, ci, ci, C.POINTER(Epilogue), vp]
         l.tbg_rgb_project_f32.argtypes = [vp] * 6 + [ci] * 5 + [cf, cf, vp, ci, ci, vp]
         l.tbg_rgb_backproject_f32.argtypes = [vp] * 6 + [ci] * 5 + [cf, vp, ci, ci, vp, vp]
@@ -276,11 +280,12 @@ def stream() -> int:
 
 
 def epilogue(out_scale=None, bias=None, noise=None, strength=None, residual=None, alpha=1.0, bias_mul=1.0,
-             act=ACT_LINEAR, slope=0.2, gain=None, res_scale=1.0, dot_aux=None, dot_out=None, res_first=0, gate=None) -> Epilogue:
+             act=ACT_LINEAR, slope=0.2, gain=None, res_scale=1.0, dot_aux=None, dot_out=None, res_first=0, gate=None,
+             units_out=None, units_scale=None, units_planes=0) -> Epilogue:
     if gain is None:
         gain = SQRT2 if act == ACT_LRELU else 1.0
     return Epilogue(ptr(out_scale), ptr(bias), ptr(noise), ptr(strength), ptr(residual), ptr(dot_aux), ptr(dot_out), ptr(gate), alpha, bias_mul, slope, gain,
-                    res_scale, act, res_first)
+                    res_scale, act, res_first, ptr(units_out), ptr(units_scale), int(units_planes))
 
 
 def conv_kernel_name(desc: ConvDesc, has_in_scale: bool, fmt=0) -> str:
