@@ -319,14 +319,14 @@ def test_merged_class_transposed_kernel(dev, case, bf16):
     ref = F.conv_transpose2d(xr, wr.permute(2, 3, 0, 1), stride=2)
     f = lambda t: t.float().to(dev).contiguous()
     try:
-        ops.FORCE_VARIANT = 5
+        ops.TUNING.force_variant = 5
         with ops.compute_dtype("bf16" if bf16 else "f32"):
             y = ops.conv2d_raw(f(x), f(w), Mo, 3, 3, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, in_scale=f(s))
             y2 = ops.conv2d_raw(f(x), f(w), Mo, 3, 3, (2 * H + 2, 2 * W + 2), (2, 2), (0, 0), transposed=True, in_scale=f(s))
             yflip = ops.conv2d_raw(f(x), f(w), Mo, 3, 3, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, flip=True,
                                    in_scale=f(s))
     finally:
-        ops.FORCE_VARIANT = 0
+        ops.TUNING.force_variant = 0
     assert rel_err(y, ref) < 3e-5
     assert rel_err(y2, F.pad(ref, (0, 1, 0, 1))) < 3e-5
     assert rel_err(yflip, F.conv_transpose2d(xr, torch.flip(wr, (0, 1)).permute(2, 3, 0, 1), stride=2)) < 3e-5

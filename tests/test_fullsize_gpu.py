@@ -88,10 +88,10 @@ def test_split_k_slabs_equal_unsplit(dev):
     outs = []
     try:
         for ks in (1, 2, 8, 64):  # 64 = one chunk per split (and exactly the chunk count)
-            ops.FORCE_KSPLIT = ks
+            ops.TUNING.force_ksplit = ks
             outs.append(ops.conv2d_raw(x, w, M, 3, 3, (H, W), (1, 1), (1, 1)))
     finally:
-        ops.FORCE_KSPLIT = None
+        ops.TUNING.force_ksplit = None
     for o in outs[1:]:
         assert float((o - outs[0]).abs().max()) <= 2e-5 * float(outs[0].abs().max())
 

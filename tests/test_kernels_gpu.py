@@ -354,7 +354,7 @@ def test_conv2d_gate_epilogue(dev, ksplit):
     gate = torch.where(gate.abs() < 0.3, torch.zeros_like(gate), gate)  # exact zeros gate off, as relu outputs do
     ref = (F.conv2d(x, w.permute(3, 2, 0, 1), padding=1) + res) * (gate > 0)
     rd, gd = f(res), f(gate)
-    ops.FORCE_KSPLIT = ksplit
+    ops.TUNING.force_ksplit = ksplit
     try:
         y = ops.conv2d_raw(f(x), f(w), M, 3, 3, (H, W), (1, 1), (1, 1), epi=N.epilogue(residual=rd, res_first=1, gate=gd))
         assert rel_err(y, ref) < 2e-5
@@ -369,7 +369,7 @@ def test_conv2d_gate_epilogue(dev, ksplit):
                             epi=N.epilogue(residual=r2, res_first=1, gate=g2))
         assert rel_err(y2, ref2) < 2e-5
     finally:
-        ops.FORCE_KSPLIT = None
+        ops.TUNING.force_ksplit = None
 
 
 WG_CASES = [

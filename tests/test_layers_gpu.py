@@ -95,7 +95,7 @@ def test_modconv_fused_fwd_bwd(dev, up, shape):
                          ids=["small", "mapping", "style", "ragged", "head", "rows33", "library-gemm", "k768"])
 def test_dense_bias_act(dev, dims):
     """equalised-LR dense + bias (+lrelu*sqrt2 / +offset): forward and the three gradients vs the oracle layers -- the
-    one-launch kernels (K <= ops.DENSE_SMALL_K) at the step's sizes and ragged ones, and the library-GEMM form above."""
+    one-launch kernels (K <= ops.TUNING.dense_small_k) at the step's sizes and ragged ones, and the library-GEMM form above."""
     from textboxgan_amd import ops
     B, I, O = dims
     lrmul = 0.01
@@ -108,7 +108,7 @@ def test_dense_bias_act(dev, dims):
         grads = torch.autograd.grad(ref, leaves, dout)
         xd, wd, bd = f(x), f(w), f(b)
         # both launch forms are product paths (ops.dense_bias_act routes by activation and K): test each directly
-        form = ops._DenseBiasAct if I <= ops.DENSE_SMALL_K else ops._DenseBiasActGemm
+        form = ops._DenseBiasAct if I <= ops.TUNING.dense_small_k else ops._DenseBiasActGemm
         out = form.apply(xd, wd, bd, lrmul / math.sqrt(I), lrmul, lrelu, offset)
         assert rel_err(out, ref) < 1e-5
         assert rel_err(ops.dense_bias_act(xd, wd, bd, lrmul / math.sqrt(I), lrmul, lrelu=lrelu, offset=offset), ref) < 1e-5
@@ -458,7 +458,7 @@ def test_discriminator_block_fused_skip_gradient_equals_two_nodes(dev):
     img = (torch.randn(8, 3, cfg.char_height, cfg.image_width, device=dev) * 0.5)
     res = {}
     for fused in (True, False):
-        ops.FUSE_SKIP_GRAD = fused
+        ops.TUNING.fuse_skip_grad = fused
         try:
             with ops.STATE_LOCK, ops.filter_cache():
                 x = img.clone().requires_grad_(True)
@@ -471,7 +471,7 @@ def test_discriminator_block_fused_skip_gradient_equals_two_nodes(dev):
                     ops.FLAGS.skip_d_wgrad, ops.FLAGS.d_first_half = False, 0
             res[fused] = (sc.detach(), [g.detach() for g in g_full], g_half[:4].detach())
         finally:
-            ops.FUSE_SKIP_GRAD = True
+            ops.TUNING.fuse_skip_grad = True
     assert torch.equal(res[True][0], res[False][0])
     for a, b in zip(res[True][1], res[False][1]):
         assert l2_err(a, b) < 1e-6

@@ -181,7 +181,7 @@ def test_blur_conv_s2_fused_equals_the_nchw_layers(dev, mode, monkeypatch):
     """ops._BlurConvS2Fused (FIR -> phase units -> strided convolution; backward: units(dpre) -> filter gradient from unit tensors)
     against the two launches + NCHW backward it replaces (ops.upfirdn2d + ops.conv_bias_act_fused): output, input gradient,
     filter gradient and bias gradient at the kernels' own agreement (same products, other summation orders)."""
-    monkeypatch.setattr(ops, "UNITS_MIN_BLOCKS", 1)
+    monkeypatch.setattr(ops.TUNING, "units_min_blocks", 1)
     B, I, O, H, W = 2, 64, 128, 32, 128
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, I, H, W, generator=g).to(dev).requires_grad_(True)
@@ -194,7 +194,7 @@ def test_blur_conv_s2_fused_equals_the_nchw_layers(dev, mode, monkeypatch):
         y0 = ops.conv_bias_act_fused(ops.upfirdn2d(x, k, pad=(2, 3, 2, 3)), w, b, stride=(2, 2), out_mul=0.7)
         g0 = torch.autograd.grad(y0, (x, w, b), dout)
         for t2 in (False, True):  # the data gradient through the NCHW transposed kernel, then through tbg_conv2d_units_t2
-            monkeypatch.setattr(ops, "USE_UNITS_T2", t2)
+            monkeypatch.setattr(ops.TUNING, "use_units_t2", t2)
             y1 = ops.blur_conv_s2_fused(x, w, b, out_mul=0.7)
             g1 = torch.autograd.grad(y1, (x, w, b), dout)
             if not t2:
@@ -212,7 +212,7 @@ def test_blur_conv_s2_fused_equals_the_nchw_layers(dev, mode, monkeypatch):
 def test_modconv_up_backward_through_phase_units_equals_the_nchw_path(dev, mode, monkeypatch):
     """ops._ModConvUpFused's backward with the blur^T output as a phase unit tensor (data gradient = tbg_conv2d_units_s2 with the
     fused style dot, filter gradient = tbg_conv2d_wgrad_units_s2 with the demodulation term) against its NCHW launches."""
-    monkeypatch.setattr(ops, "UNITS_MIN_BLOCKS", 1)
+    monkeypatch.setattr(ops.TUNING, "units_min_blocks", 1)
     B, I, O, H, W = 2, 128, 64, 16, 64
     g = torch.Generator().manual_seed(4)
     x = torch.randn(B, I, H, W, generator=g).to(dev).requires_grad_(True)
@@ -224,8 +224,8 @@ def test_modconv_up_backward_through_phase_units_equals_the_nchw_path(dev, mode,
     dout = torch.randn(B, O, 2 * H, 2 * W, generator=g).to(dev)
     res = []
     for on in (False, True):  # NCHW launches, then every stride-2 launch of the layer from unit tensors
-        monkeypatch.setattr(ops, "USE_UNITS_S2", on)
-        monkeypatch.setattr(ops, "USE_UNITS_T2", on)
+        monkeypatch.setattr(ops.TUNING, "use_units_s2", on)
+        monkeypatch.setattr(ops.TUNING, "use_units_t2", on)
         with ops.compute_dtype(mode):
             y = ops.modconv_up_fused(x, w, s, noise, strength, b)
             res.append((y,) + torch.autograd.grad(y, (x, w, s, strength, b), dout))

@@ -386,14 +386,14 @@ class DiscriminatorBlock(nn.Module):
         rs = 1.0 / math.sqrt(2.0)
         # skip: blur + strided 1x1 conv == (blur evaluated only at the strided sites) + 1x1 conv
         role = "d" if mode == "fused" else None  # (ops.FLAGS: which backward work a pass may skip)
-        if mode == "fused" and ops.FUSE_SKIP_GRAD:  # conv_0 and the skip FIR as one node: d(x) without an add pass
+        if mode == "fused" and ops.TUNING.fuse_skip_grad:  # conv_0 and the skip FIR as one node: d(x) without an add pass
             t, xd = ops.conv_bias_act_skip_fused(x, self.conv_0.w, self.apply_bias_act_0.b, k, (2, sh), (1, 2, 1, 2), role="d")
         else:
             xd = ops.upfirdn2d(x, k, down=(2, sh), pad=(1, 2, 1, 2), role=role)
         if mode == "fused":
-            if not ops.FUSE_SKIP_GRAD:
+            if not ops.TUNING.fuse_skip_grad:
                 t = ops.conv_bias_act_fused(x, self.conv_0.w, self.apply_bias_act_0.b, pad=(1, 1), role="d")
-            fold = ops.FOLD_RES_SCALE and ops.compute_mode() != "bf16"
+            fold = ops.TUNING.fold_res_scale and ops.compute_mode() != "bf16"
             if sh == 2 and ops.blur_conv_s2_units(t.shape[0], t.shape[1], self.conv_1.w.shape[3], t.shape[2], t.shape[3]):
                 # blur + strided convolution with the blurred tensor as a phase unit tensor only (ops._BlurConvS2Fused)
                 u = ops.blur_conv_s2_fused(t, self.conv_1.w, self.apply_bias_act_1.b, role="d", out_mul=rs if fold else 1.0)

@@ -84,6 +84,39 @@ class _FlagsProxy:
 
 FLAGS = _FlagsProxy()
 
+class _Tuning:
+    """Every host-side tuning constant and measurement (A/B) switch of the package in ONE documented object (VERDICT round 4,
+    item 9: they were module-level globals scattered over ops.py / ops2.py).  Production never changes them; tools/ab_step.py,
+    tools/bench_*.py and a few tests set attributes of ``ops.TUNING`` (process-wide, like FLAGS: hold STATE_LOCK around a pass that
+    depends on a changed value).  The C library has no such state: what a launch does is a function of its arguments."""
+
+    def __init__(self):
+        # ---- unit tensors (tbg.h "UNIT TENSORS")
+        self.use_units = True        # 3x3 stride-1 layers consume unit tensors (tbg_conv2d_units / tbg_conv2d_wgrad_units) where they apply
+        self.units_min_blocks = 200  # tbg_conv2d_units runs ONE 512-thread block per CU: launches of fewer blocks keep the NCHW
+                                     # kernel (profiles/r04_units_isolated.txt: 128 blocks 136 vs 145 TFLOP/s, 256 blocks 196 vs 154)
+        self.use_units_s2 = True     # blur + 3x3 stride-2 layers (and the up-convolution's backward) through PHASE unit tensors where
+                                     # both the strided convolution and its filter gradient take them
+        self.use_units_t2 = True     # 3x3 stride-2 TRANSPOSED convolutions (up-conv forward, data gradient of the strided layers)
+        self.unit_sinks = True       # round 5: producers (conv / FIR / split-K epilogues) write the NEXT layer's unit tensor themselves
+                                     # (tbg_epilogue.units_out); False = the stand-alone tbg_units_pack_f32 pass of round 4
+        # ---- split-K of the small-map launches
+        self.force_ksplit = None     # experiment knob (tools/bench_ksplit.py)
+        self.ksplit_target_blocks = 448  # blocks a split-K launch aims for (A/B on one box: 288 -> 21.22, 448 -> 21.11, 512 -> 20.97
+                                     # vs 448 -> 20.94, 640 -> 21.02, 900 -> 21.04, 200 -> 21.50 ms per step)
+        self.one_per_cu_split = True  # two K splits for launches of exactly one tile per CU (profiles/r03_cold_conv.txt)
+        self.force_variant = 0       # experiment knob (tools/bench_variants_conv.py): tbg_conv2d_*_variant's instantiation family
+        # ---- graph structure
+        self.fold_res_scale = True   # DiscriminatorBlock folds its 1/sqrt(2) into both branches (fp32-grade arithmetics only)
+        self.fuse_skip_grad = True   # DiscriminatorBlock: conv_0 + skip FIR as ONE node (False = two nodes + the engine's add)
+        self.use_fused2 = True       # path-length pass on the twice-differentiable node pairs of ops2 (False = composable primitives)
+        # ---- dense layers
+        self.dense_small_k = 768     # above: a library GEMM; below: launch-bound, one hand-written launch per direction
+
+
+TUNING = _Tuning()
+
+
 # ----------------------------------------------------------------------------------------
 # arithmetic of the MFMA contractions:
 #   "f32"   v_mfma_f32_32x32x2_f32, exact fp32 products
@@ -230,12 +263,6 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
     return y
 
 
-FORCE_KSPLIT = None  # experiment knob (tools/bench_ksplit.py)
-KSPLIT_TARGET_BLOCKS = 448  # blocks a split-K launch aims for (A/B on one box, tools/ab_step.py: 288 -> 21.22, 448 -> 21.11,
-                            # 512 -> 20.97 vs 448 -> 20.94, 640 -> 21.02, 900 -> 21.04, 200 -> 21.50 ms per step)
-FOLD_RES_SCALE = True  # measurement aid (tools/ab_step.py): DiscriminatorBlock folds 1/sqrt(2) into its two branches
-ONE_PER_CU_SPLIT = True  # measurement aid (tools/ab_step.py): two K splits for launches of exactly one tile per CU
-FORCE_VARIANT = 0    # experiment knob (tools/bench_variants_conv.py): tbg_conv2d_f32_variant's instantiation family
 
 
 def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_hw: Tuple[int, int], stride=(1, 1),
@@ -253,8 +280,8 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     fmt = w.fmt
     bf16 = fmt != FMT_F32  # a 16-bit operand pipe (bf16 or f32x3): shares the merged-class rule of the library
     _conv = (N.lib().tbg_conv2d_f32, N.lib().tbg_conv2d_bf16, N.lib().tbg_conv2d_x3)[fmt]
-    if FORCE_VARIANT:
-        _v, _fn = FORCE_VARIANT, (N.lib().tbg_conv2d_f32_variant, N.lib().tbg_conv2d_bf16_variant,
+    if TUNING.force_variant:
+        _v, _fn = TUNING.force_variant, (N.lib().tbg_conv2d_f32_variant, N.lib().tbg_conv2d_bf16_variant,
                                   N.lib().tbg_conv2d_x3_variant)[fmt]
         _conv = lambda d_, x_, w_, y_, s_, e_, st_: _fn(d_, x_, w_, y_, s_, e_, _v, st_)
     w = w.data
@@ -271,15 +298,15 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         # exactly one block per CU (256 tiles) leaves the second block slot of a stride-1 tile empty -- nothing overlaps its
         # staging: two splits there measured 165 vs 126-138 TFLOP/s (f32x3 16x64 256->256, profiles/r03_cold_conv.txt); a
         # stride-2 f32x3 tile fills the CU's LDS alone and only loses to the slab pass (109 vs 132)
-        one_per_cu = (ONE_PER_CU_SPLIT and tiles == 256 and tuple(stride) == (1, 1) and not transposed and
+        one_per_cu = (TUNING.one_per_cu_split and tiles == 256 and tuple(stride) == (1, 1) and not transposed and
                       dot is None)  # (a fused dot needs K whole)
         if (tiles < 256 or one_per_cu) and nchunks >= 8:  # tools/bench_ksplit.py: ~300 blocks is the sweet spot (slab traffic ~ ksplit)
-            target = max(1, min(nchunks // 4, math.ceil(KSPLIT_TARGET_BLOCKS / tiles)))
+            target = max(1, min(nchunks // 4, math.ceil(TUNING.ksplit_target_blocks / tiles)))
             # a split that divides the chunk count keeps the splits even (32 chunks: 6 splits = 6,6,6,6,6,2 ran slower than 4)
             divs = [k for k in range(1, nchunks // 2 + 1) if nchunks % k == 0]
             ksplit = min(divs, key=lambda k: abs(math.log(k / target)))
-        if FORCE_KSPLIT is not None:
-            ksplit = max(1, min(nchunks, FORCE_KSPLIT))
+        if TUNING.force_ksplit is not None:
+            ksplit = max(1, min(nchunks, TUNING.force_ksplit))
     d = N.ConvDesc(B, Cc, M, Hin, Win, Hout, Wout, KH, KW, stride[0], stride[1], pad[0], pad[1], int(transposed),
                    int(flip), ldw, ksplit)
     if epi is None:
@@ -1134,57 +1161,50 @@ def bias_act_c(y, noise, strength, b):
 # ----------------------------------------------------------------------------------------
 # fused first-order layers
 # ----------------------------------------------------------------------------------------
-USE_UNITS = True         # 3x3 stride-1 layers consume unit tensors (tbg_conv2d_units / tbg_conv2d_wgrad_units) where they apply
-UNITS_MIN_BLOCKS = 200   # tbg_conv2d_units runs ONE 512-thread block per CU: launches of fewer blocks keep the NCHW kernel
-                         # (measured, profiles/r04_units_isolated.txt: 128 blocks 136 vs 145 TFLOP/s, 256 blocks 196 vs 154)
 
 
 def _units_conv(B, C_in, M, H, W) -> bool:
     """does a 3x3 stride-1 pad-1 convolution C_in -> M on B x H x W take tbg_conv2d_units in the current arithmetic?"""
     fmt = _FMT[_TLS.compute]
-    if not USE_UNITS or fmt == FMT_F32:
+    if not TUNING.use_units or fmt == FMT_F32:
         return False
     if not conv_units_ok(C_in, M, H, W, 3, 3, (1, 1), (1, 1), False, unit_planes(fmt)):
         return False
     # the tile choice (128- or 64-channel blocks) belongs to the library: ask it for the block count
     d = N.ConvDesc(B, C_in, M, H, W, H, W, 3, 3, 1, 1, 1, 1, 0, 0, M, 1)
-    return N.lib().tbg_conv2d_units_blocks(C.byref(d), unit_planes(fmt)) >= UNITS_MIN_BLOCKS
+    return N.lib().tbg_conv2d_units_blocks(C.byref(d), unit_planes(fmt)) >= TUNING.units_min_blocks
 
 
 def _units_wgrad(I, O, H, W) -> bool:
     fmt = _FMT[_TLS.compute]
-    return USE_UNITS and fmt != FMT_F32 and wgrad_units_ok(O, I, H, W, H, W, 3, 3, (1, 1), (1, 1))
+    return TUNING.use_units and fmt != FMT_F32 and wgrad_units_ok(O, I, H, W, H, W, 3, 3, (1, 1), (1, 1))
 
 
-USE_UNITS_S2 = True      # blur + 3x3 stride-2 layers (and the up-convolution's backward) through phase unit tensors where both the
-                         # strided convolution AND its filter gradient take them (the fp32 tensor between blur and convolution is then
-                         # never written)
 
 
 def _units_s2(B, C_in, M, Ht, Wt) -> bool:
     """does a 3x3 stride-2 pad-0 convolution C_in -> M of a B x Ht x Wt tensor take the phase-unit kernels (forward / data-gradient
     form tbg_conv2d_units_s2 AND the filter gradient tbg_conv2d_wgrad_units_s2) in the current arithmetic?"""
     fmt = _FMT[_TLS.compute]
-    if not (USE_UNITS and USE_UNITS_S2) or fmt == FMT_F32 or Ht < 3 or Wt < 3:
+    if not (TUNING.use_units and TUNING.use_units_s2) or fmt == FMT_F32 or Ht < 3 or Wt < 3:
         return False
     planes = unit_planes(fmt)
     Ho, Wo = (Ht - 3) // 2 + 1, (Wt - 3) // 2 + 1
     if not conv_units_s2_ok(C_in, M, Ht, Wt, planes) or not wgrad_units_s2_ok(M, C_in, Ho, Wo, Ht, Wt):
         return False
     d = N.ConvDesc(B, C_in, M, Ht, Wt, Ho, Wo, 3, 3, 2, 2, 0, 0, 0, 0, M, 1)
-    return N.lib().tbg_conv2d_units_s2_blocks(C.byref(d), planes) >= UNITS_MIN_BLOCKS
+    return N.lib().tbg_conv2d_units_s2_blocks(C.byref(d), planes) >= TUNING.units_min_blocks
 
 
-USE_UNITS_T2 = True      # 3x3 stride-2 TRANSPOSED convolutions (up-convolution forward, data gradient of the strided layers) from unit tensors
 
 
 def _units_t2(B, C_in, M, H, W, Hout, Wout) -> bool:
     """does the 3x3 stride-2 transposed convolution C_in -> M of a B x H x W map take tbg_conv2d_units_t2 in the current arithmetic?"""
     fmt = _FMT[_TLS.compute]
-    if not (USE_UNITS and USE_UNITS_T2) or fmt == FMT_F32 or not conv_units_t2_ok(C_in, M, unit_planes(fmt)):
+    if not (TUNING.use_units and TUNING.use_units_t2) or fmt == FMT_F32 or not conv_units_t2_ok(C_in, M, unit_planes(fmt)):
         return False
     d = N.ConvDesc(B, C_in, M, H, W, Hout, Wout, 3, 3, 2, 2, 0, 0, 1, 0, M, 1)
-    return N.lib().tbg_conv2d_units_t2_blocks(C.byref(d), unit_planes(fmt)) >= UNITS_MIN_BLOCKS
+    return N.lib().tbg_conv2d_units_t2_blocks(C.byref(d), unit_planes(fmt)) >= TUNING.units_min_blocks
 
 
 def _unit_tensor(data, like: torch.Tensor, planes=None) -> UnitTensor:
@@ -1556,7 +1576,6 @@ def conv_bias_act_skip_fused(x, w, b, k, down, fpad, role=None):
     return _ConvBiasActSkipFused.apply(x, w, b, k, tuple(down), tuple(fpad), role)
 
 
-FUSE_SKIP_GRAD = True  # measurement aid (tools/ab_step.py): False = two nodes and the autograd engine's add
 
 
 class _BlurConvS2Fused(torch.autograd.Function):
@@ -1731,7 +1750,6 @@ def minibatch_std_fused(x, group=4, parts=1, role=None):
 # ----------------------------------------------------------------------------------------
 # equalised-LR dense layers (1-4 MFLOP each: one hand-written launch per direction instead of 3-5 library launches)
 # ----------------------------------------------------------------------------------------
-DENSE_SMALL_K = 768  # above: a real GEMM (library); below: launch-bound, one hand-written launch per direction
 
 
 class _DenseBiasAct(torch.autograd.Function):
@@ -1902,7 +1920,7 @@ def dense_bias_act(x, w, b, coef, lrmul=1.0, lrelu=False, offset=0.0):
     # measured per layer in graph replay (tools/bench_dense.py, profiles/r02_dense_forms.txt): the one-launch kernels halve
     # the lrelu layers (mapping network: 47 -> 24 us forward + backward); the linear style affines are a single library
     # launch forward already (4.7 us) and a wash backward, so they keep the library form
-    fn = _DenseBiasAct if (lrelu and x.shape[1] <= DENSE_SMALL_K) else _DenseBiasActGemm
+    fn = _DenseBiasAct if (lrelu and x.shape[1] <= TUNING.dense_small_k) else _DenseBiasActGemm
     return fn.apply(x, w, b, float(coef), float(lrmul), bool(lrelu), float(offset))
 
 

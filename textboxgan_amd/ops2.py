@@ -42,7 +42,7 @@ from .ops import (ACT_LRELU, FLAGS, _Geom, _bwd_data_launch, _bwd_weight_launch,
                   torgb_bwd_smalls_raw, upfirdn2d_raw, wgrad_raw)
 
 
-USE_FUSED2 = True  # measurement aid (tools/ab_step.py): False = the composable primitives of rounds 1-3
+# (the A/B switch of this path is ops.TUNING.use_fused2)
 
 
 # ----------------------------------------------------------------------------------------

@@ -448,8 +448,7 @@ class TrainingStep:
         pl_mb = max(1, self.batch_size_per_gpu // self.pl_minibatch_shrink)
         dev = input_words.device
         pl_z = rand["pl_z"] if "pl_z" in rand else torch.randn(pl_mb, cfg.z_dim, device=dev)
-        from . import ops2
-        mode = "fused2" if (dev.type == "cuda" and ops2.USE_FUSED2) else "composable"  # (models.py: execution modes)
+        mode = "fused2" if (dev.type == "cuda" and ops.TUNING.use_fused2) else "composable"  # (models.py: execution modes)
         img, style = self.generator((input_words[:pl_mb], pl_z), batch_size=pl_mb, ret_style=True, training=False,
                                     rand=rand, noises_key="pl_noises", mode=mode)
         noise = rand["pl_noise"] if "pl_noise" in rand else torch.randn_like(img)

@@ -8,7 +8,7 @@ if sys.argv[1] == "--child":
     native.LIB_PATH = os.path.abspath(sys.argv[2])
     if len(sys.argv) > 3 and "=" in sys.argv[3]:  # an ops attribute that has to change with the library (mirrored rules)
         from textboxgan_amd import ops as _ops
-        setattr(_ops, sys.argv[3].split("=")[0], eval(sys.argv[3].split("=")[1]))
+        setattr(_ops.TUNING, sys.argv[3].split("=")[0], eval(sys.argv[3].split("=")[1]))
     import torch, time
     from textboxgan_amd.config import Config
     from textboxgan_amd.training_step import build_trainer_state
@@ -30,7 +30,7 @@ if sys.argv[1] == "--child":
 else:
     libs = sys.argv[1:3]
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-    extra = {libs[0]: sys.argv[4:5], libs[1]: sys.argv[5:6]}  # optional "ATTR=value" per library
+    extra = {libs[0]: sys.argv[4:5], libs[1]: sys.argv[5:6]}  # optional "attr=value" (an ops.TUNING attribute) per library
     out = {l: [] for l in libs}
     for r in range(rounds):
         for l in libs:

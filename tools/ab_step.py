@@ -1,6 +1,6 @@
 """A/B of a host-side knob on the SAME box: graph-replayed plain step (f32x3, B=16), alternating settings.
-usage: python tools/ab_step.py <[module.]attribute> <value A> <value B> [rounds] [dtype] [batch] [plain|pl|r1]
-(module: ops (default) or ops2; pl = a path-length step, r1 = a path-length + R1 step)"""
+usage: python tools/ab_step.py <attribute of ops.TUNING | module.attribute> <value A> <value B> [rounds] [dtype] [batch] [plain|pl|r1]
+(pl = a path-length step, r1 = a path-length + R1 step)"""
 import sys; sys.path.insert(0, '.')
 import torch, time
 from textboxgan_amd import ops
@@ -9,7 +9,7 @@ from textboxgan_amd.training_step import build_trainer_state
 from bench import synthetic_batch, bench_init_
 dev = torch.device('cuda:0')
 attr, va, vb = sys.argv[1], eval(sys.argv[2]), eval(sys.argv[3])
-mod = ops
+mod = ops.TUNING
 if "." in attr:
     import importlib
     mname, attr = attr.split(".")

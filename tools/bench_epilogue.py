@@ -18,7 +18,7 @@ for (M, H, W) in ((128, 64, 256), (128, 32, 128), (256, 16, 64), (256, 8, 32)):
     ts = {}
     for C in (8, 64, 128):
         x = torch.randn(B, C, H, W, device=dev); w = ops.pack_filter(torch.randn(9, C, M, device=dev), False, False)
-        ops.FORCE_KSPLIT = 1
+        ops.TUNING.force_ksplit = 1
         ts[C] = timeit(lambda: ops.conv2d_raw(x, w, M, 3, 3, (H, W), (1, 1), (1, 1)))
     slope = (ts[128] - ts[64]) / 64
     print(f"M={M} {H}x{W}: fill {tf:6.1f} us | C=8 {ts[8]:6.1f}  C=64 {ts[64]:6.1f}  C=128 {ts[128]:6.1f} us | "

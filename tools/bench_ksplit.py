@@ -19,7 +19,7 @@ for C, M, Hin, Win, Hout, Wout, st in shapes:
     x = torch.randn(B, C, Hin, Win, device=dev); w = ops.pack_filter(torch.randn(9, C, M, device=dev), False, False)
     row = []
     for ks in (None, 1, 2, 3, 4, 6, 8, 16):
-        ops.FORCE_KSPLIT = ks
+        ops.TUNING.force_ksplit = ks
         f = (lambda: ops.conv2d_raw(x, w, M, 3, 3, (Hout, Wout), st, (0, 0), transposed=True)) if st else \
             (lambda: ops.conv2d_raw(x, w, M, 3, 3, (Hout, Wout), (1, 1), (1, 1)))
         for _ in range(3): f()

@@ -25,8 +25,8 @@ for B, bf in MODES:
         flops = 2.0 * B * C * M * 9 * H * W
         row = f"{name:28s}"
         for v in ((0, 4, 8, 9, 5) if not bf else (0, 4, 5)):
-            ops.FORCE_VARIANT = v
+            ops.TUNING.force_variant = v
             t = timeit(lambda: ops.conv2d_raw(x, wp, M, 3, 3, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True, flip=True))
             row += f" {flops / t / 1e9:7.1f}"
-        ops.FORCE_VARIANT = 0
+        ops.TUNING.force_variant = 0
         print(row)

@@ -36,11 +36,11 @@ for name, C, M, H, W, stride in L:
     flops = 2.0 * B * C * M * 9 * ohw[0] * ohw[1]
     row = f"{name:34s}"
     for v in names:
-        ops.FORCE_VARIANT = v
+        ops.TUNING.force_variant = v
         try:
             t = timeit(lambda: ops.conv2d_raw(x, wp, M, 3, 3, ohw, stride, pad))
             row += f" {names[v]}={flops / t / 1e9:6.1f}"
         except Exception:
             row += f" {names[v]}=  n/a "
-    ops.FORCE_VARIANT = 0
+    ops.TUNING.force_variant = 0
     print(row)

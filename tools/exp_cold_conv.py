@@ -39,9 +39,9 @@ for name, C, M, H, W, stride in L:
     flops = 2.0 * B * C * M * 9 * ohw[0] * ohw[1]
     row = f"{name:24s}"
     for ks in (None, 1, 2, 4):
-        ops.FORCE_KSPLIT = ks
+        ops.TUNING.force_ksplit = ks
         fn = lambda: ops.conv2d_raw(x, wp, M, 3, 3, ohw, stride, pad)
         h, c = t_hot(fn), t_cold(fn)
         row += f"  ks={ks}: hot {h:6.1f}us {flops / h / 1e6:5.1f}TF cold {c:6.1f}us {flops / c / 1e6:5.1f}TF |"
-    ops.FORCE_KSPLIT = None
+    ops.TUNING.force_ksplit = None
     print(row, flush=True)

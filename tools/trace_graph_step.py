@@ -6,7 +6,7 @@ from textboxgan_amd import ops
 from textboxgan_amd.config import Config
 from textboxgan_amd.training_step import build_trainer_state
 from bench import synthetic_batch, bench_init_
-ops.USE_UNITS = bool(int(sys.argv[1]))
+ops.TUNING.use_units = bool(int(sys.argv[1]))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device('cuda:0')
 cfg = Config(batch_size_per_gpu=16)
