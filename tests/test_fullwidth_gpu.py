@@ -428,6 +428,14 @@ def _covered(dev, arith):
         if arith != "f32":  # the 3x3 stride-1 layers of these arithmetics consume unit tensors
             cov |= _run_units_case(dev, arith, 128, 700) | _run_units_case(dev, arith, 64, 701)
             cov |= _run_units_s2_case(dev, arith, 128, 702) | _run_units_s2_case(dev, arith, 64, 703)
+            # the unit-sink forms (round 5): every producer against the definition of the unit tensor of its own fp32 result
+            import test_units_gpu as TU
+            from textboxgan_amd import native as N
+            with N.record_calls() as log:
+                for case in TU.SINK_CONVS:
+                    TU.test_conv_unit_sink_equals_units_pack(dev, arith, case)
+                TU.test_conv_units_and_fir_unit_sinks_equal_units_pack(dev, arith)
+            cov |= set(log)
         for reg in ((False, False), (True, True)):
             cov |= set(_step_vs_oracle(dev, arith, 4, reg)[0])
         _COVERED[arith] = cov
@@ -463,3 +471,8 @@ def test_every_step_instantiation_is_oracle_compared(dev, arith, B, reg):
     assert any(k.startswith("conv_fprop") for k in used) and any(k.startswith("upfirdn2d") for k in used), sorted(used)
     missing = sorted(set(used) - covered)
     assert not missing, f"launched by the {arith} B={B} step but never compared with the oracle: {missing}"
+    if reg == (False, False):
+        # round 5: unit tensors are written by the launch that PRODUCES the activation (tbg_epilogue.units_out), never by a
+        # stand-alone pass over a finished fp32 tensor: no plain step of the benchmarked configurations launches units_pack
+        packs = sorted(k for k in used if k.startswith("units_pack_kernel"))
+        assert not packs, f"the {arith} B={B} plain step still launches the stand-alone unit producer: {packs}"

@@ -178,3 +178,101 @@ def test_bias_act_bwd_units_equals_bias_act_bwd_then_pack(dev, planes, shape):
         assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max() + 1e-30)
     DU2, none, _, _, _ = ops.bias_act_bwd_units_raw(dout, out, epi(), planes=planes)
     assert none is None and torch.equal(DU2.data.view(torch.int16), U_ref.data.view(torch.int16))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# UNIT SINKS (tbg.h, round 5): a producer launch writes units(out * scale) itself -- the bits of tbg_units_pack_f32(out, scale)
+# ----------------------------------------------------------------------------------------------------------------
+class _AlwaysSink(ops.UnitSink):
+    """a sink that is wanted whatever the consumer's geometry (the unit tests exercise the producers, not the dispatch rule)"""
+
+    def wanted(self, B, Cc, H, W):
+        return True
+
+
+def _check_sink(y, U, y_ref, scale, planes, what):
+    assert U is not None and U.planes == planes, what
+    assert torch.equal(y, y_ref), (what, "the fp32 output must not change with a sink", float((y - y_ref).abs().max()))
+    ref = ops.units_pack(y_ref, scale, planes=planes)
+    assert U.data.numel() == ref.data.numel(), what
+    same = torch.equal(U.data.view(torch.int16), ref.data.view(torch.int16))
+    if not same:
+        a, b = _planes(U), _planes(ref)
+        bad = (a != b).nonzero()
+        raise AssertionError((what, "unit tensor differs from units_pack", bad.shape[0], bad[:5].tolist()))
+
+
+SINK_CONVS = [  # (B, C, M, H, W, k, stride, pad, transposed, residual)
+    (2, 64, 128, 16, 64, 3, (1, 1), (1, 1), False, False),    # 128x128 tiles, one image per tile
+    (3, 32, 64, 8, 32, 3, (1, 1), (1, 1), False, False),      # 64-channel tile
+    (5, 128, 128, 4, 16, 3, (1, 1), (1, 1), False, False),    # several images per tile (ring from every image's borders)
+    (4, 64, 64, 2, 8, 1, (1, 1), (0, 0), False, True),        # 1x1 + residual (the discriminator block's output launch)
+    (2, 8, 64, 16, 64, 1, (1, 1), (0, 0), False, False),      # thin input (fromRGB-like)
+    (2, 64, 64, 9, 33, 3, (2, 2), (0, 0), False, False),      # strided VALID: 4 x 16 output
+    (16, 512, 512, 4, 16, 3, (1, 1), (1, 1), False, False),   # split-K: the sink rides on slab_epilogue_units
+]
+
+
+@pytest.mark.parametrize("arith", ["f32x3", "bf16"])
+@pytest.mark.parametrize("case", SINK_CONVS, ids=[str(c[:9]) for c in SINK_CONVS])
+def test_conv_unit_sink_equals_units_pack(dev, arith, case):
+    """tbg_conv2d_{x3,bf16} with tbg_epilogue.units_out (conv_epilogue's sink; tbg_slab_epilogue_units_f32 for split K): the unit
+    tensor -- interior, ring of zero units, every plane -- is bit for bit tbg_units_pack_f32 of the launch's own fp32 output times
+    the scale, and the fp32 output is bit for bit that of the launch without a sink."""
+    B, C, M, H, W, k, stride, pad, transposed, has_res = case
+    planes = 3 if arith == "f32x3" else 1
+    f = lambda t: t.float().to(dev).contiguous()
+    x, w = f(_rnd(B, C, H, W, seed=60)), f(_rnd(k, k, C, M, seed=61) / math.sqrt(k * k * C))
+    Ho, Wo = (H + 2 * pad[0] - k) // stride[0] + 1, (W + 2 * pad[1] - k) // stride[1] + 1
+    res = f(_rnd(B, M, Ho, Wo, seed=62)) if has_res else None
+    d, bias, scale = f(_rnd(B, M, seed=63).abs() + 0.5), f(_rnd(M, seed=64)), f(_rnd(B, M, seed=65))
+    with ops.compute_dtype(arith):
+        mk = lambda: (N.epilogue(alpha=0.5, bias=bias, residual=res, res_scale=0.7) if has_res else
+                      ops._lrelu_epi(out_scale=d, bias=bias, alpha=0.5))
+        pf = ops.pack_filter(w, False, False)
+        y_ref = ops.conv2d_raw(x, pf, M, k, k, (Ho, Wo), stride, pad, epi=mk())
+        for sc in (scale, None):
+            y, U = ops.conv2d_raw(x, pf, M, k, k, (Ho, Wo), stride, pad, epi=mk(), sink=_AlwaysSink(sc, "s1", M))
+            _check_sink(y, U, y_ref, sc, planes, ("conv2d_raw", case, sc is not None))
+
+
+@pytest.mark.parametrize("arith", ["f32x3", "bf16"])
+def test_conv_units_and_fir_unit_sinks_equal_units_pack(dev, arith):
+    """the same for tbg_conv2d_units (64- and 128-channel tiles), tbg_conv2d_units_s2 and the blur's sink form
+    (tbg_upfirdn2d_sep_f32 with units_out: fir_units_kernel), which must also reproduce upfirdn2d_tile_kernel's fp32 output."""
+    planes = 3 if arith == "f32x3" else 1
+    f = lambda t: t.float().to(dev).contiguous()
+    with ops.compute_dtype(arith):
+        for (B, C, M, H, W) in ((2, 64, 128, 16, 64), (1, 32, 64, 8, 32), (3, 64, 256, 8, 64)):
+            x, w = f(_rnd(B, C, H, W, seed=70)), f(_rnd(3, 3, C, M, seed=71) / math.sqrt(9 * C))
+            s, d, bias, nz, scale = (f(_rnd(B, C, seed=72)), f(_rnd(B, M, seed=73).abs() + 0.5), f(_rnd(M, seed=74)),
+                                     f(_rnd(B, 1, H, W, seed=75)), f(_rnd(B, M, seed=76)))
+            strength = f(torch.tensor(0.3, dtype=torch.float64))
+            XU = ops.units_pack(x, s)
+            pf = ops.pack_filter(w, False, False)
+            mk = lambda: ops._lrelu_epi(out_scale=d, bias=bias, noise=nz, strength=strength, alpha=0.25)
+            y_ref = ops.conv2d_units_raw(XU, pf, M, epi=mk())
+            y, U = ops.conv2d_units_raw(XU, pf, M, epi=mk(), sink=_AlwaysSink(scale, "up", M))
+            _check_sink(y, U, y_ref, scale, planes, ("conv2d_units_raw", B, C, M, H, W))
+        # stride-2 form: 17 x 65 -> 8 x 32
+        B, C, M = 2, 64, 128
+        t, w = f(_rnd(B, C, 17, 65, seed=80)), f(_rnd(3, 3, C, M, seed=81) / math.sqrt(9 * C))
+        bias, scale = f(_rnd(M, seed=82)), f(_rnd(B, M, seed=83))
+        TP = ops.units_pack_s2(t)
+        pf = ops.pack_filter(w, False, False)
+        mk = lambda: N.epilogue(alpha=0.3, bias=bias, act=N.ACT_LRELU, gain=1.1)
+        y_ref = ops.conv2d_units_s2_raw(TP, pf, M, epi=mk())
+        y, U = ops.conv2d_units_s2_raw(TP, pf, M, epi=mk(), sink=_AlwaysSink(None, "s1", M))
+        _check_sink(y, U, y_ref, None, planes, "conv2d_units_s2_raw")
+        # the blur behind the up-convolution (pad 1, gain-4 [1,3,3,1] x [1,3,3,1]) with the full epilogue, ragged and whole tiles
+        for (B, C, H, W) in ((2, 16, 8, 32), (1, 64, 32, 128), (3, 8, 5, 19)):
+            yu = f(_rnd(B, C, 2 * H + 1, 2 * W + 1, seed=90))
+            d, bias, nz, scale = f(_rnd(B, C, seed=91).abs() + 0.5), f(_rnd(C, seed=92)), f(_rnd(B, 1, 2 * H, 2 * W, seed=93)), f(_rnd(B, C, seed=94))
+            strength = f(torch.tensor(0.2, dtype=torch.float64))
+            k = ops.fir_kernel(dev, gain=4.0)
+            mk = lambda: ops._lrelu_epi(out_scale=d.reshape(-1), bias=bias, noise=nz, strength=strength, alpha=1.0)
+            y_tile = ops.upfirdn2d_raw(yu, k, pad=(1, 1, 1, 1), epi=mk())
+            y, U = ops.upfirdn2d_raw(yu, k, pad=(1, 1, 1, 1), epi=mk(), sink=_AlwaysSink(scale, "s1", C))
+            # against the tile kernel: the same expression, but the compiler may contract multiply-adds differently (<= 2 ulp)
+            assert float((y - y_tile).abs().max()) <= 4e-7 * float(y_tile.abs().max()), ("fir sink vs tile kernel", B, C, H, W)
+            _check_sink(y, U, y, scale, planes, ("fir_units_kernel", B, C, H, W))

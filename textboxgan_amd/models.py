@@ -236,13 +236,17 @@ class SynthesisBlock(nn.Module):
         self.apply_noise_1 = Noise()
         self.apply_bias_act_1 = BiasAct(fmaps, 1.0, "lrelu")
 
-    def forward(self, x, w0, w1, noise0, noise1, mode="fused", s0=None, s1=None, d0=None, d1=None):
+    def forward(self, x, w0, w1, noise0, noise1, mode="fused", s0=None, s1=None, d0=None, d1=None, next_sink=None):
+        """next_sink (fused mode): ops.UnitSink of the layer that consumes this block's output (the next block's up-convolution):
+        conv_1's epilogue then writes that layer's unit tensor; conv_0's FIR epilogue always writes conv_1's."""
         for conv, nz, ba, style, noise, s, d in ((self.conv_0, self.apply_noise_0, self.apply_bias_act_0, w0, noise0, s0, d0),
                                                  (self.conv_1, self.apply_noise_1, self.apply_bias_act_1, w1, noise1, s1, d1)):
             s = conv.style(style, mode) if s is None else s
             if mode == "fused":
                 fn = ops.modconv_up_fused if conv.up else ops.modconv_fused
-                x = fn(x, conv.w, s, noise, nz.noise_strength, ba.b)
+                # the product the NEXT convolution contracts is (this output) * (its style): written by this layer's epilogue
+                sink = (ops.UnitSink(s1, "s1", self.conv_1.w.shape[3]) if s1 is not None else None) if conv.up else next_sink
+                x = fn(x, conv.w, s, noise, nz.noise_strength, ba.b, sink=sink)
             elif mode == "fused2":  # twice-differentiable fused layer: two autograd nodes with hand-written gradients
                 x = ops2.mod_layer2(x, conv.w, s, conv.demod(s, mode) if d is None else d, noise, nz.noise_strength, ba.b,
                                     up=conv.up)
@@ -304,8 +308,11 @@ class Synthesis(nn.Module):
                 d_c0[i], d_c1[i] = dd[1 + 3 * i], dd[2 + 3 * i]
         y = self.initial_torgb(x, ws[0], None, mode, s=s_tr[0])
         for i, (block, torgb) in enumerate(zip(self.synth_blocks, self.torgbs)):
+            nxt = None
+            if mode == "fused" and i + 1 < nb:  # block i + 1 starts with the up-convolution conv_0 (style s_c0[i + 1])
+                nxt = ops.UnitSink(s_c0[i + 1], "up", self.synth_blocks[i + 1].conv_0.w.shape[3])
             x = block(x, ws[3 * i], ws[3 * i + 1], noises[2 * i], noises[2 * i + 1], mode, s0=s_c0[i], s1=s_c1[i],
-                      d0=d_c0[i], d1=d_c1[i])
+                      d0=d_c0[i], d1=d_c1[i], next_sink=nxt)
             y = ops.upfirdn2d(y, k_up, up=(2, 2), pad=(2, 1, 2, 1))  # upsample_2d, :152
             last = i == nb - 1
             y = torgb(x, ws[3 * i + 2], y, mode, s=s_tr[i + 1], colmask=colmask if last else None, mask_cw=mask_cw if last else 0)
@@ -362,9 +369,9 @@ class FromRGB(nn.Module):
         self.conv = Conv2D(3, fmaps, 1)
         self.apply_bias_act = BiasAct(fmaps, 1.0, "lrelu")
 
-    def forward(self, x, mode="fused"):
+    def forward(self, x, mode="fused", next_sink=None):
         if mode == "fused":
-            return ops.conv_bias_act_fused(x, self.conv.w, self.apply_bias_act.b, role="d_image")
+            return ops.conv_bias_act_fused(x, self.conv.w, self.apply_bias_act.b, role="d_image", sink=next_sink)
         return ops.bias_act_c(ops.conv2d(x, self.conv.w, alpha=_coef(self.conv.w.shape)), None, None, self.apply_bias_act.b)
 
 
@@ -380,7 +387,8 @@ class DiscriminatorBlock(nn.Module):
         self.apply_bias_act_1 = BiasAct(n_f1, 1.0, "lrelu")
         self.conv_skip = Conv2D(n_f0, n_f1, 1)
 
-    def forward(self, x, mode="fused"):
+    def forward(self, x, mode="fused", next_sink=None):
+        """next_sink (fused mode): ops.UnitSink of the next block's conv_0 -- the residual sum's launch writes its unit tensor."""
         sh = 2 if self.reduce_height else 1
         k = ops.fir_kernel(x.device, 1.0)
         rs = 1.0 / math.sqrt(2.0)
@@ -398,7 +406,7 @@ class DiscriminatorBlock(nn.Module):
                 # blur + strided convolution with the blurred tensor as a phase unit tensor only (ops._BlurConvS2Fused)
                 u = ops.blur_conv_s2_fused(t, self.conv_1.w, self.apply_bias_act_1.b, role="d", out_mul=rs if fold else 1.0)
                 return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=1.0 if fold else rs,
-                                               role="d", out_mul=rs if fold else 1.0)
+                                               role="d", out_mul=rs if fold else 1.0, sink=next_sink)
             tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3), role="d")  # conv_downsample_2d, upfirdn_2d_v2.py:106-113
             if fold:
                 # (u + skip) / sqrt(2) with the factor folded into u's lrelu gain and the skip conv's scale: the sum and its
@@ -408,9 +416,10 @@ class DiscriminatorBlock(nn.Module):
                 # different order land on other bf16 rounding boundaries of the operands, and that metric is that sensitive
                 u = ops.conv_bias_act_fused(tb, self.conv_1.w, self.apply_bias_act_1.b, stride=(sh, 2), role="d", out_mul=rs)
                 return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=1.0, role="d",
-                                               out_mul=rs)
+                                               out_mul=rs, sink=next_sink)
             u = ops.conv_bias_act_fused(tb, self.conv_1.w, self.apply_bias_act_1.b, stride=(sh, 2), role="d")
-            return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=rs, role="d")
+            return ops.conv_bias_act_fused(xd, self.conv_skip.w, None, act=ACT_LINEAR, residual=u, res_scale=rs, role="d",
+                                           sink=next_sink)
         t = ops.bias_act_c(ops.conv2d(x, self.conv_0.w, (1, 1), (1, 1), alpha=_coef(self.conv_0.w.shape)), None, None,
                            self.apply_bias_act_0.b)
         tb = ops.upfirdn2d(t, k, pad=(2, 3, 2, 3))
@@ -474,12 +483,14 @@ class Discriminator(nn.Module):
         cuts: block indices k -- the activation ENTERING blocks[k] is returned too (``(scores, [h_k...])``), so that a
         caller can run the backward pass in stages (deep layers first) and exchange each stage's gradients while the next
         stage still computes (training_step.py: bucketed data-parallel all-reduce)."""
-        x = self.initial_fromrgb(images.contiguous(), mode)
+        # fused mode: every launch that produces a block's input also writes units(input) for that block's conv_0 (ops.UnitSink)
+        sink_of = lambda blk: ops.UnitSink(None, "s1", blk.conv_0.w.shape[3]) if mode == "fused" else None
+        x = self.initial_fromrgb(images.contiguous(), mode, next_sink=sink_of(self.blocks[0]))
         taps = []
         for i, block in enumerate(self.blocks):
             if cuts is not None and i in cuts:
                 taps.append(x)
-            x = block(x, mode)
+            x = block(x, mode, next_sink=sink_of(self.blocks[i + 1]) if i + 1 < len(self.blocks) else None)
         x = self.last_block(x, mode, parts)
         if mode == "fused":
             scores = ops.dense_bias_act(x, self.last_dense.w, self.last_bias.b,

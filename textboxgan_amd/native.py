@@ -219,6 +219,8 @@ def _call_key(name, a):
             return f"conv_wgrad_units_kernel<{a[3]}>"
         if name == "tbg_bias_act_bwd_units":  # dout out U planes ...
             return f"bias_act_bwd_units_kernel<{a[3]}>"
+        if name == "tbg_slab_epilogue_units_f32":  # x y B M H W nslab epi stream
+            return f"slab_epilogue_units_kernel<{a[7]._obj.units_planes}>"
         if name == "tbg_units_pack_f32":      # x scale U B C H W planes stream
             return f"units_pack_kernel<{a[7]}>"
         if name in ("tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_upfirdn2d_sep_f32"):
@@ -228,6 +230,8 @@ def _call_key(name, a):
                 minor, g = 1, a[6:16]
             else:                                # x kx ky y major inH inW kH kW upx upy downx downy padx0 padx1 pady0 pady1 ...
                 minor, g = 1, a[7:17]
+            if name == "tbg_upfirdn2d_sep_f32" and a[19] is not None and a[19]._obj.units_out:  # the blur's unit-sink form
+                return f"fir_units_kernel<{a[19]._obj.units_planes}>"
             kH, kW, upx, upy, dnx, dny, px0, _px1, py0, _py1 = g
             buf = C.create_string_buffer(96)
             _lib._l.tbg_upfirdn2d_kernel_name(minor, kH, kW, upx, upy, dnx, dny, px0, py0, int(name.endswith("sep_f32")), buf, 96)

@@ -237,9 +237,11 @@ def _sep_factors(k: torch.Tensor):
 # ----------------------------------------------------------------------------------------
 def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0),
                   in_scale: Optional[torch.Tensor] = None, epi: Optional[N.Epilogue] = None,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, sink: Optional["UnitSink"] = None):
     """x NCHW (treated as [B*C, H, W, 1], upfirdn_2d_v2.py:166-183); up/down = (x, y);
-    pad = (x0, x1, y0, y1).  out: a contiguous [B, C, outH, outW] tensor to write (e.g. a leading-batch view)."""
+    pad = (x0, x1, y0, y1).  out: a contiguous [B, C, outH, outW] tensor to write (e.g. a leading-batch view).
+    sink (the model's separable blur with an epilogue only): returns (y, UnitTensor | None) -- units(y * sink.scale) written by the
+    same launch (fir_units_kernel)."""
     B, Cc, H, W = x.shape
     kH, kW = k.shape
     outW = (W * up[0] + pad[0] + pad[1] - kW + down[0]) // down[0]
@@ -247,6 +249,17 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
     y = torch.empty((B, Cc, outH, outW), device=x.device, dtype=torch.float32) if out is None else out
     assert tuple(y.shape) == (B, Cc, outH, outW)
     sep = _sep_factors(k)
+    if sink is not None:
+        U = None
+        if sep is not None and epi is not None and tuple(up) == (1, 1) and tuple(down) == (1, 1):
+            epi, U = _sink_epi(epi, sink, B, Cc, outH, outW, x.device)
+        if U is None:
+            return upfirdn2d_raw(x, k, up, down, pad, in_scale, epi, out), None
+        _nb = 4.0 * (x.numel() + y.numel() + (B * outH * outW if epi.noise else 0)) + 2.0 * U.data.numel()
+        N.check(PROFILE.launch(f"fir_units_kernel<{U.planes}>", 0.0, lambda: N.lib().tbg_upfirdn2d_sep_f32(
+            N.ptr(x), N.ptr(sep[0]), N.ptr(sep[1]), N.ptr(y), B * Cc, H, W, kH, kW, 1, 1, 1, 1, pad[0], pad[1], pad[2], pad[3],
+            N.ptr(in_scale), Cc, C.byref(epi), N.stream()), nbytes=_nb), "tbg_upfirdn2d_sep (unit sink)")
+        return y, U
     if sep is not None:  # the model's filters: separable passes
         _nb = 4.0 * (x.numel() + y.numel() + (B * outH * outW if epi is not None and epi.noise else 0))
         rc = PROFILE.launch(f"upfirdn2d_tile_kernel up{up} down{down}", 0.0, lambda: N.lib().tbg_upfirdn2d_sep_f32(
@@ -267,10 +280,19 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
 
 def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_hw: Tuple[int, int], stride=(1, 1),
                pad=(0, 0), transposed=False, flip=False, in_scale=None, epi: Optional[N.Epilogue] = None,
-               ldw: Optional[int] = None, allow_split=True, dot=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               ldw: Optional[int] = None, allow_split=True, dot=None, out: Optional[torch.Tensor] = None,
+               sink: Optional["UnitSink"] = None):
     """w: a PackedFilter (pack_filter), or a tensor in GEMM layout [KH*KW, C, ldw] (any view with that memory layout,
     e.g. the HWIO parameter) which is packed here.
-    dot = (aux, out): out[b,m] = sum_p (alpha*acc)[b,m,p] * aux[b,m,p]  (fused when K is not split)."""
+    dot = (aux, out): out[b,m] = sum_p (alpha*acc)[b,m,p] * aux[b,m,p]  (fused when K is not split).
+    sink: returns (y, UnitTensor | None) -- units(y * sink.scale) written by the launch that writes y (the convolution's epilogue,
+    or the split-K pass's second half)."""
+    if sink is not None:
+        assert dot is None and out is None
+        epi = N.epilogue() if epi is None else epi
+        epi_s, U = _sink_epi(epi, sink, x.shape[0], M, out_hw[0], out_hw[1], x.device)
+        y = conv2d_raw(x, w, M, KH, KW, out_hw, stride, pad, transposed, flip, in_scale, epi_s, ldw, allow_split)
+        return y, U
     B, Cc, Hin, Win = x.shape
     if not isinstance(w, PackedFilter):
         ldw = M if ldw is None else ldw
@@ -325,7 +347,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         # slabs and applies the real epilogue.  (Also the route of a fused dot the tiling cannot serve -- several small
         # images per tile: one "slab", the dot from the finished accumulators.)
         slabs = torch.empty((ksplit, B, M, Hout, Wout), device=x.device, dtype=torch.float32)
-        e0 = N.epilogue(alpha=epi.alpha)
+        e0 = N.epilogue(alpha=epi.alpha)  # (store-only: a unit sink belongs to the second half)
         N.check(PROFILE.launch(_kname, _flops, lambda: _conv(
             C.byref(d), N.ptr(x), N.ptr(w), N.ptr(slabs), N.ptr(in_scale), C.byref(e0), N.stream()), _what, _bytes), _what)
         e1 = N.Epilogue.from_buffer_copy(epi)
@@ -343,6 +365,11 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         else:
             nslab = ksplit
         y = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32) if out is None else out
+        if e1.units_out:  # a unit sink rides on the split's second half
+            N.check(PROFILE.launch(f"slab_epilogue_units_kernel<{e1.units_planes}>", 0.0, lambda: N.lib().tbg_slab_epilogue_units_f32(
+                N.ptr(slabs), N.ptr(y), B, M, Hout, Wout, nslab, C.byref(e1), N.stream()),
+                nbytes=4.0 * (nslab + 1) * y.numel()), "tbg_slab_epilogue_units")
+            return y
         N.check(N.lib().tbg_slab_epilogue_f32(N.ptr(slabs), N.ptr(y), B, M, Hout * Wout, nslab, C.byref(e1), N.stream()),
                 "tbg_slab_epilogue")
         return y
@@ -410,6 +437,78 @@ def unit_planes(fmt=None) -> int:
     return {FMT_BF16: 1, FMT_X3: 3}[fmt]
 
 
+def units_alloc(B, Cc, H, W, planes, device) -> UnitTensor:
+    """an uninitialised unit tensor of the activation geometry [B, Cc, H, W] (a producer writes every unit, ring included)"""
+    nbytes = N.lib().tbg_units_bytes(B, Cc, H, W, planes)
+    N.check(min(nbytes, 0), "tbg_units_bytes")
+    return UnitTensor(torch.empty(nbytes // 2, device=device, dtype=torch.bfloat16), B, Cc, H, W, planes)
+
+
+class UnitSink:
+    """What a producer launch is asked to write BESIDE its fp32 result (tbg.h "UNIT SINK"): units(out * scale) for the convolution
+    that consumes ``out`` next -- scale = that convolution's style modulation s [B, C] (modulated_conv2d.py:94-96: x * s is exactly
+    what it and its filter gradient contract) or None for the discriminator's plain convolutions.  kind / O_next describe the
+    consumer ("s1": 3x3 stride-1 C -> O_next on the same grid; "up": the 3x3 stride-2 transposed up-convolution C -> O_next), so that
+    the producer can tell whether ANY launch of the consumer's forward or backward takes unit tensors for this geometry; if none
+    does, nothing is written."""
+    __slots__ = ("scale", "kind", "O_next")
+
+    def __init__(self, scale, kind: str, O_next: int):
+        assert kind in ("s1", "up")
+        self.scale, self.kind, self.O_next = scale, kind, int(O_next)
+
+    def wanted(self, B, Cc, H, W) -> bool:
+        if not (TUNING.use_units and TUNING.unit_sinks) or _FMT[_TLS.compute] == FMT_F32 or Cc % 8 != 0:
+            return False
+        if self.kind == "s1":
+            return _units_conv(B, Cc, self.O_next, H, W) or _units_wgrad(Cc, self.O_next, H, W)
+        return (_units_t2(B, Cc, self.O_next, H, W, 2 * H + 1, 2 * W + 1) or
+                _units_s2(B, self.O_next, Cc, 2 * H + 1, 2 * W + 1))  # (the up-convolution's backward: stride-2 conv O_next -> C)
+
+
+class _NoSink(UnitSink):
+    def __init__(self):
+        self.scale, self.kind, self.O_next = None, "s1", 0
+
+    def wanted(self, B, Cc, H, W) -> bool:
+        return False
+
+
+_NO_SINK = _NoSink()  # "no sink" for the raw helpers' (y, units) return form
+
+
+def _sink_epi(epi: N.Epilogue, sink: Optional[UnitSink], B, M, H, W, device):
+    """(epilogue carrying the sink, UnitTensor | None) for a launch with the fp32 output geometry [B, M, H, W]"""
+    if sink is None or not sink.wanted(B, M, H, W):
+        return epi, None
+    U = units_alloc(B, M, H, W, unit_planes(), device)
+    e = N.Epilogue.from_buffer_copy(epi)
+    e.units_out, e.units_planes = N.ptr(U.data), U.planes
+    e.units_scale = N.ptr(sink.scale.contiguous()) if sink.scale is not None else None
+    return e, U
+
+
+def attach_units(t: torch.Tensor, U: Optional[UnitTensor], scale) -> torch.Tensor:
+    """remember on the activation tensor ``t`` that units(t * scale) exists (a Python attribute: the consumer layer finds it)"""
+    if U is not None:
+        t._tbg_units = (U, scale, None if scale is None else scale._version)
+    return t
+
+
+def take_units(x: torch.Tensor, scale, planes: Optional[int] = None) -> Optional[UnitTensor]:
+    """the unit tensor a producer attached to ``x`` -- if it holds exactly units(x * scale) in the current arithmetic's planes"""
+    hit = getattr(x, "_tbg_units", None)
+    if hit is None:
+        return None
+    U, sc, ver = hit
+    planes = unit_planes() if planes is None else planes
+    same = (sc is None and scale is None) or (sc is not None and scale is not None and sc.data_ptr() == scale.data_ptr() and
+                                              sc.shape == scale.shape and sc._version == ver)
+    if not same or U.planes != planes or (U.B, U.C, U.H, U.W) != tuple(x.shape):
+        return None
+    return U
+
+
 def units_pack(x: torch.Tensor, scale: Optional[torch.Tensor] = None, planes: Optional[int] = None) -> UnitTensor:
     """x [B,C,H,W] fp32 (x scale[b,c]) -> its unit tensor (stand-alone producer; fused producers write it from their epilogue)."""
     B, Cc, H, W = x.shape
@@ -449,11 +548,15 @@ def conv_units_ok(C_in, M, H, W, KH, KW, stride, pad, transposed, planes) -> boo
 
 
 def conv2d_units_raw(XU: UnitTensor, w: "PackedFilter", M: int, flip=False, epi: Optional[N.Epilogue] = None, dot=None,
-                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, sink: Optional["UnitSink"] = None):
     """3x3 stride-1 pad-1 convolution of the activation behind the unit tensor XU (its scale already inside) with a packed
-    filter of the matching format; fp32 NCHW output through the fused epilogue.  dot = (aux, out) as in conv2d_raw."""
+    filter of the matching format; fp32 NCHW output through the fused epilogue.  dot = (aux, out) as in conv2d_raw.
+    sink: returns (y, UnitTensor | None), see conv2d_raw."""
     assert w.fmt == (FMT_X3 if XU.planes == 3 else FMT_BF16) and w.C == XU.C and w.M >= M and w.T == 9
     B, H, W = XU.B, XU.H, XU.W
+    if sink is not None:
+        epi_s, U = _sink_epi(N.epilogue() if epi is None else epi, sink, B, M, H, W, XU.data.device)
+        return conv2d_units_raw(XU, w, M, flip, epi_s, dot, out), U
     d = N.ConvDesc(B, XU.C, M, H, W, H, W, 3, 3, 1, 1, 1, 1, 0, int(flip), w.M, 1)
     epi = N.epilogue() if epi is None else epi
     partial = None
@@ -529,11 +632,14 @@ def conv_units_s2_ok(C_in, M, Hin, Win, planes) -> bool:
 
 
 def conv2d_units_s2_raw(XP: PhaseUnitTensor, w: "PackedFilter", M: int, flip=False, epi: Optional[N.Epilogue] = None, dot=None,
-                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                        out: Optional[torch.Tensor] = None, sink: Optional["UnitSink"] = None):
     """3x3 stride-2 pad-0 convolution of the tensor behind the phase unit tensor XP with a packed filter of the matching format;
-    fp32 NCHW output through the fused epilogue.  dot = (aux, out) as in conv2d_raw."""
+    fp32 NCHW output through the fused epilogue.  dot = (aux, out) as in conv2d_raw.  sink: returns (y, UnitTensor | None)."""
     assert w.fmt == (FMT_X3 if XP.planes == 3 else FMT_BF16) and w.C == XP.C and w.M >= M and w.T == 9
     B, Ho, Wo = XP.B, XP.Ho, XP.Wo
+    if sink is not None:
+        epi_s, U = _sink_epi(N.epilogue() if epi is None else epi, sink, B, M, Ho, Wo, XP.data.device)
+        return conv2d_units_s2_raw(XP, w, M, flip, epi_s, dot, out), U
     d = N.ConvDesc(B, XP.C, M, XP.Hin, XP.Win, Ho, Wo, 3, 3, 2, 2, 0, 0, 0, int(flip), w.M, 1)
     epi = N.epilogue() if epi is None else epi
     partial = None
@@ -1207,10 +1313,19 @@ def _units_t2(B, C_in, M, H, W, Hout, Wout) -> bool:
     return N.lib().tbg_conv2d_units_t2_blocks(C.byref(d), unit_planes(fmt)) >= TUNING.units_min_blocks
 
 
-def _unit_tensor(data, like: torch.Tensor, planes=None) -> UnitTensor:
-    """re-wrap the flat buffer of a unit tensor saved by a forward pass"""
+def _unit_tensor(data, like: torch.Tensor, planes=None) -> Optional[UnitTensor]:
+    """re-wrap the flat buffer of a unit tensor saved by a forward pass.  The plane count is read off the buffer's SIZE, not off
+    the current arithmetic (a forward in bf16 and a backward in f32x3 would otherwise read 3 planes from a 1-plane
+    buffer); a tensor whose planes do not match the arithmetic now in force is not reused (None: the caller packs again)."""
+    if data is None:
+        return None
     B, Cc, H, W = like.shape
-    return UnitTensor(data, B, Cc, H, W, unit_planes() if planes is None else planes)
+    per_plane = N.lib().tbg_units_bytes(B, Cc, H, W, 1) // 2
+    have = data.numel() // per_plane
+    want = unit_planes() if planes is None else planes
+    if have * per_plane != data.numel() or have != want:
+        return None
+    return UnitTensor(data, B, Cc, H, W, have)
 
 
 class _Bwd3x3:
@@ -1274,33 +1389,40 @@ class _ModConvFused(torch.autograd.Function):
     """out = lrelu(d * coef*conv(s*x, w) + noise*strength + b) * sqrt2   (3x3, SAME), d = demodulation of (s, w).
     modulated_conv2d.py:66-122 (activation-scaling form :94-96,:119-121) + noise.py + bias_act.py.  The demodulation
     coefficients and their gradient live inside the node: the filter-gradient launch adds the demodulation term
-    2 coef^2 w * dwsq while it writes dW (tbg_conv2d_wgrad_ex_f32), so no extra pass over the filter is needed."""
+    2 coef^2 w * dwsq while it writes dW (tbg_conv2d_wgrad_ex_f32), so no extra pass over the filter is needed.
+    Unit tensors: units(x * s) comes from the layer that produced x (take_units) or is packed here; with ``sink`` this launch's
+    epilogue writes units(out * sink.scale) for the next layer (second output: its flat buffer, non-differentiable)."""
 
     @staticmethod
-    def forward(ctx, x, w, s, noise, strength, b):
+    def forward(ctx, x, w, s, noise, strength, b, sink=None):
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
         assert x.shape[0] == s.shape[0] and s.shape[1] == I, "one style row per sample (a short batch must not reach the fused layers)"
+        XU = take_units(x, s) if (x.is_contiguous() and s.is_contiguous()) else None
         x = x.contiguous(); s = s.contiguous()
         d, wsq = demod_coefs_raw(s, w.contiguous(), coef)
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=coef)
-        xu = None
-        if KH == 3 and _units_conv(x.shape[0], I, O, x.shape[2], x.shape[3]):
-            # x * s written ONCE as a unit tensor: this launch DMAs its halo tiles from it, and the filter gradient of the
+        B, H, W = x.shape[0], x.shape[2], x.shape[3]
+        if KH == 3 and _units_conv(B, I, O, H, W):
+            # x * s exists ONCE as a unit tensor: this launch DMAs its halo tiles from it, and the filter gradient of the
             # backward pass consumes the same tensor (modulated_conv2d.py:94-96: both use exactly this product)
-            XU = units_pack(x, s)
-            out = conv2d_units_raw(XU, pack_filter(w, False, False), O, epi=epi)
-            xu = XU.data
+            XU = units_pack(x, s) if XU is None else XU
+            out, U = conv2d_units_raw(XU, pack_filter(w, False, False), O, epi=epi, sink=sink or _NO_SINK)
         else:
-            out = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (x.shape[2], x.shape[3]), (1, 1), (KH // 2, KW // 2),
-                             in_scale=s, epi=epi)
-        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, xu)
+            out, U = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (H, W), (1, 1), (KH // 2, KW // 2), in_scale=s, epi=epi,
+                                sink=sink or _NO_SINK)
+            if XU is not None and not (KH == 3 and _units_wgrad(I, O, H, W)):
+                XU = None  # nobody in the backward pass reads it
+        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, XU.data if XU is not None else None)
         ctx.coef = coef
-        return out
+        if U is None:
+            return out, None
+        ctx.mark_non_differentiable(U.data)
+        return out, U.data
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dout):
+    def backward(ctx, dout, _du=None):
         x, w, s, d, wsq, noise, strength, b, out, xu = ctx.saved_tensors
         KH, KW, I, O = w.shape
         coef = ctx.coef
@@ -1313,50 +1435,54 @@ class _ModConvFused(torch.autograd.Function):
             pdb, pdn, pdy = bw.from_bias_act(dout.contiguous(), out, epi, d, want_dn=True, want_dyy=True)  # units(dpre * d)
             dx = bw.dx(w, N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
             db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)  # (dwsq needs ds_conv)
-            dw = bw.dw(x, _unit_tensor(xu, x) if xu is not None else None, coef, x_scale=s, add=(w, dwsq, -coef * coef)) if want_dw else None
-            return dx, dw, ds, None, dstrength, db
+            dw = bw.dw(x, _unit_tensor(xu, x), coef, x_scale=s, add=(w, dwsq, -coef * coef)) if want_dw else None
+            return dx, dw, ds, None, dstrength, db, None
         _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
         dx = _bwd_data_launch(dpre, w, g, in_scale=d, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
         db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)
         dw = None
         if want_dw:
             dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef, x_scale=s, dy_scale=d, add=(w, dwsq, -coef * coef))
-        return dx, dw, ds, None, dstrength, db
+        return dx, dw, ds, None, dstrength, db, None
 
 
 class _ModConvUpFused(torch.autograd.Function):
     """out = lrelu(d * FIR(coef*convT_s2(s*x, flip w)) + noise*strength + b) * sqrt2.
     upfirdn_2d_v2.py:65-103 (upsample_conv_2d) + the same epilogue, the FIR pass carries the epilogue;
-    demodulation inside the node as in _ModConvFused."""
+    demodulation inside the node as in _ModConvFused.  Unit tensors as in _ModConvFused (the sink rides on the FIR launch)."""
 
     @staticmethod
-    def forward(ctx, x, w, s, noise, strength, b):
+    def forward(ctx, x, w, s, noise, strength, b, sink=None):
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
         assert x.shape[0] == s.shape[0] and s.shape[1] == I, "one style row per sample (a short batch must not reach the fused layers)"
+        XU = take_units(x, s) if (x.is_contiguous() and s.is_contiguous()) else None
         x = x.contiguous(); s = s.contiguous()
         d, wsq = demod_coefs_raw(s, w.contiguous(), coef)
-        H, W = x.shape[2], x.shape[3]
-        xu = None
-        if KH == 3 and _units_t2(x.shape[0], I, O, H, W, 2 * H + 1, 2 * W + 1):
-            # x * s written ONCE as a unit tensor: the transposed convolution DMAs its tiles from it, and the filter gradient of the
+        B, H, W = x.shape[0], x.shape[2], x.shape[3]
+        if KH == 3 and _units_t2(B, I, O, H, W, 2 * H + 1, 2 * W + 1):
+            # x * s exists ONCE as a unit tensor: the transposed convolution DMAs its tiles from it, and the filter gradient of the
             # backward pass contracts the same tensor with the blur^T phase tensor
-            XU = units_pack(x, s)
+            XU = units_pack(x, s) if XU is None else XU
             y_up = conv2d_units_t2_raw(XU, pack_filter(w, False, False), O, (2 * H + 1, 2 * W + 1), flip=True, alpha=coef)
-            xu = XU.data
         else:
             y_up = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True,
                               flip=True, in_scale=s, epi=N.epilogue(alpha=coef))
+            if XU is not None and not (KH == 3 and _units_s2(B, O, I, 2 * H + 1, 2 * W + 1)):
+                XU = None  # nobody in the backward pass reads it
         k = fir_kernel(x.device, gain=4.0)
         epi = _lrelu_epi(out_scale=d.reshape(-1), bias=b, noise=noise, strength=strength, alpha=1.0)
-        out = upfirdn2d_raw(y_up, k, pad=(1, 1, 1, 1), epi=epi)
-        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, xu)
+        out, U = upfirdn2d_raw(y_up, k, pad=(1, 1, 1, 1), epi=epi, sink=sink or _NO_SINK)
+        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, XU.data if XU is not None else None)
         ctx.coef = coef
-        return out
+        if U is None:
+            return out, None
+        ctx.mark_non_differentiable(U.data)
+        return out, U.data
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dout):
+    def backward(ctx, dout, _du=None):
         x, w, s, d, wsq, noise, strength, b, out, xu = ctx.saved_tensors
         KH, KW, I, O = w.shape
         coef = ctx.coef
@@ -1384,13 +1510,14 @@ class _ModConvUpFused(torch.autograd.Function):
             dw = torch.empty_like(w)
             # dW_t[t][i][o] = sum x*s . dy_up shifted;  w = flip(w_t)  -> write tap t at T-1-t
             if s2:
-                wgrad_units_s2_raw(_unit_tensor(xu, x) if xu is not None else units_pack(x, s), DYP, dw, -I * O, 1, O, coef,
+                XU = _unit_tensor(xu, x)
+                wgrad_units_s2_raw(XU if XU is not None else units_pack(x, s), DYP, dw, -I * O, 1, O, coef,
                                    out_offset=(T - 1) * I * O,
                                    add=(w, dwsq, -coef * coef))
             else:
                 wgrad_raw(x, dy_up, KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O,
                           add=(w, dwsq, -coef * coef))
-        return dx, dw, ds, None, dstrength, db
+        return dx, dw, ds, None, dstrength, db, None
 
 
 class _ToRGBFused(torch.autograd.Function):
@@ -1431,9 +1558,11 @@ class _ConvBiasActFused(torch.autograd.Function):
     conv.py:51-73 + bias_act.py:25-34; discriminator.py:68-84 for the residual form."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, stride, pad, act, res_scale, role, out_mul=1.0):
+    def forward(ctx, x, w, b, residual, stride, pad, act, res_scale, role, out_mul=1.0, sink=None):
         """out_mul: a constant folded into the launch -- the conv scale of a linear layer, the gain of an lrelu layer
-        (DiscriminatorBlock folds its 1/sqrt(2) into both branches so that no pass has to scale the sum or its gradient)."""
+        (DiscriminatorBlock folds its 1/sqrt(2) into both branches so that no pass has to scale the sum or its gradient).
+        sink: the convolution that consumes the result next (UnitSink): its unit tensor leaves this launch's epilogue; the
+        second output is that tensor's flat buffer (non-differentiable) or None."""
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
         gain = SQRT2 if act == ACT_LRELU else 1.0
@@ -1442,27 +1571,33 @@ class _ConvBiasActFused(torch.autograd.Function):
         else:
             coef *= out_mul
             assert b is None or out_mul == 1.0, "a bias would need the factor too"
+        XU = take_units(x, None) if x.is_contiguous() else None
         x = x.contiguous()
         H, W = x.shape[2], x.shape[3]
         yhw = ((H + 2 * pad[0] - KH) // stride[0] + 1, (W + 2 * pad[1] - KW) // stride[1] + 1)
         epi = N.epilogue(alpha=coef, bias=b, act=act, gain=gain, residual=residual, res_scale=res_scale)
-        xu = None
         ctx.s1_3x3 = KH == 3 and KW == 3 and stride == (1, 1) and pad == (1, 1)
         if ctx.s1_3x3 and _units_conv(x.shape[0], I, O, H, W):
-            XU = units_pack(x)  # written once: this launch's halo tiles and the backward pass's filter gradient read it
-            out = conv2d_units_raw(XU, pack_filter(w, False, False), O, epi=epi)
-            xu = XU.data
+            # units(x) exists once (written by the layer that produced x, or packed here): this launch's halo tiles and the
+            # backward pass's filter gradient read it
+            XU = units_pack(x) if XU is None else XU
+            out, U = conv2d_units_raw(XU, pack_filter(w, False, False), O, epi=epi, sink=sink or _NO_SINK)
         else:
-            out = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, yhw, stride, pad, epi=epi)
-        ctx.save_for_backward(x, w, b, out if act == ACT_LRELU else None, xu)
+            out, U = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, yhw, stride, pad, epi=epi, sink=sink or _NO_SINK)
+            if XU is not None and not (ctx.s1_3x3 and _units_wgrad(I, O, H, W)):
+                XU = None  # nobody in the backward pass reads it
+        ctx.save_for_backward(x, w, b, out if act == ACT_LRELU else None, XU.data if XU is not None else None)
         ctx.cfgv = (stride, pad, act, res_scale, coef, residual is not None, yhw)
         ctx.role = role
         ctx.gain = gain
-        return out
+        if U is None:
+            return out, None
+        ctx.mark_non_differentiable(U.data)
+        return out, U.data
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dout):
+    def backward(ctx, dout, _du=None):
         x, w, b, out, xu = ctx.saved_tensors
         stride, pad, act, res_scale, coef, has_res, yhw = ctx.cfgv
         KH, KW, I, O = w.shape
@@ -1527,12 +1662,12 @@ class _ConvBiasActFused(torch.autograd.Function):
                 _, G = rgb_backproject_raw(dpre, x, None, None, 1.0, want_dx=False, want_G=True)
                 dw = (coef * G.sum(dim=0).t()).reshape(w.shape).contiguous()
             elif bw is not None:
-                dw = bw.dw(x, _unit_tensor(xu, x) if (xu is not None and not h) else None, coef)
+                dw = bw.dw(x, _unit_tensor(xu, x) if not h else None, coef)
             else:
                 dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef)
         else:
             db = None
-        return dx, dw, db, dres, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
 class _ConvBiasActSkipFused(torch.autograd.Function):
@@ -1543,7 +1678,7 @@ class _ConvBiasActSkipFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, k, down, fpad, role):
-        out = _ConvBiasActFused.forward(ctx, x, w, b, None, (1, 1), (1, 1), ACT_LRELU, 1.0, role)  # (saves its tensors on ctx)
+        out, _ = _ConvBiasActFused.forward(ctx, x, w, b, None, (1, 1), (1, 1), ACT_LRELU, 1.0, role)  # (saves its tensors on ctx)
         ctx.fir = (k, tuple(down), tuple(fpad))
         return out, upfirdn2d_raw(x.contiguous(), k, (1, 1), down, fpad)
 
@@ -1656,13 +1791,24 @@ def blur_conv_s2_fused(x, w, b, role=None, out_mul=1.0):
     return _BlurConvS2Fused.apply(x, w, b, role, out_mul)
 
 
-def modconv_fused(x, w, s, noise, strength, b):
-    """demodulated 3x3 modulated conv + noise + bias + lrelu (demodulation computed inside the node)."""
-    return _ModConvFused.apply(x, w, s, noise, strength, b)
+def _with_units(out, u, sink):
+    """attach the unit tensor a fused layer wrote beside ``out`` (flat buffer ``u``) for the consumer named by ``sink``"""
+    if u is not None:
+        B, M, H, W = out.shape
+        attach_units(out, UnitTensor(u, B, M, H, W, unit_planes()), sink.scale)
+    return out
 
 
-def modconv_up_fused(x, w, s, noise, strength, b):
-    return _ModConvUpFused.apply(x, w, s, noise, strength, b)
+def modconv_fused(x, w, s, noise, strength, b, sink: Optional[UnitSink] = None):
+    """demodulated 3x3 modulated conv + noise + bias + lrelu (demodulation computed inside the node).
+    sink: the layer that consumes the result next (UnitSink): its unit tensor is written by this layer's epilogue."""
+    out, u = _ModConvFused.apply(x, w, s, noise, strength, b, sink)
+    return _with_units(out, u, sink)
+
+
+def modconv_up_fused(x, w, s, noise, strength, b, sink: Optional[UnitSink] = None):
+    out, u = _ModConvUpFused.apply(x, w, s, noise, strength, b, sink)
+    return _with_units(out, u, sink)
 
 
 def torgb_fused(x, w, s, b, skip=None, colmask=None, mask_cw=0):
@@ -1671,11 +1817,12 @@ def torgb_fused(x, w, s, b, skip=None, colmask=None, mask_cw=0):
 
 
 def conv_bias_act_fused(x, w, b, stride=(1, 1), pad=(0, 0), act=ACT_LRELU, residual=None, res_scale=1.0, role=None,
-                        out_mul=1.0):
+                        out_mul=1.0, sink: Optional[UnitSink] = None):
     """role: None (never pruned), "d" (a discriminator layer: its filter/bias gradients are skipped while
     FLAGS.skip_d_wgrad), "d_image" (the discriminator's fromRGB: additionally its input gradient is skipped while
-    FLAGS.skip_image_grad)."""
-    return _ConvBiasActFused.apply(x, w, b, residual, tuple(stride), tuple(pad), act, res_scale, role, float(out_mul))
+    FLAGS.skip_image_grad).  sink: the convolution that consumes the result next (its unit tensor is written by this launch)."""
+    out, u = _ConvBiasActFused.apply(x, w, b, residual, tuple(stride), tuple(pad), act, res_scale, role, float(out_mul), sink)
+    return _with_units(out, u, sink)
 
 
 class _DemodCoefs(torch.autograd.Function):
