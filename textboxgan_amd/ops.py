@@ -451,11 +451,16 @@ class UnitSink:
     consumer ("s1": 3x3 stride-1 C -> O_next on the same grid; "up": the 3x3 stride-2 transposed up-convolution C -> O_next), so that
     the producer can tell whether ANY launch of the consumer's forward or backward takes unit tensors for this geometry; if none
     does, nothing is written."""
-    __slots__ = ("scale", "kind", "O_next")
+    __slots__ = ("scale", "kind", "O_next", "produced")
 
     def __init__(self, scale, kind: str, O_next: int):
         assert kind in ("s1", "up")
         self.scale, self.kind, self.O_next = scale, kind, int(O_next)
+        # the UnitTensor the producer wrote (set inside the producing autograd node's forward; read by the layer wrapper, which
+        # attaches it to the output tensor).  Deliberately NOT a second output of the node: autograd materialises a zero
+        # "gradient" for every non-differentiable output in the backward pass -- a fill of the whole unit tensor per node and pass
+        # (measured: 20 launches, 0.25 ms per step, and the L2 pollution slowed the kernels behind them).
+        self.produced = None
 
     def wanted(self, B, Cc, H, W) -> bool:
         if not (TUNING.use_units and TUNING.unit_sinks) or _FMT[_TLS.compute] == FMT_F32 or Cc % 8 != 0:
@@ -468,7 +473,7 @@ class UnitSink:
 
 class _NoSink(UnitSink):
     def __init__(self):
-        self.scale, self.kind, self.O_next = None, "s1", 0
+        self.scale, self.kind, self.O_next, self.produced = None, "s1", 0, None
 
     def wanted(self, B, Cc, H, W) -> bool:
         return False
@@ -1391,7 +1396,7 @@ class _ModConvFused(torch.autograd.Function):
     coefficients and their gradient live inside the node: the filter-gradient launch adds the demodulation term
     2 coef^2 w * dwsq while it writes dW (tbg_conv2d_wgrad_ex_f32), so no extra pass over the filter is needed.
     Unit tensors: units(x * s) comes from the layer that produced x (take_units) or is packed here; with ``sink`` this launch's
-    epilogue writes units(out * sink.scale) for the next layer (second output: its flat buffer, non-differentiable)."""
+    epilogue writes units(out * sink.scale) for the next layer (handed back through sink.produced)."""
 
     @staticmethod
     def forward(ctx, x, w, s, noise, strength, b, sink=None):
@@ -1415,14 +1420,13 @@ class _ModConvFused(torch.autograd.Function):
                 XU = None  # nobody in the backward pass reads it
         ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, XU.data if XU is not None else None)
         ctx.coef = coef
-        if U is None:
-            return out, None
-        ctx.mark_non_differentiable(U.data)
-        return out, U.data
+        if sink is not None:
+            sink.produced = U
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dout, _du=None):
+    def backward(ctx, dout):
         x, w, s, d, wsq, noise, strength, b, out, xu = ctx.saved_tensors
         KH, KW, I, O = w.shape
         coef = ctx.coef
@@ -1460,7 +1464,9 @@ class _ModConvUpFused(torch.autograd.Function):
         x = x.contiguous(); s = s.contiguous()
         d, wsq = demod_coefs_raw(s, w.contiguous(), coef)
         B, H, W = x.shape[0], x.shape[2], x.shape[3]
-        if KH == 3 and _units_t2(B, I, O, H, W, 2 * H + 1, 2 * W + 1):
+        # (a map nobody wrote units for -- the word encoder's 2 x 8 output -- keeps the NCHW kernel unless it is big enough for a
+        # stand-alone pack launch's fixed cost to disappear in it)
+        if KH == 3 and _units_t2(B, I, O, H, W, 2 * H + 1, 2 * W + 1) and (XU is not None or H * W >= 256 or not TUNING.unit_sinks):
             # x * s exists ONCE as a unit tensor: the transposed convolution DMAs its tiles from it, and the filter gradient of the
             # backward pass contracts the same tensor with the blur^T phase tensor
             XU = units_pack(x, s) if XU is None else XU
@@ -1475,14 +1481,13 @@ class _ModConvUpFused(torch.autograd.Function):
         out, U = upfirdn2d_raw(y_up, k, pad=(1, 1, 1, 1), epi=epi, sink=sink or _NO_SINK)
         ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, XU.data if XU is not None else None)
         ctx.coef = coef
-        if U is None:
-            return out, None
-        ctx.mark_non_differentiable(U.data)
-        return out, U.data
+        if sink is not None:
+            sink.produced = U
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dout, _du=None):
+    def backward(ctx, dout):
         x, w, s, d, wsq, noise, strength, b, out, xu = ctx.saved_tensors
         KH, KW, I, O = w.shape
         coef = ctx.coef
@@ -1562,7 +1567,7 @@ class _ConvBiasActFused(torch.autograd.Function):
         """out_mul: a constant folded into the launch -- the conv scale of a linear layer, the gain of an lrelu layer
         (DiscriminatorBlock folds its 1/sqrt(2) into both branches so that no pass has to scale the sum or its gradient).
         sink: the convolution that consumes the result next (UnitSink): its unit tensor leaves this launch's epilogue; the
-        second output is that tensor's flat buffer (non-differentiable) or None."""
+        tensor is handed back through sink.produced."""
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
         gain = SQRT2 if act == ACT_LRELU else 1.0
@@ -1590,14 +1595,13 @@ class _ConvBiasActFused(torch.autograd.Function):
         ctx.cfgv = (stride, pad, act, res_scale, coef, residual is not None, yhw)
         ctx.role = role
         ctx.gain = gain
-        if U is None:
-            return out, None
-        ctx.mark_non_differentiable(U.data)
-        return out, U.data
+        if sink is not None:
+            sink.produced = U
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dout, _du=None):
+    def backward(ctx, dout):
         x, w, b, out, xu = ctx.saved_tensors
         stride, pad, act, res_scale, coef, has_res, yhw = ctx.cfgv
         KH, KW, I, O = w.shape
@@ -1678,7 +1682,7 @@ class _ConvBiasActSkipFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, k, down, fpad, role):
-        out, _ = _ConvBiasActFused.forward(ctx, x, w, b, None, (1, 1), (1, 1), ACT_LRELU, 1.0, role)  # (saves its tensors on ctx)
+        out = _ConvBiasActFused.forward(ctx, x, w, b, None, (1, 1), (1, 1), ACT_LRELU, 1.0, role)  # (saves its tensors on ctx)
         ctx.fir = (k, tuple(down), tuple(fpad))
         return out, upfirdn2d_raw(x.contiguous(), k, (1, 1), down, fpad)
 
@@ -1791,24 +1795,22 @@ def blur_conv_s2_fused(x, w, b, role=None, out_mul=1.0):
     return _BlurConvS2Fused.apply(x, w, b, role, out_mul)
 
 
-def _with_units(out, u, sink):
-    """attach the unit tensor a fused layer wrote beside ``out`` (flat buffer ``u``) for the consumer named by ``sink``"""
-    if u is not None:
-        B, M, H, W = out.shape
-        attach_units(out, UnitTensor(u, B, M, H, W, unit_planes()), sink.scale)
+def _with_units(out, sink):
+    """attach the unit tensor a fused layer wrote beside ``out`` (sink.produced) for the consumer named by ``sink``"""
+    if sink is not None and sink.produced is not None:
+        attach_units(out, sink.produced, sink.scale)
+        sink.produced = None
     return out
 
 
 def modconv_fused(x, w, s, noise, strength, b, sink: Optional[UnitSink] = None):
     """demodulated 3x3 modulated conv + noise + bias + lrelu (demodulation computed inside the node).
     sink: the layer that consumes the result next (UnitSink): its unit tensor is written by this layer's epilogue."""
-    out, u = _ModConvFused.apply(x, w, s, noise, strength, b, sink)
-    return _with_units(out, u, sink)
+    return _with_units(_ModConvFused.apply(x, w, s, noise, strength, b, sink), sink)
 
 
 def modconv_up_fused(x, w, s, noise, strength, b, sink: Optional[UnitSink] = None):
-    out, u = _ModConvUpFused.apply(x, w, s, noise, strength, b, sink)
-    return _with_units(out, u, sink)
+    return _with_units(_ModConvUpFused.apply(x, w, s, noise, strength, b, sink), sink)
 
 
 def torgb_fused(x, w, s, b, skip=None, colmask=None, mask_cw=0):
@@ -1821,8 +1823,8 @@ def conv_bias_act_fused(x, w, b, stride=(1, 1), pad=(0, 0), act=ACT_LRELU, resid
     """role: None (never pruned), "d" (a discriminator layer: its filter/bias gradients are skipped while
     FLAGS.skip_d_wgrad), "d_image" (the discriminator's fromRGB: additionally its input gradient is skipped while
     FLAGS.skip_image_grad).  sink: the convolution that consumes the result next (its unit tensor is written by this launch)."""
-    out, u = _ConvBiasActFused.apply(x, w, b, residual, tuple(stride), tuple(pad), act, res_scale, role, float(out_mul), sink)
-    return _with_units(out, u, sink)
+    return _with_units(_ConvBiasActFused.apply(x, w, b, residual, tuple(stride), tuple(pad), act, res_scale, role, float(out_mul), sink),
+                       sink)
 
 
 class _DemodCoefs(torch.autograd.Function):
