@@ -197,6 +197,12 @@ typedef struct tbg_wgrad_desc {
   int py, px;
   int st_t, st_l, st_s;
   float alpha;
+  /* optional rider (round 5): the BIAS gradient of the same layer, db[cs] = sum_{b < bias_B, k < bias_nch} bias_parts[(b*CS + cs)
+   * * bias_nch + k] -- the per-(sample, channel, chunk) partial sums tbg_bias_act_bwd_* left -- formed by one block of the launch
+   * that sums the filter gradient's partial tiles, instead of by a reduction launch of its own.  bias_grad NULL = off. */
+  const float *bias_parts;
+  float *bias_grad; /* [CS] */
+  int bias_B, bias_nch;
 } tbg_wgrad_desc;
 
 long long tbg_conv2d_wgrad_workspace_bytes(const tbg_wgrad_desc *d);
@@ -413,7 +419,8 @@ int tbg_attn_ctx_bwd_f32(const float *dctx, const float *a, const float *q, cons
  *               = data gradient of ToRGB plus the channel Gram from which d(weight) and d(style) follow;
  *               with dx = NULL the filter gradient of FromRGB (layers/from_rgb.py:26-29).  G holds
  *               tbg_rgb_backproject_chunks(HW) partial sums per (b, c): plain stores, no atomics, no zero-fill --
- *               deterministic; the caller adds them up.
+ *               deterministic; the caller adds them up (tbg_torgb_bwd_smalls_f32 does).  dysum (optional) [B, chunks, O] =
+ *               sum of dym over each pixel chunk: the partial sums of ToRGB's bias gradient.
  * Column mask m (NULL = 1): m[b,p] = colmask[b*ceil(maskW/maskCW) + (p % maskW) / maskCW] -- one value per maskCW-wide
  * column band of a row-major map of width maskW (HW % maskW == 0).
  * ---------------------------------------------------------------------------------------- */
@@ -423,7 +430,7 @@ int tbg_rgb_project_f32(const float *x, const float *w, const float *scale, cons
 int tbg_rgb_backproject_chunks(int HW);
 int tbg_rgb_backproject_f32(const float *x, const float *dy, const float *w, const float *scale,
                             float *dx, float *G, int B, int C, int O, int ldw, int HW, float alpha,
-                            const float *colmask, int maskW, int maskCW, float *dym, void *stream);
+                            const float *colmask, int maskW, int maskCW, float *dym, float *dysum, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * bias_act: stand-alone epilogue (x: [B,M,HW]) and its backward.
@@ -471,20 +478,22 @@ int tbg_bias_act_bwd2_f32(const float *c, const float *out_act, const float *dou
 /* ------------------------------------------------------------------------------------------
  * Small-tensor tails of the layer gradients: one launch each instead of a chain of tiny reductions / GEMMs.
  * tbg_modconv_bwd_smalls_f32 (modulated_conv2d.py:78-82, activation-scaling form), from the partial sums of
- * tbg_bias_act_bwd_f32 (pdb, pdn, pdy: [B,O,nch]), d [B,O], s [B,I], wsq [I,O] and the conv's style-dot ds_conv [B,I]:
- *   t[b,o] = (sum_ch pdy) d^2;  ds[b,i] = ds_conv - s * sum_o t wsq[i,o];  dwsq[i,o] = sum_b s^2 t;
+ * tbg_bias_act_bwd_f32 (pdb, pdn, pdy: [B,O,nch]), d [B,O], s [B,I], wsq [I,O] and the conv's style-dot ds_conv [B,I,ds_slots]
+ * (the data-gradient launch's dot_out partial sums as they are: summed here in slot order, round 5):
+ *   t[b,o] = (sum_ch pdy) d^2;  ds[b,i] = sum_slots ds_conv - s * sum_o t wsq[i,o];  dwsq[i,o] = sum_b s^2 t;
  *   db[o] = sum pdb;  dstrength = sum pdn (pdn / dstrength may both be NULL).
- * tbg_torgb_bwd_smalls_f32 (to_rgb.py:28-33), from the Gram G [B,C,O] of tbg_rgb_backproject_f32:
- *   ds[b,c] = coef sum_o G w[c,o];  dw[c,o] = coef sum_b G s[b,c].
+ * tbg_torgb_bwd_smalls_f32 (to_rgb.py:28-33), from the per-pixel-chunk Gram partials G [B,C,nchunk,O] and the masked-dy sums
+ * dysum [B,nchunk,O] of tbg_rgb_backproject_f32 (both summed here in chunk order; dysum / db may both be NULL):
+ *   ds[b,c] = coef sum_o G w[c,o];  dw[c,o] = coef sum_b G s[b,c];  db[o] = sum_{b,chunk} dysum.
  * tbg_minibatch_std_{fwd,bwd}_f32 (mini_batch_std.py:10-35, first order): x [B,C,HW] -> y [B,C+1,HW]; groups of
  * min(group, B) samples {g*M + m}; B must be a multiple of the group size (EINVAL otherwise, as the reference's reshape).
  * ---------------------------------------------------------------------------------------- */
 int tbg_modconv_bwd_smalls_f32(const float *pdb, const float *pdn, const float *pdy, const float *d,
                                const float *s, const float *wsq, const float *ds_conv, float *db,
                                float *dstrength, float *ds, float *dwsq, int B, int I, int O, int nch,
-                               void *stream);
+                               int ds_slots, void *stream);
 int tbg_torgb_bwd_smalls_f32(const float *G, const float *w, const float *s, float *ds, float *dw, int B,
-                             int C, int O, float coef, void *stream);
+                             int C, int O, float coef, int nchunk, const float *dysum, float *db, void *stream);
 int tbg_minibatch_std_fwd_f32(const float *x, float *y, int B, int C, int HW, int group, void *stream);
 int tbg_minibatch_std_bwd_f32(const float *x, const float *dy, float *dx, int B, int C, int HW, int group,
                               void *stream);

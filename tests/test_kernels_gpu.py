@@ -637,6 +637,10 @@ def test_modconv_bwd_smalls(dev):
         db, dstr, ds, dwsq = ops.modconv_bwd_smalls_raw(f(pdb), f(pdn), f(pdy), f(d), f(s), f(wsq), f(ds_conv))
         assert rel_err(db, pdb.sum(dim=(0, 2))) < 1e-5 and rel_err(dstr, pdn.sum()) < 1e-4
         assert rel_err(ds, ds_ref) < 2e-5 and rel_err(dwsq, dwsq_ref) < 2e-5
+        # round 5: the convolution's style dot arrives as its launch's partial slots [B, I, slots], summed by the kernel
+        parts = rnd(B, I, 5, seed=97)
+        _, _, ds_p, _ = ops.modconv_bwd_smalls_raw(f(pdb), f(pdn), f(pdy), f(d), f(s), f(wsq), f(parts))
+        assert rel_err(ds_p, parts.sum(dim=2) - s * (t @ wsq.t())) < 2e-5
 
 
 def test_torgb_bwd_smalls(dev):
@@ -647,6 +651,40 @@ def test_torgb_bwd_smalls(dev):
     ds, dw = ops.torgb_bwd_smalls_raw(f(G), f(w), f(s), coef)
     assert rel_err(ds, coef * (G * w[None]).sum(dim=2)) < 1e-5
     assert rel_err(dw, coef * (G * s[:, :, None]).sum(dim=0)) < 1e-5
+    # round 5: per-pixel-chunk partials of the Gram and of the masked dy, summed by the kernel (+ the bias gradient)
+    Gp, dys = rnd(B, Cc, 4, O, seed=100), rnd(B, 4, O, seed=101)
+    ds, dw, db = ops.torgb_bwd_smalls_raw(f(Gp), f(w), f(s), coef, dysum=f(dys))
+    Gs = Gp.sum(dim=2)
+    assert rel_err(ds, coef * (Gs * w[None]).sum(dim=2)) < 1e-5 and rel_err(dw, coef * (Gs * s[:, :, None]).sum(dim=0)) < 1e-5
+    assert rel_err(db, dys.sum(dim=(0, 1))) < 1e-5
+
+
+def test_rgb_backproject_parts_and_bias_rider(dev):
+    """(a) tbg_rgb_backproject_f32's dysum output = the per-chunk sums of the masked dy (ToRGB's bias gradient, to_rgb.py:28-33) and
+    its chunk partials of G add up to the summed form; (b) tbg_wgrad_desc's bias rider: db = sum of the bias_act backward's partial
+    sums, written by the filter gradient's reduce launch, for the NCHW and the unit-tensor filter gradients."""
+    from textboxgan_amd import ops
+    f = lambda a: a.float().to(dev).contiguous()
+    B, Cc, H, W = 3, 16, 64, 96   # 6144 pixels: three 2048-pixel chunks
+    x, dy, w, s = f(rnd(B, Cc, H, W, seed=110)), f(rnd(B, 3, H, W, seed=111)), f(rnd(Cc, 3, seed=112)), f(rnd(B, Cc, seed=113))
+    mask = f((rnd(B, W // 32, seed=114) > 0).double())
+    dx0, G0, dym0 = ops.rgb_backproject_raw(x, dy, w, s, 0.3, colmask=mask, mask_cw=32, want_dym=True)
+    dx1, Gp, dysum, dym1 = ops.rgb_backproject_raw(x, dy, w, s, 0.3, colmask=mask, mask_cw=32, want_dym=True, parts=True)
+    assert torch.equal(dx0, dx1) and torch.equal(dym0, dym1) and Gp.shape[2] == 3 and torch.equal(Gp.sum(dim=2), G0)
+    assert rel_err(dysum.sum(dim=(0, 1)), dym0.double().sum(dim=(0, 2, 3)).cpu()) < 1e-5
+    for arith, (B, I, O, H, W) in (("f32", (4, 24, 40, 8, 16)), ("f32x3", (2, 64, 64, 8, 32)), ("bf16", (2, 64, 128, 8, 32))):
+        with ops.compute_dtype(arith):
+            xx, dyy, parts = f(rnd(B, I, H, W, seed=120)), f(rnd(B, O, H, W, seed=121)), f(rnd(B, O, 3, seed=122))
+            g = ops._Geom((1, 1), (1, 1), 3, 3, (H, W), (H, W))
+            db = torch.full((O,), float("nan"), device=dev)
+            dw_ref = ops._bwd_weight_launch(xx, dyy, g, I, O, alpha=0.5)
+            dw = ops._bwd_weight_launch(xx, dyy, g, I, O, alpha=0.5, bias=(parts, db))
+            assert torch.equal(dw, dw_ref) and rel_err(db, parts.double().sum(dim=(0, 2)).cpu()) < 1e-5, arith
+            if arith != "f32":
+                db.fill_(float("nan"))
+                dwu = torch.empty(3, 3, I, O, device=dev)
+                ops.wgrad_units_raw(ops.units_pack(dyy), ops.units_pack(xx), dwu, I * O, O, 1, 0.5, bias=(parts, db))
+                assert rel_err(db, parts.double().sum(dim=(0, 2)).cpu()) < 1e-5, arith
 
 
 @pytest.mark.parametrize("B", [16, 4, 2, 32], ids=lambda b: f"B{b}")

@@ -2062,6 +2062,7 @@ static int wgrad_geometry(const tbg_wgrad_desc *d, WgradP &p, int &PIX, bool bf 
   p.B = d->B; p.CS = d->CS; p.CL = d->CL; p.Hs = d->Hs; p.Ws = d->Ws; p.Hl = d->Hl; p.Wl = d->Wl;
   p.KW = d->KW; p.sy = d->sy; p.sx = d->sx; p.py = d->py; p.px = d->px;
   p.st_t = d->st_t; p.st_l = d->st_l; p.st_s = d->st_s; p.alpha = d->alpha;
+  if (const int rcb = wgrad_bias_rider(p, d)) return rcb;
   const bool strided = d->sy == 2 || d->sx == 2;
   PIX = strided ? 32 : 64;
   int TW = 1, THs = 1;

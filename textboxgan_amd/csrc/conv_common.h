@@ -269,12 +269,40 @@ struct WgradP {
   int st_t, st_l, st_s;
   float alpha;
   int logTW, logTHs, NSEG, IHs, IWs, IWp, HALFW, lplane, ppc, NJ, nBG, tilesU, tilesV, nchunks, ksplit;
+  const float *bias_parts;  // rider of the reduce launch (tbg_wgrad_desc): db[cs] = sum of the bias_act backward's partial sums
+  float *bias_grad;
+  int bias_B, bias_nch;
 };
+
+static inline int wgrad_bias_rider(WgradP &p, const tbg_wgrad_desc *d) {
+  p.bias_parts = d->bias_parts; p.bias_grad = d->bias_grad; p.bias_B = d->bias_B; p.bias_nch = d->bias_nch;
+  if (d->bias_grad && (!d->bias_parts || d->bias_B < 1 || d->bias_nch < 1)) return TBG_EINVAL;
+  return TBG_OK;
+}
+
+// one block of a reduce launch: db[cs] = sum_{b, k} parts[(b * CS + cs) * nch + k], four independent chains per lane
+__device__ __forceinline__ void wgrad_bias_reduce(const WgradP &p) {
+  for (int m = threadIdx.x; m < p.CS; m += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= p.bias_B; b += 4)
+      for (int k = 0; k < p.bias_nch; ++k) {
+        a0 += p.bias_parts[((size_t)(b + 0) * p.CS + m) * p.bias_nch + k];
+        a1 += p.bias_parts[((size_t)(b + 1) * p.CS + m) * p.bias_nch + k];
+        a2 += p.bias_parts[((size_t)(b + 2) * p.CS + m) * p.bias_nch + k];
+        a3 += p.bias_parts[((size_t)(b + 3) * p.CS + m) * p.bias_nch + k];
+      }
+    for (; b < p.bias_B; ++b)
+      for (int k = 0; k < p.bias_nch; ++k) a0 += p.bias_parts[((size_t)b * p.CS + m) * p.bias_nch + k];
+    p.bias_grad[m] = (a0 + a1) + (a2 + a3);
+  }
+}
 
 // few output tiles, many partials: one block per (tile, tap, accumulator register) -- 16x more blocks than the
 // transposing kernel below, scattered 4-byte stores
 template <int WGS, int WGL, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_wide_kernel(const WgradP p) {
+  if (p.bias_grad && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) wgrad_bias_reduce(p);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ws_ = wave / WGL, wl = wave - ws_ * WGL;
   const int cs0 = blockIdx.x * (WGS * 32), cl0 = blockIdx.y * (WGL * 32);
@@ -318,6 +346,7 @@ template <int WGS, int WGL, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradP p) {
   constexpr int BS = WGS * 32, BL = WGL * 32;
   __shared__ float tile[BL][BS + 1];
+  if (p.bias_grad && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) wgrad_bias_reduce(p);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ws_ = wave / WGL, wl = wave - ws_ * WGL;
   const int cs0 = blockIdx.x * BS, cl0 = blockIdx.y * BL;

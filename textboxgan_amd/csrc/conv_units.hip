@@ -513,6 +513,7 @@ extern "C" int tbg_conv2d_wgrad_units(const tbg_wgrad_desc *d, const void *SU, c
   WgradP p{};  // what the reduce kernels read
   p.CS = d->CS; p.CL = d->CL; p.st_t = d->st_t; p.st_l = d->st_l; p.st_s = d->st_s; p.alpha = d->alpha;
   p.dW = dW; p.ws = workspace; p.addw = addw; p.addq = addq; p.gamma = gamma; p.ksplit = u.ksplit;
+  if (const int rcb = wgrad_bias_rider(p, d)) return rcb;
   return planes == 3 ? launch_wgrad_units<3>(u, p, tbg_stream(stream), nullptr) : launch_wgrad_units<1>(u, p, tbg_stream(stream), nullptr);
 }
 

@@ -731,6 +731,7 @@ extern "C" int tbg_conv2d_wgrad_units_s2(const tbg_wgrad_desc *d, const void *SU
   WgradP p{};  // what the reduce kernels read
   p.CS = d->CS; p.CL = d->CL; p.st_t = d->st_t; p.st_l = d->st_l; p.st_s = d->st_s; p.alpha = d->alpha;
   p.dW = dW; p.ws = workspace; p.addw = addw; p.addq = addq; p.gamma = gamma; p.ksplit = u.ksplit;
+  if (const int rcb = wgrad_bias_rider(p, d)) return rcb;
   return planes == 3 ? launch_wgrad_units_s2<3>(u, p, tbg_stream(stream)) : launch_wgrad_units_s2<1>(u, p, tbg_stream(stream));
 }
 

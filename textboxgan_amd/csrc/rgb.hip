@@ -10,7 +10,7 @@
 
 struct RgbP {
   const float *x, *w, *scale, *bias, *skip, *dy, *colmask;
-  float *y, *dx, *G, *dym;
+  float *y, *dx, *G, *dym, *dysum;
   int B, C, O, ldw, HW;
   int maskW, maskCW, maskN;  // colmask [B][maskN]: pixel p of a row-major map of width maskW takes colmask[b][(p % maskW) / maskCW]
   float alpha, bias_mul;
@@ -131,6 +131,14 @@ __global__ __launch_bounds__(256) void rgb_backproject_kernel(const RgbP p) {
     dys[o][px] = v;
   }
   __syncthreads();
+  if (p.dysum && blockIdx.y == 0) {  // sum_p dym[b,o,p] over this pixel chunk (the bias gradient's partial sums): wave o sums row o
+    if (wave < p.O) {
+      float a = 0.f;
+      for (int px = lane; px < RGB_CHUNK; px += 64) a += dys[wave][px];  // (positions past npx hold zeros)
+      a = wave_sum(a);
+      if (lane == 0) p.dysum[((size_t)b * gridDim.x + blockIdx.x) * p.O + wave] = a;
+    }
+  }
   const bool vec = (p.HW & 3) == 0;
   for (int cc = wave; cc < RGB_CPB; cc += 4) {
     const int c = blockIdx.y * RGB_CPB + cc;
@@ -223,13 +231,13 @@ extern "C" int tbg_rgb_backproject_chunks(int HW) { return HW < 1 ? -1 : (HW + R
 
 extern "C" int tbg_rgb_backproject_f32(const float *x, const float *dy, const float *w, const float *scale, float *dx,
                                        float *G, int B, int C, int O, int ldw, int HW, float alpha, const float *colmask,
-                                       int maskW, int maskCW, float *dym, void *stream) {
+                                       int maskW, int maskCW, float *dym, float *dysum, void *stream) {
   if (!dy || B < 1 || C < 1 || O < 1 || O > RGB_MAXO || HW < 1 || (!dx && !G)) return TBG_EINVAL;
   if ((dx && (!w || ldw < O)) || (G && !x)) return TBG_EINVAL;
   if (!rgb_mask_ok(colmask, maskW, maskCW, HW)) return TBG_EINVAL;
   if ((double)B * C * HW > 2147483647.0) return TBG_ERANGE;
   RgbP p{};
-  p.x = x; p.dy = dy; p.w = w; p.scale = scale; p.dx = dx; p.G = G; p.dym = dym;
+  p.x = x; p.dy = dy; p.w = w; p.scale = scale; p.dx = dx; p.G = G; p.dym = dym; p.dysum = dysum;
   p.B = B; p.C = C; p.O = O; p.ldw = ldw; p.HW = HW; p.alpha = alpha;
   p.colmask = colmask; p.maskW = colmask ? maskW : 1; p.maskCW = colmask ? maskCW : 1;
   p.maskN = colmask ? (maskW + maskCW - 1) / maskCW : 1;

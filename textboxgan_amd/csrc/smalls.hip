@@ -14,7 +14,7 @@
 struct ModSmallP {
   const float *pdb, *pdn, *pdy, *d, *s, *wsq, *ds_conv;
   float *db, *dstrength, *ds, *dwsq;
-  int B, I, O, nch;
+  int B, I, O, nch, ds_slots;
 };
 
 #define MS_IT 2  // input channels per block: 256 blocks at I = 512 (16: 33 blocks, 30 us; 4: 12.6 us; 2: 11.3 us at B = 16, 16.2 vs 20.8 at B = 32 -- the per-block LDS dot chains scale with it, tools/bench_smalls.py)
@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP
     if (i0 + ii < p.I) {
       const float a = part[4 * pair] + part[4 * pair + 1] + part[4 * pair + 2] + part[4 * pair + 3];
       const size_t idx = (size_t)b * p.I + i0 + ii;
-      p.ds[idx] = p.ds_conv[idx] - s2[pair] * a;
+      float dsc = 0.f;  // the convolution's style dot: its per-(pixel tile, wave column) partial sums, in slot order
+      for (int k = 0; k < p.ds_slots; ++k) dsc += p.ds_conv[idx * p.ds_slots + k];
+      p.ds[idx] = dsc - s2[pair] * a;
     }
   }
   for (int e = tid; e < MS_IT * p.O; e += 256) {  // dwsq
@@ -165,16 +167,16 @@ __global__ __launch_bounds__(256) void modconv_bwd_smalls_kernel(const ModSmallP
 extern "C" int tbg_modconv_bwd_smalls_f32(const float *pdb, const float *pdn, const float *pdy, const float *d,
                                           const float *s, const float *wsq, const float *ds_conv, float *db,
                                           float *dstrength, float *ds, float *dwsq, int B, int I, int O, int nch,
-                                          void *stream) {
+                                          int ds_slots, void *stream) {
   if (!pdb || !pdy || !d || !s || !wsq || !ds_conv || !db || !ds || !dwsq) return TBG_EINVAL;
-  if (B < 1 || I < 1 || O < 1 || nch < 1 || ((pdn == nullptr) != (dstrength == nullptr))) return TBG_EINVAL;
+  if (B < 1 || I < 1 || O < 1 || nch < 1 || ds_slots < 1 || ((pdn == nullptr) != (dstrength == nullptr))) return TBG_EINVAL;
   const size_t lds = ((size_t)B * O + (size_t)MS_IT * O + (size_t)B * MS_IT * 5) * sizeof(float);
   if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void *>(modconv_bwd_smalls_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
     return TBG_EHIP;
-  ModSmallP p{pdb, pdn, pdy, d, s, wsq, ds_conv, db, dstrength, ds, dwsq, B, I, O, nch};
+  ModSmallP p{pdb, pdn, pdy, d, s, wsq, ds_conv, db, dstrength, ds, dwsq, B, I, O, nch, ds_slots};
   const int blocks = (I + MS_IT - 1) / MS_IT + (O + 255) / 256;
   hipLaunchKernelGGL(modconv_bwd_smalls_kernel, dim3(blocks), dim3(256), lds, tbg_stream(stream), p);
   TBG_LAUNCH_CHECK();
@@ -187,28 +189,43 @@ extern "C" int tbg_modconv_bwd_smalls_f32(const float *pdb, const float *pdn, co
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void torgb_bwd_smalls_kernel(const float *__restrict__ G, const float *__restrict__ w,
                                                               const float *__restrict__ s, float *__restrict__ ds,
-                                                              float *__restrict__ dw, int B, int C, int O, float coef) {
+                                                              float *__restrict__ dw, int B, int C, int O, float coef, int nchunk,
+                                                              const float *__restrict__ dysum, float *__restrict__ db) {
+  // G [B][C][nchunk][O]: per-pixel-chunk partial sums of tbg_rgb_backproject_f32, summed here in chunk order
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < B * C) {
     const int c = e % C;
     float a = 0.f;
-    for (int o = 0; o < O; ++o) a += G[(size_t)e * O + o] * w[c * O + o];
+    for (int o = 0; o < O; ++o) {
+      float g = 0.f;
+      for (int k = 0; k < nchunk; ++k) g += G[((size_t)e * nchunk + k) * O + o];
+      a += g * w[c * O + o];
+    }
     ds[e] = a * coef;
   }
   if (e < C * O) {
     const int c = e / O, o = e - c * O;
     float a = 0.f;
-    for (int b = 0; b < B; ++b) a += G[((size_t)b * C + c) * O + o] * s[(size_t)b * C + c];
+    for (int b = 0; b < B; ++b) {
+      float g = 0.f;
+      for (int k = 0; k < nchunk; ++k) g += G[(((size_t)b * C + c) * nchunk + k) * O + o];
+      a += g * s[(size_t)b * C + c];
+    }
     dw[e] = a * coef;
+  }
+  if (db && e < O) {  // db[o] = sum_{b, chunk} dysum[b][chunk][o]  (the bias gradient: sum of the masked dy over samples and pixels)
+    float a = 0.f;
+    for (int i = 0; i < B * nchunk; ++i) a += dysum[(size_t)i * O + e];
+    db[e] = a;
   }
 }
 
 extern "C" int tbg_torgb_bwd_smalls_f32(const float *G, const float *w, const float *s, float *ds, float *dw, int B, int C,
-                                        int O, float coef, void *stream) {
-  if (!G || !w || !s || !ds || !dw || B < 1 || C < 1 || O < 1) return TBG_EINVAL;
+                                        int O, float coef, int nchunk, const float *dysum, float *db, void *stream) {
+  if (!G || !w || !s || !ds || !dw || B < 1 || C < 1 || O < 1 || nchunk < 1 || ((dysum == nullptr) != (db == nullptr))) return TBG_EINVAL;
   const int n = B * C > C * O ? B * C : C * O;
   hipLaunchKernelGGL(torgb_bwd_smalls_kernel, dim3((n + 255) / 256), dim3(256), 0, tbg_stream(stream), G, w, s, ds, dw, B, C, O,
-                     coef);
+                     coef, nchunk, dysum, db);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }

@@ -277,8 +277,14 @@ class Synthesis(nn.Module):
     def forward(self, x, style, noises: Optional[List[torch.Tensor]] = None, mode="fused", colmask=None, mask_cw=0):
         """colmask / mask_cw: the text-box mask of the final image, applied inside the last toRGB launch."""
         B = x.shape[0]
-        if noises is None:  # fresh noise on every call, also at inference (noise.py:16-19)
-            noises = [torch.randn(s, device=x.device) for s in self.noise_shapes(B)]
+        if noises is None:  # fresh noise on every call, also at inference (noise.py:16-19): ONE generator launch for all ten maps
+            shapes = self.noise_shapes(B)
+            sizes = [b_ * c_ * h_ * w_ for (b_, c_, h_, w_) in shapes]
+            flat = torch.randn(sum(-(-n // 4) * 4 for n in sizes), device=x.device)  # (every map starts 16-byte aligned)
+            noises, o = [], 0
+            for shp, n in zip(shapes, sizes):
+                noises.append(flat[o:o + n].view(shp))
+                o += -(-n // 4) * 4
         k_up = ops.fir_kernel(x.device, 4.0)
         ws = style.unbind(dim=1)  # one node: its backward is ONE stack of the per-layer latent gradients (16 selects
         # would each zero-fill a [B, n, 512] tensor and be summed pairwise by the autograd engine)

@@ -61,8 +61,10 @@ class ConvDesc(C.Structure):
 
 
 class WgradDesc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "CS", "CL", "Hs", "Ws", "Hl", "Wl", "KH", "KW", "sy", "sx", "py", "px",
-                                       "st_t", "st_l", "st_s")] + [("alpha", C.c_float)]
+    _fields_ = ([(n, C.c_int) for n in ("B", "CS", "CL", "Hs", "Ws", "Hl", "Wl", "KH", "KW", "sy", "sx", "py", "px",
+                                        "st_t", "st_l", "st_s")] + [("alpha", C.c_float)] +
+                # rider: the layer's bias gradient summed by the filter gradient's reduce launch (tbg.h)
+                [("bias_parts", C.c_void_p), ("bias_grad", C.c_void_p), ("bias_B", C.c_int), ("bias_nch", C.c_int)])
 
 
 _lib = None
@@ -105,10 +107,10 @@ def lib():
         l.tbg_conv2d_wgrad_bf16.argtypes = [C.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, vp, cf, vp, ll, vp]
         l.tbg_weight_pack_bf16.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
         l.tbg_weight_pack_multi.argtypes = [vp, ci, vp]
-        l.tbg_modconv_bwd_smalls_f32.argtypes = [vp] * 11 + [ci] * 4 + [vp]
+        l.tbg_modconv_bwd_smalls_f32.argtypes = [vp] * 11 + [ci] * 5 + [vp]
         l.tbg_axpby_planes_f32.argtypes = [vp] * 7 + [ci, ci, vp]
         l.tbg_bias_act_bwd2_f32.argtypes = [vp] * 6 + [ci, ci, ci, C.POINTER(Epilogue), vp]
-        l.tbg_torgb_bwd_smalls_f32.argtypes = [vp] * 5 + [ci] * 3 + [cf, vp]
+        l.tbg_torgb_bwd_smalls_f32.argtypes = [vp] * 5 + [ci] * 3 + [cf, ci, vp, vp, vp]
         l.tbg_minibatch_std_fwd_f32.argtypes = [vp, vp, ci, ci, ci, ci, vp]
         l.tbg_minibatch_std_bwd_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
         l.tbg_dense_fwd_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, cf, cf, ci, cf, vp]
@@ -160,7 +162,7 @@ def lib():
         l.tbg_slab_epilogue_units_f32.argtypes = [vp, vp, ci, ci, ci, ci, ci, C.POINTER(Epilogue), vp]
         l.tbg_bias_act_bwd_f32.argtypes = [vp] * 7 + [ci, ci, ci, C.POINTER(Epilogue), vp]
         l.tbg_rgb_project_f32.argtypes = [vp] * 6 + [ci] * 5 + [cf, cf, vp, ci, ci, vp]
-        l.tbg_rgb_backproject_f32.argtypes = [vp] * 6 + [ci] * 5 + [cf, vp, ci, ci, vp, vp]
+        l.tbg_rgb_backproject_f32.argtypes = [vp] * 6 + [ci] * 5 + [cf, vp, ci, ci, vp, vp, vp]
         l.tbg_rgb_backproject_chunks.argtypes = [ci]
         l.tbg_adam_tf_f32.argtypes = [vp, vp, vp, vp, ll, cf, cf, cf, cf, vp, vp]
         l.tbg_ema_lerp_f32.argtypes = [vp, vp, ll, cf, vp]

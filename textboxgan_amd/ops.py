@@ -284,7 +284,9 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
                sink: Optional["UnitSink"] = None):
     """w: a PackedFilter (pack_filter), or a tensor in GEMM layout [KH*KW, C, ldw] (any view with that memory layout,
     e.g. the HWIO parameter) which is packed here.
-    dot = (aux, out): out[b,m] = sum_p (alpha*acc)[b,m,p] * aux[b,m,p]  (fused when K is not split).
+    dot = (aux, out): out[b,m] = sum_p (alpha*acc)[b,m,p] * aux[b,m,p]  (fused when K is not split).  dot = (aux, None): the
+    launch's partial sums are returned as they are -- (y, partial [B, M, slots]) -- for a consumer that sums the slots itself
+    (tbg_modconv_bwd_smalls_f32: one reduction launch less per layer and pass).
     sink: returns (y, UnitTensor | None) -- units(y * sink.scale) written by the launch that writes y (the convolution's epilogue,
     or the split-K pass's second half)."""
     if sink is not None:
@@ -352,7 +354,8 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
             C.byref(d), N.ptr(x), N.ptr(w), N.ptr(slabs), N.ptr(in_scale), C.byref(e0), N.stream()), _what, _bytes), _what)
         e1 = N.Epilogue.from_buffer_copy(epi)
         e1.alpha = 1.0
-        if dot is not None:  # the fused dot needs the complete sum: reduce first (rare: the smallest G layers' backward)
+        dpart = None
+        if dot is not None:  # the fused dot needs the complete sum: reduce first (the smallest G layers' backward)
             e1.dot_aux, e1.dot_out = None, None
             if ksplit == 1:
                 tmp = slabs[0]
@@ -360,7 +363,10 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
                 tmp = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32)
                 N.check(N.lib().tbg_slab_epilogue_f32(N.ptr(slabs), N.ptr(tmp), B, M, Hout * Wout, ksplit,
                                                       C.byref(N.epilogue()), N.stream()), "tbg_slab_epilogue")
-            dot[1].copy_((tmp * dot[0]).sum(dim=(2, 3)))
+            # sum_p tmp * aux per (b, m) as ONE launch: the per-plane sums of tbg_bias_act_bwd_f32 (dpre = tmp, y_rec = aux)
+            _, _, _, _, dpart = bias_act_bwd_raw(tmp, dot[0], N.epilogue(), want_dpre=False, want_db=False, want_dyy=True)
+            if dot[1] is not None:
+                torch.sum(dpart, dim=2, out=dot[1].view(B, M))
             slabs, nslab = tmp, 1
         else:
             nslab = ksplit
@@ -372,7 +378,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
             return y
         N.check(N.lib().tbg_slab_epilogue_f32(N.ptr(slabs), N.ptr(y), B, M, Hout * Wout, nslab, C.byref(e1), N.stream()),
                 "tbg_slab_epilogue")
-        return y
+        return (y, dpart) if (dot is not None and dot[1] is None) else y
     partial = None
     if dot is not None:  # per-(tile, wave column) partial sums, plain stores: summed here in a fixed order (deterministic)
         partial = torch.empty((B, M, dot_slots), device=x.device, dtype=torch.float32)
@@ -382,6 +388,8 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
     N.check(PROFILE.launch(_kname, _flops, lambda: _conv(
         C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(in_scale), C.byref(epi), N.stream()), _what, _bytes), _what)
     if partial is not None:
+        if dot[1] is None:
+            return y, partial
         torch.sum(partial, dim=2, out=dot[1].view(B, M))
     return y
 
@@ -394,13 +402,23 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
     return torch.empty((max(nbytes, 16) + 3) // 4, device=device, dtype=torch.float32)
 
 
+def _bias_rider(d: N.WgradDesc, bias):
+    """bias = (parts [Bp, CS, nch], db [CS]): the bias gradient db = sum of the bias_act backward's partial sums rides on the filter
+    gradient's reduce launch (tbg_wgrad_desc.bias_*) instead of being a reduction launch of its own."""
+    if bias is not None:
+        parts, db = bias
+        assert parts.dim() == 3 and parts.shape[1] == d.CS and db.numel() == d.CS and parts.is_contiguous()
+        d.bias_parts, d.bias_grad, d.bias_B, d.bias_nch = N.ptr(parts), N.ptr(db), parts.shape[0], parts.shape[2]
+    return d
+
+
 def wgrad_raw(S: torch.Tensor, L: torch.Tensor, KH: int, KW: int, stride, pad, out: torch.Tensor, st_t: int, st_l: int,
-              st_s: int, alpha: float, s_scale=None, l_scale=None, out_offset: int = 0, add=None):
+              st_s: int, alpha: float, s_scale=None, l_scale=None, out_offset: int = 0, add=None, bias=None):
     """Overwrites ``out`` (every in-range element written exactly once).
-    add = (addw, addq, gamma): out += gamma * addw (laid out like out) * addq[CL x CS plane]."""
+    add = (addw, addq, gamma): out += gamma * addw (laid out like out) * addq[CL x CS plane].  bias: see _bias_rider."""
     B, CS, Hs, Ws = S.shape
     _, CL, Hl, Wl = L.shape
-    d = N.WgradDesc(B, CS, CL, Hs, Ws, Hl, Wl, KH, KW, stride[0], stride[1], pad[0], pad[1], st_t, st_l, st_s, alpha)
+    d = _bias_rider(N.WgradDesc(B, CS, CL, Hs, Ws, Hl, Wl, KH, KW, stride[0], stride[1], pad[0], pad[1], st_t, st_l, st_s, alpha), bias)
     nbytes = N.lib().tbg_conv2d_wgrad_workspace_bytes(C.byref(d))
     if nbytes < 0:
         raise N.TbgError("tbg_conv2d_wgrad: unsupported geometry")
@@ -579,6 +597,8 @@ def conv2d_units_raw(XU: UnitTensor, w: "PackedFilter", M: int, flip=False, epi:
         f"conv_units[B={B} C={XU.C} M={M} {H}x{W}]", 2.0 * XU.data.numel() + 4.0 * y.numel() + 2.0 * XU.planes * 9 * XU.C * M),
         "tbg_conv2d_units")
     if partial is not None:
+        if dot[1] is None:
+            return y, partial
         torch.sum(partial, dim=2, out=dot[1].view(B, M))
     return y
 
@@ -663,6 +683,8 @@ def conv2d_units_s2_raw(XP: PhaseUnitTensor, w: "PackedFilter", M: int, flip=Fal
         f"conv_units_s2[B={B} C={XP.C} M={M} {XP.Hin}x{XP.Win}->{Ho}x{Wo}]",
         2.0 * XP.data.numel() + 4.0 * y.numel() + 2.0 * XP.planes * 9 * XP.C * M), "tbg_conv2d_units_s2")
     if partial is not None:
+        if dot[1] is None:
+            return y, partial
         torch.sum(partial, dim=2, out=dot[1].view(B, M))
     return y
 
@@ -674,11 +696,11 @@ def wgrad_units_ok(CS, CL, Hs, Ws, Hl, Wl, KH, KW, stride, pad) -> bool:
 
 
 def wgrad_units_raw(SU: UnitTensor, LU: UnitTensor, out: torch.Tensor, st_t: int, st_l: int, st_s: int, alpha: float,
-                    out_offset: int = 0, add=None):
+                    out_offset: int = 0, add=None, bias=None):
     """filter gradient of a 3x3 stride-1 pad-1 convolution from the unit tensors of S (output-grid tensor, scale inside) and
     L (input-grid tensor, scale inside).  Overwrites ``out`` like wgrad_raw."""
     assert SU.planes == LU.planes and SU.B == LU.B
-    d = N.WgradDesc(SU.B, SU.C, LU.C, SU.H, SU.W, LU.H, LU.W, 3, 3, 1, 1, 1, 1, st_t, st_l, st_s, alpha)
+    d = _bias_rider(N.WgradDesc(SU.B, SU.C, LU.C, SU.H, SU.W, LU.H, LU.W, 3, 3, 1, 1, 1, 1, st_t, st_l, st_s, alpha), bias)
     nbytes = N.lib().tbg_conv2d_wgrad_units_workspace_bytes(C.byref(d))
     N.check(min(nbytes, 0), "tbg_conv2d_wgrad_units_workspace_bytes")
     ws = _workspace(out.device, nbytes)
@@ -720,11 +742,11 @@ def wgrad_units_s2_ok(CS, CL, Hs, Ws, Hl, Wl) -> bool:
 
 
 def wgrad_units_s2_raw(SU: UnitTensor, LP: PhaseUnitTensor, out: torch.Tensor, st_t: int, st_l: int, st_s: int, alpha: float,
-                       out_offset: int = 0, add=None):
+                       out_offset: int = 0, add=None, bias=None):
     """filter gradient of a 3x3 stride-2 pad-0 convolution from the unit tensor of S (output-grid tensor, scale inside) and the
     phase unit tensor of L (input-grid tensor, scale inside).  Overwrites ``out`` like wgrad_raw."""
     assert SU.planes == LP.planes and SU.B == LP.B and (SU.H, SU.W) == (LP.Ho, LP.Wo)
-    d = N.WgradDesc(SU.B, SU.C, LP.C, SU.H, SU.W, LP.Hin, LP.Win, 3, 3, 2, 2, 0, 0, st_t, st_l, st_s, alpha)
+    d = _bias_rider(N.WgradDesc(SU.B, SU.C, LP.C, SU.H, SU.W, LP.Hin, LP.Win, 3, 3, 2, 2, 0, 0, st_t, st_l, st_s, alpha), bias)
     nbytes = N.lib().tbg_conv2d_wgrad_units_s2_workspace_bytes(C.byref(d))
     N.check(min(nbytes, 0), "tbg_conv2d_wgrad_units_s2_workspace_bytes")
     ws = _workspace(out.device, nbytes)
@@ -948,10 +970,12 @@ def rgb_project_raw(x, w2d, O, scale, bias, skip, alpha, bias_mul=1.0, out=None,
     return y
 
 
-def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True, colmask=None, mask_cw=0, want_dym=False):
+def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True, colmask=None, mask_cw=0, want_dym=False,
+                        parts=False):
     """dym = dy * m;  dx[b,c,p] = alpha*scale[b,c]*sum_o w2d[c,o] dym[b,o,p];  G[b,c,o] = sum_p x[b,c,p] dym[b,o,p]
     (the kernel writes one partial G per 2048-pixel chunk -- no atomics, deterministic -- summed here).
-    returns (dx, G) or (dx, G, dym)."""
+    returns (dx, G) or (dx, G, dym).  parts=True: G stays [B, C, chunks, O] and the per-chunk sums of dym [B, chunks, O] come
+    too -- (dx, Gparts, dysum[, dym]) -- for tbg_torgb_bwd_smalls_f32, which sums both (no reduction launches in between)."""
     B, Cc, H, W = x.shape
     O = dy.shape[1]
     _check_colmask(colmask, B, W, mask_cw)
@@ -959,10 +983,13 @@ def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True, col
     nchunk = N.lib().tbg_rgb_backproject_chunks(H * W)
     Gp = torch.empty((B, Cc, nchunk, O), device=x.device, dtype=torch.float32) if want_G else None
     dym = torch.empty_like(dy) if want_dym else None
+    dysum = torch.empty((B, nchunk, O), device=x.device, dtype=torch.float32) if parts else None
     _nb = 4.0 * (x.numel() * (int(want_dx) + int(want_G)) + dy.numel())
     N.check(PROFILE.launch("rgb_backproject_kernel", 0.0, lambda: N.lib().tbg_rgb_backproject_f32(
         N.ptr(x), N.ptr(dy), N.ptr(w2d), N.ptr(scale), N.ptr(dx), N.ptr(Gp), B, Cc, O, O, H * W, alpha, N.ptr(colmask), W,
-        int(mask_cw), N.ptr(dym), N.stream()), nbytes=_nb), "tbg_rgb_backproject")
+        int(mask_cw), N.ptr(dym), N.ptr(dysum), N.stream()), nbytes=_nb), "tbg_rgb_backproject")
+    if parts:
+        return (dx, Gp, dysum, dym) if want_dym else (dx, Gp, dysum)
     G = (Gp.sum(dim=2) if nchunk > 1 else Gp[:, :, 0]) if want_G else None
     return (dx, G, dym) if want_dym else (dx, G)
 
@@ -972,23 +999,28 @@ def modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv):
     B, O, nch = pdy.shape
     I = s.shape[1]
     dev = s.device
+    slots = ds_conv.shape[2] if ds_conv.dim() == 3 else 1  # [B, I, slots]: the conv launch's dot partials, summed by the kernel
     db = torch.empty(O, device=dev, dtype=torch.float32)
     dstrength = torch.empty((), device=dev, dtype=torch.float32) if pdn is not None else None
     ds = torch.empty_like(s)
     dwsq = torch.empty((I, O), device=dev, dtype=torch.float32)
     N.check(N.lib().tbg_modconv_bwd_smalls_f32(N.ptr(pdb), N.ptr(pdn), N.ptr(pdy), N.ptr(d), N.ptr(s), N.ptr(wsq),
                                                N.ptr(ds_conv), N.ptr(db), N.ptr(dstrength), N.ptr(ds), N.ptr(dwsq), B, I, O,
-                                               nch, N.stream()), "tbg_modconv_bwd_smalls")
+                                               nch, slots, N.stream()), "tbg_modconv_bwd_smalls")
     return db, dstrength, ds, dwsq
 
 
-def torgb_bwd_smalls_raw(G, w2d, s, coef):
-    B, Cc, O = G.shape
+def torgb_bwd_smalls_raw(G, w2d, s, coef, dysum=None):
+    """G [B, C, O] or its per-chunk partials [B, C, chunks, O]; dysum [B, chunks, O] (optional) -> (ds, dw[, db])."""
+    if G.dim() == 3:
+        G = G.unsqueeze(2)
+    B, Cc, nchunk, O = G.shape
     ds = torch.empty((B, Cc), device=G.device, dtype=torch.float32)
     dw = torch.empty((Cc, O), device=G.device, dtype=torch.float32)
-    N.check(N.lib().tbg_torgb_bwd_smalls_f32(N.ptr(G), N.ptr(w2d), N.ptr(s), N.ptr(ds), N.ptr(dw), B, Cc, O, coef, N.stream()),
-            "tbg_torgb_bwd_smalls")
-    return ds, dw
+    db = torch.empty(O, device=G.device, dtype=torch.float32) if dysum is not None else None
+    N.check(N.lib().tbg_torgb_bwd_smalls_f32(N.ptr(G.contiguous()), N.ptr(w2d), N.ptr(s), N.ptr(ds), N.ptr(dw), B, Cc, O, coef, nchunk,
+                                             N.ptr(dysum), N.ptr(db), N.stream()), "tbg_torgb_bwd_smalls")
+    return (ds, dw, db) if dysum is not None else (ds, dw)
 
 
 def demod_coefs_raw(s: torch.Tensor, w: torch.Tensor, coef: float):
@@ -1100,9 +1132,9 @@ def _bwd_data_launch(dy, w, g: _Geom, alpha=1.0, in_scale=None, epi=None, dot=No
                       dot=dot, out=out)
 
 
-def _bwd_weight_launch(x, dy, g: _Geom, I, O, alpha=1.0, x_scale=None, dy_scale=None, add=None):
+def _bwd_weight_launch(x, dy, g: _Geom, I, O, alpha=1.0, x_scale=None, dy_scale=None, add=None, bias=None):
     dw = torch.empty((g.KH, g.KW, I, O), device=x.device, dtype=torch.float32)
-    wgrad_raw(dy, x, g.KH, g.KW, g.stride, g.pad, dw, I * O, O, 1, alpha, s_scale=dy_scale, l_scale=x_scale, add=add)
+    wgrad_raw(dy, x, g.KH, g.KW, g.stride, g.pad, dw, I * O, O, 1, alpha, s_scale=dy_scale, l_scale=x_scale, add=add, bias=bias)
     return dw
 
 
@@ -1369,12 +1401,13 @@ class _Bwd3x3:
             return conv2d_units_raw(self.DU, pack_filter(w, transpose=True, flip=True), self.I, epi=epi, dot=dot, out=out)
         return _bwd_data_launch(self.dpre, w, self.g, in_scale=self.dscale, epi=epi, dot=dot, out=out)
 
-    def dw(self, x, XU, coef, x_scale=None, add=None):
+    def dw(self, x, XU, coef, x_scale=None, add=None, bias=None):
         if self.u_dw:
             XU = units_pack(x, x_scale) if XU is None else XU
             dw = torch.empty((3, 3, self.I, self.O), device=x.device, dtype=torch.float32)
-            return wgrad_units_raw(self.DU, XU, dw, self.I * self.O, self.O, 1, coef, add=add)
-        return _bwd_weight_launch(x, self.dpre, self.g, self.I, self.O, alpha=coef, x_scale=x_scale, dy_scale=self.dscale, add=add)
+            return wgrad_units_raw(self.DU, XU, dw, self.I * self.O, self.O, 1, coef, add=add, bias=bias)
+        return _bwd_weight_launch(x, self.dpre, self.g, self.I, self.O, alpha=coef, x_scale=x_scale, dy_scale=self.dscale, add=add,
+                                  bias=bias)
 
 
 def _lrelu_epi(**kw):
@@ -1432,17 +1465,16 @@ class _ModConvFused(torch.autograd.Function):
         coef = ctx.coef
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
         g = _Geom((1, 1), (KH // 2, KW // 2), KH, KW, (x.shape[2], x.shape[3]), (out.shape[2], out.shape[3]))
-        ds_conv = torch.empty_like(s)  # every element written (sum of the launch's partial slots)
         want_dw = ctx.needs_input_grad[1]  # frozen generator (projector.py: only the latent is optimised): no filter gradient
         if KH == 3:
             bw = _Bwd3x3(x.shape[0], I, O, x.shape[2], x.shape[3], want_dw=want_dw)
             pdb, pdn, pdy = bw.from_bias_act(dout.contiguous(), out, epi, d, want_dn=True, want_dyy=True)  # units(dpre * d)
-            dx = bw.dx(w, N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
+            dx, ds_conv = bw.dx(w, N.epilogue(alpha=coef, out_scale=s), dot=(x, None))  # (the style dot's partial slots)
             db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)  # (dwsq needs ds_conv)
             dw = bw.dw(x, _unit_tensor(xu, x), coef, x_scale=s, add=(w, dwsq, -coef * coef)) if want_dw else None
             return dx, dw, ds, None, dstrength, db, None
         _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
-        dx = _bwd_data_launch(dpre, w, g, in_scale=d, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
+        dx, ds_conv = _bwd_data_launch(dpre, w, g, in_scale=d, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, None))
         db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)
         dw = None
         if want_dw:
@@ -1496,7 +1528,6 @@ class _ModConvUpFused(torch.autograd.Function):
         _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
         k = fir_kernel(x.device, gain=4.0)  # symmetric: flipped == itself
         wt = pack_filter(w, transpose=True, flip=True)
-        ds_conv = torch.empty_like(s)  # every element written (sum of the launch's partial slots)
         T = KH * KW
         # the data gradient is a 3x3 stride-2 convolution O -> I of dy_up = blur^T(dpre * d) [B,O,2H+1,2W+1], the filter gradient
         # contracts dy_up with x * s: where the phase-unit kernels take the layer, the blur writes dy_up ONCE as a phase unit tensor
@@ -1504,11 +1535,11 @@ class _ModConvUpFused(torch.autograd.Function):
         s2 = KH == 3 and _units_s2(x.shape[0], O, I, 2 * H + 1, 2 * W + 1)
         if s2:
             DYP = upfirdn2d_units_s2(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))
-            dx = conv2d_units_s2_raw(DYP, wt, I, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
+            dx, ds_conv = conv2d_units_s2_raw(DYP, wt, I, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, None))
         else:
             dy_up = upfirdn2d_raw(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))  # [B,O,2H+1,2W+1]
-            dx = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0),
-                            epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, ds_conv))
+            dx, ds_conv = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0),
+                                     epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, None))
         db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)
         dw = None
         if ctx.needs_input_grad[1]:
@@ -1549,12 +1580,13 @@ class _ToRGBFused(torch.autograd.Function):
         x, w, s, colmask = ctx.saved_tensors
         _, _, I, O = w.shape
         dy = dy.contiguous()
+        # two launches: the streaming pass (dx, per-chunk Gram and dy sums) and the small-tensor tail that sums the chunks
         if colmask is not None:
-            dx, G, dy = rgb_backproject_raw(x, dy, w, s, ctx.coef, colmask=colmask, mask_cw=ctx.mask_cw, want_dym=True)
+            dx, Gp, dysum, dy = rgb_backproject_raw(x, dy, w, s, ctx.coef, colmask=colmask, mask_cw=ctx.mask_cw, want_dym=True,
+                                                    parts=True)
         else:
-            dx, G = rgb_backproject_raw(x, dy, w, s, ctx.coef, want_dx=True, want_G=True)  # G[b,c,o] = sum_p x*dy
-        db = dy.sum(dim=(0, 2, 3))
-        ds, dw = torgb_bwd_smalls_raw(G.contiguous(), w.reshape(I, O), s, ctx.coef)
+            dx, Gp, dysum = rgb_backproject_raw(x, dy, w, s, ctx.coef, want_dx=True, want_G=True, parts=True)  # G = sum_p x*dy
+        ds, dw, db = torgb_bwd_smalls_raw(Gp, w.reshape(I, O), s, ctx.coef, dysum=dysum)
         return dx, dw.reshape(w.shape), ds, db, (dy if ctx.has_skip else None), None, None
 
 
@@ -1612,6 +1644,7 @@ class _ConvBiasActFused(torch.autograd.Function):
             dout_f, x_f, out_f = dout, x, out
             dout, x, out = dout[:h], x[:h], (out[:h] if out is not None else None)
         dres = None
+        bias_rider = None
         prune_w = FLAGS.skip_d_wgrad and ctx.role in ("d", "d_image")
         want_dx = ctx.needs_input_grad[0] and not (FLAGS.skip_image_grad and ctx.role == "d_image")
         bw = _Bwd3x3(dout.shape[0], I, O, x.shape[2], x.shape[3], want_dx=want_dx, want_dw=not prune_w) if ctx.s1_3x3 else None
@@ -1623,7 +1656,14 @@ class _ConvBiasActFused(torch.autograd.Function):
                 dpre = bw.dpre
             else:
                 _, dpre, pdb, _, _ = bias_act_bwd_raw(dout, out, epi_b, want_db=b is not None)
-            db = pdb.sum(dim=(0, 2)) if b is not None else None
+            db = None
+            if b is not None and not prune_w:
+                thin_ = KH == 1 and KW == 1 and I <= 4 and stride == (1, 1)
+                if thin_:
+                    db = pdb.sum(dim=(0, 2))
+                else:  # summed by the filter gradient's reduce launch below (tbg_wgrad_desc.bias_*): no reduction launch of its own
+                    db = torch.empty(O, device=dout.device, dtype=torch.float32)
+                    bias_rider = (pdb, db)
         elif has_res and res_scale == 1.0:  # (the sum's scale folded into both branches: the gradient passes through as it is)
             dpre = dout
             dres = dout_f if h else dout
@@ -1666,9 +1706,9 @@ class _ConvBiasActFused(torch.autograd.Function):
                 _, G = rgb_backproject_raw(dpre, x, None, None, 1.0, want_dx=False, want_G=True)
                 dw = (coef * G.sum(dim=0).t()).reshape(w.shape).contiguous()
             elif bw is not None:
-                dw = bw.dw(x, _unit_tensor(xu, x) if not h else None, coef)
+                dw = bw.dw(x, _unit_tensor(xu, x) if not h else None, coef, bias=bias_rider)
             else:
-                dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef)
+                dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef, bias=bias_rider)
         else:
             db = None
         return dx, dw, db, dres, None, None, None, None, None, None, None
@@ -1761,7 +1801,7 @@ class _BlurConvS2Fused(torch.autograd.Function):
             DU, dpre, pdb, _, _ = bias_act_bwd_units_raw(dout, out, epi_b, want_dpre=want_dx and not t2, want_db=b is not None)
         else:
             _, dpre, pdb, _, _ = bias_act_bwd_raw(dout, out, epi_b, want_db=b is not None)
-        db = pdb.sum(dim=(0, 2)) if b is not None else None
+        db = torch.empty(O, device=dout.device, dtype=torch.float32) if (b is not None and not prune_w) else None
         dx = None
         if want_dx:
             g = _Geom((2, 2), (0, 0), 3, 3, (Ht, Wt), (Ho, Wo))
@@ -1779,7 +1819,7 @@ class _BlurConvS2Fused(torch.autograd.Function):
         dw = None
         if not prune_w:
             dw = torch.empty_like(w)
-            wgrad_units_s2_raw(DU, PhaseUnitTensor(tp, *tpm), dw, I * O, O, 1, coef)
+            wgrad_units_s2_raw(DU, PhaseUnitTensor(tp, *tpm), dw, I * O, O, 1, coef, bias=(pdb, db) if db is not None else None)
         else:
             db = None
         return dx, dw, db, None, None
