@@ -81,7 +81,7 @@ typedef struct tbg_epilogue {
   /* UNIT SINK (round 5; see "UNIT TENSORS" below): the launch ALSO writes its result as the unit tensor the next
    * convolution consumes -- units_out = units(out * units_scale[b*M + m]) over the launch's [B, M, Hout, Wout] output, ring of
    * zero units included (every unit of the tensor is written by the launch; the bits are those of tbg_units_pack_f32(out,
-   * units_scale)).  Served by tbg_conv2d_{f32,bf16,x3} (ksplit == 1), tbg_conv2d_units, tbg_conv2d_units_s2 and
+   * units_scale)).  Served by tbg_conv2d_{bf16,x3} (ksplit == 1; the exact-fp32 entry: TBG_EUNSUPPORTED), tbg_conv2d_units, tbg_conv2d_units_s2 and
    * tbg_upfirdn2d_sep_f32 (up = down = 1); M % 8 == 0.  With a sink the fp32 output pointer of those entries may be NULL:
    * the activation then exists as a unit tensor only.  Other entries return TBG_EINVAL when units_out is set. */
   void *units_out;            /* bf16 U[units_planes][B][M/8][Hout+2][Wout+2][8], 16-byte aligned, or NULL */

@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     e_b[j] = okpix ? b : 0;
   }
   constexpr int RG = OCC == 4 ? 2 : 4;  // rows per load batch (register budget: the epilogue must not raise the kernel's allocation)
-  conv_epilogue<WTM, WTN, RG>(acc[0], p.e, p.y, p.ksplit > 1 ? p.y + (size_t)ks * p.slab : nullptr, p.M, HWout,
+  conv_epilogue<WTM, WTN, RG, BF>(acc[0], p.e, p.y, p.ksplit > 1 ? p.y + (size_t)ks * p.slab : nullptr, p.M, HWout,
                               m0 + wm * WTM * 32, lane, e_pix, e_b, bg < p.B, bg, p.dot_slots, (tu * ci.tilesV + tv) * WGN + wn,
                               p.Hout, p.Wout);
 }
@@ -706,6 +706,7 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
   p.B = d->B; p.C = d->C; p.M = d->M; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
   p.ldw = d->ldw;
   p.e = make_epi(epi);
+  if (p.e.units_out && mode == 0) return TBG_EUNSUPPORTED;  // unit tensors belong to the bf16-pipe arithmetics (bf16, f32x3)
   if (const int rcs = epi_sink_geometry(p.e, d->B, d->M, d->Hout, d->Wout)) return rcs;
   const int T = d->KH * d->KW;
   p.wplane = T * ((d->C + 7) / 8) * d->ldw * 4;

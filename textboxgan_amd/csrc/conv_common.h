@@ -102,7 +102,9 @@ __device__ __forceinline__ void sink_zero(char *ub, long long plane_bytes, int p
   for (int pl = 0; pl < planes; ++pl) *reinterpret_cast<u32x2v *>(ub + pl * plane_bytes + off) = u32x2v{0u, 0u};
 }
 
-template <int WTM, int WTN, int RG>
+// SINK = false compiles the sink out (the exact-fp32 instantiations: no unit consumer exists in that arithmetic, and the sink's
+// registers pushed the 4-waves/SIMD builds into scratch -- 320 bytes per lane, exact-fp32 step 27.1 -> 31.7 ms).
+template <int WTM, int WTN, int RG, bool SINK = true>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], const EpiK &e, float *y, float *slab, int M_, int HWout,
                                               int mrow0, int lane, const int (&e_pix)[WTN], const int (&e_b)[WTN], bool dot_ok,
                                               int dot_b, int dot_slots, int dot_slot, int Hout = 0, int Wout = 0) {
@@ -114,8 +116,8 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
   const float str = e.noise ? e.strength[0] : 0.f;
   const bool split = slab != nullptr;
   const bool do_dot = e_aux != nullptr && !split;
-  char *const e_ub = static_cast<char *>(e.units_out);
-  const bool sink = e_ub != nullptr && !split;
+  char *const e_ub = SINK ? static_cast<char *>(e.units_out) : nullptr;
+  const bool sink = SINK && e_ub != nullptr && !split;
   const bool plain = !e_os && !e_bias && !e.noise && !e_res && !e_aux && !e_gate && !e_lrelu && e_gain == 1.f && !sink;
   const int M = M_;
   float *const ybase = split ? slab : y;
