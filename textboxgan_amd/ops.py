@@ -98,8 +98,11 @@ class _Tuning:
         self.use_units_s2 = True     # blur + 3x3 stride-2 layers (and the up-convolution's backward) through PHASE unit tensors where
                                      # both the strided convolution and its filter gradient take them
         self.use_units_t2 = True     # 3x3 stride-2 TRANSPOSED convolutions (up-conv forward, data gradient of the strided layers)
-        self.units_min_blocks_t2 = 96    # the same gate for tbg_conv2d_units_t2 (its NCHW alternative -- four output-parity classes
-                                     # of mostly-empty tiles, 38-80 TFLOP/s -- loses earlier than the stride-1 kernel's)
+        self.units_min_blocks_t2 = 96    # the same gate for tbg_conv2d_units_t2 in f32x3 (its NCHW alternative -- four output-parity
+                                     # classes of mostly-empty tiles, 38-80 TFLOP/s -- loses earlier than the stride-1 kernel's): -0.10 ms
+                                     # per step.  bf16 keeps units_min_blocks: there the gain is 0.07 ms, and the full-width step's
+                                     # noisiest scalar gradient (a noise strength: one heavily cancelling sum) moved from 0.22 to 0.27
+                                     # relative against its 0.25 bar when more layers changed kernels (profiles/r05_ab_one_box.txt)
         self.unit_sinks = True       # round 5: producers (conv / FIR / split-K epilogues) write the NEXT layer's unit tensor themselves
                                      # (tbg_epilogue.units_out); False = the stand-alone tbg_units_pack_f32 pass of round 4
         # ---- split-K of the small-map launches
@@ -1349,7 +1352,8 @@ def _units_t2(B, C_in, M, H, W, Hout, Wout) -> bool:
     if not (TUNING.use_units and TUNING.use_units_t2) or fmt == FMT_F32 or not conv_units_t2_ok(C_in, M, unit_planes(fmt)):
         return False
     d = N.ConvDesc(B, C_in, M, H, W, Hout, Wout, 3, 3, 2, 2, 0, 0, 1, 0, M, 1)
-    return N.lib().tbg_conv2d_units_t2_blocks(C.byref(d), unit_planes(fmt)) >= TUNING.units_min_blocks_t2
+    gate = TUNING.units_min_blocks_t2 if fmt == FMT_X3 else max(TUNING.units_min_blocks, TUNING.units_min_blocks_t2)
+    return N.lib().tbg_conv2d_units_t2_blocks(C.byref(d), unit_planes(fmt)) >= gate
 
 
 def _unit_tensor(data, like: torch.Tensor, planes=None) -> Optional[UnitTensor]:
