@@ -2223,8 +2223,12 @@ class _FrozenAttnDecoder(torch.autograd.Function):
             torch.addmm(W.b_d, h[0], W.w_dT, out=qs[s])
             N.check(N.lib().tbg_attn_ctx_fwd_f32(N.ptr(qs[s]), N.ptr(ep), N.ptr(enc), N.ptr(W.v), N.ptr(ctxs[s]),
                                                  N.ptr(a_all[s]), B, T, H, E, N.stream()), "tbg_attn_ctx_fwd")
-            g = torch.addmm(W.etab.index_select(0, prev), ctxs[s], W.w_ctxT)
-            torch.addmm(g, h[0], W.w_hhT, out=gbuf[0, s])
+            # gates = etab[prev] + ctx @ w_ctx^T + h @ w_hh^T, accumulated IN PLACE in the buffer the cell kernel reads (addmm with a
+            # full-matrix `self` first copies it into the result: two device copies per step)
+            gs = gbuf[0, s]
+            torch.index_select(W.etab, 0, prev, out=gs)
+            gs.addmm_(ctxs[s], W.w_ctxT)
+            gs.addmm_(h[0], W.w_hhT)
             N.check(N.lib().tbg_lstm_step_fwd_f32(N.ptr(gbuf), None, N.ptr(act), N.ptr(cs), N.ptr(h), None, 1, steps, B, H, s,
                                                   N.stream()), "tbg_lstm_step_fwd")
             torch.addmm(W.b_o, h[0], W.w_oT, out=lbuf[s])
@@ -2252,8 +2256,9 @@ class _FrozenAttnDecoder(torch.autograd.Function):
         for s in range(steps - 1, -1, -1):
             if dh_next is None:
                 torch.mm(dl[s], W.w_o, out=dh[0])
-            else:
-                torch.addmm(dh_next, dl[s], W.w_o, out=dh[0])
+            else:  # dh = dh_next + dl[s] @ w_o, in place in dh_next's buffer (no copy into a second one)
+                dh_next.addmm_(dl[s], W.w_o)
+                dh = dh_next.view(1, B, H)
             N.check(N.lib().tbg_lstm_step_bwd_f32(None, N.ptr(dh), N.ptr(dc), N.ptr(act), N.ptr(cs), None, N.ptr(dgates), 1,
                                                   steps, B, H, s, int(s == steps - 1), N.stream()), "tbg_lstm_step_bwd")
             torch.mm(dgates[0], W.w_ctx, out=dctxs[s])
@@ -2261,7 +2266,7 @@ class _FrozenAttnDecoder(torch.autograd.Function):
                                                  N.ptr(dq), N.ptr(dep), None, B, T, H, E, N.stream()),
                     "tbg_attn_ctx_bwd")
             if s > 0:  # h_{s-1} feeds the cell (W_hh) and the attention query (att_dec)
-                dh_next = torch.addmm(torch.mm(dgates[0], W.w_hh), dq, W.w_d)
+                dh_next = torch.mm(dgates[0], W.w_hh).addmm_(dq, W.w_d)
         # d(enc) through the context sums: sum_s a_s (x) dctx_s as ONE batched GEMM over the images, + through enc_proj
         denc = torch.bmm(a_all.permute(1, 2, 0), dctxs.permute(1, 0, 2))  # [B,T,S] @ [B,S,E]
         denc.view(B * T, E).addmm_(dep.view(B * T, H), W.w_enc)

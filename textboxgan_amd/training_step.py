@@ -224,8 +224,11 @@ class TrainingStep:
                     return self._train_step(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl, st["w"], None)
                 self._graphs[key] = ([g], outs)
         graphs, outs = self._graphs[key]
-        # the graph's output tensors are static (overwritten by the next replay): hand CLONES to the caller (7 scalars)
-        fresh = lambda o: (tuple(t.clone() for t in o[0]), tuple(t.clone() for t in o[1]), o[2].clone())
+        # the graph's output tensors are static (overwritten by the next replay): hand a COPY to the caller -- the 7 scalars as one
+        # stacked tensor (one launch, not seven clones)
+        def fresh(o):
+            v = torch.stack([*o[0], *o[1], o[2]]).unbind(0)
+            return tuple(v[0:3]), tuple(v[3:6]), v[6]
         if len(graphs) == 1:
             graphs[0].replay()
             return fresh(outs)
