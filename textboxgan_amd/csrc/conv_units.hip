@@ -131,13 +131,14 @@ __global__ __launch_bounds__(256) void slab_epilogue_units_kernel(const SlabUnit
       for (int cc = 0; cc < 8; ++cc) v[cc] += tv[cc];
     }
     const float str = p.e.noise ? p.e.strength[0] : 0.f;
-    const float nz = p.e.noise ? p.e.noise[(size_t)b * HW + pix] * str : 0.f;
+    const int bs = epi_sb(p.e, b);
+    const float nz = p.e.noise ? p.e.noise[(size_t)bs * HW + pix] * str : 0.f;
     const bool rf = p.e.residual && p.e.res_first;
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
       const int m = cu * 8 + cc, plane = b * p.M + m;
       const size_t gi = g0 + (size_t)cc * HW;
-      const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[plane] : 1.f);
+      const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[bs * p.M + m] : 1.f);
       float o = v[cc] * sc + (p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f);
       if (p.e.noise) o += nz;
       if (rf) o += p.e.residual[gi];
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_units_kernel(const BabUnitsP
   __shared__ float red[4][24];
   const int Wp = p.W + 2, Hp = p.H + 2, C8 = (p.M + 7) >> 3, HW = p.H * p.W;
   const int cu = blockIdx.x % C8, b = blockIdx.x / C8;
+  const int bs = epi_sb(p.e, b);  // the SAVED tensors' sample (out_act, noise, out_scale: tbg_epilogue.saved_batch)
   const int r0 = blockIdx.y * UB_ROWS, r1 = min(r0 + UB_ROWS, Hp);
   const float str = p.e.noise ? p.e.strength[0] : 0.f;
   const float gin = p.e.residual ? p.e.res_scale : 1.f;  // residual != NULL only flags "fused residual"
@@ -207,13 +209,13 @@ __global__ __launch_bounds__(256) void bias_act_bwd_units_kernel(const BabUnitsP
   for (int cc = 0; cc < 8; ++cc) {
     const int m = cu * 8 + cc;
     chok[cc] = m < p.M;
-    sc[cc] = chok[cc] ? p.e.alpha * (p.e.out_scale ? p.e.out_scale[b * p.M + m] : 1.f) : 0.f;
+    sc[cc] = chok[cc] ? p.e.alpha * (p.e.out_scale ? p.e.out_scale[bs * p.M + m] : 1.f) : 0.f;
     bias[cc] = (chok[cc] && p.e.bias) ? p.e.bias[m] * p.e.bias_mul : 0.f;
   }
   float s_db[8], s_dn[8], s_dy[8];
 #pragma unroll
   for (int cc = 0; cc < 8; ++cc) { s_db[cc] = 0.f; s_dn[cc] = 0.f; s_dy[cc] = 0.f; }
-  const size_t g0 = ((size_t)b * p.M + cu * 8) * HW;
+  const size_t g0 = ((size_t)b * p.M + cu * 8) * HW, gs0 = ((size_t)bs * p.M + cu * 8) * HW;
   bf16x8 *Ub = p.U + ((size_t)b * C8 + cu) * Hp * Wp;
   const int npos = (r1 - r0) * Wp;
   for (int e = threadIdx.x; e < npos; e += 256) {
@@ -223,11 +225,11 @@ __global__ __launch_bounds__(256) void bias_act_bwd_units_kernel(const BabUnitsP
     float ov[8], dv[8];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
-      const size_t gi = (inside && chok[cc]) ? g0 + (size_t)cc * HW + pix : 0;
-      ov[cc] = p.out_act[gi];
-      dv[cc] = p.dout[gi];
+      const bool okc = inside && chok[cc];
+      ov[cc] = p.out_act[okc ? gs0 + (size_t)cc * HW + pix : 0];
+      dv[cc] = p.dout[okc ? g0 + (size_t)cc * HW + pix : 0];
     }
-    const float n = (inside && p.e.noise) ? p.e.noise[(size_t)b * HW + pix] : 0.f;
+    const float n = (inside && p.e.noise) ? p.e.noise[(size_t)bs * HW + pix] : 0.f;
     float v[8];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {

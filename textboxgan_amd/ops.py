@@ -976,15 +976,16 @@ def rgb_project_raw(x, w2d, O, scale, bias, skip, alpha, bias_mul=1.0, out=None,
 
 
 def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True, colmask=None, mask_cw=0, want_dym=False,
-                        parts=False):
+                        parts=False, saved_batch=0):
     """dym = dy * m;  dx[b,c,p] = alpha*scale[b,c]*sum_o w2d[c,o] dym[b,o,p];  G[b,c,o] = sum_p x[b,c,p] dym[b,o,p]
     (the kernel writes one partial G per 2048-pixel chunk -- no atomics, deterministic -- summed here).
     returns (dx, G) or (dx, G, dym).  parts=True: G stays [B, C, chunks, O] and the per-chunk sums of dym [B, chunks, O] come
     too -- (dx, Gparts, dysum[, dym]) -- for tbg_torgb_bwd_smalls_f32, which sums both (no reduction launches in between)."""
-    B, Cc, H, W = x.shape
-    O = dy.shape[1]
-    _check_colmask(colmask, B, W, mask_cw)
-    dx = torch.empty_like(x) if want_dx else None
+    Bx, Cc, H, W = x.shape
+    B, O = dy.shape[0], dy.shape[1]  # (saved_batch > 0: dy holds several cotangents per saved sample, x / scale / colmask Bx of them)
+    assert (saved_batch == 0 and B == Bx) or (saved_batch == Bx and B % Bx == 0)
+    _check_colmask(colmask, Bx, W, mask_cw)
+    dx = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32) if want_dx else None
     nchunk = N.lib().tbg_rgb_backproject_chunks(H * W)
     Gp = torch.empty((B, Cc, nchunk, O), device=x.device, dtype=torch.float32) if want_G else None
     dym = torch.empty_like(dy) if want_dym else None
@@ -992,7 +993,7 @@ def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True, col
     _nb = 4.0 * (x.numel() * (int(want_dx) + int(want_G)) + dy.numel())
     N.check(PROFILE.launch("rgb_backproject_kernel", 0.0, lambda: N.lib().tbg_rgb_backproject_f32(
         N.ptr(x), N.ptr(dy), N.ptr(w2d), N.ptr(scale), N.ptr(dx), N.ptr(Gp), B, Cc, O, O, H * W, alpha, N.ptr(colmask), W,
-        int(mask_cw), N.ptr(dym), N.ptr(dysum), N.stream()), nbytes=_nb), "tbg_rgb_backproject")
+        int(mask_cw), N.ptr(dym), N.ptr(dysum), int(saved_batch), N.stream()), nbytes=_nb), "tbg_rgb_backproject")
     if parts:
         return (dx, Gp, dysum, dym) if want_dym else (dx, Gp, dysum)
     G = (Gp.sum(dim=2) if nchunk > 1 else Gp[:, :, 0]) if want_G else None
