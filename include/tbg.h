@@ -209,6 +209,9 @@ typedef struct tbg_wgrad_desc {
   const float *bias_parts;
   float *bias_grad; /* [CS] */
   int bias_B, bias_nch;
+  /* unit-tensor entries only: 16-byte units between two PLANES of the S / L unit tensor when the operand is a leading-batch
+   * SLICE of a larger unit tensor (B samples starting at the pointer, planes laid out for the whole tensor); 0 = dense. */
+  long long s_plane_units, l_plane_units;
 } tbg_wgrad_desc;
 
 long long tbg_conv2d_wgrad_workspace_bytes(const tbg_wgrad_desc *d);

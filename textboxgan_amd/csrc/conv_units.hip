@@ -500,7 +500,9 @@ extern "C" int tbg_conv2d_wgrad_units(const tbg_wgrad_desc *d, const void *SU, c
   if (d->B < 1 || d->CS < 1 || d->CL < 1 || d->Hs < 1 || d->Ws < 1 || d->Hl < 1 || d->Wl < 1) return TBG_EINVAL;
   if (((reinterpret_cast<uintptr_t>(SU) | reinterpret_cast<uintptr_t>(LU)) & 15) != 0) return TBG_EINVAL;
   if (!wgrad_units_ok(d)) return TBG_EUNSUPPORTED;
-  const long long s_plane = units_per_plane(d->B, d->CS, d->Hs, d->Ws), l_plane = units_per_plane(d->B, d->CL, d->Hl, d->Wl);
+  if (d->s_plane_units < 0 || d->l_plane_units < 0) return TBG_EINVAL;
+  const long long s_plane = d->s_plane_units ? d->s_plane_units : units_per_plane(d->B, d->CS, d->Hs, d->Ws);
+  const long long l_plane = d->l_plane_units ? d->l_plane_units : units_per_plane(d->B, d->CL, d->Hl, d->Wl);
   if (s_plane * planes > 2147483647LL / 2 || l_plane * planes > 2147483647LL / 2) return TBG_ERANGE;
   WgUnitsP u{};
   u.SU = reinterpret_cast<const char *>(SU); u.LU = reinterpret_cast<const char *>(LU);

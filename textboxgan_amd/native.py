@@ -66,7 +66,9 @@ class WgradDesc(C.Structure):
     _fields_ = ([(n, C.c_int) for n in ("B", "CS", "CL", "Hs", "Ws", "Hl", "Wl", "KH", "KW", "sy", "sx", "py", "px",
                                         "st_t", "st_l", "st_s")] + [("alpha", C.c_float)] +
                 # rider: the layer's bias gradient summed by the filter gradient's reduce launch (tbg.h)
-                [("bias_parts", C.c_void_p), ("bias_grad", C.c_void_p), ("bias_B", C.c_int), ("bias_nch", C.c_int)])
+                [("bias_parts", C.c_void_p), ("bias_grad", C.c_void_p), ("bias_B", C.c_int), ("bias_nch", C.c_int),
+                 # unit-tensor operands that are a leading-batch slice of a larger tensor: units between planes (0 = dense)
+                 ("s_plane_units", C.c_longlong), ("l_plane_units", C.c_longlong)])
 
 
 _lib = None
