@@ -1894,7 +1894,7 @@ class _BlurConvS2Fused(torch.autograd.Function):
         TP = upfirdn2d_units_s2(x, k, pad=(2, 3, 2, 3))
         out = conv2d_units_s2_raw(TP, pack_filter(w, False, False), O, epi=N.epilogue(alpha=coef, bias=b, act=ACT_LRELU, gain=gain))
         ctx.save_for_backward(w, b, out, TP.data)
-        ctx.meta = (tuple(x.shape), tuple(TP[1:]), coef, gain, role)
+        ctx.meta = (tuple(x.shape), tuple(TP[1:8]), coef, gain, role)
         return out
 
     @staticmethod
