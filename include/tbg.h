@@ -87,12 +87,6 @@ typedef struct tbg_epilogue {
   void *units_out;            /* bf16 U[units_planes][B][M/8][Hout+2][Wout+2][8], 16-byte aligned, or NULL */
   const float *units_scale;   /* [B*M] (the NEXT layer's style modulation, modulated_conv2d.py:94-96) or NULL = 1 */
   int units_planes;           /* 1 (bf16: RNE) | 3 (f32x3: hi | mid | lo) */
-  /* SAVED BATCH (round 5): > 0 = the tensors the epilogue READS per sample -- out_scale, noise, dot_aux, and the saved output
-   * `out_act` of the bias_act backward entries -- hold saved_batch samples and sample b of the launch reads sample b % saved_batch:
-   * a backward launch over SEVERAL cotangents of one forward pass (the training step differentiates the generator once for the
-   * GAN-loss and OCR-loss gradient sets together, reference training_step.py:194-206) shares the saved activations instead of
-   * needing copies.  Honoured by tbg_conv2d_*, tbg_conv2d_units*, tbg_slab_epilogue*_f32 and tbg_bias_act_bwd_*; 0 = off. */
-  int saved_batch;
 } tbg_epilogue;
 
 /* ------------------------------------------------------------------------------------------
@@ -209,9 +203,6 @@ typedef struct tbg_wgrad_desc {
   const float *bias_parts;
   float *bias_grad; /* [CS] */
   int bias_B, bias_nch;
-  /* unit-tensor entries only: 16-byte units between two PLANES of the S / L unit tensor when the operand is a leading-batch
-   * SLICE of a larger unit tensor (B samples starting at the pointer, planes laid out for the whole tensor); 0 = dense. */
-  long long s_plane_units, l_plane_units;
 } tbg_wgrad_desc;
 
 long long tbg_conv2d_wgrad_workspace_bytes(const tbg_wgrad_desc *d);
@@ -429,9 +420,7 @@ int tbg_attn_ctx_bwd_f32(const float *dctx, const float *a, const float *q, cons
  *               with dx = NULL the filter gradient of FromRGB (layers/from_rgb.py:26-29).  G holds
  *               tbg_rgb_backproject_chunks(HW) partial sums per (b, c): plain stores, no atomics, no zero-fill --
  *               deterministic; the caller adds them up (tbg_torgb_bwd_smalls_f32 does).  dysum (optional) [B, chunks, O] =
- *               sum of dym over each pixel chunk: the partial sums of ToRGB's bias gradient.  saved_B > 0: x, scale and colmask hold
- *               saved_B samples and sample b reads sample b % saved_B (several cotangents of one forward pass, see
- *               tbg_epilogue.saved_batch).
+ *               sum of dym over each pixel chunk: the partial sums of ToRGB's bias gradient.
  * Column mask m (NULL = 1): m[b,p] = colmask[b*ceil(maskW/maskCW) + (p % maskW) / maskCW] -- one value per maskCW-wide
  * column band of a row-major map of width maskW (HW % maskW == 0).
  * ---------------------------------------------------------------------------------------- */
@@ -441,8 +430,7 @@ int tbg_rgb_project_f32(const float *x, const float *w, const float *scale, cons
 int tbg_rgb_backproject_chunks(int HW);
 int tbg_rgb_backproject_f32(const float *x, const float *dy, const float *w, const float *scale,
                             float *dx, float *G, int B, int C, int O, int ldw, int HW, float alpha,
-                            const float *colmask, int maskW, int maskCW, float *dym, float *dysum, int saved_B,
-                            void *stream);
+                            const float *colmask, int maskW, int maskCW, float *dym, float *dysum, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * bias_act: stand-alone epilogue (x: [B,M,HW]) and its backward.

@@ -151,21 +151,8 @@ def _step_vs_oracle(dev, arith, B, reg, tol_override=None):
     for name, a, e in zip(("reg_g", "g", "pl", "reg_d", "d", "r1", "ocr"), got, exp):
         assert abs(a - e) <= tol["loss"] * max(1.0, abs(e)), (arith, name, a, e)
     gnames = [n for n in prod["generator"]._flat.names if n.startswith(("latent_encoder.", "synthesis."))]
-    if arith == "bf16":
-        # bf16 mode: the set's SCALAR parameters (the ten noise strengths: each ONE heavily cancelling sum over a whole activation,
-        # relative error 6e-2 ... 2.7e-1 whichever kernels run, profiles/r05_bf16_step_error_table_plain.txt) are compared as ONE
-        # vector at the per-tensor bar -- the criterion the fp32 suites apply to the OCR-weighted set's scalars below; every
-        # tensor with more than one element keeps the per-tensor bar, the flat buffer its own
-        worst = max((l2_err(v, ref_grads["g"][n]), n) for n, v in zip(gnames, ts.g_views) if v.numel() > 1)
-        assert worst[0] < tol["g"], (arith, "g", worst)
-        sg = [(v.detach().double().cpu().reshape(()), ref_grads["g"][n].double().reshape(())) for n, v in zip(gnames, ts.g_views)
-              if v.numel() == 1]
-        a_, e_ = torch.stack([x for x, _ in sg]), torch.stack([y for _, y in sg])
-        err_ = float((a_ - e_).norm() / (e_.norm() + 1e-30))
-        assert err_ < tol["g"], (arith, "g scalars as one vector", err_)
-    else:
-        worst = max((l2_err(v, ref_grads["g"][n]), n) for n, v in zip(gnames, ts.g_views))
-        assert worst[0] < tol["g"], (arith, "g", worst)
+    worst = max((l2_err(v, ref_grads["g"][n]), n) for n, v in zip(gnames, ts.g_views))
+    assert worst[0] < tol["g"], (arith, "g", worst)
     onames = [n for n in prod["generator"]._flat.names if n.startswith(("synthesis.", "word_encoder."))]
     # the OCR-weighted (1e-4) gradients are sums with heavy cancellation; a SCALAR parameter (noise_strength) is one such
     # sum, so its relative error is the conditioning of that sum (measured 2.4e-2 on synth_blocks.4.apply_noise_1)

@@ -22,11 +22,7 @@ struct EpiK {
   const float *units_scale;
   int units_planes;
   long long units_plane;      // bytes between two planes of units_out (set by the entry: epi_sink_geometry)
-  int saved_batch;            // > 0: per-sample reads (out_scale, noise, dot_aux, out_act) index sample b % saved_batch
 };
-
-// sample index of a per-sample SAVED tensor (tbg_epilogue.saved_batch)
-__device__ __forceinline__ int epi_sb(const EpiK &e, int b) { return e.saved_batch > 0 ? b % e.saved_batch : b; }
 
 static inline EpiK make_epi(const tbg_epilogue *e) {
   EpiK k;
@@ -35,11 +31,10 @@ static inline EpiK make_epi(const tbg_epilogue *e) {
     k.residual = e->residual; k.dot_aux = e->dot_aux; k.gate = e->gate; k.dot_out = e->dot_out; k.alpha = e->alpha; k.bias_mul = e->bias_mul; k.slope = e->slope;
     k.gain = e->gain; k.res_scale = e->res_scale; k.act = e->act; k.res_first = e->res_first;
     k.units_out = e->units_out; k.units_scale = e->units_scale; k.units_planes = e->units_planes; k.units_plane = 0;
-    k.saved_batch = e->saved_batch;
   } else {
     k.out_scale = k.bias = k.noise = k.strength = k.residual = k.dot_aux = k.gate = nullptr; k.dot_out = nullptr;
     k.alpha = 1.f; k.bias_mul = 1.f; k.slope = 1.f; k.gain = 1.f; k.res_scale = 1.f; k.act = TBG_ACT_LINEAR; k.res_first = 0;
-    k.units_out = nullptr; k.units_scale = nullptr; k.units_planes = 0; k.units_plane = 0; k.saved_batch = 0;
+    k.units_out = nullptr; k.units_scale = nullptr; k.units_planes = 0; k.units_plane = 0;
   }
   return k;
 }
@@ -56,7 +51,6 @@ static inline bool epi_valid(const tbg_epilogue *e) {
   } else if (e->units_scale) {
     return false;
   }
-  if (e->saved_batch < 0) return false;
   return true;
 }
 

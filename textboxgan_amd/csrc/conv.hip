@@ -624,9 +624,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     e_b[j] = okpix ? b : 0;
   }
   constexpr int RG = OCC == 4 ? 2 : 4;  // rows per load batch (register budget: the epilogue must not raise the kernel's allocation)
-  // (saved-batch indexing: not in the 128 x 256-tile builds -- 128 accumulators leave no registers for it; the host never picks
-  // them for a launch with tbg_epilogue.saved_batch)
-  conv_epilogue<WTM, WTN, RG, BF, (BF && WTM * WTN < 8)>(acc[0], p.e, p.y, p.ksplit > 1 ? p.y + (size_t)ks * p.slab : nullptr, p.M, HWout,
+  conv_epilogue<WTM, WTN, RG, BF>(acc[0], p.e, p.y, p.ksplit > 1 ? p.y + (size_t)ks * p.slab : nullptr, p.M, HWout,
                               m0 + wm * WTM * 32, lane, e_pix, e_b, bg < p.B, bg, p.dot_slots, (tu * ci.tilesV + tv) * WGN + wn,
                               p.Hout, p.Wout);
 }
@@ -708,9 +706,7 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
   p.B = d->B; p.C = d->C; p.M = d->M; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
   p.ldw = d->ldw;
   p.e = make_epi(epi);
-  // unit tensors belong to the bf16-pipe arithmetics (bf16, f32x3); the exact-fp32 builds carry neither the sink nor the
-  // saved-batch indexing (their 4-waves/SIMD instances have no registers to spare)
-  if ((p.e.units_out || p.e.saved_batch) && mode == 0) return TBG_EUNSUPPORTED;
+  if (p.e.units_out && mode == 0) return TBG_EUNSUPPORTED;  // unit tensors belong to the bf16-pipe arithmetics (bf16, f32x3)
   if (const int rcs = epi_sink_geometry(p.e, d->B, d->M, d->Hout, d->Wout)) return rcs;
   const int T = d->KH * d->KW;
   p.wplane = T * ((d->C + 7) / 8) * d->ldw * 4;
@@ -784,7 +780,7 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
       // f32x3, launches of >= 1024 128x128 tiles (the 64x256 layers; the joint discriminator pass's 32x128 layers): a
       // 128 x 256 tile halves the filter DMA per MFMA and the barrier count and still fills whole rounds of the 512 slots.
       // variant 1 forces it, variant 2 forbids it (tbg_conv2d_x3_variant).
-      if (x3 && !d->transposed && d->sy == 1 && d->sx == 1 && T == 9 && BM == 128 && d->ksplit == 1 && !p.e.saved_batch &&
+      if (x3 && !d->transposed && d->sy == 1 && d->sx == 1 && T == 9 && BM == 128 && d->ksplit == 1 &&
           (variant == 1 || (variant == 0 && tiles128 >= 1024)))
         BN = 256;
       // f32x3 stride-2 forward: the 9 x 66 halo of a 128-pixel tile (three planes, 28.5 KB) beside the 55.3 KB filter tile

@@ -104,7 +104,7 @@ __device__ __forceinline__ void sink_zero(char *ub, long long plane_bytes, int p
 
 // SINK = false compiles the sink out (the exact-fp32 instantiations: no unit consumer exists in that arithmetic, and the sink's
 // registers pushed the 4-waves/SIMD builds into scratch -- 320 bytes per lane, exact-fp32 step 27.1 -> 31.7 ms).
-template <int WTM, int WTN, int RG, bool SINK = true, bool SB = SINK>
+template <int WTM, int WTN, int RG, bool SINK = true>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], const EpiK &e, float *y, float *slab, int M_, int HWout,
                                               int mrow0, int lane, const int (&e_pix)[WTN], const int (&e_b)[WTN], bool dot_ok,
                                               int dot_b, int dot_slots, int dot_slot, int Hout = 0, int Wout = 0) {
@@ -121,12 +121,9 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
   const bool plain = !e_os && !e_bias && !e.noise && !e_res && !e_aux && !e_gate && !e_lrelu && e_gain == 1.f && !sink;
   const int M = M_;
   float *const ybase = split ? slab : y;
-  int e_bs[WTN];  // sample of the per-sample SAVED tensors (out_scale, noise, dot_aux): tbg_epilogue.saved_batch
-#pragma unroll
-  for (int j = 0; j < WTN; ++j) e_bs[j] = SB ? epi_sb(e, e_b[j]) : e_b[j];  // (SB = false: compiled out, see the callers)
   float e_nz[WTN];
 #pragma unroll
-  for (int j = 0; j < WTN; ++j) e_nz[j] = (e_pix[j] >= 0 && e.noise) ? e.noise[(size_t)e_bs[j] * HWout + e_pix[j]] * str : 0.f;
+  for (int j = 0; j < WTN; ++j) e_nz[j] = (e_pix[j] >= 0 && e.noise) ? e.noise[(size_t)e_b[j] * HWout + e_pix[j]] * str : 0.f;
   if (split || plain) {  // store-only: alpha * acc (split-K slabs, plain data gradients)
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
@@ -181,7 +178,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
 #pragma unroll
         for (int q = 0; q < RG; ++q)
 #pragma unroll
-          for (int j = 0; j < WTN; ++j) osv[q][j] = e_os[idx[q][j] >= 0 ? e_bs[j] * M + mrow[q] : 0];
+          for (int j = 0; j < WTN; ++j) osv[q][j] = e_os[idx[q][j] >= 0 ? e_b[j] * M + mrow[q] : 0];
       }
       if (e_res) {
 #pragma unroll
@@ -193,8 +190,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
 #pragma unroll
         for (int q = 0; q < RG; ++q)
 #pragma unroll
-          for (int j = 0; j < WTN; ++j)
-            axv[q][j] = e_aux[idx[q][j] >= 0 ? (e_bs[j] * M + mrow[q]) * HWout + e_pix[j] : 0];  // (the saved tensor's sample)
+          for (int j = 0; j < WTN; ++j) axv[q][j] = e_aux[max(idx[q][j], 0)];
       } else if (e_gate) {  // never together with the dot operand (epi_valid): the gate values share its registers
 #pragma unroll
         for (int q = 0; q < RG; ++q)

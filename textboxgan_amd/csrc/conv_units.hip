@@ -131,14 +131,13 @@ __global__ __launch_bounds__(256) void slab_epilogue_units_kernel(const SlabUnit
       for (int cc = 0; cc < 8; ++cc) v[cc] += tv[cc];
     }
     const float str = p.e.noise ? p.e.strength[0] : 0.f;
-    const int bs = epi_sb(p.e, b);
-    const float nz = p.e.noise ? p.e.noise[(size_t)bs * HW + pix] * str : 0.f;
+    const float nz = p.e.noise ? p.e.noise[(size_t)b * HW + pix] * str : 0.f;
     const bool rf = p.e.residual && p.e.res_first;
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
       const int m = cu * 8 + cc, plane = b * p.M + m;
       const size_t gi = g0 + (size_t)cc * HW;
-      const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[bs * p.M + m] : 1.f);
+      const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[plane] : 1.f);
       float o = v[cc] * sc + (p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f);
       if (p.e.noise) o += nz;
       if (rf) o += p.e.residual[gi];
@@ -197,7 +196,6 @@ __global__ __launch_bounds__(256) void bias_act_bwd_units_kernel(const BabUnitsP
   __shared__ float red[4][24];
   const int Wp = p.W + 2, Hp = p.H + 2, C8 = (p.M + 7) >> 3, HW = p.H * p.W;
   const int cu = blockIdx.x % C8, b = blockIdx.x / C8;
-  const int bs = epi_sb(p.e, b);  // the SAVED tensors' sample (out_act, noise, out_scale: tbg_epilogue.saved_batch)
   const int r0 = blockIdx.y * UB_ROWS, r1 = min(r0 + UB_ROWS, Hp);
   const float str = p.e.noise ? p.e.strength[0] : 0.f;
   const float gin = p.e.residual ? p.e.res_scale : 1.f;  // residual != NULL only flags "fused residual"
@@ -209,13 +207,13 @@ __global__ __launch_bounds__(256) void bias_act_bwd_units_kernel(const BabUnitsP
   for (int cc = 0; cc < 8; ++cc) {
     const int m = cu * 8 + cc;
     chok[cc] = m < p.M;
-    sc[cc] = chok[cc] ? p.e.alpha * (p.e.out_scale ? p.e.out_scale[bs * p.M + m] : 1.f) : 0.f;
+    sc[cc] = chok[cc] ? p.e.alpha * (p.e.out_scale ? p.e.out_scale[b * p.M + m] : 1.f) : 0.f;
     bias[cc] = (chok[cc] && p.e.bias) ? p.e.bias[m] * p.e.bias_mul : 0.f;
   }
   float s_db[8], s_dn[8], s_dy[8];
 #pragma unroll
   for (int cc = 0; cc < 8; ++cc) { s_db[cc] = 0.f; s_dn[cc] = 0.f; s_dy[cc] = 0.f; }
-  const size_t g0 = ((size_t)b * p.M + cu * 8) * HW, gs0 = ((size_t)bs * p.M + cu * 8) * HW;
+  const size_t g0 = ((size_t)b * p.M + cu * 8) * HW;
   bf16x8 *Ub = p.U + ((size_t)b * C8 + cu) * Hp * Wp;
   const int npos = (r1 - r0) * Wp;
   for (int e = threadIdx.x; e < npos; e += 256) {
@@ -225,11 +223,11 @@ __global__ __launch_bounds__(256) void bias_act_bwd_units_kernel(const BabUnitsP
     float ov[8], dv[8];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
-      const bool okc = inside && chok[cc];
-      ov[cc] = p.out_act[okc ? gs0 + (size_t)cc * HW + pix : 0];
-      dv[cc] = p.dout[okc ? g0 + (size_t)cc * HW + pix : 0];
+      const size_t gi = (inside && chok[cc]) ? g0 + (size_t)cc * HW + pix : 0;
+      ov[cc] = p.out_act[gi];
+      dv[cc] = p.dout[gi];
     }
-    const float n = (inside && p.e.noise) ? p.e.noise[(size_t)bs * HW + pix] : 0.f;
+    const float n = (inside && p.e.noise) ? p.e.noise[(size_t)b * HW + pix] : 0.f;
     float v[8];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
@@ -500,9 +498,7 @@ extern "C" int tbg_conv2d_wgrad_units(const tbg_wgrad_desc *d, const void *SU, c
   if (d->B < 1 || d->CS < 1 || d->CL < 1 || d->Hs < 1 || d->Ws < 1 || d->Hl < 1 || d->Wl < 1) return TBG_EINVAL;
   if (((reinterpret_cast<uintptr_t>(SU) | reinterpret_cast<uintptr_t>(LU)) & 15) != 0) return TBG_EINVAL;
   if (!wgrad_units_ok(d)) return TBG_EUNSUPPORTED;
-  if (d->s_plane_units < 0 || d->l_plane_units < 0) return TBG_EINVAL;
-  const long long s_plane = d->s_plane_units ? d->s_plane_units : units_per_plane(d->B, d->CS, d->Hs, d->Ws);
-  const long long l_plane = d->l_plane_units ? d->l_plane_units : units_per_plane(d->B, d->CL, d->Hl, d->Wl);
+  const long long s_plane = units_per_plane(d->B, d->CS, d->Hs, d->Ws), l_plane = units_per_plane(d->B, d->CL, d->Hl, d->Wl);
   if (s_plane * planes > 2147483647LL / 2 || l_plane * planes > 2147483647LL / 2) return TBG_ERANGE;
   WgUnitsP u{};
   u.SU = reinterpret_cast<const char *>(SU); u.LU = reinterpret_cast<const char *>(LU);

@@ -715,9 +715,8 @@ extern "C" int tbg_conv2d_wgrad_units_s2(const tbg_wgrad_desc *d, const void *SU
   if (d->B < 1 || d->CS < 1 || d->CL < 1 || d->Hs < 1 || d->Ws < 1 || d->Hl < 1 || d->Wl < 1) return TBG_EINVAL;
   if (((reinterpret_cast<uintptr_t>(SU) | reinterpret_cast<uintptr_t>(LU)) & 15) != 0) return TBG_EINVAL;
   if (!wgrad_units_s2_ok(d)) return TBG_EUNSUPPORTED;
-  if (d->s_plane_units < 0 || d->l_plane_units < 0) return TBG_EINVAL;
-  const long long s_plane = d->s_plane_units ? d->s_plane_units : (long long)d->B * (d->CS / 8) * (d->Hs + 2) * (d->Ws + 2);
-  const long long l_plane = d->l_plane_units ? d->l_plane_units : s2_units_per_plane(d->B, d->CL, d->Hs, d->Ws);
+  const long long s_plane = (long long)d->B * (d->CS / 8) * (d->Hs + 2) * (d->Ws + 2);
+  const long long l_plane = s2_units_per_plane(d->B, d->CL, d->Hs, d->Ws);
   if (s_plane * planes > 2147483647LL / 16 || l_plane * planes > 2147483647LL / 16) return TBG_ERANGE;  // 32-bit unit offsets
   WgS2P u{};
   u.SU = reinterpret_cast<const char *>(SU); u.LU = reinterpret_cast<const char *>(LU);

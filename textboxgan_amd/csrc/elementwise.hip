@@ -65,7 +65,6 @@ extern "C" int tbg_bias_act_fwd_f32(const float *x, float *y, int B, int M, int 
                                     void *stream) {
   if (!x || !y || B < 1 || M < 1 || HW < 1 || !epi_valid(epi) || epi_has_sink(epi)) return TBG_EINVAL;
   if ((double)B * M * HW > 2147483647.0) return TBG_ERANGE;
-  if (epi && epi->saved_batch && !(HW <= 1024 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)) return TBG_EINVAL;  // (slab form only)
   if (HW <= 1024 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && !(epi && epi->dot_aux))
     return tbg_slab_epilogue_f32(x, y, B, M, HW, 1, epi, stream);  // small planes: one flat pass
   BiasActP p{x, y, B, M, HW, make_epi(epi)};
@@ -94,8 +93,7 @@ __global__ __launch_bounds__(256) void slab_epilogue_kernel(const SlabEpiP p) {
     const long long i = vec ? q << 2 : q;
     const int plane = (int)(i / p.HW), pix = (int)(i - (long long)plane * p.HW);
     const int b = plane / p.M, m = plane - b * p.M;
-    const int bs = epi_sb(p.e, b);
-    const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[bs * p.M + m] : 1.f);
+    const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[plane] : 1.f);
     const float bias = p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     const int w = vec ? 4 : 1;
@@ -119,7 +117,7 @@ __global__ __launch_bounds__(256) void slab_epilogue_kernel(const SlabEpiP p) {
     for (int k = 0; k < 4; ++k) {
       if (k < w) {
         float o = v[k] * sc + bias;
-        if (p.e.noise) o += p.e.noise[(size_t)bs * p.HW + pix + k] * str;
+        if (p.e.noise) o += p.e.noise[(size_t)b * p.HW + pix + k] * str;
         if (rf) o += p.e.residual[i + k];
         o = epi_act(p.e, o);
         if (p.e.residual && !rf) o = (o + p.e.residual[i + k]) * p.e.res_scale;
@@ -157,18 +155,17 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const BiasActBwdP p) 
   __shared__ float red[3][4];
   const int plane = blockIdx.x;
   const int b = plane / p.M, m = plane - b * p.M;
-  const int bs = epi_sb(p.e, b), splane = bs * p.M + m;  // the SAVED tensors' sample (tbg_epilogue.saved_batch)
   const int p0 = blockIdx.y * BA_CHUNK;
   const int p1 = min(p0 + BA_CHUNK, p.HW);
-  const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[splane] : 1.f);
+  const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[plane] : 1.f);
   const float bias = p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f;
   const float str = p.e.noise ? p.e.strength[0] : 0.f;
   const float gin = p.e.residual ? p.e.res_scale : 1.f;  // residual != NULL only flags "fused residual"
   const float g_pos = p.e.gain, g_neg = p.e.gain * (p.e.act == TBG_ACT_LRELU ? p.e.slope : 1.f);
   const float ig_pos = 1.f / g_pos, ig_neg = g_neg != 0.f ? 1.f / g_neg : 0.f;  // slope 0 = ReLU
   const float *dout = p.dout + (size_t)plane * p.HW;
-  const float *oa = p.out_act + (size_t)splane * p.HW;
-  const float *nz = p.e.noise ? p.e.noise + (size_t)bs * p.HW : nullptr;
+  const float *oa = p.out_act + (size_t)plane * p.HW;
+  const float *nz = p.e.noise ? p.e.noise + (size_t)b * p.HW : nullptr;
   float s_db = 0.f, s_dn = 0.f, s_dyy = 0.f;
   if ((p.HW & 3) == 0) {  // 16-byte loads / stores: 4 independent quads per lane and chunk in flight
     float *dxo = p.dx ? p.dx + (size_t)plane * p.HW : nullptr;
@@ -225,16 +222,15 @@ __global__ __launch_bounds__(256) void bias_act_bwd_small_kernel(const BiasActBw
   const int plane = blockIdx.x * 4 + wave;
   if (plane >= p.B * p.M) return;
   const int b = plane / p.M, m = plane - b * p.M;
-  const int bs = epi_sb(p.e, b), splane = bs * p.M + m;
-  const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[splane] : 1.f);
+  const float sc = p.e.alpha * (p.e.out_scale ? p.e.out_scale[plane] : 1.f);
   const float bias = p.e.bias ? p.e.bias[m] * p.e.bias_mul : 0.f;
   const float str = p.e.noise ? p.e.strength[0] : 0.f;
   const float gin = p.e.residual ? p.e.res_scale : 1.f;
   const float g_pos = p.e.gain, g_neg = p.e.gain * (p.e.act == TBG_ACT_LRELU ? p.e.slope : 1.f);
   const float ig_pos = 1.f / g_pos, ig_neg = g_neg != 0.f ? 1.f / g_neg : 0.f;
   const float *dout = p.dout + (size_t)plane * p.HW;
-  const float *oa = p.out_act + (size_t)splane * p.HW;
-  const float *nz = p.e.noise ? p.e.noise + (size_t)bs * p.HW : nullptr;
+  const float *oa = p.out_act + (size_t)plane * p.HW;
+  const float *nz = p.e.noise ? p.e.noise + (size_t)b * p.HW : nullptr;
   float *dxo = p.dx ? p.dx + (size_t)plane * p.HW : nullptr;
   float *dpo = p.dpre_out ? p.dpre_out + (size_t)plane * p.HW : nullptr;
   float s_db = 0.f, s_dn = 0.f, s_dyy = 0.f;

@@ -12,7 +12,6 @@ struct RgbP {
   const float *x, *w, *scale, *bias, *skip, *dy, *colmask;
   float *y, *dx, *G, *dym, *dysum;
   int B, C, O, ldw, HW;
-  int savedB;                // backproject: > 0 = x, scale and colmask hold savedB samples (sample b reads b % savedB)
   int maskW, maskCW, maskN;  // colmask [B][maskN]: pixel p of a row-major map of width maskW takes colmask[b][(p % maskW) / maskCW]
   float alpha, bias_mul;
 };
@@ -117,7 +116,6 @@ __global__ __launch_bounds__(256) void rgb_project_kernel(const RgbP p) {
 __global__ __launch_bounds__(256) void rgb_backproject_kernel(const RgbP p) {
   __shared__ __attribute__((aligned(16))) float dys[RGB_MAXO][RGB_CHUNK];
   const int b = blockIdx.z;
-  const int bs = p.savedB > 0 ? b % p.savedB : b;  // sample of the SAVED tensors (x, scale, colmask)
   const int pc0 = blockIdx.x * RGB_CHUNK;
   const int npx = min(RGB_CHUNK, p.HW - pc0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -127,7 +125,7 @@ __global__ __launch_bounds__(256) void rgb_backproject_kernel(const RgbP p) {
     if (o < p.O && px < npx) {
       const size_t off = ((size_t)b * p.O + o) * p.HW + pc0 + px;
       v = p.dy[off];
-      if (p.colmask) v *= rgb_mask_at(p, bs, pc0 + px);
+      if (p.colmask) v *= rgb_mask_at(p, b, pc0 + px);
       if (p.dym && blockIdx.y == 0) p.dym[off] = v;
     }
     dys[o][px] = v;
@@ -146,10 +144,10 @@ __global__ __launch_bounds__(256) void rgb_backproject_kernel(const RgbP p) {
     const int c = blockIdx.y * RGB_CPB + cc;
     if (c >= p.C) break;
     float wv[RGB_MAXO];
-    const float sc = p.alpha * (p.scale ? p.scale[bs * p.C + c] : 1.f);
+    const float sc = p.alpha * (p.scale ? p.scale[b * p.C + c] : 1.f);
 #pragma unroll
     for (int o = 0; o < RGB_MAXO; ++o) wv[o] = (p.dx && o < p.O) ? p.w[c * p.ldw + o] * sc : 0.f;
-    const size_t base = ((size_t)b * p.C + c) * p.HW + pc0, xbase = ((size_t)bs * p.C + c) * p.HW + pc0;
+    const size_t base = ((size_t)b * p.C + c) * p.HW + pc0;
     float g[RGB_MAXO] = {0.f, 0.f, 0.f, 0.f};
     if (vec) {
       // all x loads of this channel's pixel chunk are issued first (8 float4 per lane in flight): one load per loop
@@ -160,7 +158,7 @@ __global__ __launch_bounds__(256) void rgb_backproject_kernel(const RgbP p) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
           const int px = lane * 4 + it * 256;
-          xv[it] = px < npx ? *reinterpret_cast<const float4 *>(p.x + xbase + px) : make_float4(0, 0, 0, 0);
+          xv[it] = px < npx ? *reinterpret_cast<const float4 *>(p.x + base + px) : make_float4(0, 0, 0, 0);
         }
       }
 #pragma unroll
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(256) void rgb_backproject_kernel(const RgbP p) {
           p.dx[base + px] = r;
         }
         if (p.G) {
-          const float xv = p.x[xbase + px];
+          const float xv = p.x[base + px];
           for (int o = 0; o < RGB_MAXO; ++o) g[o] += xv * dys[o][px];
         }
       }
@@ -233,13 +231,13 @@ extern "C" int tbg_rgb_backproject_chunks(int HW) { return HW < 1 ? -1 : (HW + R
 
 extern "C" int tbg_rgb_backproject_f32(const float *x, const float *dy, const float *w, const float *scale, float *dx,
                                        float *G, int B, int C, int O, int ldw, int HW, float alpha, const float *colmask,
-                                       int maskW, int maskCW, float *dym, float *dysum, int saved_B, void *stream) {
-  if (!dy || B < 1 || C < 1 || O < 1 || O > RGB_MAXO || HW < 1 || (!dx && !G) || saved_B < 0) return TBG_EINVAL;
+                                       int maskW, int maskCW, float *dym, float *dysum, void *stream) {
+  if (!dy || B < 1 || C < 1 || O < 1 || O > RGB_MAXO || HW < 1 || (!dx && !G)) return TBG_EINVAL;
   if ((dx && (!w || ldw < O)) || (G && !x)) return TBG_EINVAL;
   if (!rgb_mask_ok(colmask, maskW, maskCW, HW)) return TBG_EINVAL;
   if ((double)B * C * HW > 2147483647.0) return TBG_ERANGE;
   RgbP p{};
-  p.x = x; p.dy = dy; p.w = w; p.scale = scale; p.dx = dx; p.G = G; p.dym = dym; p.dysum = dysum; p.savedB = saved_B;
+  p.x = x; p.dy = dy; p.w = w; p.scale = scale; p.dx = dx; p.G = G; p.dym = dym; p.dysum = dysum;
   p.B = B; p.C = C; p.O = O; p.ldw = ldw; p.HW = HW; p.alpha = alpha;
   p.colmask = colmask; p.maskW = colmask ? maskW : 1; p.maskCW = colmask ? maskCW : 1;
   p.maskN = colmask ? (maskW + maskCW - 1) / maskCW : 1;

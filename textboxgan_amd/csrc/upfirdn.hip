@@ -519,7 +519,6 @@ static int upfirdn_fill(UpfirdnP &p, const float *x, float *y, int major, int in
 static int upfirdn_epi(UpfirdnP &p, const float *in_scale, int M, const tbg_epilogue *epi, bool sink_ok = false) {
   if (!epi_valid(epi) || (epi && (epi->residual || epi->dot_aux || epi->gate))) return TBG_EINVAL;
   if (epi_has_sink(epi) && !sink_ok) return TBG_EINVAL;
-  if (epi && epi->saved_batch) return TBG_EINVAL;  // (a forward epilogue: nothing saved to share)
   if (epi && (M < 1 || p.major % M != 0)) return TBG_EINVAL;
   p.in_scale = in_scale;
   if (epi) { p.has_epi = 1; p.M = M; p.e = make_epi(epi); }

@@ -209,14 +209,12 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2D(cfg, in_ch, 3, 1, up=False, demodulate=False)
         self.apply_bias = BiasAct(3, 1.0, "linear")
 
-    def forward(self, x, style, skip=None, mode="fused", s=None, colmask=None, mask_cw=0, car=None):
+    def forward(self, x, style, skip=None, mode="fused", s=None, colmask=None, mask_cw=0):
         """s: the precomputed style affine of this layer (fused mode: ops.style_affines does all layers in one launch).
-        colmask [B, W // mask_cw]: mask_text_box (utils/utils.py:11-45) applied by the same launch (last block only).
-        car: the dual pass's gradient carriers by parameter (Synthesis.forward(dual=True))."""
+        colmask [B, W // mask_cw]: mask_text_box (utils/utils.py:11-45) applied by the same launch (last block only)."""
         s = self.conv.style(style, mode) if s is None else s
         if mode == "fused":
-            carriers = None if car is None else (car[self.conv.w], car[self.apply_bias.b])
-            return ops.torgb_fused(x, self.conv.w, s, self.apply_bias.b, skip, colmask, mask_cw, carriers=carriers)
+            return ops.torgb_fused(x, self.conv.w, s, self.apply_bias.b, skip, colmask, mask_cw)
         if mode == "fused2" and colmask is None:  # twice-differentiable fused node (path-length pass)
             return ops2.torgb2(x, self.conv.w, s, self.apply_bias.b, skip)
         y = self.apply_bias(self.conv.conv_composable(x, s, None))
@@ -238,7 +236,7 @@ class SynthesisBlock(nn.Module):
         self.apply_noise_1 = Noise()
         self.apply_bias_act_1 = BiasAct(fmaps, 1.0, "lrelu")
 
-    def forward(self, x, w0, w1, noise0, noise1, mode="fused", s0=None, s1=None, d0=None, d1=None, next_sink=None, car=None):
+    def forward(self, x, w0, w1, noise0, noise1, mode="fused", s0=None, s1=None, d0=None, d1=None, next_sink=None):
         """next_sink (fused mode): ops.UnitSink of the layer that consumes this block's output (the next block's up-convolution):
         conv_1's epilogue then writes that layer's unit tensor; conv_0's FIR epilogue always writes conv_1's."""
         for conv, nz, ba, style, noise, s, d in ((self.conv_0, self.apply_noise_0, self.apply_bias_act_0, w0, noise0, s0, d0),
@@ -248,8 +246,7 @@ class SynthesisBlock(nn.Module):
                 fn = ops.modconv_up_fused if conv.up else ops.modconv_fused
                 # the product the NEXT convolution contracts is (this output) * (its style): written by this layer's epilogue
                 sink = (ops.UnitSink(s1, "s1", self.conv_1.w.shape[3]) if s1 is not None else None) if conv.up else next_sink
-                carriers = None if car is None else (car[conv.w], car[nz.noise_strength], car[ba.b])
-                x = fn(x, conv.w, s, noise, nz.noise_strength, ba.b, sink=sink, carriers=carriers)
+                x = fn(x, conv.w, s, noise, nz.noise_strength, ba.b, sink=sink)
             elif mode == "fused2":  # twice-differentiable fused layer: two autograd nodes with hand-written gradients
                 x = ops2.mod_layer2(x, conv.w, s, conv.demod(s, mode) if d is None else d, noise, nz.noise_strength, ba.b,
                                     up=conv.up)
@@ -277,23 +274,9 @@ class Synthesis(nn.Module):
     def noise_shapes(self, B):
         return [(B, 1, h, w) for (h, w) in self.resolutions[1:] for _ in range(2)]
 
-    def forward(self, x, style, noises: Optional[List[torch.Tensor]] = None, mode="fused", colmask=None, mask_cw=0, dual=False):
-        """colmask / mask_cw: the text-box mask of the final image, applied inside the last toRGB launch.
-        dual (fused mode): the pass will be differentiated ONCE for TWO cotangents -- the training step's GAN-loss and OCR-loss
-        gradient sets (reference training_step.py:194-206 runs the generator's backward twice).  Returns the image as
-        [2, B, 3, H, W] (row 0 feeds the discriminator, row 1 the recogniser; same values); every activation between the fused
-        layers is the [2, B, ...] expansion of the real one, so each layer's backward sees both cotangents in one call (ops.
-        _ModConvFused.forward).  Parameter gradients arrive at ``self.dual_carriers`` -- (name, leaf [2, *param.shape]) in
-        named_parameters() order: row 0 = the GAN-loss set, row 1 = the OCR-loss set.  x's gradient flows from row 1 only (the
-        word encoder belongs to ocr_optimizer), the styles' from row 0 only (latent_encoder belongs to g_optimizer): train.py:58-75."""
+    def forward(self, x, style, noises: Optional[List[torch.Tensor]] = None, mode="fused", colmask=None, mask_cw=0):
+        """colmask / mask_cw: the text-box mask of the final image, applied inside the last toRGB launch."""
         B = x.shape[0]
-        car = None
-        if dual:
-            assert mode == "fused"
-            car = {p: p.detach().unsqueeze(0).expand(2, *p.shape).requires_grad_() for p in self.parameters()}
-            self.dual_carriers = [(n, car[p]) for n, p in self.named_parameters()]
-            x = torch.stack([x.detach(), x])
-            style = torch.stack([style, style.detach()])
         if noises is None:  # fresh noise on every call, also at inference (noise.py:16-19): ONE generator launch for all ten maps
             shapes = self.noise_shapes(B)
             sizes = [b_ * c_ * h_ * w_ for (b_, c_, h_, w_) in shapes]
@@ -303,7 +286,7 @@ class Synthesis(nn.Module):
                 noises.append(flat[o:o + n].view(shp))
                 o += -(-n // 4) * 4
         k_up = ops.fir_kernel(x.device, 4.0)
-        ws = style.unbind(dim=-2)  # one node: its backward is ONE stack of the per-layer latent gradients (16 selects
+        ws = style.unbind(dim=1)  # one node: its backward is ONE stack of the per-layer latent gradients (16 selects
         # would each zero-fill a [B, n, 512] tensor and be summed pairwise by the autograd engine)
         nb = len(self.synth_blocks)
         s_tr, s_c0, s_c1 = [None] * (nb + 1), [None] * nb, [None] * nb
@@ -311,9 +294,8 @@ class Synthesis(nn.Module):
             convs = [self.initial_torgb.conv] + [c for b, t in zip(self.synth_blocks, self.torgbs)
                                                   for c in (b.conv_0, b.conv_1, t.conv)]
             rows = [0] + [r for i in range(nb) for r in (3 * i, 3 * i + 1, 3 * i + 2)]  # the latent row each layer reads
-            sa_car = None if car is None else [car[c.mod_dense.w] for c in convs] + [car[c.mod_bias.b] for c in convs]
             ss = ops.style_affines(style, [c.mod_dense.w for c in convs], [c.mod_bias.b for c in convs],
-                                   _coef(convs[0].mod_dense.w.shape), rows, carriers=sa_car)
+                                   _coef(convs[0].mod_dense.w.shape), rows)
             s_tr[0] = ss[0]
             for i in range(nb):
                 s_c0[i], s_c1[i], s_tr[i + 1] = ss[1 + 3 * i], ss[2 + 3 * i], ss[3 + 3 * i]
@@ -330,21 +312,16 @@ class Synthesis(nn.Module):
             for i in range(nb):
                 s_c0[i], s_c1[i], s_tr[i + 1] = ss[1 + 3 * i], ss[2 + 3 * i], ss[3 + 3 * i]
                 d_c0[i], d_c1[i] = dd[1 + 3 * i], dd[2 + 3 * i]
-        y = self.initial_torgb(x, ws[0], None, mode, s=s_tr[0], car=car)
+        y = self.initial_torgb(x, ws[0], None, mode, s=s_tr[0])
         for i, (block, torgb) in enumerate(zip(self.synth_blocks, self.torgbs)):
             nxt = None
             if mode == "fused" and i + 1 < nb:  # block i + 1 starts with the up-convolution conv_0 (style s_c0[i + 1])
-                nxt = ops.UnitSink(s_c0[i + 1], "up", self.synth_blocks[i + 1].conv_0.w.shape[3], bwd_mult=2 if dual else 1)
+                nxt = ops.UnitSink(s_c0[i + 1], "up", self.synth_blocks[i + 1].conv_0.w.shape[3])
             x = block(x, ws[3 * i], ws[3 * i + 1], noises[2 * i], noises[2 * i + 1], mode, s0=s_c0[i], s1=s_c1[i],
-                      d0=d_c0[i], d1=d_c1[i], next_sink=nxt, car=car)
-            if dual:  # the RGB skip image of both rows through the (parameter-free, linear) upsampling filter as one 2B batch
-                y = ops.upfirdn2d(y.reshape(2 * B, *y.shape[2:]), k_up, up=(2, 2), pad=(2, 1, 2, 1))
-                y = y.view(2, B, *y.shape[1:])
-            else:
-                y = ops.upfirdn2d(y, k_up, up=(2, 2), pad=(2, 1, 2, 1))  # upsample_2d, :152
+                      d0=d_c0[i], d1=d_c1[i], next_sink=nxt)
+            y = ops.upfirdn2d(y, k_up, up=(2, 2), pad=(2, 1, 2, 1))  # upsample_2d, :152
             last = i == nb - 1
-            y = torgb(x, ws[3 * i + 2], y, mode, s=s_tr[i + 1], colmask=colmask if last else None, mask_cw=mask_cw if last else 0,
-                      car=car)
+            y = torgb(x, ws[3 * i + 2], y, mode, s=s_tr[i + 1], colmask=colmask if last else None, mask_cw=mask_cw if last else 0)
         return y
 
 
@@ -360,7 +337,7 @@ class Generator(nn.Module):
         self.latent_encoder = LatentEncoder(cfg, self.n_style)
 
     def forward(self, inputs, batch_size=None, ret_style=False, truncation_psi=1.0, training=False,
-                rand: Optional[dict] = None, noises_key="noises", mode="fused", mask_words=None, dual=False):
+                rand: Optional[dict] = None, noises_key="noises", mode="fused", mask_words=None):
         """mask_words [B, max_char_number]: return mask_text_box(image, mask_words, char_width) -- the mask
         (utils/utils.py:11-45) is then the epilogue of the last toRGB launch instead of a pass over the image."""
         words, z = inputs
@@ -371,7 +348,7 @@ class Generator(nn.Module):
         if ret_style:
             style = style.clone()
         img = self.synthesis(we, style, rand.get(noises_key), mode, colmask=colmask,
-                             mask_cw=self.cfg.char_width if colmask is not None else 0, dual=dual)  # dual: [2, B, 3, H, W]
+                             mask_cw=self.cfg.char_width if colmask is not None else 0)
         return (img, style) if ret_style else img
 
     @torch.no_grad()

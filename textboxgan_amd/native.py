@@ -39,9 +39,7 @@ class Epilogue(C.Structure):
                 ("residual", C.c_void_p), ("dot_aux", C.c_void_p), ("dot_out", C.c_void_p), ("gate", C.c_void_p), ("alpha", C.c_float), ("bias_mul", C.c_float), ("slope", C.c_float),
                 ("gain", C.c_float), ("res_scale", C.c_float), ("act", C.c_int), ("res_first", C.c_int),
                 # unit sink (tbg.h): units(out * units_scale) written beside / instead of the fp32 output
-                ("units_out", C.c_void_p), ("units_scale", C.c_void_p), ("units_planes", C.c_int),
-                # > 0: the per-sample tensors the epilogue reads (out_scale, noise, dot_aux, out_act) hold this many samples (b % n)
-                ("saved_batch", C.c_int)]
+                ("units_out", C.c_void_p), ("units_scale", C.c_void_p), ("units_planes", C.c_int)]
 
 
 class PackItem(C.Structure):
@@ -66,9 +64,7 @@ class WgradDesc(C.Structure):
     _fields_ = ([(n, C.c_int) for n in ("B", "CS", "CL", "Hs", "Ws", "Hl", "Wl", "KH", "KW", "sy", "sx", "py", "px",
                                         "st_t", "st_l", "st_s")] + [("alpha", C.c_float)] +
                 # rider: the layer's bias gradient summed by the filter gradient's reduce launch (tbg.h)
-                [("bias_parts", C.c_void_p), ("bias_grad", C.c_void_p), ("bias_B", C.c_int), ("bias_nch", C.c_int),
-                 # unit-tensor operands that are a leading-batch slice of a larger tensor: units between planes (0 = dense)
-                 ("s_plane_units", C.c_longlong), ("l_plane_units", C.c_longlong)])
+                [("bias_parts", C.c_void_p), ("bias_grad", C.c_void_p), ("bias_B", C.c_int), ("bias_nch", C.c_int)])
 
 
 _lib = None
@@ -166,7 +162,7 @@ def lib():
         l.tbg_slab_epilogue_units_f32.argtypes = [vp, vp, ci, ci, ci, ci, ci, C.POINTER(Epilogue), vp]
         l.tbg_bias_act_bwd_f32.argtypes = [vp] * 7 + [ci, ci, ci, C.POINTER(Epilogue), vp]
         l.tbg_rgb_project_f32.argtypes = [vp] * 6 + [ci] * 5 + [cf, cf, vp, ci, ci, vp]
-        l.tbg_rgb_backproject_f32.argtypes = [vp] * 6 + [ci] * 5 + [cf, vp, ci, ci, vp, vp, ci, vp]
+        l.tbg_rgb_backproject_f32.argtypes = [vp] * 6 + [ci] * 5 + [cf, vp, ci, ci, vp, vp, vp]
         l.tbg_rgb_backproject_chunks.argtypes = [ci]
         l.tbg_adam_tf_f32.argtypes = [vp, vp, vp, vp, ll, cf, cf, cf, cf, vp, vp]
         l.tbg_ema_lerp_f32.argtypes = [vp, vp, ll, cf, vp]
@@ -291,11 +287,11 @@ def stream() -> int:
 
 def epilogue(out_scale=None, bias=None, noise=None, strength=None, residual=None, alpha=1.0, bias_mul=1.0,
              act=ACT_LINEAR, slope=0.2, gain=None, res_scale=1.0, dot_aux=None, dot_out=None, res_first=0, gate=None,
-             units_out=None, units_scale=None, units_planes=0, saved_batch=0) -> Epilogue:
+             units_out=None, units_scale=None, units_planes=0) -> Epilogue:
     if gain is None:
         gain = SQRT2 if act == ACT_LRELU else 1.0
     return Epilogue(ptr(out_scale), ptr(bias), ptr(noise), ptr(strength), ptr(residual), ptr(dot_aux), ptr(dot_out), ptr(gate), alpha, bias_mul, slope, gain,
-                    res_scale, act, res_first, ptr(units_out), ptr(units_scale), int(units_planes), int(saved_batch))
+                    res_scale, act, res_first, ptr(units_out), ptr(units_scale), int(units_planes))
 
 
 def conv_kernel_name(desc: ConvDesc, has_in_scale: bool, fmt=0) -> str:

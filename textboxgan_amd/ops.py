@@ -115,8 +115,6 @@ class _Tuning:
         self.fold_res_scale = True   # DiscriminatorBlock folds its 1/sqrt(2) into both branches (fp32-grade arithmetics only)
         self.fuse_skip_grad = True   # DiscriminatorBlock: conv_0 + skip FIR as ONE node (False = two nodes + the engine's add)
         self.use_fused2 = True       # path-length pass on the twice-differentiable node pairs of ops2 (False = composable primitives)
-        self.merge_g_passes = True   # round 5: the generator's GAN-loss and OCR-loss gradient sets from ONE backward pass over both
-                                     # cotangents (dual forward, tbg_epilogue.saved_batch); False = the reference's two passes
         # ---- dense layers
         self.dense_small_k = 768     # above: a library GEMM; below: launch-bound, one hand-written launch per direction
 
@@ -371,8 +369,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
                 N.check(N.lib().tbg_slab_epilogue_f32(N.ptr(slabs), N.ptr(tmp), B, M, Hout * Wout, ksplit,
                                                       C.byref(N.epilogue()), N.stream()), "tbg_slab_epilogue")
             # sum_p tmp * aux per (b, m) as ONE launch: the per-plane sums of tbg_bias_act_bwd_f32 (dpre = tmp, y_rec = aux)
-            _, _, _, _, dpart = bias_act_bwd_raw(tmp, dot[0], N.epilogue(saved_batch=epi.saved_batch), want_dpre=False, want_db=False,
-                                                 want_dyy=True)
+            _, _, _, _, dpart = bias_act_bwd_raw(tmp, dot[0], N.epilogue(), want_dpre=False, want_db=False, want_dyy=True)
             if dot[1] is not None:
                 torch.sum(dpart, dim=2, out=dot[1].view(B, M))
             slabs, nslab = tmp, 1
@@ -456,16 +453,6 @@ class UnitTensor(NamedTuple):
     H: int
     W: int
     planes: int
-    plane_units: int = 0  # > 0: this is a leading-batch SLICE of a larger unit tensor -- 16-byte units between two planes
-
-
-def units_batch_slice(U, b0: int, nb: int):
-    """samples b0 .. b0 + nb - 1 of a (phase) unit tensor as an operand of the filter-gradient entries (tbg_wgrad_desc.s_plane_units /
-    l_plane_units): the flat buffer from sample b0 of plane 0 on, the planes' pitch that of the whole tensor."""
-    assert U.plane_units == 0 and 0 <= b0 and b0 + nb <= U.B
-    per_plane = U.data.numel() // U.planes           # bf16 elements per plane
-    per_sample = per_plane // U.B
-    return U._replace(data=U.data[b0 * per_sample:], B=nb, plane_units=per_plane // 8)
 
 
 def unit_planes(fmt=None) -> int:
@@ -487,12 +474,11 @@ class UnitSink:
     consumer ("s1": 3x3 stride-1 C -> O_next on the same grid; "up": the 3x3 stride-2 transposed up-convolution C -> O_next), so that
     the producer can tell whether ANY launch of the consumer's forward or backward takes unit tensors for this geometry; if none
     does, nothing is written."""
-    __slots__ = ("scale", "kind", "O_next", "produced", "bwd_mult")
+    __slots__ = ("scale", "kind", "O_next", "produced")
 
-    def __init__(self, scale, kind: str, O_next: int, bwd_mult: int = 1):
+    def __init__(self, scale, kind: str, O_next: int):
         assert kind in ("s1", "up")
         self.scale, self.kind, self.O_next = scale, kind, int(O_next)
-        self.bwd_mult = int(bwd_mult)  # cotangents per sample in the consumer's backward pass (2: the dual generator pass)
         # the UnitTensor the producer wrote (set inside the producing autograd node's forward; read by the layer wrapper, which
         # attaches it to the output tensor).  Deliberately NOT a second output of the node: autograd materialises a zero
         # "gradient" for every non-differentiable output in the backward pass -- a fill of the whole unit tensor per node and pass
@@ -505,12 +491,12 @@ class UnitSink:
         if self.kind == "s1":
             return _units_conv(B, Cc, self.O_next, H, W) or _units_wgrad(Cc, self.O_next, H, W)
         return (_units_t2(B, Cc, self.O_next, H, W, 2 * H + 1, 2 * W + 1) or
-                _units_s2(B * self.bwd_mult, self.O_next, Cc, 2 * H + 1, 2 * W + 1))  # (its backward: stride-2 conv O_next -> C)
+                _units_s2(B, self.O_next, Cc, 2 * H + 1, 2 * W + 1))  # (the up-convolution's backward: stride-2 conv O_next -> C)
 
 
 class _NoSink(UnitSink):
     def __init__(self):
-        self.scale, self.kind, self.O_next, self.produced, self.bwd_mult = None, "s1", 0, None, 1
+        self.scale, self.kind, self.O_next, self.produced = None, "s1", 0, None
 
     def wanted(self, B, Cc, H, W) -> bool:
         return False
@@ -526,10 +512,7 @@ def _sink_epi(epi: N.Epilogue, sink: Optional[UnitSink], B, M, H, W, device):
     U = units_alloc(B, M, H, W, unit_planes(), device)
     e = N.Epilogue.from_buffer_copy(epi)
     e.units_out, e.units_planes = N.ptr(U.data), U.planes
-    sc = sink.scale
-    if sc is not None and sc.dim() == 3:  # dual style [2, B, C]: both rows hold the forward's values
-        sc = sc[0]
-    e.units_scale = N.ptr(sc.contiguous()) if sc is not None else None
+    e.units_scale = N.ptr(sink.scale.contiguous()) if sink.scale is not None else None
     return e, U
 
 
@@ -548,8 +531,8 @@ def take_units(x: torch.Tensor, scale, planes: Optional[int] = None) -> Optional
     U, sc, ver = hit
     planes = unit_planes() if planes is None else planes
     same = (sc is None and scale is None) or (sc is not None and scale is not None and sc.data_ptr() == scale.data_ptr() and
-                                              sc.shape[-2:] == scale.shape[-2:] and sc._version == ver)
-    if not same or U.planes != planes or (U.B, U.C, U.H, U.W) != tuple(x.shape[-4:]):  # (a dual activation is [2, B, C, H, W])
+                                              sc.shape == scale.shape and sc._version == ver)
+    if not same or U.planes != planes or (U.B, U.C, U.H, U.W) != tuple(x.shape):
         return None
     return U
 
@@ -597,7 +580,7 @@ def conv2d_units_raw(XU: UnitTensor, w: "PackedFilter", M: int, flip=False, epi:
     """3x3 stride-1 pad-1 convolution of the activation behind the unit tensor XU (its scale already inside) with a packed
     filter of the matching format; fp32 NCHW output through the fused epilogue.  dot = (aux, out) as in conv2d_raw.
     sink: returns (y, UnitTensor | None), see conv2d_raw."""
-    assert w.fmt == (FMT_X3 if XU.planes == 3 else FMT_BF16) and w.C == XU.C and w.M >= M and w.T == 9 and XU.plane_units == 0
+    assert w.fmt == (FMT_X3 if XU.planes == 3 else FMT_BF16) and w.C == XU.C and w.M >= M and w.T == 9
     B, H, W = XU.B, XU.H, XU.W
     if sink is not None:
         epi_s, U = _sink_epi(N.epilogue() if epi is None else epi, sink, B, M, H, W, XU.data.device)
@@ -636,7 +619,6 @@ class PhaseUnitTensor(NamedTuple):
     Ho: int
     Wo: int
     planes: int
-    plane_units: int = 0  # (see UnitTensor.plane_units)
 
 
 def units_pack_s2(x: torch.Tensor, scale: Optional[torch.Tensor] = None, planes: Optional[int] = None) -> PhaseUnitTensor:
@@ -724,7 +706,6 @@ def wgrad_units_raw(SU: UnitTensor, LU: UnitTensor, out: torch.Tensor, st_t: int
     L (input-grid tensor, scale inside).  Overwrites ``out`` like wgrad_raw."""
     assert SU.planes == LU.planes and SU.B == LU.B
     d = _bias_rider(N.WgradDesc(SU.B, SU.C, LU.C, SU.H, SU.W, LU.H, LU.W, 3, 3, 1, 1, 1, 1, st_t, st_l, st_s, alpha), bias)
-    d.s_plane_units, d.l_plane_units = SU.plane_units, LU.plane_units
     nbytes = N.lib().tbg_conv2d_wgrad_units_workspace_bytes(C.byref(d))
     N.check(min(nbytes, 0), "tbg_conv2d_wgrad_units_workspace_bytes")
     ws = _workspace(out.device, nbytes)
@@ -771,7 +752,6 @@ def wgrad_units_s2_raw(SU: UnitTensor, LP: PhaseUnitTensor, out: torch.Tensor, s
     phase unit tensor of L (input-grid tensor, scale inside).  Overwrites ``out`` like wgrad_raw."""
     assert SU.planes == LP.planes and SU.B == LP.B and (SU.H, SU.W) == (LP.Ho, LP.Wo)
     d = _bias_rider(N.WgradDesc(SU.B, SU.C, LP.C, SU.H, SU.W, LP.Hin, LP.Win, 3, 3, 2, 2, 0, 0, st_t, st_l, st_s, alpha), bias)
-    d.s_plane_units, d.l_plane_units = SU.plane_units, LP.plane_units
     nbytes = N.lib().tbg_conv2d_wgrad_units_s2_workspace_bytes(C.byref(d))
     N.check(min(nbytes, 0), "tbg_conv2d_wgrad_units_s2_workspace_bytes")
     ws = _workspace(out.device, nbytes)
@@ -996,16 +976,15 @@ def rgb_project_raw(x, w2d, O, scale, bias, skip, alpha, bias_mul=1.0, out=None,
 
 
 def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True, colmask=None, mask_cw=0, want_dym=False,
-                        parts=False, saved_batch=0):
+                        parts=False):
     """dym = dy * m;  dx[b,c,p] = alpha*scale[b,c]*sum_o w2d[c,o] dym[b,o,p];  G[b,c,o] = sum_p x[b,c,p] dym[b,o,p]
     (the kernel writes one partial G per 2048-pixel chunk -- no atomics, deterministic -- summed here).
     returns (dx, G) or (dx, G, dym).  parts=True: G stays [B, C, chunks, O] and the per-chunk sums of dym [B, chunks, O] come
     too -- (dx, Gparts, dysum[, dym]) -- for tbg_torgb_bwd_smalls_f32, which sums both (no reduction launches in between)."""
-    Bx, Cc, H, W = x.shape
-    B, O = dy.shape[0], dy.shape[1]  # (saved_batch > 0: dy holds several cotangents per saved sample, x / scale / colmask Bx of them)
-    assert (saved_batch == 0 and B == Bx) or (saved_batch == Bx and B % Bx == 0)
-    _check_colmask(colmask, Bx, W, mask_cw)
-    dx = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32) if want_dx else None
+    B, Cc, H, W = x.shape
+    O = dy.shape[1]
+    _check_colmask(colmask, B, W, mask_cw)
+    dx = torch.empty_like(x) if want_dx else None
     nchunk = N.lib().tbg_rgb_backproject_chunks(H * W)
     Gp = torch.empty((B, Cc, nchunk, O), device=x.device, dtype=torch.float32) if want_G else None
     dym = torch.empty_like(dy) if want_dym else None
@@ -1013,7 +992,7 @@ def rgb_backproject_raw(x, dy, w2d, scale, alpha, want_dx=True, want_G=True, col
     _nb = 4.0 * (x.numel() * (int(want_dx) + int(want_G)) + dy.numel())
     N.check(PROFILE.launch("rgb_backproject_kernel", 0.0, lambda: N.lib().tbg_rgb_backproject_f32(
         N.ptr(x), N.ptr(dy), N.ptr(w2d), N.ptr(scale), N.ptr(dx), N.ptr(Gp), B, Cc, O, O, H * W, alpha, N.ptr(colmask), W,
-        int(mask_cw), N.ptr(dym), N.ptr(dysum), int(saved_batch), N.stream()), nbytes=_nb), "tbg_rgb_backproject")
+        int(mask_cw), N.ptr(dym), N.ptr(dysum), N.stream()), nbytes=_nb), "tbg_rgb_backproject")
     if parts:
         return (dx, Gp, dysum, dym) if want_dym else (dx, Gp, dysum)
     G = (Gp.sum(dim=2) if nchunk > 1 else Gp[:, :, 0]) if want_G else None
@@ -1409,10 +1388,7 @@ class _Bwd3x3:
         self.dpre = self.dscale = self.DU = None
 
     def from_bias_act(self, dout, out_act, epi, dscale, **want):
-        """bias / noise / LeakyReLU backward: returns (pdb, pdn, pdy); epi.out_scale must be dscale (or None).  dout may hold
-        several cotangents per saved sample (epi.saved_batch = the saved tensors' batch)."""
-        if dscale is not None and dscale.shape[0] != dout.shape[0] and self.need_dpre:
-            dscale = dscale.repeat(dout.shape[0] // dscale.shape[0], 1)  # (the NCHW launches index their input scale by sample)
+        """bias / noise / LeakyReLU backward: returns (pdb, pdn, pdy); epi.out_scale must be dscale (or None)"""
         self.dscale = dscale
         if self.units:
             self.DU, self.dpre, pdb, pdn, pdy = bias_act_bwd_units_raw(dout, out_act, epi, want_dpre=self.need_dpre, **want)
@@ -1431,26 +1407,13 @@ class _Bwd3x3:
             return conv2d_units_raw(self.DU, pack_filter(w, transpose=True, flip=True), self.I, epi=epi, dot=dot, out=out)
         return _bwd_data_launch(self.dpre, w, self.g, in_scale=self.dscale, epi=epi, dot=dot, out=out)
 
-    def dw(self, x, XU, coef, x_scale=None, add=None, bias=None, half=None, out=None):
-        """half = (h, nb): the filter gradient of cotangent h alone (samples h*nb .. of the gradient tensors against the nb saved
-        samples of x); out: a [3,3,I,O] tensor to write."""
-        DU, dpre, dscale = self.DU, self.dpre, self.dscale
-        if half is not None:
-            h, nb = half
-            if self.u_dw:
-                DU = units_batch_slice(DU, h * nb, nb)
-            else:
-                dpre = dpre[h * nb:(h + 1) * nb]
-                dscale = dscale[h * nb:(h + 1) * nb] if dscale is not None else None
+    def dw(self, x, XU, coef, x_scale=None, add=None, bias=None):
         if self.u_dw:
             XU = units_pack(x, x_scale) if XU is None else XU
-            dw = torch.empty((3, 3, self.I, self.O), device=x.device, dtype=torch.float32) if out is None else out
-            return wgrad_units_raw(DU, XU, dw, self.I * self.O, self.O, 1, coef, add=add, bias=bias)
-        dw = _bwd_weight_launch(x, dpre, self.g, self.I, self.O, alpha=coef, x_scale=x_scale, dy_scale=dscale, add=add, bias=bias)
-        if out is not None:
-            out.copy_(dw)
-            return out
-        return dw
+            dw = torch.empty((3, 3, self.I, self.O), device=x.device, dtype=torch.float32)
+            return wgrad_units_raw(self.DU, XU, dw, self.I * self.O, self.O, 1, coef, add=add, bias=bias)
+        return _bwd_weight_launch(x, self.dpre, self.g, self.I, self.O, alpha=coef, x_scale=x_scale, dy_scale=self.dscale, add=add,
+                                  bias=bias)
 
 
 def _lrelu_epi(**kw):
@@ -1475,27 +1438,15 @@ class _ModConvFused(torch.autograd.Function):
     epilogue writes units(out * sink.scale) for the next layer (handed back through sink.produced)."""
 
     @staticmethod
-    def forward(ctx, x, w, s, noise, strength, b, sink=None, w2=None, strength2=None, b2=None):
-        """DUAL form (x [2, B, C, H, W], s [2, B, I]; both rows hold the same values): the layer of a generator pass that will be
-        differentiated ONCE for two cotangents (TrainingStep: the GAN-loss and the OCR-loss gradient sets, reference
-        training_step.py:194-206).  The forward runs on row 0 and returns the result expanded to [2, B, ...]; the backward receives
-        both cotangents, runs every launch once over 2B samples against the B saved ones (tbg_epilogue.saved_batch) and hands the
-        two parameter gradients to the CARRIERS w2 [2,k,k,I,O] / strength2 [2] / b2 [2,O] (expanded leaves of the real parameters,
-        unused by the forward)."""
+    def forward(ctx, x, w, s, noise, strength, b, sink=None):
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
-        dual = x.dim() == 5
-        XU = take_units(x, s) if (x.is_contiguous() or dual) else None
-        if dual:
-            assert s.dim() == 3 and x.shape[0] == 2 and w2 is not None
-            x, s = x[0], s[0]
         assert x.shape[0] == s.shape[0] and s.shape[1] == I, "one style row per sample (a short batch must not reach the fused layers)"
-        XU = XU if s.is_contiguous() else None
+        XU = take_units(x, s) if (x.is_contiguous() and s.is_contiguous()) else None
         x = x.contiguous(); s = s.contiguous()
         d, wsq = demod_coefs_raw(s, w.contiguous(), coef)
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=coef)
         B, H, W = x.shape[0], x.shape[2], x.shape[3]
-        ctx.dual = dual
         if KH == 3 and _units_conv(B, I, O, H, W):
             # x * s exists ONCE as a unit tensor: this launch DMAs its halo tiles from it, and the filter gradient of the
             # backward pass consumes the same tensor (modulated_conv2d.py:94-96: both use exactly this product)
@@ -1510,7 +1461,7 @@ class _ModConvFused(torch.autograd.Function):
         ctx.coef = coef
         if sink is not None:
             sink.produced = U
-        return out.unsqueeze(0).expand(2, *out.shape) if dual else out
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -1518,8 +1469,6 @@ class _ModConvFused(torch.autograd.Function):
         x, w, s, d, wsq, noise, strength, b, out, xu = ctx.saved_tensors
         KH, KW, I, O = w.shape
         coef = ctx.coef
-        if ctx.dual:
-            return _ModConvFused._backward_dual(ctx, dout)
         epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
         g = _Geom((1, 1), (KH // 2, KW // 2), KH, KW, (x.shape[2], x.shape[3]), (out.shape[2], out.shape[3]))
         want_dw = ctx.needs_input_grad[1]  # frozen generator (projector.py: only the latent is optimised): no filter gradient
@@ -1529,39 +1478,14 @@ class _ModConvFused(torch.autograd.Function):
             dx, ds_conv = bw.dx(w, N.epilogue(alpha=coef, out_scale=s), dot=(x, None))  # (the style dot's partial slots)
             db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)  # (dwsq needs ds_conv)
             dw = bw.dw(x, _unit_tensor(xu, x), coef, x_scale=s, add=(w, dwsq, -coef * coef)) if want_dw else None
-            return dx, dw, ds, None, dstrength, db, None, None, None, None
+            return dx, dw, ds, None, dstrength, db, None
         _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
         dx, ds_conv = _bwd_data_launch(dpre, w, g, in_scale=d, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, None))
         db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)
         dw = None
         if want_dw:
             dw = _bwd_weight_launch(x, dpre, g, I, O, alpha=coef, x_scale=s, dy_scale=d, add=(w, dwsq, -coef * coef))
-        return dx, dw, ds, None, dstrength, db, None, None, None, None
-
-    @staticmethod
-    def _backward_dual(ctx, dout):
-        """both cotangents at once: dout [2, B, O, H, W] -> one bias_act backward and one data-gradient launch over 2B samples (the
-        saved out / x / noise / d / s hold B: saved_batch), the small-tensor tail and the filter gradient once per cotangent."""
-        x, w, s, d, wsq, noise, strength, b, out, xu = ctx.saved_tensors
-        KH, KW, I, O = w.shape
-        assert KH == 3, "the synthesis network's modulated layers are 3x3"
-        coef, B, H, W = ctx.coef, x.shape[0], x.shape[2], x.shape[3]
-        dout = dout.contiguous().view(2 * B, O, H, W)
-        epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0, saved_batch=B)
-        bw = _Bwd3x3(2 * B, I, O, H, W)
-        pdb, pdn, pdy = bw.from_bias_act(dout, out, epi, d, want_dn=True, want_dyy=True)
-        dx, ds_conv = bw.dx(w, N.epilogue(alpha=coef, out_scale=s, saved_batch=B), dot=(x, None))
-        XU = _unit_tensor(xu, x)
-        dw2 = torch.empty((2, KH, KW, I, O), device=x.device, dtype=torch.float32)
-        ds2, db2, dstr2 = [], [], []
-        for h in range(2):
-            sl = slice(h * B, (h + 1) * B)
-            db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb[sl], pdn[sl], pdy[sl], d, s, wsq, ds_conv[sl])
-            if XU is None and bw.u_dw:
-                XU = units_pack(x, s)  # (once for both cotangents)
-            bw.dw(x, XU, coef, x_scale=s, add=(w, dwsq, -coef * coef), half=(h, B), out=dw2[h])
-            ds2.append(ds); db2.append(db); dstr2.append(dstrength)
-        return (dx.view(2, B, I, H, W), None, torch.stack(ds2), None, None, None, None, dw2, torch.stack(dstr2), torch.stack(db2))
+        return dx, dw, ds, None, dstrength, db, None
 
 
 class _ModConvUpFused(torch.autograd.Function):
@@ -1570,21 +1494,14 @@ class _ModConvUpFused(torch.autograd.Function):
     demodulation inside the node as in _ModConvFused.  Unit tensors as in _ModConvFused (the sink rides on the FIR launch)."""
 
     @staticmethod
-    def forward(ctx, x, w, s, noise, strength, b, sink=None, w2=None, strength2=None, b2=None):
-        """(dual form: see _ModConvFused.forward)"""
+    def forward(ctx, x, w, s, noise, strength, b, sink=None):
         KH, KW, I, O = w.shape
         coef = 1.0 / math.sqrt(KH * KW * I)
-        dual = x.dim() == 5
-        XU = take_units(x, s) if (x.is_contiguous() or dual) else None
-        if dual:
-            assert s.dim() == 3 and x.shape[0] == 2 and w2 is not None
-            x, s = x[0], s[0]
         assert x.shape[0] == s.shape[0] and s.shape[1] == I, "one style row per sample (a short batch must not reach the fused layers)"
-        XU = XU if s.is_contiguous() else None
+        XU = take_units(x, s) if (x.is_contiguous() and s.is_contiguous()) else None
         x = x.contiguous(); s = s.contiguous()
         d, wsq = demod_coefs_raw(s, w.contiguous(), coef)
         B, H, W = x.shape[0], x.shape[2], x.shape[3]
-        ctx.dual = dual
         # (a map nobody wrote units for -- the word encoder's 2 x 8 output -- keeps the NCHW kernel unless it is big enough for a
         # stand-alone pack launch's fixed cost to disappear in it)
         if KH == 3 and _units_t2(B, I, O, H, W, 2 * H + 1, 2 * W + 1) and (XU is not None or H * W >= 256 or not TUNING.unit_sinks):
@@ -1595,7 +1512,7 @@ class _ModConvUpFused(torch.autograd.Function):
         else:
             y_up = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, (2 * H + 1, 2 * W + 1), (2, 2), (0, 0), transposed=True,
                               flip=True, in_scale=s, epi=N.epilogue(alpha=coef))
-            if XU is not None and not (KH == 3 and _units_s2((2 if dual else 1) * B, O, I, 2 * H + 1, 2 * W + 1)):
+            if XU is not None and not (KH == 3 and _units_s2(B, O, I, 2 * H + 1, 2 * W + 1)):
                 XU = None  # nobody in the backward pass reads it
         k = fir_kernel(x.device, gain=4.0)
         epi = _lrelu_epi(out_scale=d.reshape(-1), bias=b, noise=noise, strength=strength, alpha=1.0)
@@ -1604,7 +1521,7 @@ class _ModConvUpFused(torch.autograd.Function):
         ctx.coef = coef
         if sink is not None:
             sink.produced = U
-        return out.unsqueeze(0).expand(2, *out.shape) if dual else out
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -1613,12 +1530,7 @@ class _ModConvUpFused(torch.autograd.Function):
         KH, KW, I, O = w.shape
         coef = ctx.coef
         H, W = x.shape[2], x.shape[3]
-        B, nc = x.shape[0], (2 if ctx.dual else 1)  # nc cotangents per saved sample (dual form: both gradient sets at once)
-        sb = B if ctx.dual else 0
-        if ctx.dual:
-            dout = dout.contiguous().view(2 * B, O, 2 * H, 2 * W)
-        dd = d.repeat(nc, 1) if ctx.dual else d  # (the blur's per-plane input scale is indexed by the launch's own sample)
-        epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0, saved_batch=sb)
+        epi = _lrelu_epi(out_scale=d, bias=b, noise=noise, strength=strength, alpha=1.0)
         _, dpre, pdb, pdn, pdy = bias_act_bwd_raw(dout.contiguous(), out, epi, want_dn=True, want_dyy=True)
         k = fir_kernel(x.device, gain=4.0)  # symmetric: flipped == itself
         wt = pack_filter(w, transpose=True, flip=True)
@@ -1626,40 +1538,28 @@ class _ModConvUpFused(torch.autograd.Function):
         # the data gradient is a 3x3 stride-2 convolution O -> I of dy_up = blur^T(dpre * d) [B,O,2H+1,2W+1], the filter gradient
         # contracts dy_up with x * s: where the phase-unit kernels take the layer, the blur writes dy_up ONCE as a phase unit tensor
         # (no fp32 dy_up) and both launches DMA their tiles from it
-        s2 = KH == 3 and _units_s2(nc * B, O, I, 2 * H + 1, 2 * W + 1)
-        epi_dx = N.epilogue(alpha=coef, out_scale=s, saved_batch=sb)
+        s2 = KH == 3 and _units_s2(x.shape[0], O, I, 2 * H + 1, 2 * W + 1)
         if s2:
-            DYP = upfirdn2d_units_s2(dpre, k, pad=(2, 2, 2, 2), in_scale=dd.reshape(-1))
-            dx, ds_conv = conv2d_units_s2_raw(DYP, wt, I, epi=epi_dx, dot=(x, None))
+            DYP = upfirdn2d_units_s2(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))
+            dx, ds_conv = conv2d_units_s2_raw(DYP, wt, I, epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, None))
         else:
-            dy_up = upfirdn2d_raw(dpre, k, pad=(2, 2, 2, 2), in_scale=dd.reshape(-1))  # [B,O,2H+1,2W+1]
-            dx, ds_conv = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0), epi=epi_dx, dot=(x, None))
-        XU = _unit_tensor(xu, x) if s2 else None
-        if s2 and XU is None:
-            XU = units_pack(x, s)
-
-        def tail(h, dw):
-            """small-tensor tail + filter gradient of cotangent h (dW_t[t][i][o] = sum x*s . dy_up shifted; w = flip(w_t): tap t is
-            written at T-1-t)"""
-            sl = slice(h * B, (h + 1) * B)
-            db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb[sl], pdn[sl], pdy[sl], d, s, wsq, ds_conv[sl])
-            if dw is not None:
-                if s2:
-                    wgrad_units_s2_raw(XU, units_batch_slice(DYP, h * B, B) if ctx.dual else DYP, dw, -I * O, 1, O, coef,
-                                       out_offset=(T - 1) * I * O, add=(w, dwsq, -coef * coef))
-                else:
-                    wgrad_raw(x, dy_up[sl], KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O,
-                              add=(w, dwsq, -coef * coef))
-            return db, dstrength, ds
-
-        if not ctx.dual:
-            dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-            db, dstrength, ds = tail(0, dw)
-            return dx, dw, ds, None, dstrength, db, None, None, None, None
-        dw2 = torch.empty((2, KH, KW, I, O), device=x.device, dtype=torch.float32)
-        r = [tail(h, dw2[h]) for h in range(2)]
-        return (dx.view(2, B, I, H, W), None, torch.stack([t[2] for t in r]), None, None, None, None, dw2,
-                torch.stack([t[1] for t in r]), torch.stack([t[0] for t in r]))
+            dy_up = upfirdn2d_raw(dpre, k, pad=(2, 2, 2, 2), in_scale=d.reshape(-1))  # [B,O,2H+1,2W+1]
+            dx, ds_conv = conv2d_raw(dy_up, wt, I, KH, KW, (H, W), (2, 2), (0, 0),
+                                     epi=N.epilogue(alpha=coef, out_scale=s), dot=(x, None))
+        db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            # dW_t[t][i][o] = sum x*s . dy_up shifted;  w = flip(w_t)  -> write tap t at T-1-t
+            if s2:
+                XU = _unit_tensor(xu, x)
+                wgrad_units_s2_raw(XU if XU is not None else units_pack(x, s), DYP, dw, -I * O, 1, O, coef,
+                                   out_offset=(T - 1) * I * O,
+                                   add=(w, dwsq, -coef * coef))
+            else:
+                wgrad_raw(x, dy_up, KH, KW, (2, 2), (0, 0), dw, -I * O, 1, O, coef, s_scale=s, out_offset=(T - 1) * I * O,
+                          add=(w, dwsq, -coef * coef))
+        return dx, dw, ds, None, dstrength, db, None
 
 
 class _ToRGBFused(torch.autograd.Function):
@@ -1669,45 +1569,31 @@ class _ToRGBFused(torch.autograd.Function):
     backward launch masks dy while it stages it."""
 
     @staticmethod
-    def forward(ctx, x, w, s, b, skip, colmask, mask_cw, w2=None, b2=None):
-        """(dual form -- x [2, B, C, H, W], s [2, B, I], skip [2, B, 3, H, W], carriers w2 / b2: see _ModConvFused.forward)"""
+    def forward(ctx, x, w, s, b, skip, colmask, mask_cw):
         _, _, I, O = w.shape
         coef = 1.0 / math.sqrt(I)
-        dual = x.dim() == 5
-        if dual:
-            assert s.dim() == 3 and w2 is not None
-            x, s, skip = x[0], s[0], (None if skip is None else skip[0])
         assert x.shape[0] == s.shape[0] and s.shape[1] == I, "one style row per sample"
-        x = x.contiguous(); s = s.contiguous()
+        x = x.contiguous()
         y = rgb_project_raw(x, w, O, s, b, None if skip is None else skip.contiguous(), coef, colmask=colmask, mask_cw=mask_cw)
         ctx.save_for_backward(x, w, s, colmask)
         ctx.has_skip = skip is not None
-        ctx.coef, ctx.mask_cw, ctx.dual = coef, mask_cw, dual
-        return y.unsqueeze(0).expand(2, *y.shape) if dual else y
+        ctx.coef, ctx.mask_cw = coef, mask_cw
+        return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, w, s, colmask = ctx.saved_tensors
         _, _, I, O = w.shape
-        B, nc = x.shape[0], (2 if ctx.dual else 1)
         dy = dy.contiguous()
-        if ctx.dual:
-            dy = dy.view(2 * B, O, x.shape[2], x.shape[3])
-        sb = B if ctx.dual else 0
         # two launches: the streaming pass (dx, per-chunk Gram and dy sums) and the small-tensor tail that sums the chunks
         if colmask is not None:
             dx, Gp, dysum, dy = rgb_backproject_raw(x, dy, w, s, ctx.coef, colmask=colmask, mask_cw=ctx.mask_cw, want_dym=True,
-                                                    parts=True, saved_batch=sb)
+                                                    parts=True)
         else:
-            dx, Gp, dysum = rgb_backproject_raw(x, dy, w, s, ctx.coef, want_dx=True, want_G=True, parts=True, saved_batch=sb)
-        if not ctx.dual:
-            ds, dw, db = torgb_bwd_smalls_raw(Gp, w.reshape(I, O), s, ctx.coef, dysum=dysum)
-            return dx, dw.reshape(w.shape), ds, db, (dy if ctx.has_skip else None), None, None, None, None
-        r = [torgb_bwd_smalls_raw(Gp[h * B:(h + 1) * B], w.reshape(I, O), s, ctx.coef, dysum=dysum[h * B:(h + 1) * B]) for h in range(2)]
-        dskip = dy.view(2, B, O, x.shape[2], x.shape[3]) if ctx.has_skip else None
-        return (dx.view(2, B, I, x.shape[2], x.shape[3]), None, torch.stack([t[0] for t in r]), None, dskip, None, None,
-                torch.stack([t[1].reshape(w.shape) for t in r]), torch.stack([t[2] for t in r]))
+            dx, Gp, dysum = rgb_backproject_raw(x, dy, w, s, ctx.coef, want_dx=True, want_G=True, parts=True)  # G = sum_p x*dy
+        ds, dw, db = torgb_bwd_smalls_raw(Gp, w.reshape(I, O), s, ctx.coef, dysum=dysum)
+        return dx, dw.reshape(w.shape), ds, db, (dy if ctx.has_skip else None), None, None
 
 
 class _ConvBiasActFused(torch.autograd.Function):
@@ -1894,7 +1780,7 @@ class _BlurConvS2Fused(torch.autograd.Function):
         TP = upfirdn2d_units_s2(x, k, pad=(2, 3, 2, 3))
         out = conv2d_units_s2_raw(TP, pack_filter(w, False, False), O, epi=N.epilogue(alpha=coef, bias=b, act=ACT_LRELU, gain=gain))
         ctx.save_for_backward(w, b, out, TP.data)
-        ctx.meta = (tuple(x.shape), tuple(TP[1:8]), coef, gain, role)
+        ctx.meta = (tuple(x.shape), tuple(TP[1:]), coef, gain, role)
         return out
 
     @staticmethod
@@ -1963,21 +1849,19 @@ def _with_units(out, sink):
     return out
 
 
-def modconv_fused(x, w, s, noise, strength, b, sink: Optional[UnitSink] = None, carriers=None):
+def modconv_fused(x, w, s, noise, strength, b, sink: Optional[UnitSink] = None):
     """demodulated 3x3 modulated conv + noise + bias + lrelu (demodulation computed inside the node).
-    sink: the layer that consumes the result next (UnitSink): its unit tensor is written by this layer's epilogue.
-    carriers = (w2, strength2, b2): the dual form (two cotangents in one backward pass, see _ModConvFused.forward)."""
-    return _with_units(_ModConvFused.apply(x, w, s, noise, strength, b, sink, *(carriers or (None, None, None))), sink)
+    sink: the layer that consumes the result next (UnitSink): its unit tensor is written by this layer's epilogue."""
+    return _with_units(_ModConvFused.apply(x, w, s, noise, strength, b, sink), sink)
 
 
-def modconv_up_fused(x, w, s, noise, strength, b, sink: Optional[UnitSink] = None, carriers=None):
-    return _with_units(_ModConvUpFused.apply(x, w, s, noise, strength, b, sink, *(carriers or (None, None, None))), sink)
+def modconv_up_fused(x, w, s, noise, strength, b, sink: Optional[UnitSink] = None):
+    return _with_units(_ModConvUpFused.apply(x, w, s, noise, strength, b, sink), sink)
 
 
-def torgb_fused(x, w, s, b, skip=None, colmask=None, mask_cw=0, carriers=None):
-    """colmask [B, W // mask_cw] (float 0/1): multiply the output's column bands by it (mask_text_box fused in).
-    carriers = (w2, b2): the dual form (see _ModConvFused.forward)."""
-    return _ToRGBFused.apply(x, w, s, b, skip, colmask, int(mask_cw), *(carriers or (None, None)))
+def torgb_fused(x, w, s, b, skip=None, colmask=None, mask_cw=0):
+    """colmask [B, W // mask_cw] (float 0/1): multiply the output's column bands by it (mask_text_box fused in)."""
+    return _ToRGBFused.apply(x, w, s, b, skip, colmask, int(mask_cw))
 
 
 def conv_bias_act_fused(x, w, b, stride=(1, 1), pad=(0, 0), act=ACT_LRELU, residual=None, res_scale=1.0, role=None,
@@ -2138,65 +2022,20 @@ def b_like(dout):
     return dout.new_empty(dout.shape[1])
 
 
-def _style_affines_bwd(style, ws, douts, coef, rows, need_x, need_w, need_b):
-    """one backward launch of the batched style affines (tbg_dense_multi_bwd_f32): (dstyle | None, [dw | None], [db | None])"""
-    B, NR, K = style.shape
-    L = len(rows)
-    dstyle = torch.empty_like(style) if need_x else None
-    dws = [torch.empty_like(w) if need_w[l] else None for l, w in enumerate(ws)]
-    dbs = [torch.empty(w.shape[1], device=w.device, dtype=torch.float32) if need_b[l] else None for l, w in enumerate(ws)]
-    items = (N.DenseItem * L)()
-    sp, dsp = N.ptr(style), N.ptr(dstyle)
-    keep, n, written, extra = [], 0, set(), []
-    for l, w in enumerate(ws):
-        d = douts[l]
-        if d is None:  # an unused style (never on the training path)
-            if dws[l] is not None: dws[l].zero_()
-            if dbs[l] is not None: dbs[l].zero_()
-            continue
-        d = d.contiguous(); keep.append(d)
-        if not (need_x or dws[l] is not None or dbs[l] is not None):
-            continue
-        xp, dxp, ldx = sp + 4 * rows[l] * K, None, NR * K
-        if need_x and rows[l] not in written:
-            dxp = dsp + 4 * rows[l] * K
-            written.add(rows[l])
-        elif need_x:  # second layer on the same latent row: x and dx share one row pitch in the kernel, so both go dense
-            xrow = style[:, rows[l]].contiguous()
-            scratch = torch.empty((B, K), device=style.device, dtype=torch.float32)
-            keep.append(xrow); extra.append((rows[l], scratch))
-            xp, dxp, ldx = N.ptr(xrow), N.ptr(scratch), K
-        items[n] = N.DenseItem(x=xp, w=N.ptr(w), dout=N.ptr(d), dx=dxp, dw=N.ptr(dws[l]), db=N.ptr(dbs[l]),
-                               N=w.shape[1], ldx=ldx)
-        n += 1
-    if n:
-        N.check(N.lib().tbg_dense_multi_bwd_f32(items, n, B, K, coef, 1.0, N.stream()), "tbg_dense_multi_bwd")
-    if need_x:
-        for r in range(NR):
-            if r not in written:
-                dstyle[:, r].zero_()
-        for r, scratch in extra:
-            dstyle[:, r] += scratch
-    return dstyle, dws, dbs
-
-
 class _StyleAffines(torch.autograd.Function):
     """s_l = coef * style[:, rows[l], :] @ W_l + b_l + 1 for every modulated layer l of the synthesis network at once
     (modulated_conv2d.py:52-56, 74-76; synthesis_block.py:120-156: layer l reads row rows[l] of the broadcast latents -- the
     first toRGB and the first conv share row 0): one launch forward, one backward (tbg_dense_multi_*), instead of 2 and
     3-4 library launches per layer.  d(style) is written row by row into ONE [B, n_rows, K] tensor (a row used by two
-    layers: the second contribution goes through a [B, K] scratch and one add).
-    Dual form (style [2, B, n_rows, K], both rows equal; wb = ws + bs + carriers ws2 + bs2): outputs [2, B, I_l]; the backward runs
-    once per cotangent and hands the parameter gradients to the carriers (see _ModConvFused.forward)."""
+    layers: the second contribution goes through a [B, K] scratch and one add)."""
 
     @staticmethod
     def forward(ctx, style, coef, rows, *wb):
-        dual = style.dim() == 4
-        style = (style[0] if dual else style).contiguous()
+        style = style.contiguous()
         B, NR, K = style.shape
         L = len(rows)
-        ws, bs = wb[:L], wb[L:2 * L]
-        assert len(ws) == L and len(bs) == L and len(wb) == (4 * L if dual else 2 * L) and L <= N.DENSE_MAX_ITEMS and max(rows) < NR
+        ws, bs = wb[:L], wb[L:]
+        assert len(ws) == L and len(bs) == L and L <= N.DENSE_MAX_ITEMS and max(rows) < NR
         outs = [torch.empty((B, w.shape[1]), device=style.device, dtype=torch.float32) for w in ws]
         items = (N.DenseItem * L)()
         sp = N.ptr(style)
@@ -2204,33 +2043,61 @@ class _StyleAffines(torch.autograd.Function):
             items[l] = N.DenseItem(x=sp + 4 * rows[l] * K, w=N.ptr(w), b=N.ptr(b), out=N.ptr(o), N=w.shape[1], ldx=NR * K)
         N.check(N.lib().tbg_dense_multi_fwd_f32(items, L, B, K, coef, 1.0, 1.0, N.stream()), "tbg_dense_multi_fwd")
         ctx.save_for_backward(style, *ws)
-        ctx.cfgv = (coef, rows, dual)
-        return tuple(o.unsqueeze(0).expand(2, *o.shape) for o in outs) if dual else tuple(outs)
+        ctx.cfgv = (coef, rows)
+        return tuple(outs)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *douts):
         style, *ws = ctx.saved_tensors
-        coef, rows, dual = ctx.cfgv
+        coef, rows = ctx.cfgv
+        B, NR, K = style.shape
         L = len(rows)
-        if not dual:
-            dstyle, dws, dbs = _style_affines_bwd(style, ws, douts, coef, rows, ctx.needs_input_grad[0],
-                                                  [ctx.needs_input_grad[3 + l] for l in range(L)],
-                                                  [ctx.needs_input_grad[3 + L + l] for l in range(L)])
-            return (dstyle, None, None, *dws, *dbs)
-        r = [_style_affines_bwd(style, ws, [None if d is None else d[h] for d in douts], coef, rows, ctx.needs_input_grad[0],
-                                [True] * L, [True] * L) for h in range(2)]
-        dstyle = torch.stack([r[0][0], r[1][0]]) if ctx.needs_input_grad[0] else None
-        dws2 = [torch.stack([r[0][1][l], r[1][1][l]]) for l in range(L)]
-        dbs2 = [torch.stack([r[0][2][l], r[1][2][l]]) for l in range(L)]
-        return (dstyle, None, None, *([None] * (2 * L)), *dws2, *dbs2)
+        need_x = ctx.needs_input_grad[0]
+        dstyle = torch.empty_like(style) if need_x else None
+        dws = [torch.empty_like(w) if ctx.needs_input_grad[3 + l] else None for l, w in enumerate(ws)]
+        dbs = [torch.empty(w.shape[1], device=w.device, dtype=torch.float32) if ctx.needs_input_grad[3 + L + l] else None
+               for l, w in enumerate(ws)]
+        items = (N.DenseItem * L)()
+        sp, dsp = N.ptr(style), N.ptr(dstyle)
+        keep, n, written, extra = [], 0, set(), []
+        for l, w in enumerate(ws):
+            d = douts[l]
+            if d is None:  # an unused style (never on the training path)
+                if dws[l] is not None: dws[l].zero_()
+                if dbs[l] is not None: dbs[l].zero_()
+                continue
+            d = d.contiguous(); keep.append(d)
+            if not (need_x or dws[l] is not None or dbs[l] is not None):
+                continue
+            xp, dxp, ldx = sp + 4 * rows[l] * K, None, NR * K
+            if need_x and rows[l] not in written:
+                dxp = dsp + 4 * rows[l] * K
+                written.add(rows[l])
+            elif need_x:  # second layer on the same latent row: x and dx share one row pitch in the kernel, so both go dense
+                xrow = style[:, rows[l]].contiguous()
+                scratch = torch.empty((B, K), device=style.device, dtype=torch.float32)
+                keep.append(xrow); extra.append((rows[l], scratch))
+                xp, dxp, ldx = N.ptr(xrow), N.ptr(scratch), K
+            items[n] = N.DenseItem(x=xp, w=N.ptr(w), dout=N.ptr(d), dx=dxp, dw=N.ptr(dws[l]), db=N.ptr(dbs[l]),
+                                   N=w.shape[1], ldx=ldx)
+            n += 1
+        if n:
+            N.check(N.lib().tbg_dense_multi_bwd_f32(items, n, B, K, coef, 1.0, N.stream()), "tbg_dense_multi_bwd")
+        if need_x:
+            for r in range(NR):
+                if r not in written:
+                    dstyle[:, r].zero_()
+            for r, scratch in extra:
+                dstyle[:, r] += scratch
+        return (dstyle, None, None, *dws, *dbs)
 
 
-def style_affines(style, ws, bs, coef, rows=None, carriers=None):
+def style_affines(style, ws, bs, coef, rows=None):
     """style [B, NR, K]; ws[l] [K, I_l], bs[l] [I_l]; rows[l] = the latent row layer l reads (default l)
     ->  tuple of L tensors [B, I_l] = coef * style[:, rows[l]] @ ws[l] + bs[l] + 1."""
     rows = tuple(range(len(ws))) if rows is None else tuple(int(r) for r in rows)
-    return _StyleAffines.apply(style, float(coef), rows, *ws, *bs, *(carriers or ()))
+    return _StyleAffines.apply(style, float(coef), rows, *ws, *bs)
 
 
 _ONES = {}

@@ -98,13 +98,6 @@ class TrainingStep:
         self.g_grad, self.g_views = gf.make_grad_buffer(*self.g_range)
         self.o_grad, self.o_views = gf.make_grad_buffer(*self.o_range)
         self.d_grad, self.d_views = df.make_grad_buffer(0, df.total)
-        # ONE generator backward pass for both of its gradient sets (ops.TUNING.merge_g_passes; bf16-pipe arithmetics): the forward
-        # runs in the DUAL form (models.Synthesis.forward(dual=True)) and the backward carries the GAN-loss and the OCR-loss
-        # cotangents together -- every launch once over 2B samples instead of twice over B.  The path-length term (its own
-        # generator pass) is differentiated separately in the steps that have it and added to the GAN-loss set.
-        self.merge_g = bool(ops.TUNING.merge_g_passes) and self.compute_dtype != "f32"
-        self._syn_names = [n for n in gf.names if n.startswith("synthesis.")]
-        self.g_tmp = None  # second gradient buffer of the g-set (path-length steps of the merged form), made on first use
         # D's gradient exchange in BUCKETS, deepest layers first (the reference hides one 62 MB all-reduce
         # inside apply_gradients, training_step.py:233-235).  D's backward reaches the deep layers first: at the default
         # cuts (5, 3) the blocks[5:] + head hold 74% of D's gradient bytes after ~8% of its backward FLOPs and blocks[3:5]
@@ -247,22 +240,19 @@ class TrainingStep:
         # data-parallel: [fwd + g-pass] -> all-reduce(g) || [ocr-pass] -> all-reduce(ocr) || [d stage 0 (deepest)] ->
         # all-reduce(bucket 0) || [d stage 1] -> all-reduce(bucket 1) || ... -> [Adam x3]
         handles = []
-        for g, bufs in zip(graphs[:-1], self._exchange_buffers(do_r1)):
+        for g, buf in zip(graphs[:-1], self._exchange_buffers(do_r1)):
             g.replay()
-            for buf in bufs:
-                handles.append(self.exchange.start(buf))  # ordered after the graph on this stream, runs on the RCCL stream
+            handles.append(self.exchange.start(buf))  # ordered after the graph on this stream, runs on the RCCL stream
         for h in handles:
             GradExchange.finish(h)
         graphs[-1].replay()
         return fresh(outs)
 
     def _exchange_buffers(self, do_r1):
-        """the flat gradient slices exchanged after each gradient graph, in order: one LIST per graph (the merged generator pass
-        produces the g- and the ocr-set together)."""
-        gen = [[self.g_grad, self.o_grad]] if self.merge_g else [[self.g_grad], [self.o_grad]]
+        """the flat gradient slices exchanged after each gradient graph, in order."""
         if self.d_cuts and not do_r1:
-            return gen + [[self.d_grad[b0:b1]] for _, _, (b0, b1) in self.d_stages]
-        return gen + [[self.d_grad]]
+            return [self.g_grad, self.o_grad] + [self.d_grad[b0:b1] for _, _, (b0, b1) in self.d_stages]
+        return [self.g_grad, self.o_grad, self.d_grad]
 
     def _capture_split(self, st, do_r1, do_pl):
         """Capture the step as SEVERAL HIP graphs sharing one memory pool (the autograd state of the forward lives across
@@ -290,7 +280,7 @@ class TrainingStep:
             try:
                 outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl, st["w"], {},
                                            None, boundary)
-                assert idx[0] == n_grad - 1, "one capture boundary per gradient graph"
+                assert idx[0] == n_grad - 1, "one capture boundary per exchanged gradient slice"
                 graphs[idx[0]].capture_end()
                 idx[0] = n_grad
                 graphs[n_grad].capture_begin(pool=pool, capture_error_mode="thread_local")
@@ -349,12 +339,7 @@ class TrainingStep:
         z = rand["z"] if "z" in rand else torch.randn(self.batch_size_per_gpu, cfg.z_dim, device=dev)
 
         # generator forward; mask_text_box (training_step.py:160-163, utils/utils.py:11-45) is the last toRGB's epilogue
-        merged = self.merge_g
-        if merged:  # dual form: row 0 of the image feeds the discriminator, row 1 the recogniser (same values, two cotangents)
-            fake2 = G((input_words, z), training=True, rand=rand, mask_words=input_words, dual=True)
-            fake_images, fake_ocr = fake2[0], fake2[1]
-        else:
-            fake_images = fake_ocr = G((input_words, z), training=True, rand=rand, mask_words=input_words)
+        fake_images = G((input_words, z), training=True, rand=rand, mask_words=input_words)
 
         # frozen OCR branch and its own backward, issued in line (training_step.py:375-402): only d(ocr_loss)/d(fake_images)
         # is kept for the generator's ocr-pass below
@@ -363,9 +348,9 @@ class TrainingStep:
         # set), so bf16 operands (2^-9) leave nothing of it (relative L2 1.09 against the fp32 oracle).  In bf16 mode its
         # convolutions therefore take the f32x3 kernels (the frozen filters are packed per arithmetic by their owner).
         with ops.compute_dtype("f32x3" if self.compute_dtype == "bf16" else self.compute_dtype):
-            ocr_loss = self._get_ocr_loss(fake_ocr, ocr_labels, ocr_images)
+            ocr_loss = self._get_ocr_loss(fake_images, ocr_labels, ocr_images)
             ocr_loss_w = ocr_loss_weight * ocr_loss
-            (dfake_ocr,) = torch.autograd.grad(ocr_loss_w, fake_ocr, retain_graph=False)
+            (dfake_ocr,) = torch.autograd.grad(ocr_loss_w, fake_images, retain_graph=False)
 
         staged = bool(self.d_cuts) and not do_r1_reg  # R1 steps (1 in 16) keep the single exchange: their D graph is second order
         cuts = sorted(self.d_cuts) if staged else None
@@ -396,35 +381,27 @@ class TrainingStep:
         d_loss = discriminator_loss(fake_scores, real_scores, self.batch_size)
         reg_d_loss = d_loss + r1_penalty
 
-        # --- three gradient sets at the pre-update weights (training_step.py:194-213)
-        if merged:
-            self._merged_g_passes(g_loss, pl_penalty if do_pl_reg else None, fake_ocr, dfake_ocr, nb if joint else 0)
-            if handles is not None:
-                handles.append(self._all_reduce_async(self.g_grad))
-                handles.append(self._all_reduce_async(self.o_grad))
-            if boundary is not None:
-                boundary()
-        else:
-            ops.FLAGS.skip_d_wgrad = True
-            ops.FLAGS.d_first_half = nb if joint else 0
-            try:
-                grads = torch.autograd.grad(reg_g_loss, self.g_params, retain_graph=True, allow_unused=True)
-            finally:
-                ops.FLAGS.skip_d_wgrad = False
-                ops.FLAGS.d_first_half = 0
-            write_grads(self.g_views, grads)
-            if handles is not None:
-                handles.append(self._all_reduce_async(self.g_grad))
-            if boundary is not None:
-                boundary()
+        # --- three backward passes at the pre-update weights (training_step.py:194-213)
+        ops.FLAGS.skip_d_wgrad = True
+        ops.FLAGS.d_first_half = nb if joint else 0
+        try:
+            grads = torch.autograd.grad(reg_g_loss, self.g_params, retain_graph=True, allow_unused=True)
+        finally:
+            ops.FLAGS.skip_d_wgrad = False
+            ops.FLAGS.d_first_half = 0
+        write_grads(self.g_views, grads)
+        if handles is not None:
+            handles.append(self._all_reduce_async(self.g_grad))
+        if boundary is not None:
+            boundary()
 
-            grads = torch.autograd.grad(fake_images, self.o_params, grad_outputs=dfake_ocr, retain_graph=True,
-                                        allow_unused=True)
-            write_grads(self.o_views, grads)
-            if handles is not None:
-                handles.append(self._all_reduce_async(self.o_grad))
-            if boundary is not None:
-                boundary()
+        grads = torch.autograd.grad(fake_images, self.o_params, grad_outputs=dfake_ocr, retain_graph=True,
+                                    allow_unused=True)
+        write_grads(self.o_views, grads)
+        if handles is not None:
+            handles.append(self._all_reduce_async(self.o_grad))
+        if boundary is not None:
+            boundary()
 
         ops.FLAGS.skip_image_grad = True
         try:
@@ -457,41 +434,6 @@ class TrainingStep:
         return ((reg_g_loss.detach(), g_loss.detach(), pl_penalty.detach()),
                 (reg_d_loss.detach(), d_loss.detach(), r1_penalty.detach()),
                 (ocr_loss_w / ocr_loss_weight).detach())
-
-    def _merged_g_passes(self, g_loss, pl_penalty, fake_ocr, dfake_ocr, first_half):
-        """the GAN-loss and the OCR-loss gradient sets of the generator from ONE backward pass (reference training_step.py:194-206
-        takes two): cotangent 0 enters through the discriminator's fake half (g_loss), cotangent 1 is d(w * ocr_loss)/d(image) at
-        row 1 of the dual image; the synthesis network's parameter gradients arrive at its carriers as [2, ...] (row 0 -> the
-        g-set, row 1 -> the ocr-set), latent_encoder's come through row 0 of the styles, word_encoder's through row 1 of the
-        synthesis input.  The path-length penalty (its own generator pass) is differentiated separately and added to the g-set."""
-        G = self.generator
-        names = [n for n, _ in G.synthesis.dual_carriers]
-        carriers = [c for _, c in G.synthesis.dual_carriers]
-        le = [p for n, p in zip(G._flat.names, G._flat.params) if n.startswith("latent_encoder.")]
-        we = [p for n, p in zip(G._flat.names, G._flat.params) if n.startswith("word_encoder.")]
-        ops.FLAGS.skip_d_wgrad = True
-        ops.FLAGS.d_first_half = first_half
-        try:
-            grads = torch.autograd.grad([g_loss, fake_ocr], le + we + carriers, grad_outputs=[None, dfake_ocr],
-                                        retain_graph=True, allow_unused=True)
-        finally:
-            ops.FLAGS.skip_d_wgrad = False
-            ops.FLAGS.d_first_half = 0
-        g_le, g_we, g_car = grads[:len(le)], grads[len(le):len(le) + len(we)], grads[len(le) + len(we):]
-        by_name = {"synthesis." + n: c for n, c in zip(names, g_car)}
-        row = lambda n, h: None if by_name[n] is None else by_name[n][h]
-        gnames = [n for n in G._flat.names if n.startswith(("latent_encoder.", "synthesis."))]
-        onames = [n for n in G._flat.names if n.startswith(("synthesis.", "word_encoder."))]
-        le_by = dict(zip([n for n in G._flat.names if n.startswith("latent_encoder.")], g_le))
-        we_by = dict(zip([n for n in G._flat.names if n.startswith("word_encoder.")], g_we))
-        write_grads(self.g_views, [le_by[n] if n in le_by else row(n, 0) for n in gnames])
-        write_grads(self.o_views, [we_by[n] if n in we_by else row(n, 1) for n in onames])
-        if pl_penalty is not None:
-            if self.g_tmp is None:
-                self.g_tmp = G._flat.make_grad_buffer(*self.g_range)
-            gp = torch.autograd.grad(pl_penalty, self.g_params, retain_graph=True, allow_unused=True)
-            write_grads(self.g_tmp[1], gp)
-            self.g_grad.add_(self.g_tmp[0])
 
     def _apply_updates(self, handles=None):
         """three Adam updates in the reference's order (g, ocr, d)."""
