@@ -1047,7 +1047,7 @@ extern "C" int tbg_conv2d_x3_kernel_name(const tbg_conv_desc *d, int has_in_scal
 // ---- float4 staging of one 32 x 2 pixel chunk of a stride-1 3x3 filter gradient (NSEG == 1, Ws % 4 == Wl % 4 == 0, px == 1):
 // the S tile and the interior of the 4 x 34 L halo tile are read as float4 (4 + 8 loads per lane instead of 16 + 48 scalars),
 // the two halo columns as scalars, all issued together (the compiler merges the two source-level rounds: 241 VGPRs, no
-// spill) -- the scalar form needed six dependent round trips per chunk and cost a quarter of the fp32 kernel (tools/exp_wgrad_split.py: 801 us -> 594 us without staging).
+// spill) -- the scalar form needed six dependent round trips per chunk and cost a quarter of the fp32 kernel (tools/archive/exp_wgrad_split.py: 801 us -> 594 us without staging).
 // BF: round to bf16 (RNE) on the way into LDS.  Tile pitches are compile-time constants (immediate LDS offsets).
 // v_mul_legacy_f32: x * 0 = 0 for EVERY x (Inf and NaN included), IEEE otherwise.  The branch-free staging loads of padding /
 // out-of-range positions read a clamped (valid) address whose content is unrelated data; their scale factor is 0, and this
@@ -1644,7 +1644,7 @@ template <int VEC> struct WgX3Regs {
   // validity bits of the loads above and the row-edge flags of the L quads.  wgrad_x3_load only ISSUES loads and sets these
   // bits; every operation on a loaded value (scale select, the edge shifts) waits for wgrad_x3_store -- a select on a loaded
   // register inside the load function made the compiler wait for the loads right there (vmcnt(18) .. vmcnt(0) in front of the
-  // MFMA phase), i.e. nothing was in flight under the MFMAs (tools/exp_wgx3_split.py: the loads cost 90-140 us of 530).
+  // MFMA phase), i.e. nothing was in flight under the MFMAs (tools/archive/exp_wgx3_split.py: the loads cost 90-140 us of 530).
   unsigned lok, sok, eok, edge;  // edge: bit 0 = first quad starts before the row, bit 1 = last column alone
 };
 
@@ -1864,7 +1864,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(const WgradP p) {
     }
     // MFMA phase as NG x 3 steps of (16-pixel group, filter row): the LDS reads of step i+1 are issued before the 18 MFMAs of
     // step i (two small register sets, order pinned with sched_barrier).  With ONE wave per SIMD nothing else covers an LDS round
-    // trip: tools/exp_wgx3_split.py measured the phase at 400 us with its operand reads and 255 us without (64x256 layer) when
+    // trip: tools/archive/exp_wgx3_split.py measured the phase at 400 us with its operand reads and 255 us without (64x256 layer) when
     // the compiler batched a group's 21 reads in front of its 54 MFMAs.  (Double-buffering whole GROUPS instead cost 256 VGPRs
     // + accumulator-file copies and ran slower: 103 vs 140 TFLOP/s.)
     // The stride-2 form (two groups per chunk, a fourth read per plane) measured 6 % SLOWER this way (105 vs 114 TFLOP/s) and

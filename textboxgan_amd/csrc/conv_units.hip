@@ -16,7 +16,7 @@
 #include "conv_common.h"
 
 #define UNIT_RING 1
-// TBG_EXP: ablation builds of conv_units_fprop_kernel for tools/exp_units_fprop.sh (where its time goes).  0 = product.
+// TBG_EXP: ablation builds of conv_units_fprop_kernel for tools/archive/exp_units_fprop.sh (where its time goes).  0 = product.
 #ifndef TBG_EXP
 #define TBG_EXP 0
 #endif

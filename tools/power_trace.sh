@@ -17,8 +17,8 @@ sample() {  # one line per sample: t, sclk, mclk, power
   done
 }
 echo "# idle" > $OUT; (sample >> $OUT) & SP=$!; sleep 2
-echo "# tools/bench_units.py (the unit-tensor kernels back to back)" >> $OUT
-(cd $R && python tools/bench_units.py > $R/gpurun_out/${TAG}_bench_units.txt 2>&1)
+echo "# tools/loop_units.py 4: conv_units_fprop_kernel<3,2> for 4 s, then conv_wgrad_units_kernel<3> for 4 s (64x256 128->128, B=16)" >> $OUT
+(cd $R && python tools/loop_units.py 4 > $R/gpurun_out/${TAG}_loop_units.txt 2>&1)
 echo "# graph-replayed plain steps (tools/trace_graph_step.py 1 200)" >> $OUT
 (cd $R && python tools/trace_graph_step.py 1 200 > /dev/null 2>&1)
 echo "# idle again" >> $OUT; sleep 2
