@@ -245,7 +245,8 @@ int tbg_conv2d_bf16(const tbg_conv_desc *d, const float *x, const void *w, float
 int tbg_conv2d_bf16_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
 /* explicit instantiation family (tuning / test aid): 0 = library's choice, 1 = 128x256 tile, 2 = 32-channel chunks,
  * 3 = the register-prefetch K loop (128x128 tile; the library's choice for stride-1 layers), 4 / 5 = class-per-block /
- * merged-class transposed form (both with the plain K loop). */
+ * merged-class transposed form (both with the plain K loop); 10 .. 13 = an explicit (channel x pixel) tile -- 32x256, 64x256,
+ * 64x64, 128x128 -- for any non-merged launch (tools/bench_ksplit_ocr.py: the small-map tile choice, profiles/r05_l_*). */
 int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                             const float *in_scale, const tbg_epilogue *epi, int variant, void *stream);
 /* filter gradient; tile rows narrower than 8 pixels (Ws <= 4) fall back to the exact fp32 kernel.  Workspace size =
@@ -272,20 +273,6 @@ int tbg_weight_pack_x3(const float *src, void *dst, int T, int I, int O, int tra
 int tbg_conv2d_x3(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,
                   const tbg_epilogue *epi, void *stream);
 int tbg_conv2d_x3_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
-/* Split-K convolution FINISHED IN THE LAUNCH (mode 1 = tbg_conv2d_bf16, 2 = tbg_conv2d_x3; d->ksplit >= 2): every split of an
- * output tile stores alpha*acc into its own slab and the LAST split of the tile to arrive sums the slabs IN SLAB ORDER
- * (whichever block is last, the sum is the same bits) and applies the real epilogue `epi` -- any tbg_epilogue without a fused
- * dot, a unit sink included -- writing y (and / or the sink).  One launch instead of the convolution + tbg_slab_epilogue_f32.
- * `slabs`: scratch of slab_floats >= tbg_conv2d_splitk_slab_floats(d, ...) floats, 16-byte aligned; its layout is private to the
- * launch ([tile][split][accumulator quad][thread] float4: writers and reducer share the thread -> accumulator mapping, so both
- * move whole coalesced 16-byte vectors).  `tickets`: n_tickets ints (>= tbg_conv2d_blocks(d at ksplit = 1)), ZERO on entry and
- * left zero on exit, not shared with a launch that may run concurrently.  Visibility across the XCDs (whose L2s are not coherent
- * with each other): write-through (sc1) slab stores, a relaxed agent-scope ticket per split, one agent-scope acquire per tile.
- * TBG_EUNSUPPORTED (from both entries; the caller keeps the two-launch form): mode 0 (the exact-fp32 builds), the merged
- * stride-2 transposed form and the 128 x 256 tile (launches of many tiles, which never split). */
-int tbg_conv2d_splitk(const tbg_conv_desc *d, const float *x, const void *w, float *y, float *slabs, long long slab_floats,
-                      int *tickets, int n_tickets, const float *in_scale, const tbg_epilogue *epi, int mode, void *stream);
-long long tbg_conv2d_splitk_slab_floats(const tbg_conv_desc *d, int has_in_scale, int mode);
 /* filter gradient in f32x3 arithmetic: the float4-staged geometries (stride-1 3x3 with 16-byte-aligned rows, stride-2 VALID
  * 3x3 with Ws % 32 == 0 -- the layers that hold the FLOPs) run conv_wgrad_x3_kernel (both operands split into three bf16
  * terms while staged, six products per tap, fp32 accumulate); every other geometry runs the exact fp32 kernel of
@@ -296,7 +283,7 @@ int tbg_conv2d_wgrad_x3(const tbg_wgrad_desc *d, const float *S, const float *L,
                         long long workspace_bytes, void *stream);
 int tbg_conv2d_wgrad_x3_kernel_name(const tbg_wgrad_desc *d, char *buf, int n);
 /* explicit form of the stride-2 transposed 3x3 launches (tuning / test aid): 0 = library's choice, 4 / 5 = class-per-block /
- * merged-class. */
+ * merged-class; 1 / 2 = force / forbid the 128x256 tile; 10 .. 13 = an explicit tile as tbg_conv2d_bf16_variant. */
 int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,
                           const tbg_epilogue *epi, int variant, void *stream);
 

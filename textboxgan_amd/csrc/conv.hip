@@ -52,10 +52,6 @@ struct ConvP {
   int logTW, logTHs, NSEG, IHs, IWs, IWp, HALFW, planeStride, ppc, NJ, nBG;
   int nclass, ksplit, nchunks, cps;
   long long slab;  // elements per split-K slab (= B*M*Hout*Wout)
-  float *ws;       // in-launch finish (tbg_conv2d_splitk): the slabs live here, y is the finished output ...
-  int *tickets;    // ... and tile t's splits draw tickets[t] (NULL: slabs in y, the caller runs tbg_slab_epilogue_f32)
-  int n_tickets;   // (host side: capacity of `tickets` ...
-  long long ws_floats;  // ... and of `ws`)
   int a_floats, ck_rt, dot_slots;
   int wplane;  // X3: floats between two planes (hi | mid | lo) of the packed filter
   ClassInfo cls[MAXCLS];
@@ -589,14 +585,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
 
   // ---- epilogue (conv_common.h conv_epilogue)
   const int HWout = p.Hout * p.Wout;
-  // in-launch finish (p.tickets, conv_common.h): this tile's private slabs, one per split
-  constexpr int NT = NC * WTM * WTN;
-  const int tile_id = (cls * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  const bool fin = (BF && WTN < 4 && !TM) && p.ksplit > 1 && p.tickets != nullptr;
-  float *const tile_ws = fin ? p.ws + (size_t)tile_id * p.ksplit * (NT * 4096) : nullptr;
   if constexpr (TM) {  // the four classes of input position (u, v) land on outputs (2u + cy, 2v + cx)
-    const float alpha = p.e.alpha;
     float *const yb = p.ksplit > 1 ? p.y + (size_t)ks * p.slab : p.y;
+    const float alpha = p.e.alpha;
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
       const int n = (wn * WTN + j) * 32 + (lane & 31);
@@ -633,19 +624,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fprop_kernel(const ConvP p) {
     e_b[j] = okpix ? b : 0;
   }
   constexpr int RG = OCC == 4 ? 2 : 4;  // rows per load batch (register budget: the epilogue must not raise the kernel's allocation)
-  float *slab = p.ksplit > 1 ? p.y + (size_t)ks * p.slab : nullptr;  // split-K (two launches): alpha * acc into this split's slab
-  bool finish = false;
-  if constexpr (BF && WTN < 4 && !TM) {  // (the 128 x 256 tiles and the merged transposed form never split: compiled out there)
-    if (fin) {  // in-launch finish: the last split to arrive runs the real epilogue on the sum of the slabs
-      splitk_store<NT>(&acc[0][0][0], p.e.alpha, tile_ws + (size_t)ks * (NT * 4096));
-      if (!splitk_arrive_last(p.tickets + tile_id, p.ksplit, smem)) return;
-      splitk_sum<NT>(&acc[0][0][0], tile_ws, p.ksplit);
-      finish = true;
-      slab = nullptr;
-    }
-  }
-  conv_epilogue<WTM, WTN, RG, BF>(acc[0], p.e, p.y, slab, p.M, HWout, m0 + wm * WTM * 32, lane, e_pix, e_b, bg < p.B, bg,
-                                  p.dot_slots, (tu * ci.tilesV + tv) * WGN + wn, p.Hout, p.Wout, finish);
+  conv_epilogue<WTM, WTN, RG, BF>(acc[0], p.e, p.y, p.ksplit > 1 ? p.y + (size_t)ks * p.slab : nullptr, p.M, HWout,
+                              m0 + wm * WTM * 32, lane, e_pix, e_b, bg < p.B, bg, p.dot_slots, (tu * ci.tilesV + tv) * WGN + wn,
+                              p.Hout, p.Wout);
 }
 
 template <int WGM, int WGN, int WTM, int WTN, int CK, int MT, int PF = 0, int OCC = 3, bool BF = false, bool TM = false, bool X3 = false>
@@ -664,10 +645,6 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
   // fused dot product: one slot per (pixel tile of the image, wave column); needs one image per tile and one class
   p.dot_slots = (p.NSEG == 1 && p.nclass == 1 && p.ksplit == 1 && !TM) ? p.cls[0].tilesU * p.cls[0].tilesV * WGN : 0;
   if (p.e.dot_aux && p.dot_slots == 0) return TBG_EUNSUPPORTED;
-  const long long ws_need = (long long)maxTilesN * ceil_div(p.M, BM) * p.nclass * p.ksplit * (WTM * WTN * 4096);
-  if (name && name->ws_floats) *name->ws_floats = (BF && WTN < 4 && !TM) ? ws_need : 0;
-  if (p.tickets && (!BF || WTN >= 4 || TM)) return TBG_EUNSUPPORTED;  // in-launch finish: the 16-bit-pipe tiles that ever split
-  if (p.tickets && (p.n_tickets < maxTilesN * ceil_div(p.M, BM) * p.nclass || p.ws_floats < ws_need)) return TBG_EINVAL;
   if (name) {
     if (name->dot_slots) *name->dot_slots = p.dot_slots;
     if (name->blocks) *name->blocks = maxTilesN * ceil_div(p.M, BM) * p.nclass * p.ksplit;
@@ -689,24 +666,20 @@ static int launch_fprop(ConvP &p, hipStream_t st, int maxtaps, int maxTilesN, co
 
 
 // mode: 0 = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = bf16 operands, 2 = f32x3 (three bf16 terms per fp32 operand)
-struct SplitK { float *ws; long long ws_floats; int *tickets; int n; };  // in-launch split-K finish (tbg_conv2d_splitk): slabs, tile tickets, their count
 static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, float *y, const float *in_scale,
-                        const tbg_epilogue *epi, void *stream, const NameOut *name, int mode, int variant, bool force64,
-                        const SplitK *sk);
+                        const tbg_epilogue *epi, void *stream, const NameOut *name, int mode, int variant, bool force64);
 
 static int conv2d_impl(const tbg_conv_desc *d, const float *x, const float *w, float *y, const float *in_scale,
-                       const tbg_epilogue *epi, void *stream, const NameOut *name, int mode = 0, int variant = 0,
-                       const SplitK *sk = nullptr) {
-  int rc = conv2d_tiled(d, x, w, y, in_scale, epi, stream, name, mode, variant, false, sk);
+                       const tbg_epilogue *epi, void *stream, const NameOut *name, int mode = 0, int variant = 0) {
+  int rc = conv2d_tiled(d, x, w, y, in_scale, epi, stream, name, mode, variant, false);
   // a tile whose halo does not fit LDS (three operand planes in f32x3; many small images per 256-pixel tile): the 64 x 64
   // tile packs a quarter of the images.  launch_fprop refuses BEFORE launching anything, so the retry is clean.
-  if (rc == TBG_EUNSUPPORTED && variant == 0) rc = conv2d_tiled(d, x, w, y, in_scale, epi, stream, name, mode, variant, true, sk);
+  if (rc == TBG_EUNSUPPORTED && variant == 0) rc = conv2d_tiled(d, x, w, y, in_scale, epi, stream, name, mode, variant, true);
   return rc;
 }
 
 static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, float *y, const float *in_scale,
-                        const tbg_epilogue *epi, void *stream, const NameOut *name, int mode, int variant, bool force64,
-                        const SplitK *sk) {
+                        const tbg_epilogue *epi, void *stream, const NameOut *name, int mode, int variant, bool force64) {
   const bool bf = mode == 1, x3 = mode == 2;
   if (!d || !epi_valid(epi)) return TBG_EINVAL;
   if (!name && (!x || !w || (!y && !epi_has_sink(epi)))) return TBG_EINVAL;  // (a unit sink may be the only output)
@@ -715,11 +688,9 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
   if (d->sy < 1 || d->sy > 2 || d->sx < 1 || d->sx > 2) return TBG_EUNSUPPORTED;
   if (d->ldw < d->M || (reinterpret_cast<uintptr_t>(w) & 15) != 0) return TBG_EINVAL;
   if (d->ksplit < 1) return TBG_EINVAL;
-  const bool finish = sk && d->ksplit > 1;  // in-launch finish: the real epilogue (no fused dot) runs on the sum of the slabs
-  if (d->ksplit > 1 && !finish && epi && (epi->out_scale || epi->bias || epi->noise || epi->residual || epi->dot_aux || epi->gate ||
-                                          epi->act != TBG_ACT_LINEAR || epi->units_out))
+  if (d->ksplit > 1 && epi && (epi->out_scale || epi->bias || epi->noise || epi->residual || epi->dot_aux || epi->gate || epi->act != TBG_ACT_LINEAR ||
+                               epi->units_out))
     return TBG_EINVAL;
-  if (finish && (mode == 0 || !sk->ws || !sk->tickets || (epi && epi->dot_aux))) return mode == 0 ? TBG_EUNSUPPORTED : TBG_EINVAL;
   if ((double)d->B * d->C * d->Hin * d->Win > 2147483647.0 || (double)d->B * d->M * d->Hout * d->Wout > 2147483647.0)
     return TBG_ERANGE;
   if (d->transposed) {
@@ -732,8 +703,6 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
 
   ConvP p;
   p.x = x; p.w = w; p.in_scale = in_scale; p.y = y;
-  p.ws = finish ? sk->ws : nullptr; p.tickets = finish ? sk->tickets : nullptr; p.n_tickets = finish ? sk->n : 0;
-  p.ws_floats = finish ? sk->ws_floats : 0;
   p.B = d->B; p.C = d->C; p.M = d->M; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
   p.ldw = d->ldw;
   p.e = make_epi(epi);
@@ -1035,23 +1004,6 @@ extern "C" int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, con
                                      const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
   if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 5 && (variant < 10 || variant > 13)) return TBG_EINVAL;
   return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, 2, variant);
-}
-
-extern "C" int tbg_conv2d_splitk(const tbg_conv_desc *d, const float *x, const void *w, float *y, float *slabs, long long slab_floats,
-                                 int *tickets, int n_tickets, const float *in_scale, const tbg_epilogue *epi, int mode, void *stream) {
-  if (mode != 1 && mode != 2) return mode == 0 ? TBG_EUNSUPPORTED : TBG_EINVAL;
-  if (!d || d->ksplit < 2 || !slabs || !tickets || n_tickets < 1 || (reinterpret_cast<uintptr_t>(slabs) & 15) != 0) return TBG_EINVAL;
-  const SplitK sk{slabs, slab_floats, tickets, n_tickets};
-  return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, mode, 0, &sk);
-}
-
-extern "C" long long tbg_conv2d_splitk_slab_floats(const tbg_conv_desc *d, int has_in_scale, int mode) {
-  if (mode != 1 && mode != 2) return mode == 0 ? TBG_EUNSUPPORTED : TBG_EINVAL;
-  long long fl = 0;
-  NameOut no{nullptr, 0, nullptr, nullptr, &fl};
-  static const float dummy = 0.f;
-  const int rc = conv2d_impl(d, nullptr, nullptr, nullptr, has_in_scale ? &dummy : nullptr, nullptr, nullptr, &no, mode);
-  return rc != TBG_OK ? rc : (fl > 0 ? fl : TBG_EUNSUPPORTED);
 }
 
 static int conv_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n, int mode) {

@@ -53,7 +53,7 @@ static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // name-only mode (name != NULL): write the instantiation the descriptor selects (rocprofv3 spelling) and launch nothing
-struct NameOut { char *buf; int n; int *dot_slots; int *blocks; long long *ws_floats = nullptr; };
+struct NameOut { char *buf; int n; int *dot_slots; int *blocks; };
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to the lane-linear LDS range starting at the
 // wave-uniform byte address `lds_base` (M0).  Inline assembly ON PURPOSE: hipcc's waitcnt pass treats a
@@ -102,84 +102,16 @@ __device__ __forceinline__ void sink_zero(char *ub, long long plane_bytes, int p
   for (int pl = 0; pl < planes; ++pl) *reinterpret_cast<u32x2v *>(ub + pl * plane_bytes + off) = u32x2v{0u, 0u};
 }
 
-// ---- in-launch finish of a split-K convolution (tbg_conv2d_splitk): every split of an output tile stores alpha * acc into its
-// own slab; the LAST of them to arrive (a ticket per tile) sums the slabs in slab order -- whoever arrives last, the sum is the
-// same bits -- and runs the real epilogue, so the second launch (tbg_slab_epilogue_f32: 5.5 us x 144 per plain step) goes.
-// The slabs of this form are PRIVATE to the tile: [tile][split][accumulator quad][thread] float4 -- the reducer has the same
-// thread -> accumulator mapping as the writers, so both sides move whole 16-byte, fully coalesced vectors and no index math.
-// Cross-XCD visibility (the XCD L2s are not coherent; MI355X_MICROARCH.md / cdna_hip_programming.md "in-launch split-K
-// reduction", sc1 form): slab stores are 16-byte WRITE-THROUGH stores (sc1: no agent-scope release fence, whose buffer_wbl2
-// was measured at 13-140 us per launch here -- every block flushing the XCD's L2) -> every wave s_waitcnt vmcnt(0) -> barrier
-// -> lane 0: relaxed agent-scope ticket; the last arriver: agent-scope ACQUIRE fence (buffer_inv) -> barrier -> plain loads.
-// The ticket is reset by the last arriver (the buffer is zero before its first use and after every launch).  `flag` is a word
-// of the kernel's own LDS array (no second __shared__ object: hipcc would wait vmcnt(0) before every LDS read of the DMA
-// pipeline) -- every LDS read of the K loop is behind the first barrier here.
-__device__ __forceinline__ bool splitk_arrive_last(int *ticket, int nsplit, float *flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  volatile int *const f = reinterpret_cast<volatile int *>(flag);
-  if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = t == nsplit - 1 ? 1 : 0;
-    if (last) {
-      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    f[0] = last;
-  }
-  __syncthreads();
-  return f[0] != 0;
-}
-
-typedef float f32x4s __attribute__((ext_vector_type(4)));
-// 16-byte write-through store (sc1); the trailing s_nop keeps hipcc's next instruction off the data registers
-__device__ __forceinline__ void store16_sc1(float *dst, f32x4s v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
-}
-// this block's NT accumulator tiles (alpha * acc) -> its private slab: quad q of tile t at ((t * 4 + q) * 256 + tid) float4
-template <int NT>
-__device__ __forceinline__ void splitk_store(const f32x16 *acc, float alpha, float *slab) {
-  float *const base = slab + threadIdx.x * 4;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4s v = {acc[t][4 * q] * alpha, acc[t][4 * q + 1] * alpha, acc[t][4 * q + 2] * alpha, acc[t][4 * q + 3] * alpha};
-      store16_sc1(base + (t * 4 + q) * 1024, v);
-    }
-}
-// acc = sum over the nsplit private slabs of this tile, in slab order; the 4 NT loads of one slab are in flight together
-template <int NT>
-__device__ __forceinline__ void splitk_sum(f32x16 *acc, const float *slabs, int nsplit) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const float *base = slabs + threadIdx.x * 4;
-  for (int s = 0; s < nsplit; ++s, base += NT * 4096) {
-    f32x4s v[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[t][q] = *reinterpret_cast<const f32x4s *>(base + (t * 4 + q) * 1024);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[t][4 * q] += v[t][q][0]; acc[t][4 * q + 1] += v[t][q][1]; acc[t][4 * q + 2] += v[t][q][2]; acc[t][4 * q + 3] += v[t][q][3];
-      }
-  }
-}
-
 // SINK = false compiles the sink out (the exact-fp32 instantiations: no unit consumer exists in that arithmetic, and the sink's
 // registers pushed the 4-waves/SIMD builds into scratch -- 320 bytes per lane, exact-fp32 step 27.1 -> 31.7 ms).
 template <int WTM, int WTN, int RG, bool SINK = true>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], const EpiK &e, float *y, float *slab, int M_, int HWout,
                                               int mrow0, int lane, const int (&e_pix)[WTN], const int (&e_b)[WTN], bool dot_ok,
-                                              int dot_b, int dot_slots, int dot_slot, int Hout = 0, int Wout = 0,
-                                              bool unit_alpha = false) {
+                                              int dot_b, int dot_slots, int dot_slot, int Hout = 0, int Wout = 0) {
   const float *const e_os = e.out_scale, *const e_bias = e.bias, *const e_res = e.residual, *const e_aux = e.dot_aux;
   const float *const e_gate = e.gate;
   float *const e_dot = e.dot_out;
-  const float e_alpha = unit_alpha ? 1.f : e.alpha, e_bmul = e.bias_mul, e_slope = e.slope, e_gain = e.gain, e_rscale = e.res_scale;
+  const float e_alpha = e.alpha, e_bmul = e.bias_mul, e_slope = e.slope, e_gain = e.gain, e_rscale = e.res_scale;
   const bool e_lrelu = e.act == TBG_ACT_LRELU, e_rfirst = e.res_first != 0;
   const float str = e.noise ? e.strength[0] : 0.f;
   const bool split = slab != nullptr;

@@ -17,7 +17,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtbg_hip.so")
 
 ACT_LINEAR, ACT_LRELU = 0, 1
-EUNSUPPORTED = -4  # TBG_EUNSUPPORTED (tbg.h)
 SQRT2 = 1.4142135623730951
 
 EXPORTS = [
@@ -26,7 +25,7 @@ EXPORTS = [
     "tbg_upfirdn2d_kernel_name", "tbg_upfirdn2d_f16", "tbg_weight_pack_x3_bytes", "tbg_weight_pack_x3", "tbg_conv2d_x3", "tbg_conv2d_x3_kernel_name", "tbg_conv2d_x3_variant", "tbg_conv2d_wgrad_x3", "tbg_conv2d_wgrad_x3_kernel_name", "tbg_conv2d_dot_slots", "tbg_conv2d_blocks", "tbg_units_bytes", "tbg_units_pack_f32",
     "tbg_conv2d_wgrad_units", "tbg_conv2d_wgrad_units_workspace_bytes", "tbg_conv2d_units", "tbg_conv2d_units_dot_slots", "tbg_conv2d_units_blocks", "tbg_conv2d_units_tile_channels", "tbg_bias_act_bwd_units", "tbg_bias_act_bwd_units_chunks",
     "tbg_units_s2_bytes", "tbg_units_pack_s2_f32", "tbg_upfirdn2d_units_s2_f32", "tbg_conv2d_units_s2_blocks", "tbg_conv2d_units_s2_tile_channels", "tbg_conv2d_units_s2_dot_slots", "tbg_conv2d_units_s2", "tbg_conv2d_wgrad_units_s2_workspace_bytes", "tbg_conv2d_wgrad_units_s2", "tbg_conv2d_units_t2_blocks", "tbg_conv2d_units_t2",
-    "tbg_slab_epilogue_units_f32", "tbg_conv2d_splitk", "tbg_conv2d_splitk_slab_floats",
+    "tbg_slab_epilogue_units_f32",
     "tbg_bias_act_bwd_f32", "tbg_axpby_planes_f32", "tbg_bias_act_bwd2_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_rgb_backproject_chunks", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -127,9 +126,6 @@ def lib():
         l.tbg_weight_pack_x3_bytes.restype = C.c_longlong
         l.tbg_weight_pack_x3.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
         l.tbg_conv2d_x3.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(Epilogue), vp]
-        l.tbg_conv2d_splitk.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, C.c_longlong, vp, ci, vp, C.POINTER(Epilogue), ci, vp]
-        l.tbg_conv2d_splitk_slab_floats.argtypes = [C.POINTER(ConvDesc), ci, ci]
-        l.tbg_conv2d_splitk_slab_floats.restype = C.c_longlong
         l.tbg_conv2d_x3_variant.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(Epilogue), ci, vp]
         l.tbg_conv2d_x3_kernel_name.argtypes = [C.POINTER(ConvDesc), ci, C.c_char_p, ci]
         l.tbg_conv2d_dot_slots.argtypes = [C.POINTER(ConvDesc), ci, ci]
@@ -207,8 +203,6 @@ def _call_key(name, a):
     try:
         if name in _CONV_FMT and not name.endswith("_variant"):
             return conv_kernel_name(a[0]._obj, a[4] is not None, _CONV_FMT[name])
-        if name == "tbg_conv2d_splitk":       # d x w y slabs slab_floats tickets n in_scale epi mode stream
-            return conv_kernel_name(a[0]._obj, a[8] is not None, a[10])
         if name in _WGRAD_FMT:
             return wgrad_kernel_name(a[0]._obj, _WGRAD_FMT[name])
         if name == "tbg_conv2d_units":        # d XU planes w y epi stream
@@ -249,7 +243,7 @@ def _call_key(name, a):
     return name
 
 
-_NOT_COMPUTE = ("tbg_version", "tbg_strerror", "tbg_crc32c", "_kernel_name", "_bytes", "_floats", "_slab_floats", "_chunks", "_dot_slots", "_blocks", "_tile_channels")  # queries: no device work
+_NOT_COMPUTE = ("tbg_version", "tbg_strerror", "tbg_crc32c", "_kernel_name", "_bytes", "_floats", "_chunks", "_dot_slots", "_blocks", "_tile_channels")  # queries: no device work
 
 
 class _LibProxy:
@@ -280,7 +274,7 @@ def ptr(t: Optional[torch.Tensor]):
         return None
     if not t.is_cuda:
         raise TbgError("libtbg_hip kernels need device tensors (no CPU path in the product)")
-    if t.dtype not in (torch.float32, torch.int64, torch.int32, torch.bfloat16, torch.float16):
+    if t.dtype not in (torch.float32, torch.int64, torch.bfloat16, torch.float16):
         raise TbgError(f"unsupported dtype {t.dtype}")
     if not t.is_contiguous():
         raise TbgError("tensor must be contiguous")

@@ -111,9 +111,6 @@ class _Tuning:
                                      # vs 448 -> 20.94, 640 -> 21.02, 900 -> 21.04, 200 -> 21.50 ms per step)
         self.one_per_cu_split = True  # two K splits for launches of exactly one tile per CU (profiles/r03_cold_conv.txt)
         self.force_variant = 0       # experiment knob (tools/bench_variants_conv.py): tbg_conv2d_*_variant's instantiation family
-        self.fused_splitk = True     # split-K launches of the 16-bit-pipe arithmetics finish in the launch (tbg_conv2d_splitk: the last
-                                     # split of a tile to arrive sums the slabs in slab order and runs the real epilogue); False = the
-                                     # second launch (tbg_slab_epilogue_f32) of rounds 1-4
         # ---- graph structure
         self.fold_res_scale = True   # DiscriminatorBlock folds its 1/sqrt(2) into both branches (fp32-grade arithmetics only)
         self.fuse_skip_grad = True   # DiscriminatorBlock: conv_0 + skip FIR as ONE node (False = two nodes + the engine's add)
@@ -286,25 +283,6 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
 
 
 
-_TICKETS = {}
-
-
-def _splitk_tickets(device, n: int) -> torch.Tensor:
-    """Tile tickets of tbg_conv2d_splitk: zero before the first launch, left zero by every launch (the last arriver resets its
-    ticket).  One buffer per (device, stream): launches of one stream are ordered, so they may share it."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    t = _TICKETS.get(key)
-    if t is None or t.numel() < n:
-        t = torch.zeros(max(4096, n), device=device, dtype=torch.int32)
-        _TICKETS[key] = t
-    return t
-
-
-def _epi_alpha_only(e) -> bool:
-    return not (e.out_scale or e.bias or e.noise or e.residual or e.dot_aux or e.gate or e.units_out) and \
-        e.act == N.ACT_LINEAR and e.gain == 1.0
-
-
 def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_hw: Tuple[int, int], stride=(1, 1),
                pad=(0, 0), transposed=False, flip=False, in_scale=None, epi: Optional[N.Epilogue] = None,
                ldw: Optional[int] = None, allow_split=True, dot=None, out: Optional[torch.Tensor] = None,
@@ -375,30 +353,12 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         # split-K: every split stores alpha*acc into its own slab (no zero-fill, no atomics); one flat pass sums the
         # slabs and applies the real epilogue.  (Also the route of a fused dot the tiling cannot serve -- several small
         # images per tile: one "slab", the dot from the finished accumulators.)
+        slabs = torch.empty((ksplit, B, M, Hout, Wout), device=x.device, dtype=torch.float32)
         e0 = N.epilogue(alpha=epi.alpha)  # (store-only: a unit sink belongs to the second half)
+        N.check(PROFILE.launch(_kname, _flops, lambda: _conv(
+            C.byref(d), N.ptr(x), N.ptr(w), N.ptr(slabs), N.ptr(in_scale), C.byref(e0), N.stream()), _what, _bytes), _what)
         e1 = N.Epilogue.from_buffer_copy(epi)
         e1.alpha = 1.0
-        launched = False
-        nfl = 0
-        if TUNING.fused_splitk and ksplit > 1 and dot is None and fmt != FMT_F32 and not TUNING.force_variant:
-            nfl = N.lib().tbg_conv2d_splitk_slab_floats(C.byref(d), int(in_scale is not None), int(fmt))
-        if nfl > 0:
-            # finished in the launch: the last split of a tile to arrive sums the slabs and runs the epilogue (tbg_conv2d_splitk).
-            # A transposed launch may take the merged, store-only form: anything but alpha stays a (one-slab) second half.
-            whole = _epi_alpha_only(epi) or not transposed
-            y_run = torch.empty((B, M, Hout, Wout), device=x.device, dtype=torch.float32) if (out is None or not whole) else out
-            tk = _splitk_tickets(x.device, tiles)
-            ws = torch.empty(nfl, device=x.device, dtype=torch.float32)  # private tile slabs (padded tiles: >= the NCHW slabs)
-            N.check(PROFILE.launch(_kname, _flops, lambda: N.lib().tbg_conv2d_splitk(
-                C.byref(d), N.ptr(x), N.ptr(w), N.ptr(y_run), N.ptr(ws), nfl, N.ptr(tk), tk.numel(), N.ptr(in_scale),
-                C.byref(epi if whole else e0), int(fmt), N.stream()), _what, _bytes), _what)
-            if whole:
-                return y_run
-            slabs, ksplit, launched = y_run.unsqueeze(0), 1, True
-        if not launched:
-            slabs = torch.empty((ksplit, B, M, Hout, Wout), device=x.device, dtype=torch.float32)
-            N.check(PROFILE.launch(_kname, _flops, lambda: _conv(
-                C.byref(d), N.ptr(x), N.ptr(w), N.ptr(slabs), N.ptr(in_scale), C.byref(e0), N.stream()), _what, _bytes), _what)
         dpart = None
         if dot is not None:  # the fused dot needs the complete sum: reduce first (the smallest G layers' backward)
             e1.dot_aux, e1.dot_out = None, None
