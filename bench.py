@@ -541,6 +541,9 @@ def main():
                        "conv_gflop_per_image_nonreg_step": CONV_GFLOP_PER_IMAGE},
             "conv_tflops_vs_step_time": round(value * CONV_GFLOP_PER_IMAGE / 1e3 / world, 2),
             "graph_mode": graph_mode(ts), "capture_error": ts.capture_error,
+            # peak device memory of the timed loop (all lazy-regularisation variants captured; torch's caching allocator): the unit
+            # tensors kept beside the fp32 activations (ops.TUNING.save_units) are in here
+            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
         }
     if world == 1:
         # headline = one ALIGNED 16-step cycle of the caller protocol (14 plain + 1 PL + 1 PL+R1 steps, config.py:86,93), from

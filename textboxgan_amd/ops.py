@@ -103,6 +103,10 @@ class _Tuning:
                                      # per step.  bf16 keeps units_min_blocks: there the gain is 0.07 ms, and the full-width step's
                                      # noisiest scalar gradient (a noise strength: one heavily cancelling sum) moved from 0.22 to 0.27
                                      # relative against its 0.25 bar when more layers changed kernels (profiles/r05_ab_one_box.txt)
+        self.save_units = True       # keep units(x * s) of a layer input alive from forward to backward for the filter gradient
+                                     # (beside the fp32 x: +6 B / element in f32x3, +2 B in bf16); False = drop it and pack again in
+                                     # the backward pass (one tbg_units_pack_f32 launch per layer) when activation memory matters.
+                                     # Peak memory of a step is in bench.py's line (`peak_hbm_gb`)
         self.unit_sinks = True       # round 5: producers (conv / FIR / split-K epilogues) write the NEXT layer's unit tensor themselves
                                      # (tbg_epilogue.units_out); False = the stand-alone tbg_units_pack_f32 pass of round 4
         # ---- split-K of the small-map launches
@@ -1457,7 +1461,7 @@ class _ModConvFused(torch.autograd.Function):
                                 sink=sink or _NO_SINK)
             if XU is not None and not (KH == 3 and _units_wgrad(I, O, H, W)):
                 XU = None  # nobody in the backward pass reads it
-        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, XU.data if XU is not None else None)
+        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, XU.data if (XU is not None and TUNING.save_units) else None)
         ctx.coef = coef
         if sink is not None:
             sink.produced = U
@@ -1517,7 +1521,7 @@ class _ModConvUpFused(torch.autograd.Function):
         k = fir_kernel(x.device, gain=4.0)
         epi = _lrelu_epi(out_scale=d.reshape(-1), bias=b, noise=noise, strength=strength, alpha=1.0)
         out, U = upfirdn2d_raw(y_up, k, pad=(1, 1, 1, 1), epi=epi, sink=sink or _NO_SINK)
-        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, XU.data if XU is not None else None)
+        ctx.save_for_backward(x, w, s, d, wsq, noise, strength, b, out, XU.data if (XU is not None and TUNING.save_units) else None)
         ctx.coef = coef
         if sink is not None:
             sink.produced = U
@@ -1629,7 +1633,7 @@ class _ConvBiasActFused(torch.autograd.Function):
             out, U = conv2d_raw(x, pack_filter(w, False, False), O, KH, KW, yhw, stride, pad, epi=epi, sink=sink or _NO_SINK)
             if XU is not None and not (ctx.s1_3x3 and _units_wgrad(I, O, H, W)):
                 XU = None  # nobody in the backward pass reads it
-        ctx.save_for_backward(x, w, b, out if act == ACT_LRELU else None, XU.data if XU is not None else None)
+        ctx.save_for_backward(x, w, b, out if act == ACT_LRELU else None, XU.data if (XU is not None and TUNING.save_units) else None)
         ctx.cfgv = (stride, pad, act, res_scale, coef, residual is not None, yhw)
         ctx.role = role
         ctx.gain = gain
