@@ -209,8 +209,13 @@ class TrainingStep:
                 self._graphs[key] = ([ga, gb], outs)
             else:
                 g = torch.cuda.CUDAGraph()
+                # a process group may exist although this step does not exchange (world size 1): RCCL's watchdog thread polls its
+                # events while we capture -- under the default "global" mode that call fails, kills the watchdog (and with it the
+                # process) and invalidates the capture (seen once in tests/test_distributed_gpu.py: timing dependent)
+                import torch.distributed as _dist
+                mode = "thread_local" if (_dist.is_available() and _dist.is_initialized()) else "global"
                 try:
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, capture_error_mode=mode):
                         outs = self._compute_grads(st["real"], st["ocr_img"], st["words"], st["labels"], do_r1, do_pl,
                                                    st["w"], {})
                         self._apply_updates()
