@@ -285,21 +285,26 @@ def timed_loop(state, batch, steps, warmup, world):
     return dt
 
 
-def variant_step_ms(state, batch, reps=(6, 3, 3)):
+def variant_step_ms(state, batch, reps=(4, 2, 2), blocks=3):
     """milliseconds of ONE step of each lazy-regularisation variant (SURVEY 8(d) Config 2: "non-reg step and the 16-step
-    average"): plain, +PL (every 8th step), +PL+R1 (every 16th).  Real optimisation steps, flags forced."""
+    average"): plain, +PL (every 8th step), +PL+R1 (every 16th).  Real optimisation steps, flags forced.  Each variant is timed as
+    `blocks` back-to-back blocks of n steps (one synchronize per block) and the MEDIAN block is reported: a single host hiccup
+    (seen once: +21 ms inside a 6-step block, profiles/r05_o_bench.json configs2_bf16) moves one block, not the figure."""
     ts = state["training_step"]
     a = (batch["real_images"], batch["ocr_images"], batch["input_words"], batch["ocr_labels"])
     out = {}
     for name, (r1, pl), n in (("plain", (False, False), reps[0]), ("pl", (False, True), reps[1]), ("pl_r1", (True, True), reps[2])):
         ts.dist_train_step(*a, r1, pl, 1e-4)  # untimed
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            ts.dist_train_step(*a, r1, pl, 1e-4)
-            state["g_clone"].set_as_moving_average_of(state["generator"])
-        torch.cuda.synchronize()
-        out[name] = round(1e3 * (time.perf_counter() - t0) / n, 3)
+        per = []
+        for _ in range(blocks):
+            t0 = time.perf_counter()
+            for _ in range(n):
+                ts.dist_train_step(*a, r1, pl, 1e-4)
+                state["g_clone"].set_as_moving_average_of(state["generator"])
+            torch.cuda.synchronize()
+            per.append(1e3 * (time.perf_counter() - t0) / n)
+        out[name] = round(sorted(per)[len(per) // 2], 3)
     return out
 
 
@@ -556,7 +561,7 @@ def main():
         out["value"] = out["value_16step"]
         out["ms_per_step"] = round((14 * sm["plain"] + sm["pl"] + sm["pl_r1"]) / 16, 3)
         out["value_basis"] = ("value and ms_per_step are the average of ONE ALIGNED 16-STEP CYCLE (14 plain + 1 PL + 1 PL+R1) built "
-                              "from step_ms (plain x6, pl x3, pl_r1 x3 separately timed steps) -- NOT window / steps: steps * "
+                              "from step_ms (each variant: the median of 3 separately timed blocks of 4 / 2 / 2 steps) -- NOT window / steps: steps * "
                               "ms_per_step is not a wall interval.  The wall-clock figure of the --steps window (barrier + "
                               "synchronize on both sides, images * steps / wall time) is value_window / ms_per_step_window, and "
                               "steps * ms_per_step_window is that interval")
