@@ -518,7 +518,14 @@ def main():
     if graphs:  # untimed: warm up + capture the three step variants (6 real steps)
         state["training_step"].prepare_graphs(*a4)
     ts = state["training_step"]
-    if world > 1 and graphs and graph_mode(ts) != "split" and not args.allow_fallback:
+    lost = world > 1 and graphs and graph_mode(ts) != "split"
+    if world > 1 and graphs:  # every rank takes the same branch: one rank leaving alone would hang the others' collectives
+        flag = torch.tensor([1.0 if lost else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        lost_any = bool(flag.item() > 0)
+    else:
+        lost_any = False
+    if lost_any and not args.allow_fallback:
         # the overlapped exchange IS the N > 1 design: a run that lost it must not produce a number
         sys.stderr.write(f"[bench] rank {rank}: graph_mode={graph_mode(ts)!r} (wanted 'split'); capture_error="
                          f"{ts.capture_error!r}; pass --allow-fallback to measure the fallback anyway\n")
