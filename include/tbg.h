@@ -323,6 +323,26 @@ int tbg_conv2d_units_tile_channels(const tbg_conv_desc *d, int planes);
 int tbg_conv2d_units(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
                      const tbg_epilogue *epi, void *stream);
 
+/* SMALL MAPS (round 6; csrc/conv_small.hip): the same contract as tbg_conv2d_units -- input = the unit tensor XU of x * in_scale
+ * with the geometry [B, C, Hin, Win], packed filter tbg_weight_pack_x3 / _bf16, full epilogue incl. the unit sink, fp32 NCHW output
+ * (y may be NULL with a sink) -- for the layers whose GEMM is too small for one tile per block and K whole: the 1x25 ... 8x32 maps
+ * of both networks (conv.py:51-73, discriminator.py:68-84, modulated_conv2d.py:98-112) and of the recogniser's trunk
+ * (aster_inferer.py:28-37).  A block owns 32 output channels x 32 (or 64) pixels of the FLATTENED pixel list n = (b Hout + y) Wout + x
+ * (tiles may span rows and samples: no padding waste on 25-wide maps), its 8 waves split K and sum their partial tiles through LDS
+ * before the epilogue: ONE launch, no slabs, no tbg_slab_epilogue_f32 pass, deterministic (fixed summation order).
+ * Geometries (TBG_EUNSUPPORTED otherwise; ksplit must be 1):
+ *   3x3, stride 1, pad 1, not transposed, Wout >= 3;
+ *   1x1, pad 0, stride (1|2, 1|2): Hout = (Hin - 1) / sy + 1;
+ *   1x1 transposed with stride (sy, sx) (the data gradient of the strided form: y[b, m, sy a, sx b'] = sum_c x[b, c, a, b'] W[c][m],
+ *   every other output pixel = epilogue(0)), Hout >= (Hin - 1) sy + 1.
+ * Any M (channel tiles are clamped; a sink needs M % 8 == 0), any C with planes = 3, ceil(C/8) even with planes = 1.
+ * Fused dot: tbg_conv2d_units_small_dot_slots slots per (b, m) = Hout Wout / 32 when a pixel tile never straddles two samples,
+ * 0 (dot not served: TBG_EUNSUPPORTED) otherwise.  tbg_conv2d_units_small_blocks: blocks of the launch (for the caller's dispatch). */
+int tbg_conv2d_units_small_blocks(const tbg_conv_desc *d, int planes);
+int tbg_conv2d_units_small_dot_slots(const tbg_conv_desc *d, int planes);
+int tbg_conv2d_units_small(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
+                           const tbg_epilogue *epi, void *stream);
+
 /* PHASE unit tensors and the stride-2 convolution that reads them (csrc/conv_units_s2.hip).  The input t [B, C, Hin, Win] of a 3x3 /
  * stride-2 / pad-0 convolution with Ho x Wo outputs (conv_downsample_2d's strided convolution after its blur,
  * upfirdn_2d_v2.py:106-113; the data gradient of upsample_conv_2d's transposed convolution, :65-103), de-interleaved by parity:

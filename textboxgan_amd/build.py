@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtbg_hip.so")
 HOST_LIB = os.path.join(HERE, "libtbg_host.so")
-SOURCES = ["elementwise.hip", "upfirdn.hip", "conv.hip", "conv_units.hip", "conv_units_s2.hip", "rgb.hip", "lstm.hip", "smalls.hip", "host_util.hip"]
+SOURCES = ["elementwise.hip", "upfirdn.hip", "conv.hip", "conv_units.hip", "conv_units_s2.hip", "conv_small.hip", "rgb.hip", "lstm.hip", "smalls.hip", "host_util.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

@@ -104,7 +104,9 @@ __device__ __forceinline__ void sink_zero(char *ub, long long plane_bytes, int p
 
 // SINK = false compiles the sink out (the exact-fp32 instantiations: no unit consumer exists in that arithmetic, and the sink's
 // registers pushed the 4-waves/SIMD builds into scratch -- 320 bytes per lane, exact-fp32 step 27.1 -> 31.7 ms).
-template <int WTM, int WTN, int RG, bool SINK = true>
+// NROW < 16 (conv_small.hip): the wave holds only accumulator rows 0 .. NROW-1 of its tile (one 4-channel row group after the
+// in-block K reduction) -- the loops stop there, everything else is unchanged.
+template <int WTM, int WTN, int RG, bool SINK = true, int NROW = 16>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], const EpiK &e, float *y, float *slab, int M_, int HWout,
                                               int mrow0, int lane, const int (&e_pix)[WTN], const int (&e_b)[WTN], bool dot_ok,
                                               int dot_b, int dot_slots, int dot_slot, int Hout = 0, int Wout = 0) {
@@ -128,7 +130,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
-      for (int r16 = 0; r16 < 16; ++r16) {
+      for (int r16 = 0; r16 < NROW; ++r16) {
         const int m = mrow0 + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (lane >> 5);
 #pragma unroll
         for (int j = 0; j < WTN; ++j)
@@ -157,7 +159,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
 #pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += RG) {  // accumulator rows r0 .. r0+RG-1
+    for (int r0 = 0; r0 < NROW; r0 += RG) {  // accumulator rows r0 .. r0+RG-1
       int idx[RG][WTN];  // output offsets fit 31 bits (checked on the host)
       int mrow[RG];
       float bias4[RG], osv[RG][WTN], rsv[RG][WTN], axv[RG][WTN];

@@ -1,0 +1,308 @@
+// Small-map convolutions from unit tensors: the K split lives INSIDE the block, no HBM slabs, the real epilogue in the same launch.
+//
+// Where it applies: the 1x25 ... 8x32 maps of both networks and of the frozen recogniser's trunk (conv.py:51-73,
+// discriminator.py:68-84, modulated_conv2d.py:98-112; the ResNet behind aster_inferer.py:28-37) -- GEMMs of M = 32 ... 512 output
+// channels x N = 400 ... 3200 pixels x K = 256 ... 4608: 0.1 - 5 GFLOP, i.e. 0.3 - 12 us of the bf16 matrix pipe.  conv_fprop_kernel
+// ran them as 64 x 64 tiles with K split over BLOCKS into HBM slabs + a second launch (tbg_slab_epilogue_f32): a launch was 6.5 us of
+// fixed cost + the K loop + a 5 us second half, half of it slab traffic (profiles/r05_ab_one_box.txt (d), (e)).
+//
+// This kernel: one 512-thread block owns a 32-channel x (32 TN)-pixel output tile, its 8 waves split K -- wave w takes the row units
+// u = w, w + 8, ... of the (8- or 16-channel chunk, filter row kh) list -- and every wave holds the WHOLE tile in accumulators.  The
+// waves never synchronise inside the K loop: each stages only what it contracts itself.
+//   * A (filter): straight from the packed filter (tbg_weight_pack_x3 / _bf16: 16-byte units of 8 channels of one output channel)
+//     into VGPRs -- lane (m, K half) loads its own MFMA operand, 512 contiguous bytes per half-wave; no LDS at all (with K split
+//     over waves no two waves of a block share a filter byte, so an LDS copy would only add a write and a read per byte);
+//   * B (activations): from the unit tensor.  Pixels are tiled in FLATTENED order n = (b Ho + y) Wo + x (a 2 x 25 map wastes nothing:
+//     800 pixels = 25 tiles), so a tile is a list of row segments; per filter row the wave needs, for every segment, the padded
+//     columns xa .. xb + 2 -- "slot" s of the row.  One 16-byte load per lane fetches slot s (per-lane unit addresses computed
+//     once: the zero ring of the unit tensor serves every padding case), one ds_write_b128 puts it into the wave's PRIVATE LDS row,
+//     and the tap kw operand of pixel p is the ds_read_b128 of slot q(p) + kw.  1 x 1 filters (stride 1 / 2, and the
+//     transposed-strided form whose in-between pixels read a ring unit = zero) use the same path with one slot per pixel.
+//   * software pipeline per wave (plain loads: hipcc counts vmcnt itself): loads of row unit s + 2 are issued before the MFMAs of
+//     unit s, the LDS row of unit s + 1 is written and its first operands read under the last tap of unit s.
+//   * the 8 partial tiles meet in LDS (16 B per lane and row group, summed in wave order: deterministic), and 4 TN waves run
+//     conv_epilogue (bias / noise / LeakyReLU / demodulation / residual / gate / dot slots / unit sink) on one 4-channel row group each.
+// Arithmetic: the f32x3 / bf16 term pairing of conv_units_fprop_kernel (conv_units.hip).
+#include <type_traits>
+
+#include "conv_common.h"
+
+struct ConvSmallP {
+  const char *XU, *Wf;
+  long long x_plane, w_plane;  // 16-byte units per plane
+  float *y;
+  int B, C8, M, Hin, Win, Hout, Wout, ldw;
+  int sy, sx, flip, mode;  // mode 0: 3x3 stride 1 pad 1 | 1: 1x1 stride (sy, sx) | 2: 1x1 transposed stride (sy, sx)
+  int Ntot, tilesM, nunits, dot_slots;
+  EpiK e;
+};
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <int NP, int KW, int TN>
+__global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) {
+  constexpr int KH = KW, KK = KH * KW;
+  constexpr int CKU = NP == 3 ? 1 : 2;             // channel units per chunk
+  constexpr int ROWS = NP == 3 ? 3 : 2;            // LDS rows of one row unit: planes (x3) | the chunk's two channel units (bf16)
+  constexpr int LPU = KW == 3 ? TN : 1;            // 64-slot loads per row
+  constexpr int SLOTS = LPU * 64;
+  constexpr int STG = ROWS * SLOTS * 16;           // bytes of one wave's staging row set
+  constexpr int NA = NP == 3 ? 2 : 1, NB = (NP == 3 ? 3 : 1) * TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // consecutive block ids sit on consecutive XCDs: the channel tile varies fastest, so an XCD's L2 sees few filter slices
+  const int mt = blockIdx.x % p.tilesM, nt = blockIdx.x / p.tilesM;
+  const int m0 = mt * 32, n0 = nt * 32 * TN;
+  const int Hp = p.Hin + 2, Wp = p.Win + 2, HWo = p.Hout * p.Wout;
+
+  // ---- per-lane sources
+  const char *bsrc[LPU];  // this lane's slot of the row unit (chunk 0, kh 0, plane 0)
+  const int r0 = n0 / p.Wout, x0 = n0 - r0 * p.Wout;
+#pragma unroll
+  for (int jj = 0; jj < LPU; ++jj) {
+    long long u;
+    if constexpr (KW == 3) {
+      const int t = jj * 64 + lane + x0;
+      const int g = t / Wp, pc = t - g * Wp;
+      const int r = min(r0 + g, p.B * p.Hout - 1);
+      const int b = r / p.Hout, y = r - b * p.Hout;
+      u = ((long long)b * p.C8 * Hp + y) * Wp + pc;
+    } else {
+      const int n = min(n0 + min(lane, 32 * TN - 1), p.Ntot - 1);
+      const int b = n / HWo, rem = n - b * HWo;
+      const int y = rem / p.Wout, x = rem - y * p.Wout;
+      if (p.mode == 1) {
+        u = ((long long)b * p.C8 * Hp + y * p.sy + 1) * Wp + x * p.sx + 1;
+      } else {  // transposed: output pixel (y, x) has a source only where both coordinates are multiples of the stride
+        const int ys = y / p.sy, xs = x / p.sx;
+        const bool hit = ys * p.sy == y && xs * p.sx == x && ys < p.Hin && xs < p.Win;
+        u = hit ? ((long long)b * p.C8 * Hp + ys + 1) * Wp + xs + 1 : (long long)b * p.C8 * Hp * Wp;  // (0, 0) of the ring: zero
+      }
+    }
+    bsrc[jj] = p.XU + (u << 4);
+  }
+  const int mcl = min(m0 + l31, p.M - 1);  // rows past M re-read the last one (never stored)
+  const char *const aX = p.Wf + (((long long)mcl + (NP == 3 ? half * p.w_plane : (long long)half * p.ldw)) << 4);
+  const char *const aY = p.Wf + (((long long)mcl + 2 * half * p.w_plane) << 4);  // x3 only
+  // operand slots of this lane's pixels
+  int q[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int pp = 32 * j + l31;
+    q[j] = KW == 3 ? pp + 2 * ((n0 + pp) / p.Wout - r0) : pp;
+  }
+  char *const stg = smem + wave * STG;
+  const long long cu_step = (long long)Hp * Wp * 16;  // bytes between two channel units of a sample
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int n_w = wave < p.nunits ? (p.nunits - wave + 7) >> 3 : 0;  // row units of this wave
+  bf16x8 Areg[3][KW][NA], Breg[3][ROWS][LPU], Op[3][NB];
+
+  auto issue = [&](auto S_, int s) {  // every global load of row unit s (clamped: past the end the last unit is fetched again)
+    constexpr int S = decltype(S_)::value;
+    const int u = wave + 8 * min(s, n_w - 1);
+    const int kc = u / KH, kh = u - kc * KH;
+#pragma unroll
+    for (int row = 0; row < ROWS; ++row) {
+      const long long off = NP == 3 ? ((row * p.x_plane) << 4) + kc * cu_step + (long long)kh * Wp * 16
+                                    : (2 * kc + row) * cu_step + (long long)kh * Wp * 16;
+#pragma unroll
+      for (int jj = 0; jj < LPU; ++jj) Breg[S][row][jj] = *reinterpret_cast<const bf16x8 *>(bsrc[jj] + off);
+    }
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw) {
+      const int t = kh * KW + kw, tt = p.flip ? KK - 1 - t : t;
+      const long long off = ((long long)(tt * p.C8 + CKU * kc) * p.ldw) << 4;
+      Areg[S][kw][0] = *reinterpret_cast<const bf16x8 *>(aX + off);
+      if constexpr (NP == 3) Areg[S][kw][1] = *reinterpret_cast<const bf16x8 *>(aY + off);
+    }
+  };
+  auto stage = [&](auto S_) {  // the row unit's slots -> this wave's LDS rows
+    constexpr int S = decltype(S_)::value;
+#pragma unroll
+    for (int row = 0; row < ROWS; ++row)
+#pragma unroll
+      for (int jj = 0; jj < LPU; ++jj)
+        *reinterpret_cast<bf16x8 *>(stg + ((row * SLOTS + jj * 64 + lane) << 4)) = Breg[S][row][jj];
+  };
+  // x3: half-wave h supplies K half h of each MFMA:  A (hi | mid) x B hi,  A (hi | mid) x B mid,  A (hi | lo) x B (lo | hi)
+  // bf16: half-wave h holds channel unit h of the chunk
+  auto read_ops = [&](auto O_, int kw) {
+    constexpr int O = decltype(O_)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const char *base = stg + ((q[j] + kw) << 4);
+      if constexpr (NP == 3) {
+        Op[O][3 * j + 0] = *reinterpret_cast<const bf16x8 *>(base);
+        Op[O][3 * j + 1] = *reinterpret_cast<const bf16x8 *>(base + SLOTS * 16);
+        Op[O][3 * j + 2] = *reinterpret_cast<const bf16x8 *>(base + 2 * (1 - half) * SLOTS * 16);
+      } else {
+        Op[O][j] = *reinterpret_cast<const bf16x8 *>(base + half * SLOTS * 16);
+      }
+    }
+  };
+  auto mfmas = [&](auto S_, auto O_, int kw) {
+    constexpr int S = decltype(S_)::value, O = decltype(O_)::value;
+    if constexpr (NP == 3) {  // smallest terms first
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[S][kw][1], Op[O][3 * j + 2], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[S][kw][0], Op[O][3 * j + 1], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[S][kw][0], Op[O][3 * j + 0], acc[j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[S][kw][0], Op[O][j], acc[j], 0, 0, 0);
+    }
+  };
+  // one row unit: ring slot S holds its operands; the loads of unit s + 2 go out first, the LDS rows of unit s + 1 are written (and
+  // its first operands read) under the last tap
+  auto body = [&](auto S_, int s) {
+    constexpr int S = decltype(S_)::value, S1 = (S + 1) % 3, S2 = (S + 2) % 3;
+    issue(IC<S2>{}, s + 2);
+    if constexpr (KW == 3) {
+      read_ops(IC<1>{}, 1);
+      mfmas(IC<S>{}, IC<0>{}, 0);
+      read_ops(IC<2>{}, 2);
+      mfmas(IC<S>{}, IC<1>{}, 1);
+      stage(IC<S1>{});
+      read_ops(IC<0>{}, 0);
+      mfmas(IC<S>{}, IC<2>{}, 2);
+    } else {
+      stage(IC<S1>{});
+      read_ops(IC<S1>{}, 0);
+      mfmas(IC<S>{}, IC<S>{}, 0);
+    }
+  };
+  if (n_w > 0) {
+    issue(IC<0>{}, 0);
+    issue(IC<1>{}, 1);
+    stage(IC<0>{});
+    read_ops(IC<0>{}, 0);
+    for (int s = 0; s < n_w; s += 3) {
+      body(IC<0>{}, s);
+      if (s + 1 < n_w) body(IC<1>{}, s + 1);
+      if (s + 2 < n_w) body(IC<2>{}, s + 2);
+    }
+  }
+
+  // ---- the 8 partial tiles -> LDS, summed in wave order by the wave that finishes the row group
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v *const red = reinterpret_cast<f32x4v *>(smem + 8 * STG);
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+      red[((wave * TN + j) * 4 + rg) * 64 + lane] = f32x4v{acc[j][4 * rg], acc[j][4 * rg + 1], acc[j][4 * rg + 2], acc[j][4 * rg + 3]};
+  __syncthreads();
+  if (wave >= 4 * TN) return;
+  const int j = wave >> 2, rg = wave & 3;
+  f32x4v v = red[(j * 4 + rg) * 64 + lane];
+#pragma unroll
+  for (int w2 = 1; w2 < 8; ++w2) v += red[((w2 * TN + j) * 4 + rg) * 64 + lane];
+  f32x16 a1[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a1[0][0][r] = r < 4 ? v[r & 3] : 0.f;
+  const int nb = n0 + 32 * j, n = nb + l31;
+  int e_pix[1], e_b[1];
+  e_b[0] = min(n, p.Ntot - 1) / HWo;
+  e_pix[0] = n < p.Ntot ? n - e_b[0] * HWo : -1;
+  const int dot_b = nb / HWo;
+  conv_epilogue<1, 1, 4, true, 4>(a1, p.e, p.y, nullptr, p.M, HWo, m0 + 8 * rg, lane, e_pix, e_b, true, dot_b, p.dot_slots,
+                                  (nb - dot_b * HWo) >> 5, p.Hout, p.Wout);
+}
+
+// ---- geometry: which form of the kernel a descriptor takes (0: none)
+static int small_mode(const tbg_conv_desc *d) {
+  if (d->ksplit != 1 || d->ldw < d->M || d->B < 1 || d->C < 1 || d->M < 1) return -1;
+  if (d->KH == 3 && d->KW == 3 && !d->transposed && d->sy == 1 && d->sx == 1 && d->py == 1 && d->px == 1 && d->Hout == d->Hin &&
+      d->Wout == d->Win && d->Wout >= 3)
+    return 0;
+  if (d->KH == 1 && d->KW == 1 && d->py == 0 && d->px == 0 && d->sy >= 1 && d->sy <= 2 && d->sx >= 1 && d->sx <= 2) {
+    if (!d->transposed && d->Hout == (d->Hin - 1) / d->sy + 1 && d->Wout == (d->Win - 1) / d->sx + 1) return 1;
+    if (d->transposed && d->Hout >= (d->Hin - 1) * d->sy + 1 && d->Wout >= (d->Win - 1) * d->sx + 1) return 2;
+  }
+  return -1;
+}
+
+static bool small_ok(const tbg_conv_desc *d, int planes) {
+  if (planes != 1 && planes != 3) return false;
+  const int c8 = (d->C + 7) / 8;
+  return small_mode(d) >= 0 && (planes == 3 || (c8 & 1) == 0);
+}
+
+// pixels per tile: 64 where 32-pixel tiles would be more than two rounds of one block per CU (the filter is re-read per pixel tile)
+static int small_tn(const tbg_conv_desc *d) {
+  const long long n = (long long)d->B * d->Hout * d->Wout;
+  return (long long)ceil_div(d->M, 32) * ((n + 31) / 32) > 512 ? 2 : 1;
+}
+
+extern "C" int tbg_conv2d_units_small_blocks(const tbg_conv_desc *d, int planes) {
+  if (!d) return TBG_EINVAL;
+  if (!small_ok(d, planes)) return TBG_EUNSUPPORTED;
+  const long long n = (long long)d->B * d->Hout * d->Wout;
+  const int px = 32 * small_tn(d);
+  const long long b = (long long)ceil_div(d->M, 32) * ((n + px - 1) / px);
+  return b > 2147483647LL ? TBG_ERANGE : (int)b;
+}
+
+// slots of the fused dot product per (b, m): one per 32 pixels of the map; 0 = a tile would straddle two images (not served)
+extern "C" int tbg_conv2d_units_small_dot_slots(const tbg_conv_desc *d, int planes) {
+  if (!d) return TBG_EINVAL;
+  if (!small_ok(d, planes)) return TBG_EUNSUPPORTED;
+  const int hw = d->Hout * d->Wout;
+  return hw % (32 * small_tn(d)) == 0 ? hw / 32 : 0;
+}
+
+template <int NP, int KW, int TN>
+static int launch_small(const ConvSmallP &p, int tilesN, hipStream_t st) {
+  constexpr int ROWS = NP == 3 ? 3 : 2, LPU = KW == 3 ? TN : 1;
+  const size_t lds = (size_t)8 * ROWS * LPU * 64 * 16 + (size_t)8 * TN * 4096;
+  auto kern = conv_small_kernel<NP, KW, TN>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return TBG_EHIP;
+  hipLaunchKernelGGL(kern, dim3(p.tilesM * tilesN), dim3(512), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_conv2d_units_small(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,
+                                      const tbg_epilogue *epi, void *stream) {
+  if (!d || !XU || !w || (!y && !epi_has_sink(epi)) || (planes != 1 && planes != 3) || !epi_valid(epi)) return TBG_EINVAL;
+  if (d->B < 1 || d->C < 1 || d->M < 1 || d->Hin < 1 || d->Win < 1 || d->Hout < 1 || d->Wout < 1) return TBG_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(XU) | reinterpret_cast<uintptr_t>(w)) & 15) != 0) return TBG_EINVAL;
+  if (!small_ok(d, planes)) return TBG_EUNSUPPORTED;
+  if ((double)d->B * d->M * d->Hout * d->Wout > 2147483647.0) return TBG_ERANGE;
+  ConvSmallP p{};
+  p.XU = reinterpret_cast<const char *>(XU); p.Wf = reinterpret_cast<const char *>(w);
+  p.C8 = (d->C + 7) / 8;
+  p.x_plane = (long long)d->B * p.C8 * (d->Hin + 2) * (d->Win + 2);
+  p.w_plane = (long long)d->KH * d->KW * p.C8 * d->ldw;
+  if (p.x_plane * planes > 2147483647LL / 2 || p.w_plane * planes > 2147483647LL / 2) return TBG_ERANGE;
+  p.y = y; p.B = d->B; p.M = d->M; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.ldw = d->ldw;
+  p.sy = d->sy; p.sx = d->sx; p.flip = d->flip; p.mode = small_mode(d);
+  p.Ntot = d->B * d->Hout * d->Wout;
+  p.tilesM = ceil_div(d->M, 32);
+  const int tn = small_tn(d);
+  const int tilesN = ceil_div(p.Ntot, 32 * tn);
+  p.nunits = (p.C8 / (planes == 3 ? 1 : 2)) * d->KH;
+  p.e = make_epi(epi);
+  const int hw = d->Hout * d->Wout;
+  p.dot_slots = hw % (32 * tn) == 0 ? hw / 32 : 0;
+  if (p.e.dot_aux && p.dot_slots == 0) return TBG_EUNSUPPORTED;
+  if (const int rcs = epi_sink_geometry(p.e, d->B, d->M, d->Hout, d->Wout)) return rcs;
+  hipStream_t st = tbg_stream(stream);
+  if (d->KH == 3) {
+    if (planes == 3) return tn == 2 ? launch_small<3, 3, 2>(p, tilesN, st) : launch_small<3, 3, 1>(p, tilesN, st);
+    return tn == 2 ? launch_small<1, 3, 2>(p, tilesN, st) : launch_small<1, 3, 1>(p, tilesN, st);
+  }
+  if (planes == 3) return tn == 2 ? launch_small<3, 1, 2>(p, tilesN, st) : launch_small<3, 1, 1>(p, tilesN, st);
+  return tn == 2 ? launch_small<1, 1, 2>(p, tilesN, st) : launch_small<1, 1, 1>(p, tilesN, st);
+}

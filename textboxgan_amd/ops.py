@@ -612,6 +612,50 @@ def conv2d_units_raw(XU: UnitTensor, w: "PackedFilter", M: int, flip=False, epi:
     return y
 
 
+def conv_small_ok(C_in, M, Hin, Win, Hout, Wout, KH, KW, stride, pad, transposed, planes) -> bool:
+    """geometry of tbg_conv2d_units_small (tbg.h "SMALL MAPS"): 3x3 stride-1 pad-1, 1x1 with stride 1 | 2, 1x1 transposed"""
+    d = N.ConvDesc(1, C_in, M, Hin, Win, Hout, Wout, KH, KW, stride[0], stride[1], pad[0], pad[1], int(transposed), 0, M, 1)
+    return N.lib().tbg_conv2d_units_small_blocks(C.byref(d), planes) > 0
+
+
+def conv2d_small_raw(XU: UnitTensor, w: "PackedFilter", M: int, KH: int, out_hw, stride=(1, 1), transposed=False, flip=False,
+                     epi: Optional[N.Epilogue] = None, dot=None, out: Optional[torch.Tensor] = None,
+                     sink: Optional["UnitSink"] = None):
+    """tbg_conv2d_units_small: a small-map convolution (3x3 stride-1 pad-1, or 1x1 with stride / transposed stride) of the
+    activation behind the unit tensor XU with the K split inside the block -- one launch, no slabs.  Arguments and return forms as
+    conv2d_units_raw (dot = (aux, out | None), sink -> (y, UnitTensor | None))."""
+    assert w.fmt == (FMT_X3 if XU.planes == 3 else FMT_BF16) and w.C == XU.C and w.M >= M and w.T == KH * KH
+    B, Hin, Win = XU.B, XU.H, XU.W
+    Hout, Wout = out_hw
+    if sink is not None:
+        epi_s, U = _sink_epi(N.epilogue() if epi is None else epi, sink, B, M, Hout, Wout, XU.data.device)
+        return conv2d_small_raw(XU, w, M, KH, out_hw, stride, transposed, flip, epi_s, dot, out), U
+    pad = KH // 2
+    d = N.ConvDesc(B, XU.C, M, Hin, Win, Hout, Wout, KH, KH, stride[0], stride[1], pad, pad, int(transposed), int(flip), w.M, 1)
+    epi = N.epilogue() if epi is None else epi
+    partial = None
+    if dot is not None:
+        slots = N.lib().tbg_conv2d_units_small_dot_slots(C.byref(d), XU.planes)
+        N.check(min(slots, 0), "tbg_conv2d_units_small_dot_slots")
+        assert slots > 0, "the fused dot needs pixel tiles that stay inside one sample"
+        partial = torch.empty((B, M, slots), device=XU.data.device, dtype=torch.float32)
+        epi = N.Epilogue.from_buffer_copy(epi)
+        epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(partial)
+    y = torch.empty((B, M, Hout, Wout), device=XU.data.device, dtype=torch.float32) if out is None else out
+    _flops = 2.0 * B * M * XU.C * KH * KH * (Hin * Win if transposed else Hout * Wout)
+    _blocks = N.lib().tbg_conv2d_units_small_blocks(C.byref(d), XU.planes)
+    _tn = 1 if _blocks == math.ceil(M / 32) * math.ceil(B * Hout * Wout / 32) else 2
+    N.check(PROFILE.launch(f"conv_small_kernel<{XU.planes}, {KH}, {_tn}>", _flops, lambda: N.lib().tbg_conv2d_units_small(
+        C.byref(d), N.ptr(XU.data), XU.planes, N.ptr(w.data), N.ptr(y), C.byref(epi), N.stream()),
+        f"conv_small[B={B} C={XU.C} M={M} in={Hin}x{Win} out={Hout}x{Wout} k={KH} s={tuple(stride)} T={int(transposed)}]",
+        2.0 * XU.data.numel() + 4.0 * B * M * Hout * Wout + 2.0 * XU.planes * KH * KH * XU.C * M), "tbg_conv2d_units_small")
+    if partial is not None:
+        if dot[1] is None:
+            return y, partial
+        torch.sum(partial, dim=2, out=dot[1].view(B, M))
+    return y
+
+
 class PhaseUnitTensor(NamedTuple):
     """the input t [B,C,Hin,Win] of a 3x3 stride-2 pad-0 convolution with Ho x Wo outputs, de-interleaved by parity (tbg.h "PHASE
     unit tensors"): P[planes][B][ceil(C/8)][4][Ho+1][Wo+1][8] bf16 -- inside a phase plane the stride is gone."""
