@@ -96,7 +96,7 @@ def test_conv_small_matches_float64(dev, mode, geom):
                                 gain=math.sqrt(2.0)))
         pre = 0.9 * acc * c64(dd)[:, :, None, None] + c64(nd) * 0.3 + c64(bd)[None, :, None, None]
         errs["modconv"] = _rel(y1, F.leaky_relu(pre, 0.2) * math.sqrt(2.0))
-        y2 = run(epi=N.epilogue(bias=bd, residual=rd, res_first=1, act=N.ACT_LRELU, slope=0.0, gate=gd))
+        y2 = run(epi=N.epilogue(bias=bd, residual=rd, res_first=1, act=N.ACT_LRELU, slope=0.0, gain=1.0, gate=gd))
         ref2 = torch.relu(acc + c64(bd)[None, :, None, None] + c64(rd)) * (c64(gd) > 0)
         errs["resunit"] = _rel(y2, ref2)
         y3 = run(epi=N.epilogue(bias=bd, residual=rd, res_scale=0.7))
@@ -170,7 +170,7 @@ def test_conv_small_unit_sink_equals_units_pack(dev, mode, geom):
     bias, scale, res = f(_rnd(M, seed=64)), f(_rnd(B, M, seed=65)), f(_rnd(B, M, Ho, Wo, seed=66))
     with ops.compute_dtype(mode):
         XU, pf = ops.units_pack(x, None, planes=planes), ops.pack_filter(w, False, False)
-        mk = lambda: N.epilogue(bias=bias, residual=res, res_first=1, act=N.ACT_LRELU, slope=0.0)
+        mk = lambda: N.epilogue(bias=bias, residual=res, res_first=1, act=N.ACT_LRELU, slope=0.0, gain=1.0)
         y_ref = ops.conv2d_small_raw(XU, pf, M, k, (Ho, Wo), stride, transposed, epi=mk())
         for sc in (scale, None):
             y, U = ops.conv2d_small_raw(XU, pf, M, k, (Ho, Wo), stride, transposed, epi=mk(), sink=_AlwaysSink(sc, "s1", M))

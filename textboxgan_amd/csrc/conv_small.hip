@@ -23,7 +23,9 @@
 //   * the 8 partial tiles meet in LDS (16 B per lane and row group, summed in wave order: deterministic), and 4 TN waves run
 //     conv_epilogue (bias / noise / LeakyReLU / demodulation / residual / gate / dot slots / unit sink) on one 4-channel row group each.
 // Arithmetic: the f32x3 / bf16 term pairing of conv_units_fprop_kernel (conv_units.hip).
+#include <initializer_list>
 #include <type_traits>
+#include <utility>
 
 #include "conv_common.h"
 
@@ -38,6 +40,25 @@ struct ConvSmallP {
 };
 
 template <int V> using IC = std::integral_constant<int, V>;
+
+// prefetch distance of the per-wave software pipeline in row units (ring of SMALL_PD + 1 register sets), and whether the blocks of
+// one channel tile walk their row units from different starting points (tools/ab_small.sh measures both)
+#ifndef SMALL_PD
+#define SMALL_PD 2
+#endif
+#ifndef SMALL_ROT
+#define SMALL_ROT 0
+#endif
+// ablation builds (tools/ab_small.sh; 0 = product): 1 no MFMAs, 2 filter loads of the first row unit only, 3 activation loads of the
+// first row unit only, 4 both
+#ifndef SMALL_EXP
+#define SMALL_EXP 0
+#endif
+
+template <class F, int... I>
+__device__ __forceinline__ void small_ring(F &body, int s, int count, std::integer_sequence<int, I...>) {
+  (void)std::initializer_list<int>{(I < count ? (body(IC<I>{}, s + I), 0) : 0)...};
+}
 
 template <int NP, int KW, int TN>
 __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) {
@@ -83,8 +104,31 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
     bsrc[jj] = p.XU + (u << 4);
   }
   const int mcl = min(m0 + l31, p.M - 1);  // rows past M re-read the last one (never stored)
-  const char *const aX = p.Wf + (((long long)mcl + (NP == 3 ? half * p.w_plane : (long long)half * p.ldw)) << 4);
-  const char *const aY = p.Wf + (((long long)mcl + 2 * half * p.w_plane) << 4);  // x3 only
+  // A loads of one row unit.  bf16: one per tap (half-wave h: channel unit h of the chunk).  x3, 1x1: (hi | mid), (hi | lo).
+  // x3, 3x3: the K halves of the three MFMAs of a tap carry (A | A') x (B | B') = (hi|mid) x (hi|hi), (hi|mid) x (mid|mid),
+  // (hi|lo) x (lo|hi) -- half 0 only ever needs hi, half 1 needs mid and lo.  Swapping the halves' roles on the middle tap --
+  // (mid|hi) x (hi|hi), (mid|hi) x (mid|mid), (lo|hi) x (hi|lo): the same six products -- lets FIVE loads carry the nine plane
+  // slices of a row unit instead of six (hi is no longer fetched twice per tap):
+  //     load      0        1        2        3        4
+  //     half 0   hi t0    mid t1   lo t1    hi t2    (hi t2)
+  //     half 1   mid t0   lo t0    hi t1    mid t2   lo t2
+  constexpr int NAL = NP == 3 ? (KW == 3 ? 5 : 2) : KW;
+  const char *const abase = p.Wf + ((long long)mcl << 4);
+  unsigned aoff[NAL];  // this lane's byte offset of load i from the row unit's (chunk, first tap) slice of plane 0
+  {
+    const long long tstep = (long long)(p.flip ? -1 : 1) * p.C8 * p.ldw;  // units between two taps of a filter row
+    if constexpr (NP == 3 && KW == 3) {
+      const int pl[2][5] = {{0, 1, 2, 0, 0}, {1, 2, 0, 1, 2}}, tp[2][5] = {{0, 1, 1, 2, 2}, {0, 0, 1, 2, 2}};
+#pragma unroll
+      for (int i = 0; i < 5; ++i) aoff[i] = (unsigned)((pl[half][i] * p.w_plane + tp[half][i] * tstep + 2 * p.C8 * p.ldw) << 4);
+    } else if constexpr (NP == 3) {
+      aoff[0] = (unsigned)((half * p.w_plane) << 4);
+      aoff[1] = (unsigned)((2 * half * p.w_plane) << 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < KW; ++i) aoff[i] = (unsigned)(((long long)half * p.ldw + i * tstep + (KW - 1) * p.C8 * p.ldw) << 4);
+    }
+  }
   // operand slots of this lane's pixels
   int q[TN];
 #pragma unroll
@@ -92,6 +136,8 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
     const int pp = 32 * j + l31;
     q[j] = KW == 3 ? pp + 2 * ((n0 + pp) / p.Wout - r0) : pp;
   }
+  // slots of a row that some pixel of the tile reads: up to q of the last pixel + KW - 1
+  const int nslot = (KW == 3 ? 32 * TN - 1 + 2 * ((n0 + 32 * TN - 1) / p.Wout - r0) : 32 * TN - 1) + KW;
   char *const stg = smem + wave * STG;
   const long long cu_step = (long long)Hp * Wp * 16;  // bytes between two channel units of a sample
 
@@ -102,26 +148,30 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int n_w = wave < p.nunits ? (p.nunits - wave + 7) >> 3 : 0;  // row units of this wave
-  bf16x8 Areg[3][KW][NA], Breg[3][ROWS][LPU], Op[3][NB];
+  constexpr int PD = SMALL_PD, R = PD + 1;
+  bf16x8 Areg[R][NAL], Breg[R][ROWS][LPU], Op[R > 3 ? R : 3][NB];
+  const int rot = SMALL_ROT ? nt : 0;  // (deterministic: the summation order is a function of the tile)
 
   auto issue = [&](auto S_, int s) {  // every global load of row unit s (clamped: past the end the last unit is fetched again)
     constexpr int S = decltype(S_)::value;
-    const int u = wave + 8 * min(s, n_w - 1);
+    int si = min(s, n_w - 1) + rot;
+    si -= (si / n_w) * n_w;
+    const int u = wave + 8 * si;
     const int kc = u / KH, kh = u - kc * KH;
 #pragma unroll
     for (int row = 0; row < ROWS; ++row) {
       const long long off = NP == 3 ? ((row * p.x_plane) << 4) + kc * cu_step + (long long)kh * Wp * 16
                                     : (2 * kc + row) * cu_step + (long long)kh * Wp * 16;
 #pragma unroll
-      for (int jj = 0; jj < LPU; ++jj) Breg[S][row][jj] = *reinterpret_cast<const bf16x8 *>(bsrc[jj] + off);
+      for (int jj = 0; jj < LPU; ++jj)
+        if (jj * 64 + lane < nslot && !((SMALL_EXP == 3 || SMALL_EXP == 4) && s > 1)) Breg[S][row][jj] = *reinterpret_cast<const bf16x8 *>(bsrc[jj] + off);  // (slots past the tile's last: never read)
     }
+    // (aoff is biased by (KW - 1) taps so that it stays non-negative with flip: the row unit's base is its first tap minus that)
+    const int t0 = kh * KW, tt0 = p.flip ? KK - 1 - t0 : t0;
+    const char *const ab = abase + (((long long)(tt0 - (KW - 1)) * p.C8 + CKU * kc) * p.ldw << 4);
 #pragma unroll
-    for (int kw = 0; kw < KW; ++kw) {
-      const int t = kh * KW + kw, tt = p.flip ? KK - 1 - t : t;
-      const long long off = ((long long)(tt * p.C8 + CKU * kc) * p.ldw) << 4;
-      Areg[S][kw][0] = *reinterpret_cast<const bf16x8 *>(aX + off);
-      if constexpr (NP == 3) Areg[S][kw][1] = *reinterpret_cast<const bf16x8 *>(aY + off);
-    }
+    for (int i = 0; i < NAL; ++i)
+      if (!((SMALL_EXP == 2 || SMALL_EXP == 4) && s > 1)) Areg[S][i] = *reinterpret_cast<const bf16x8 *>(ab + aoff[i]);
   };
   auto stage = [&](auto S_) {  // the row unit's slots -> this wave's LDS rows
     constexpr int S = decltype(S_)::value;
@@ -131,8 +181,8 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
       for (int jj = 0; jj < LPU; ++jj)
         *reinterpret_cast<bf16x8 *>(stg + ((row * SLOTS + jj * 64 + lane) << 4)) = Breg[S][row][jj];
   };
-  // x3: half-wave h supplies K half h of each MFMA:  A (hi | mid) x B hi,  A (hi | mid) x B mid,  A (hi | lo) x B (lo | hi)
-  // bf16: half-wave h holds channel unit h of the chunk
+  // x3: half-wave h supplies K half h of each MFMA:  A (hi | mid) x B hi,  A (hi | mid) x B mid,  A (hi | lo) x B (lo | hi); on the
+  // middle tap of a 3x3 row the halves swap roles (see the A loads): B (hi | lo) there.  bf16: half-wave h holds channel unit h
   auto read_ops = [&](auto O_, int kw) {
     constexpr int O = decltype(O_)::value;
 #pragma unroll
@@ -141,55 +191,71 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
       if constexpr (NP == 3) {
         Op[O][3 * j + 0] = *reinterpret_cast<const bf16x8 *>(base);
         Op[O][3 * j + 1] = *reinterpret_cast<const bf16x8 *>(base + SLOTS * 16);
-        Op[O][3 * j + 2] = *reinterpret_cast<const bf16x8 *>(base + 2 * (1 - half) * SLOTS * 16);
+        Op[O][3 * j + 2] = *reinterpret_cast<const bf16x8 *>(base + 2 * ((KW == 3 && kw == 1) ? half : 1 - half) * SLOTS * 16);
       } else {
         Op[O][j] = *reinterpret_cast<const bf16x8 *>(base + half * SLOTS * 16);
       }
     }
   };
-  auto mfmas = [&](auto S_, auto O_, int kw) {
-    constexpr int S = decltype(S_)::value, O = decltype(O_)::value;
-    if constexpr (NP == 3) {  // smallest terms first
+  auto sel = [&](const bf16x8 &h1, const bf16x8 &h0) {  // half-wave 1 takes h1, half-wave 0 takes h0
+    const u32x4v a = __builtin_bit_cast(u32x4v, h1), b = __builtin_bit_cast(u32x4v, h0);
+    return __builtin_bit_cast(bf16x8, u32x4v{half ? a[0] : b[0], half ? a[1] : b[1], half ? a[2] : b[2], half ? a[3] : b[3]});
+  };
+  auto mfmas = [&](auto S_, auto O_, auto KW_) {
+    constexpr int S = decltype(S_)::value, O = decltype(O_)::value, kw = decltype(KW_)::value;
+    if constexpr (SMALL_EXP == 1) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[S][kw][1], Op[O][3 * j + 2], acc[j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j) acc[j][0] += (float)Areg[S][0][0] * (float)Op[O][0][j];
+    } else if constexpr (NP == 3) {  // smallest terms first
+      bf16x8 X, Y;
+      if constexpr (KW == 3) {
+        if constexpr (kw == 0) { X = Areg[S][0]; Y = sel(Areg[S][1], Areg[S][0]); }
+        else if constexpr (kw == 1) { X = sel(Areg[S][2], Areg[S][1]); Y = Areg[S][2]; }
+        else { X = Areg[S][3]; Y = sel(Areg[S][4], Areg[S][3]); }
+      } else {
+        X = Areg[S][0]; Y = Areg[S][1];
+      }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[S][kw][0], Op[O][3 * j + 1], acc[j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y, Op[O][3 * j + 2], acc[j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[S][kw][0], Op[O][3 * j + 0], acc[j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X, Op[O][3 * j + 1], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X, Op[O][3 * j + 0], acc[j], 0, 0, 0);
     } else {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[S][kw][0], Op[O][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[S][kw], Op[O][j], acc[j], 0, 0, 0);
     }
   };
-  // one row unit: ring slot S holds its operands; the loads of unit s + 2 go out first, the LDS rows of unit s + 1 are written (and
+  // one row unit: ring slot S holds its operands; the loads of unit s + PD go out first, the LDS rows of unit s + 1 are written (and
   // its first operands read) under the last tap
   auto body = [&](auto S_, int s) {
-    constexpr int S = decltype(S_)::value, S1 = (S + 1) % 3, S2 = (S + 2) % 3;
-    issue(IC<S2>{}, s + 2);
+    constexpr int S = decltype(S_)::value, S1 = (S + 1) % R, SP = (S + PD) % R;
+    issue(IC<SP>{}, s + PD);
     if constexpr (KW == 3) {
       read_ops(IC<1>{}, 1);
-      mfmas(IC<S>{}, IC<0>{}, 0);
+      mfmas(IC<S>{}, IC<0>{}, IC<0>{});
       read_ops(IC<2>{}, 2);
-      mfmas(IC<S>{}, IC<1>{}, 1);
+      mfmas(IC<S>{}, IC<1>{}, IC<1>{});
       stage(IC<S1>{});
       read_ops(IC<0>{}, 0);
-      mfmas(IC<S>{}, IC<2>{}, 2);
+      mfmas(IC<S>{}, IC<2>{}, IC<2>{});
     } else {
       stage(IC<S1>{});
       read_ops(IC<S1>{}, 0);
-      mfmas(IC<S>{}, IC<S>{}, 0);
+      mfmas(IC<S>{}, IC<S>{}, IC<0>{});
     }
   };
   if (n_w > 0) {
-    issue(IC<0>{}, 0);
-    issue(IC<1>{}, 1);
+    auto pro = [&](auto S_, int s) { issue(S_, s); };
+    small_ring(pro, 0, PD, std::make_integer_sequence<int, R>{});
     stage(IC<0>{});
     read_ops(IC<0>{}, 0);
-    for (int s = 0; s < n_w; s += 3) {
-      body(IC<0>{}, s);
-      if (s + 1 < n_w) body(IC<1>{}, s + 1);
-      if (s + 2 < n_w) body(IC<2>{}, s + 2);
-    }
+    // whole rounds of the ring in the loop, the ragged rest behind it: the loop header then merges only the entry and the full
+    // back edge (with the rest inside the loop hipcc's vmcnt state at the header took the early-exit paths into account and
+    // waited for all but 4 loads at the top of every unit)
+    int s = 0;
+    for (; s + R <= n_w; s += R) small_ring(body, s, R, std::make_integer_sequence<int, R>{});
+    small_ring(body, s, n_w - s, std::make_integer_sequence<int, R>{});
   }
 
   // ---- the 8 partial tiles -> LDS, summed in wave order by the wave that finishes the row group
@@ -237,10 +303,11 @@ static bool small_ok(const tbg_conv_desc *d, int planes) {
   return small_mode(d) >= 0 && (planes == 3 || (c8 & 1) == 0);
 }
 
-// pixels per tile: 64 where 32-pixel tiles would be more than two rounds of one block per CU (the filter is re-read per pixel tile)
+// pixels per tile: 64 where 32-pixel tiles would be more than one round of one block per CU (every pixel tile re-reads the filter
+// slice of its channel tile: two rounds of 32 pixels stream it twice, one round of 64 once)
 static int small_tn(const tbg_conv_desc *d) {
   const long long n = (long long)d->B * d->Hout * d->Wout;
-  return (long long)ceil_div(d->M, 32) * ((n + 31) / 32) > 512 ? 2 : 1;
+  return (long long)ceil_div(d->M, 32) * ((n + 31) / 32) > 256 ? 2 : 1;
 }
 
 extern "C" int tbg_conv2d_units_small_blocks(const tbg_conv_desc *d, int planes) {

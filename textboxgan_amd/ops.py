@@ -109,6 +109,11 @@ class _Tuning:
                                      # Peak memory of a step is in bench.py's line (`peak_hbm_gb`)
         self.unit_sinks = True       # round 5: producers (conv / FIR / split-K epilogues) write the NEXT layer's unit tensor themselves
                                      # (tbg_epilogue.units_out); False = the stand-alone tbg_units_pack_f32 pass of round 4
+        # ---- small maps (tbg.h "SMALL MAPS", csrc/conv_small.hip)
+        self.use_small = True        # small-map convolutions take tbg_conv2d_units_small (K split inside the block, one launch) instead
+                                     # of the NCHW kernel's split-K pair (convolution into HBM slabs + tbg_slab_epilogue_f32)
+        self.small_max_blocks = 512  # ... when the launch is at most this many blocks (two rounds of one block per CU): beyond, every
+                                     # pixel tile re-reads its filter slice too often and the 128 x 128 NCHW tiles win
         # ---- split-K of the small-map launches
         self.force_ksplit = None     # experiment knob (tools/bench_ksplit.py)
         self.ksplit_target_blocks = 448  # blocks a split-K launch aims for (A/B on one box: 288 -> 21.22, 448 -> 21.11, 512 -> 20.97
@@ -620,16 +625,17 @@ def conv_small_ok(C_in, M, Hin, Win, Hout, Wout, KH, KW, stride, pad, transposed
 
 def conv2d_small_raw(XU: UnitTensor, w: "PackedFilter", M: int, KH: int, out_hw, stride=(1, 1), transposed=False, flip=False,
                      epi: Optional[N.Epilogue] = None, dot=None, out: Optional[torch.Tensor] = None,
-                     sink: Optional["UnitSink"] = None):
+                     sink: Optional["UnitSink"] = None, want_y=True):
     """tbg_conv2d_units_small: a small-map convolution (3x3 stride-1 pad-1, or 1x1 with stride / transposed stride) of the
     activation behind the unit tensor XU with the K split inside the block -- one launch, no slabs.  Arguments and return forms as
-    conv2d_units_raw (dot = (aux, out | None), sink -> (y, UnitTensor | None))."""
+    conv2d_units_raw (dot = (aux, out | None), sink -> (y, UnitTensor | None)); want_y = False (with a sink that is wanted): the
+    result leaves as a unit tensor only (y = None)."""
     assert w.fmt == (FMT_X3 if XU.planes == 3 else FMT_BF16) and w.C == XU.C and w.M >= M and w.T == KH * KH
     B, Hin, Win = XU.B, XU.H, XU.W
     Hout, Wout = out_hw
     if sink is not None:
         epi_s, U = _sink_epi(N.epilogue() if epi is None else epi, sink, B, M, Hout, Wout, XU.data.device)
-        return conv2d_small_raw(XU, w, M, KH, out_hw, stride, transposed, flip, epi_s, dot, out), U
+        return conv2d_small_raw(XU, w, M, KH, out_hw, stride, transposed, flip, epi_s, dot, out, None, want_y or U is None), U
     pad = KH // 2
     d = N.ConvDesc(B, XU.C, M, Hin, Win, Hout, Wout, KH, KH, stride[0], stride[1], pad, pad, int(transposed), int(flip), w.M, 1)
     epi = N.epilogue() if epi is None else epi
@@ -641,14 +647,17 @@ def conv2d_small_raw(XU: UnitTensor, w: "PackedFilter", M: int, KH: int, out_hw,
         partial = torch.empty((B, M, slots), device=XU.data.device, dtype=torch.float32)
         epi = N.Epilogue.from_buffer_copy(epi)
         epi.dot_aux, epi.dot_out = N.ptr(dot[0]), N.ptr(partial)
-    y = torch.empty((B, M, Hout, Wout), device=XU.data.device, dtype=torch.float32) if out is None else out
+    y = out
+    if y is None and (want_y or not epi.units_out):
+        y = torch.empty((B, M, Hout, Wout), device=XU.data.device, dtype=torch.float32)
     _flops = 2.0 * B * M * XU.C * KH * KH * (Hin * Win if transposed else Hout * Wout)
     _blocks = N.lib().tbg_conv2d_units_small_blocks(C.byref(d), XU.planes)
     _tn = 1 if _blocks == math.ceil(M / 32) * math.ceil(B * Hout * Wout / 32) else 2
     N.check(PROFILE.launch(f"conv_small_kernel<{XU.planes}, {KH}, {_tn}>", _flops, lambda: N.lib().tbg_conv2d_units_small(
         C.byref(d), N.ptr(XU.data), XU.planes, N.ptr(w.data), N.ptr(y), C.byref(epi), N.stream()),
         f"conv_small[B={B} C={XU.C} M={M} in={Hin}x{Win} out={Hout}x{Wout} k={KH} s={tuple(stride)} T={int(transposed)}]",
-        2.0 * XU.data.numel() + 4.0 * B * M * Hout * Wout + 2.0 * XU.planes * KH * KH * XU.C * M), "tbg_conv2d_units_small")
+        2.0 * XU.data.numel() + (4.0 if y is not None else 0.0) * B * M * Hout * Wout + 2.0 * XU.planes * KH * KH * XU.C * M),
+        "tbg_conv2d_units_small")
     if partial is not None:
         if dot[1] is None:
             return y, partial
@@ -1402,6 +1411,29 @@ def _units_t2(B, C_in, M, H, W, Hout, Wout) -> bool:
     d = N.ConvDesc(B, C_in, M, H, W, Hout, Wout, 3, 3, 2, 2, 0, 0, 1, 0, M, 1)
     gate = TUNING.units_min_blocks_t2 if fmt == FMT_X3 else max(TUNING.units_min_blocks, TUNING.units_min_blocks_t2)
     return N.lib().tbg_conv2d_units_t2_blocks(C.byref(d), unit_planes(fmt)) >= gate
+
+
+def _small_conv(B, C_in, M, Hin, Win, Hout, Wout, k, stride=(1, 1), transposed=False) -> bool:
+    """does this convolution take tbg_conv2d_units_small in the current arithmetic?  (3x3 stride-1 pad-1, 1x1 with stride or
+    transposed stride; launches of at most TUNING.small_max_blocks blocks)"""
+    fmt = _FMT[_TLS.compute]
+    if not TUNING.use_small or fmt == FMT_F32 or k not in (1, 3):
+        return False
+    d = N.ConvDesc(B, C_in, M, Hin, Win, Hout, Wout, k, k, stride[0], stride[1], k // 2, k // 2, int(transposed), 0, M, 1)
+    return 0 < N.lib().tbg_conv2d_units_small_blocks(C.byref(d), unit_planes(fmt)) <= TUNING.small_max_blocks
+
+
+class _ForceSink(UnitSink):
+    """a sink the CALLER has already decided on (it knows its consumer): plain units(out), wanted whatever the geometry"""
+
+    def __init__(self):
+        self.scale, self.kind, self.O_next, self.produced = None, "s1", 0, None
+
+    def wanted(self, B, Cc, H, W) -> bool:
+        return _FMT[_TLS.compute] != FMT_F32 and Cc % 8 == 0
+
+
+_FORCE_SINK = _ForceSink()
 
 
 def _unit_tensor(data, like: torch.Tensor, planes=None) -> Optional[UnitTensor]:
@@ -2392,11 +2424,12 @@ class FrozenConvConst:
     def out_hw(self, H, W):
         return ((H + 2 * self.pad[0] - self.KH) // self.stride[0] + 1, (W + 2 * self.pad[1] - self.KW) // self.stride[1] + 1)
 
+    def _fwd_epi(self, residual):
+        return N.epilogue(bias=self.b, residual=residual, res_first=1, act=ACT_LRELU if self.relu else ACT_LINEAR, slope=0.0, gain=1.0)
+
     def fwd(self, x, residual=None):
-        epi = N.epilogue(bias=self.b, residual=residual, res_first=1, act=ACT_LRELU if self.relu else ACT_LINEAR, slope=0.0,
-                         gain=1.0)
         return conv2d_raw(x, self.pf_fwd, self.O, self.KH, self.KW, self.out_hw(x.shape[2], x.shape[3]), self.stride, self.pad,
-                          epi=epi)
+                          epi=self._fwd_epi(residual))
 
     def bwd(self, dy, xhw, residual=None, gate=None):
         """d/dx of the convolution, + residual, then zeroed where gate <= 0 (the ReLU in front of x), in the one launch."""
@@ -2407,21 +2440,66 @@ class FrozenConvConst:
         assert self.KH == 1 and self.KW == 1 and self.pad == (0, 0), "strided OCR convolutions are 1x1"
         return conv2d_raw(dy, self.pf_bwd, self.I, 1, 1, xhw, self.stride, (0, 0), transposed=True, epi=epi)
 
+    # ---- the same two launches with unit tensors either side (round 6): on the small maps tbg_conv2d_units_small reads units(x)
+    # and the launch that produces a tensor writes the units its consumer reads (tbg_epilogue's sink) -- (fp32 | None, units | None)
+    def small_fwd(self, B, H, W) -> bool:
+        return (self.KH == self.KW and self.pad == (self.KH // 2, self.KW // 2) and
+                _small_conv(B, self.I, self.O, H, W, *self.out_hw(H, W), self.KH, self.stride, False))
+
+    def small_bwd(self, B, Ho, Wo, xhw) -> bool:
+        return (self.KH == self.KW and self.pad == (self.KH // 2, self.KW // 2) and
+                _small_conv(B, self.O, self.I, Ho, Wo, xhw[0], xhw[1], self.KH, self.stride, self.stride != (1, 1)))
+
+    def fwd_u(self, x, XU, residual=None, want_units=False):
+        B, H, W = x.shape[0], x.shape[2], x.shape[3]
+        sink = _FORCE_SINK if want_units else _NO_SINK
+        if self.small_fwd(B, H, W):
+            XU = units_pack(x) if XU is None else XU
+            return conv2d_small_raw(XU, self.pf_fwd, self.O, self.KH, self.out_hw(H, W), self.stride, False,
+                                    epi=self._fwd_epi(residual), sink=sink)
+        return conv2d_raw(x, self.pf_fwd, self.O, self.KH, self.KW, self.out_hw(H, W), self.stride, self.pad,
+                          epi=self._fwd_epi(residual), sink=sink)
+
+    def bwd_u(self, dy, DU, xhw, residual=None, gate=None, want_units=False, want_y=True):
+        """dy: fp32 (may be None when DU is given and this launch takes the small-map kernel)"""
+        epi = N.epilogue(residual=residual, res_first=1, gate=gate)
+        sink = _FORCE_SINK if want_units else _NO_SINK
+        B, Ho, Wo = (DU.B, DU.H, DU.W) if DU is not None else (dy.shape[0], dy.shape[2], dy.shape[3])
+        if self.small_bwd(B, Ho, Wo, xhw):
+            DU = units_pack(dy) if DU is None else DU
+            return conv2d_small_raw(DU, self.pf_bwd, self.I, self.KH, xhw, self.stride, self.stride != (1, 1), epi=epi, sink=sink,
+                                    want_y=want_y)
+        assert dy is not None
+        if self.stride == (1, 1):
+            return conv2d_raw(dy, self.pf_bwd, self.I, self.KH, self.KW, xhw, (1, 1),
+                              (self.KH - 1 - self.pad[0], self.KW - 1 - self.pad[1]), epi=epi, sink=sink)
+        y = conv2d_raw(dy, self.pf_bwd, self.I, 1, 1, xhw, self.stride, (0, 0), transposed=True, epi=epi)
+        return y, (units_pack(y) if want_units and _FORCE_SINK.wanted(B, self.I, *xhw) else None)
+
 
 class _FrozenResNet(torch.autograd.Function):
     """The frozen OCR encoder's ResNet (stem + units of 1x1 -> 3x3 (+ 1x1 shortcut)) as ONE autograd node: constant
     weights, so the backward is a chain of data-gradient launches whose epilogues carry the residual sum and the ReLU gate
-    of the unit in front -- no elementwise launches between them (they were 73 of the branch's ~630 launches)."""
+    of the unit in front -- no elementwise launches between them (they were 73 of the branch's ~630 launches).
+    Round 6: every convolution on a small map is ONE launch of tbg_conv2d_units_small (no split-K slabs, no second half); the
+    activations / gradients travel between them as unit tensors written by the producing launch's epilogue, the fp32 copy is
+    written only where something reads it (residual sums, ReLU gates, a consumer on the NCHW kernel)."""
 
     @staticmethod
     def forward(ctx, x, stem, units):
         x = x.contiguous()
-        acts = [x.shape[2:], stem.fwd(x)]  # y0
-        for c1, c2, short in units:
-            xin = acts[-1]
-            sc = xin if short is None else short.fwd(xin)
-            h1 = c1.fwd(xin)
-            acts += [h1, c2.fwd(h1, residual=sc)]
+        B = x.shape[0]
+        small = lambda convs, t: any(c is not None and c.small_fwd(B, t[0], t[1]) for c in convs)
+        hw = stem.out_hw(x.shape[2], x.shape[3])
+        y, YU = stem.fwd_u(x, None, want_units=small((units[0][0], units[0][2]), hw)) if units else (stem.fwd(x), None)
+        acts = [x.shape[2:], y]  # y0
+        for u, (c1, c2, short) in enumerate(units):
+            xin, XU = acts[-1], YU
+            sc = xin if short is None else short.fwd_u(xin, XU)[0]
+            h1, HU = c1.fwd_u(xin, XU, want_units=small((c2,), c1.out_hw(xin.shape[2], xin.shape[3])))
+            nxt = (units[u + 1][0], units[u + 1][2]) if u + 1 < len(units) else ()
+            y, YU = c2.fwd_u(h1, HU, residual=sc, want_units=small(nxt, h1.shape[2:]))
+            acts += [h1, y]
         ctx.consts = (stem, units)
         ctx.in_hw = tuple(acts[0])
         ctx.save_for_backward(*acts[1:])
@@ -2432,13 +2510,29 @@ class _FrozenResNet(torch.autograd.Function):
     def backward(ctx, dy):
         stem, units = ctx.consts
         acts = ctx.saved_tensors  # y0, (h1, y) per unit
-        g = torch.ops.aten.threshold_backward(dy.contiguous(), acts[-1], 0.0)  # gradient at the last unit's pre-activation
+        B = dy.shape[0]
+        hw = lambda t: tuple(t.shape[2:])
+        # gradient at the last unit's pre-activation -- as a unit tensor too when the first data-gradient launches read one
+        c1, c2, short = units[-1]
+        yhw = hw(acts[-1])
+        if c2.small_bwd(B, *yhw, hw(acts[-2])) or (short is not None and short.small_bwd(B, *yhw, hw(acts[-3]))):
+            GU, g, _, _, _ = bias_act_bwd_units_raw(dy.contiguous(), acts[-1], N.epilogue(act=ACT_LRELU, slope=0.0, gain=1.0),
+                                                    want_dpre=True, want_db=False)
+        else:
+            g, GU = torch.ops.aten.threshold_backward(dy.contiguous(), acts[-1], 0.0), None
         for u in range(len(units) - 1, -1, -1):
             c1, c2, short = units[u]
             xin, h1 = acts[2 * u], acts[2 * u + 1]
-            t = c2.bwd(g, tuple(h1.shape[2:]), gate=h1)
-            res = g if short is None else short.bwd(g, tuple(xin.shape[2:]))
-            g = c1.bwd(t, tuple(xin.shape[2:]), residual=res, gate=xin)  # xin = relu output of the unit (or stem) in front
+            xhw, ghw = hw(xin), hw(h1)
+            t_units = c1.small_bwd(B, *ghw, xhw)  # t is read by c1's data gradient only
+            t, TU = c2.bwd_u(g, GU, ghw, gate=h1, want_units=t_units, want_y=not t_units)
+            res = g if short is None else short.bwd_u(g, GU, xhw)[0]
+            if u > 0:
+                p1, p2, pshort = units[u - 1]
+                nxt = p2.small_bwd(B, *xhw, hw(acts[2 * u - 1])) or (pshort is not None and pshort.small_bwd(B, *xhw, hw(acts[2 * u - 2])))
+            else:
+                nxt = False  # (the stem's data gradient: 3 output channels on the 32 x 100 map, the NCHW kernel)
+            g, GU = c1.bwd_u(t, TU, xhw, residual=res, gate=xin, want_units=nxt)  # xin = relu output of the unit (or stem) in front
         dx = stem.bwd(g, ctx.in_hw) if ctx.needs_input_grad[0] else None
         return dx, None, None
 

@@ -1,11 +1,14 @@
 """Small-map convolutions: tbg_conv2d_units_small (K split inside the block, one launch) against the NCHW kernel's split-K pair
 (convolution + tbg_slab_epilogue_f32), both with a real epilogue (bias + residual + ReLU), in graph replay, us per call.
-usage: python tools/bench_small.py [f32x3|bf16] [B]"""
+usage: python tools/bench_small.py [f32x3|bf16] [B] [lib.so]"""
 import sys; sys.path.insert(0, '.')
 import torch
 from textboxgan_amd import native as N, ops
 mode = sys.argv[1] if len(sys.argv) > 1 else "f32x3"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+if len(sys.argv) > 3:  # a variant build of the library (tools/build_variant.sh)
+    import os
+    N.LIB_PATH = os.path.abspath(sys.argv[3])
 ops._TLS.compute = mode
 dev = torch.device('cuda:0')
 # (C, M, Hin, Win, k, stride, transposed)
