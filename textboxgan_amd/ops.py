@@ -591,6 +591,8 @@ def conv2d_units_raw(XU: UnitTensor, w: "PackedFilter", M: int, flip=False, epi:
     sink: returns (y, UnitTensor | None), see conv2d_raw."""
     assert w.fmt == (FMT_X3 if XU.planes == 3 else FMT_BF16) and w.C == XU.C and w.M >= M and w.T == 9
     B, H, W = XU.B, XU.H, XU.W
+    if not _units_conv_big(B, XU.C, M, H, W) and _small_conv(B, XU.C, M, H, W, H, W, 3):  # small map: the K split inside the block
+        return conv2d_small_raw(XU, w, M, 3, (H, W), flip=flip, epi=epi, dot=dot, out=out, sink=sink)
     if sink is not None:
         epi_s, U = _sink_epi(N.epilogue() if epi is None else epi, sink, B, M, H, W, XU.data.device)
         return conv2d_units_raw(XU, w, M, flip, epi_s, dot, out), U
@@ -1368,8 +1370,8 @@ def bias_act_c(y, noise, strength, b):
 # ----------------------------------------------------------------------------------------
 
 
-def _units_conv(B, C_in, M, H, W) -> bool:
-    """does a 3x3 stride-1 pad-1 convolution C_in -> M on B x H x W take tbg_conv2d_units in the current arithmetic?"""
+def _units_conv_big(B, C_in, M, H, W) -> bool:
+    """does a 3x3 stride-1 pad-1 convolution C_in -> M on B x H x W take tbg_conv2d_units (one tile per block, K whole)?"""
     fmt = _FMT[_TLS.compute]
     if not TUNING.use_units or fmt == FMT_F32:
         return False
@@ -1378,6 +1380,20 @@ def _units_conv(B, C_in, M, H, W) -> bool:
     # the tile choice (128- or 64-channel blocks) belongs to the library: ask it for the block count
     d = N.ConvDesc(B, C_in, M, H, W, H, W, 3, 3, 1, 1, 1, 1, 0, 0, M, 1)
     return N.lib().tbg_conv2d_units_blocks(C.byref(d), unit_planes(fmt)) >= TUNING.units_min_blocks
+
+
+def _small_dot_ok(B, C_in, M, H, W) -> bool:
+    d = N.ConvDesc(B, C_in, M, H, W, H, W, 3, 3, 1, 1, 1, 1, 0, 0, M, 1)
+    return N.lib().tbg_conv2d_units_small_dot_slots(C.byref(d), unit_planes()) > 0
+
+
+def _units_conv(B, C_in, M, H, W, dot=False) -> bool:
+    """does a 3x3 stride-1 pad-1 convolution C_in -> M on B x H x W read a unit tensor in the current arithmetic -- tbg_conv2d_units
+    on the large maps, tbg_conv2d_units_small on the small ones (conv2d_units_raw picks)?  dot: the launch carries a fused dot
+    product (the small-map kernel serves it only when its pixel tiles stay inside one sample)."""
+    if _units_conv_big(B, C_in, M, H, W):
+        return True
+    return TUNING.use_units and _small_conv(B, C_in, M, H, W, H, W, 3) and (not dot or _small_dot_ok(B, C_in, M, H, W))
 
 
 def _units_wgrad(I, O, H, W) -> bool:
@@ -1457,10 +1473,10 @@ class _Bwd3x3:
     gradient (tbg_conv2d_units on the transposed, flipped pack) AND the filter gradient (tbg_conv2d_wgrad_units, with XU =
     units(x * x_scale) from the forward pass or packed here); geometries the unit kernels do not take keep the NCHW launches."""
 
-    def __init__(self, B, I, O, H, W, want_dx=True, want_dw=True):
+    def __init__(self, B, I, O, H, W, want_dx=True, want_dw=True, dot=False):
         self.I, self.O = I, O
         self.g = _Geom((1, 1), (1, 1), 3, 3, (H, W), (H, W))
-        self.u_dx = want_dx and _units_conv(B, O, I, H, W)
+        self.u_dx = want_dx and _units_conv(B, O, I, H, W, dot=dot)
         self.u_dw = want_dw and _units_wgrad(I, O, H, W)
         self.units = self.u_dx or self.u_dw
         # is the NCHW fp32 gradient needed at all?
@@ -1553,7 +1569,7 @@ class _ModConvFused(torch.autograd.Function):
         g = _Geom((1, 1), (KH // 2, KW // 2), KH, KW, (x.shape[2], x.shape[3]), (out.shape[2], out.shape[3]))
         want_dw = ctx.needs_input_grad[1]  # frozen generator (projector.py: only the latent is optimised): no filter gradient
         if KH == 3:
-            bw = _Bwd3x3(x.shape[0], I, O, x.shape[2], x.shape[3], want_dw=want_dw)
+            bw = _Bwd3x3(x.shape[0], I, O, x.shape[2], x.shape[3], want_dw=want_dw, dot=True)
             pdb, pdn, pdy = bw.from_bias_act(dout.contiguous(), out, epi, d, want_dn=True, want_dyy=True)  # units(dpre * d)
             dx, ds_conv = bw.dx(w, N.epilogue(alpha=coef, out_scale=s), dot=(x, None))  # (the style dot's partial slots)
             db, dstrength, ds, dwsq = modconv_bwd_smalls_raw(pdb, pdn, pdy, d, s, wsq, ds_conv)  # (dwsq needs ds_conv)

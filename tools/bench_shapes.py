@@ -19,7 +19,7 @@ for _ in range(N): ts.dist_train_step(*args)
 recs = ops.PROFILE.collect()
 tot = sum(r["ms"] for r in recs.values())
 print(f"conv kernels: {tot/N:.2f} ms/step over {sum(r['n'] for r in recs.values())//N} launches/step")
-for k, r in sorted(recs.items(), key=lambda kv: -kv[1]["ms"])[:45]:
+for k, r in sorted(recs.items(), key=lambda kv: -kv[1]["ms"])[:int(sys.argv[3]) if len(sys.argv) > 3 else 45]:
     print(f"{r['ms']/N:7.3f} ms/step n={r['n']//N:3d} avg={1e3*r['ms']/r['n']:7.1f}us {r['flops']/(r['ms']*1e-3)/1e12:6.1f} TF  {k[:150]}")
 
 import re, collections

@@ -5,6 +5,7 @@ rows = list(csv.DictReader(open(glob.glob(d + "/**/*kernel_stats.csv", recursive
 fam = collections.defaultdict(lambda: [0.0, 0])
 def family(n):
     # unit-tensor families first (their names contain none of the NCHW family substrings, or shadow them)
+    if "conv_small" in n: return "tbg conv_small (small maps from unit tensors, K split in the block)"
     if "conv_wgrad_units" in n: return "tbg conv_wgrad_units (filter gradient from unit tensors)"
     if "conv_units" in n or "conv_group" in n: return "tbg conv_units (fprop / dgrad / s2 / t2 from unit tensors)"
     if "units_pack" in n or "fir_units" in n or "bias_act_bwd_units" in n or "units_" in n: return "tbg unit-tensor producers"
