@@ -331,13 +331,18 @@ int tbg_conv2d_units(const tbg_conv_desc *d, const void *XU, int planes, const v
  * (tiles may span rows and samples: no padding waste on 25-wide maps), its 8 waves split K and sum their partial tiles through LDS
  * before the epilogue: ONE launch, no slabs, no tbg_slab_epilogue_f32 pass, deterministic (fixed summation order).
  * Geometries (TBG_EUNSUPPORTED otherwise; ksplit must be 1):
- *   3x3, stride 1, pad 1, not transposed, Wout >= 3;
- *   1x1, pad 0, stride (1|2, 1|2): Hout = (Hin - 1) / sy + 1;
- *   1x1 transposed with stride (sy, sx) (the data gradient of the strided form: y[b, m, sy a, sx b'] = sum_c x[b, c, a, b'] W[c][m],
- *   every other output pixel = epilogue(0)), Hout >= (Hin - 1) sy + 1.
+ *   3x3, stride 1, pad 1, not transposed, Wout >= 3 ("row units": one load of the input serves the three taps of a filter row);
+ *   k x k (k <= 3; KH and KW independent), pad 0, stride (1|2, 1|2), not transposed: Hout = (Hin - KH) / sy + 1 -- the 1x1 layers
+ *   and the strided VALID convolutions behind a blur (upfirdn_2d_v2.py:106-113) ("tap list": a row unit is one tap);
+ *   1x1 transposed with stride (sy, sx) (the data gradient of the strided 1x1 form: y[b, m, sy a, sx b'] = sum_c x[b, c, a, b'] W[c][m],
+ *   every other output pixel = epilogue(0)), Hout >= (Hin - 1) sy + 1;
+ *   k x k (k = 2, 3) transposed with stride (1|2, 1|2), pad 0, Hout >= (Hin - 1) sy + KH (upsample_conv_2d, :65-103, and the data
+ *   gradients of the strided layers): the sy sx output-parity classes as block ranges of ONE launch; no unit sink, no fused dot.
  * Any M (channel tiles are clamped; a sink needs M % 8 == 0), any C with planes = 3, ceil(C/8) even with planes = 1.
  * Fused dot: tbg_conv2d_units_small_dot_slots slots per (b, m) = Hout Wout / 32 when a pixel tile never straddles two samples,
- * 0 (dot not served: TBG_EUNSUPPORTED) otherwise.  tbg_conv2d_units_small_blocks: blocks of the launch (for the caller's dispatch). */
+ * 0 (dot not served: TBG_EUNSUPPORTED) otherwise.  tbg_conv2d_units_small_blocks: blocks of the launch (for the caller's dispatch);
+ * tbg_conv2d_units_small_tile_pixels: 32 | 64 pixels per block. */
+int tbg_conv2d_units_small_tile_pixels(const tbg_conv_desc *d, int planes);
 int tbg_conv2d_units_small_blocks(const tbg_conv_desc *d, int planes);
 int tbg_conv2d_units_small_dot_slots(const tbg_conv_desc *d, int planes);
 int tbg_conv2d_units_small(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,

@@ -24,14 +24,20 @@ def _rel(a, r):
     return float((a.double().cpu() - r).abs().max() / (r.abs().max() + 1e-30))
 
 
+def _pad(k, stride, transposed):
+    return 1 if (k == 3 and tuple(stride) == (1, 1) and not transposed) else 0
+
+
 def _ref_conv(xs, w, k, stride, transposed, out_hw):
     """float64 definition (tbg.h): xs [B,C,H,W], w [k,k,C,M] HWIO"""
-    wt = w.permute(3, 2, 0, 1)  # OIHW
     if not transposed:
-        return F.conv2d(xs, wt, stride=stride, padding=k // 2)
+        return F.conv2d(xs, w.permute(3, 2, 0, 1), stride=stride, padding=_pad(k, stride, transposed))
+    if k > 1:  # y[b, m, sy a + kh, sx b' + kw] += x[b, c, a, b'] W[kh, kw, c, m]
+        y = F.conv_transpose2d(xs, w.permute(2, 3, 0, 1), stride=stride)
+        return F.pad(y, (0, out_hw[1] - y.shape[3], 0, out_hw[0] - y.shape[2]))
     B, _, H, W = xs.shape
     y = torch.zeros(B, w.shape[3], *out_hw, dtype=torch.float64)
-    y[:, :, :(H - 1) * stride[0] + 1:stride[0], :(W - 1) * stride[1] + 1:stride[1]] = F.conv2d(xs, wt)
+    y[:, :, :(H - 1) * stride[0] + 1:stride[0], :(W - 1) * stride[1] + 1:stride[1]] = F.conv2d(xs, w.permute(3, 2, 0, 1))
     return y
 
 
@@ -51,13 +57,25 @@ GEOMS = [
     (16, 256, 128, 2, 25, 1, (2, 1), True),    # its data gradient: 2x25 -> 4x25, odd rows = epilogue(0)
     (4, 128, 64, 4, 13, 1, (2, 2), True),      # 4x13 -> 8x25
     (32, 64, 64, 16, 50, 1, (1, 1), False),    # many pixels, few channels: TN = 2, half the waves without a row unit
+    # tap-list forms of k x k layers
+    (16, 256, 512, 9, 33, 3, (2, 2), False),   # the blur's strided VALID convolution: 9x33 -> 4x16 (conv_downsample_2d)
+    (32, 512, 512, 6, 10, 3, (1, 2), False),   # width-only stride (the discriminator's last block): 6x10 -> 4x4
+    (3, 40, 72, 7, 12, 3, (2, 1), False),      # height-only stride, channel tails
+    (16, 512, 256, 4, 16, 3, (2, 2), True),    # stride-2 transposed (upsample_conv_2d / the strided layers' data gradient): 4x16 -> 9x33
+    (32, 512, 512, 4, 4, 3, (1, 2), True),     # 4x4 -> 6x10: a full correlation along y (sources two rows outside the map: zero units)
+    (2, 24, 40, 3, 5, 3, (2, 2), True),        # tiny, ragged classes (7x11 outputs)
+    (8, 64, 64, 4, 4, 3, (1, 2), True, (6, 10)),  # an output wider than the taps reach (the forward layer floored): zeros there
+    (4, 64, 64, 5, 9, 2, (2, 2), False),       # 2x2 stride 2
 ]
 
 
 def _out_hw(H, W, k, stride, transposed):
-    if transposed:  # the data gradient of a strided 1x1 layer whose input had an even height and an odd width (4x25, 8x25)
+    if transposed and k == 1:  # the data gradient of a strided 1x1 layer whose input had an even height and an odd width (4x25, 8x25)
         return (H * stride[0], (W - 1) * stride[1] + 1)
-    return ((H - 1) // stride[0] + 1, (W - 1) // stride[1] + 1) if k == 1 else (H, W)
+    if transposed:
+        return ((H - 1) * stride[0] + k, (W - 1) * stride[1] + k)
+    p = _pad(k, stride, transposed)
+    return ((H + 2 * p - k) // stride[0] + 1, (W + 2 * p - k) // stride[1] + 1)
 
 
 @pytest.mark.parametrize("mode", ["f32x3", "bf16"])
@@ -65,11 +83,11 @@ def _out_hw(H, W, k, stride, transposed):
 def test_conv_small_matches_float64(dev, mode, geom):
     """plain (alpha only), the modulated layer's epilogue (demodulation, noise, bias, LeakyReLU), the ResNet unit's (bias, residual
     before the ReLU, gate) and the flipped form, all against float64; repeated launches are bit-identical (fixed summation order)."""
-    B, C, M, H, W, k, stride, transposed = geom
+    B, C, M, H, W, k, stride, transposed = geom[:8]
     planes = 3 if mode == "f32x3" else 1
     if planes == 1 and ((C + 7) // 8) % 2:
         pytest.skip("bf16 chunks are two channel units")
-    Ho, Wo = _out_hw(H, W, k, stride, transposed)
+    Ho, Wo = geom[8] if len(geom) > 8 else _out_hw(H, W, k, stride, transposed)
     f = lambda t: t.float().to(dev).contiguous()
     x, w, s = _rnd(B, C, H, W, seed=1), _rnd(k, k, C, M, seed=2) / math.sqrt(k * k * C), _rnd(B, C, seed=3).abs() + 0.5
     dmod, noise, bias = _rnd(B, M, seed=4).abs() + 0.5, _rnd(B, 1, Ho, Wo, seed=5), _rnd(M, seed=6) * 0.2
@@ -83,7 +101,8 @@ def test_conv_small_matches_float64(dev, mode, geom):
     xs = xs.double().cpu()
     c64 = lambda t: t.double().cpu()
     with ops.compute_dtype(mode):
-        assert ops.conv_small_ok(C, M, H, W, Ho, Wo, k, k, stride, (k // 2, k // 2), transposed, planes)
+        pd = _pad(k, stride, transposed)
+        assert ops.conv_small_ok(C, M, H, W, Ho, Wo, k, k, stride, (pd, pd), transposed, planes)
         XU = ops.units_pack(xd, sd, planes=planes)
         pf = ops.pack_filter(wd, False, False)
         run = lambda **kw: ops.conv2d_small_raw(XU, pf, M, k, (Ho, Wo), stride, transposed, **kw)
@@ -101,7 +120,7 @@ def test_conv_small_matches_float64(dev, mode, geom):
         errs["resunit"] = _rel(y2, ref2)
         y3 = run(epi=N.epilogue(bias=bd, residual=rd, res_scale=0.7))
         errs["resafter"] = _rel(y3, (acc + c64(bd)[None, :, None, None] + c64(rd)) * 0.7)
-        if k == 3:
+        if k > 1:
             yf = ops.conv2d_small_raw(XU, ops.pack_filter(wd, False, True), M, k, (Ho, Wo), stride, transposed, flip=True,
                                       epi=N.epilogue(alpha=0.9))
             assert torch.equal(yf, y0), "flip of a flipped pack"
@@ -154,7 +173,8 @@ class _AlwaysSink(ops.UnitSink):
 
 
 SINKS = [(16, 256, 256, 2, 25, 3, (1, 1), False), (3, 64, 40, 8, 25, 3, (1, 1), False), (16, 512, 512, 4, 16, 3, (1, 1), False),
-         (16, 128, 256, 4, 25, 1, (2, 1), False), (16, 256, 128, 2, 25, 1, (2, 1), True), (5, 48, 96, 3, 3, 3, (1, 1), False)]
+         (16, 128, 256, 4, 25, 1, (2, 1), False), (16, 256, 128, 2, 25, 1, (2, 1), True), (5, 48, 96, 3, 3, 3, (1, 1), False),
+         (16, 256, 512, 9, 33, 3, (2, 2), False)]
 
 
 @pytest.mark.parametrize("mode", ["f32x3", "bf16"])

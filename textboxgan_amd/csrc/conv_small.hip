@@ -29,13 +29,29 @@
 
 #include "conv_common.h"
 
+// TAP-LIST form (the KW = 1 instantiations): a row unit is (chunk, tap) and a tap is an input offset (dy, dx) + a filter tap index,
+// so the same kernel runs 1x1 convolutions, k x k STRIDED VALID convolutions (conv_downsample_2d's strided convolution,
+// upfirdn_2d_v2.py:106-113: tap (kh, kw) at offset (kh, kw) from the input pixel (sy y, sx x)) and k x k stride-2 TRANSPOSED convolutions
+// (upsample_conv_2d, :65-103, and the data gradients of the strided layers) as their sy sx output-parity classes: class (cy, cx)
+// owns the outputs (sy u + cy, sx v + cx) = sum over taps (cy + sy i, cx + sx j) of x[u - i, v - j] -- a dense few-tap correlation on
+// the class grid, one block range per class in ONE launch.  A tap whose source falls outside the padded plane (ring included) reads
+// the sample's ring corner instead (a zero unit).
+struct SmallCls {
+  int Ug, Vg, ooy, oox;  // class grid (tiling domain) and where it sits in the output: (osy u + ooy, osx v + oox)
+  int ntaps, blk0;       // taps of the class; first block of the class in the launch
+  signed char dy[9], dx[9], wt[9];  // per tap: input offset from the pixel's source (padded coordinates), filter tap
+};
+
 struct ConvSmallP {
   const char *XU, *Wf;
   long long x_plane, w_plane;  // 16-byte units per plane
   float *y;
   int B, C8, M, Hin, Win, Hout, Wout, ldw;
-  int sy, sx, flip, mode;  // mode 0: 3x3 stride 1 pad 1 | 1: 1x1 stride (sy, sx) | 2: 1x1 transposed stride (sy, sx)
-  int Ntot, tilesM, nunits, dot_slots;
+  int flip, mode;        // mode 0: 3x3 stride 1 pad 1 (row units) | 1: tap list | 2: tap list, 1x1 transposed stride (isy, isx)
+  int isy, isx;          // tap list: the pixel (u, v) of the class grid reads from the padded input position (isy u + 1, isx v + 1)
+  int osy, osx, ncls;
+  int tilesM, nchunks, dot_slots;
+  SmallCls cls[4];
   EpiK e;
 };
 
@@ -73,13 +89,21 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // consecutive block ids sit on consecutive XCDs: the channel tile varies fastest, so an XCD's L2 sees few filter slices
-  const int mt = blockIdx.x % p.tilesM, nt = blockIdx.x / p.tilesM;
+  int c = 0;
+  if constexpr (KW == 1)
+    while (c + 1 < p.ncls && (int)blockIdx.x >= p.cls[c + 1].blk0) ++c;
+  const SmallCls &cl = p.cls[c];
+  const int bid = blockIdx.x - cl.blk0;
+  const int mt = bid % p.tilesM, nt = bid / p.tilesM;
   const int m0 = mt * 32, n0 = nt * 32 * TN;
   const int Hp = p.Hin + 2, Wp = p.Win + 2, HWo = p.Hout * p.Wout;
+  const int Ug = cl.Ug, Vg = cl.Vg, HWg = Ug * Vg, Ntot = p.B * HWg;  // (KW = 3: the class grid is the output grid)
 
   // ---- per-lane sources
-  const char *bsrc[LPU];  // this lane's slot of the row unit (chunk 0, kh 0, plane 0)
-  const int r0 = n0 / p.Wout, x0 = n0 - r0 * p.Wout;
+  const char *bsrc[LPU];  // this lane's slot of the row unit (chunk 0, kh 0 / tap offset 0, plane 0)
+  const char *bzero = nullptr;  // tap list: the ring corner of this lane's sample (a zero unit)
+  int pu = -4, pv = -4;         // tap list: padded input position of the lane's pixel (-4: no source at all)
+  const int r0 = n0 / Vg, x0 = n0 - r0 * Vg;
 #pragma unroll
   for (int jj = 0; jj < LPU; ++jj) {
     long long u;
@@ -90,16 +114,19 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
       const int b = r / p.Hout, y = r - b * p.Hout;
       u = ((long long)b * p.C8 * Hp + y) * Wp + pc;
     } else {
-      const int n = min(n0 + min(lane, 32 * TN - 1), p.Ntot - 1);
-      const int b = n / HWo, rem = n - b * HWo;
-      const int y = rem / p.Wout, x = rem - y * p.Wout;
+      const int n = min(n0 + min(lane, 32 * TN - 1), Ntot - 1);
+      const int b = n / HWg, rem = n - b * HWg;
+      const int y = rem / Vg, x = rem - y * Vg;
+      const long long z = (long long)b * p.C8 * Hp * Wp;  // (0, 0) of the ring
+      bzero = p.XU + (z << 4);
       if (p.mode == 1) {
-        u = ((long long)b * p.C8 * Hp + y * p.sy + 1) * Wp + x * p.sx + 1;
-      } else {  // transposed: output pixel (y, x) has a source only where both coordinates are multiples of the stride
-        const int ys = y / p.sy, xs = x / p.sx;
-        const bool hit = ys * p.sy == y && xs * p.sx == x && ys < p.Hin && xs < p.Win;
-        u = hit ? ((long long)b * p.C8 * Hp + ys + 1) * Wp + xs + 1 : (long long)b * p.C8 * Hp * Wp;  // (0, 0) of the ring: zero
+        pu = y * p.isy + 1; pv = x * p.isx + 1;
+      } else {  // 1x1 transposed: output pixel (y, x) has a source only where both coordinates are multiples of the stride
+        const int ys = y / p.isy, xs = x / p.isx;
+        const bool hit = ys * p.isy == y && xs * p.isx == x && ys < p.Hin && xs < p.Win;
+        pu = hit ? ys + 1 : -4; pv = hit ? xs + 1 : -4;
       }
+      u = z + (long long)pu * Wp + pv;
     }
     bsrc[jj] = p.XU + (u << 4);
   }
@@ -134,10 +161,10 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int pp = 32 * j + l31;
-    q[j] = KW == 3 ? pp + 2 * ((n0 + pp) / p.Wout - r0) : pp;
+    q[j] = KW == 3 ? pp + 2 * ((n0 + pp) / Vg - r0) : pp;
   }
   // slots of a row that some pixel of the tile reads: up to q of the last pixel + KW - 1
-  const int nslot = (KW == 3 ? 32 * TN - 1 + 2 * ((n0 + 32 * TN - 1) / p.Wout - r0) : 32 * TN - 1) + KW;
+  const int nslot = (KW == 3 ? 32 * TN - 1 + 2 * ((n0 + 32 * TN - 1) / Vg - r0) : 32 * TN - 1) + KW;
   char *const stg = smem + wave * STG;
   const long long cu_step = (long long)Hp * Wp * 16;  // bytes between two channel units of a sample
 
@@ -147,7 +174,8 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  const int n_w = wave < p.nunits ? (p.nunits - wave + 7) >> 3 : 0;  // row units of this wave
+  const int nunits = p.nchunks * (KW == 3 ? 3 : cl.ntaps);
+  const int n_w = wave < nunits ? (nunits - wave + 7) >> 3 : 0;  // row units of this wave
   constexpr int PD = SMALL_PD, R = PD + 1;
   bf16x8 Areg[R][NAL], Breg[R][ROWS][LPU], Op[R > 3 ? R : 3][NB];
   const int rot = SMALL_ROT ? nt : 0;  // (deterministic: the summation order is a function of the tile)
@@ -157,21 +185,36 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
     int si = min(s, n_w - 1) + rot;
     si -= (si / n_w) * n_w;
     const int u = wave + 8 * si;
-    const int kc = u / KH, kh = u - kc * KH;
+    if constexpr (KW == 3) {
+      const int kc = u / 3, kh = u - kc * 3;
 #pragma unroll
-    for (int row = 0; row < ROWS; ++row) {
-      const long long off = NP == 3 ? ((row * p.x_plane) << 4) + kc * cu_step + (long long)kh * Wp * 16
-                                    : (2 * kc + row) * cu_step + (long long)kh * Wp * 16;
+      for (int row = 0; row < ROWS; ++row) {
+        const long long off = NP == 3 ? ((row * p.x_plane) << 4) + kc * cu_step + (long long)kh * Wp * 16
+                                      : (2 * kc + row) * cu_step + (long long)kh * Wp * 16;
 #pragma unroll
-      for (int jj = 0; jj < LPU; ++jj)
-        if (jj * 64 + lane < nslot && !((SMALL_EXP == 3 || SMALL_EXP == 4) && s > 1)) Breg[S][row][jj] = *reinterpret_cast<const bf16x8 *>(bsrc[jj] + off);  // (slots past the tile's last: never read)
+        for (int jj = 0; jj < LPU; ++jj)
+          if (jj * 64 + lane < nslot && !((SMALL_EXP == 3 || SMALL_EXP == 4) && s > 1)) Breg[S][row][jj] = *reinterpret_cast<const bf16x8 *>(bsrc[jj] + off);  // (slots past the tile's last: never read)
+      }
+      // (aoff is biased by (KW - 1) taps so that it stays non-negative with flip: the row unit's base is its first tap minus that)
+      const int t0 = kh * KW, tt0 = p.flip ? KK - 1 - t0 : t0;
+      const char *const ab = abase + (((long long)(tt0 - (KW - 1)) * p.C8 + CKU * kc) * p.ldw << 4);
+#pragma unroll
+      for (int i = 0; i < NAL; ++i)
+        if (!((SMALL_EXP == 2 || SMALL_EXP == 4) && s > 1)) Areg[S][i] = *reinterpret_cast<const bf16x8 *>(ab + aoff[i]);
+    } else {
+      const int kc = u / cl.ntaps, ti = u - kc * cl.ntaps;
+      const int dy = cl.dy[ti], dx = cl.dx[ti], wt = cl.wt[ti];
+      const bool ok = (unsigned)(pu + dy) < (unsigned)Hp && (unsigned)(pv + dx) < (unsigned)Wp;
+      const char *const src = ok ? bsrc[0] + ((long long)(dy * Wp + dx) << 4) : bzero;
+#pragma unroll
+      for (int row = 0; row < ROWS; ++row) {
+        const long long off = NP == 3 ? ((row * p.x_plane) << 4) + kc * cu_step : (2 * kc + row) * cu_step;
+        if (lane < nslot) Breg[S][row][0] = *reinterpret_cast<const bf16x8 *>(src + off);
+      }
+      const char *const ab = abase + (((long long)wt * p.C8 + CKU * kc) * p.ldw << 4);
+#pragma unroll
+      for (int i = 0; i < NAL; ++i) Areg[S][i] = *reinterpret_cast<const bf16x8 *>(ab + aoff[i]);
     }
-    // (aoff is biased by (KW - 1) taps so that it stays non-negative with flip: the row unit's base is its first tap minus that)
-    const int t0 = kh * KW, tt0 = p.flip ? KK - 1 - t0 : t0;
-    const char *const ab = abase + (((long long)(tt0 - (KW - 1)) * p.C8 + CKU * kc) * p.ldw << 4);
-#pragma unroll
-    for (int i = 0; i < NAL; ++i)
-      if (!((SMALL_EXP == 2 || SMALL_EXP == 4) && s > 1)) Areg[S][i] = *reinterpret_cast<const bf16x8 *>(ab + aoff[i]);
   };
   auto stage = [&](auto S_) {  // the row unit's slots -> this wave's LDS rows
     constexpr int S = decltype(S_)::value;
@@ -277,24 +320,36 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
   for (int r = 0; r < 16; ++r) a1[0][0][r] = r < 4 ? v[r & 3] : 0.f;
   const int nb = n0 + 32 * j, n = nb + l31;
   int e_pix[1], e_b[1];
-  e_b[0] = min(n, p.Ntot - 1) / HWo;
-  e_pix[0] = n < p.Ntot ? n - e_b[0] * HWo : -1;
-  const int dot_b = nb / HWo;
+  e_b[0] = min(n, Ntot - 1) / HWg;
+  const int rem = n - e_b[0] * HWg;
+  if (KW == 3 || (p.osy == 1 && p.osx == 1)) {
+    e_pix[0] = n < Ntot ? rem : -1;
+  } else {  // a class of a transposed convolution: its grid sits strided in the output
+    const int u = rem / Vg, v = rem - u * Vg;
+    const int Y = u * p.osy + cl.ooy, X = v * p.osx + cl.oox;
+    e_pix[0] = (n < Ntot && Y < p.Hout && X < p.Wout) ? Y * p.Wout + X : -1;
+  }
+  const int dot_b = nb / HWg;
   conv_epilogue<1, 1, 4, true, 4>(a1, p.e, p.y, nullptr, p.M, HWo, m0 + 8 * rg, lane, e_pix, e_b, true, dot_b, p.dot_slots,
-                                  (nb - dot_b * HWo) >> 5, p.Hout, p.Wout);
+                                  (nb - dot_b * HWg) >> 5, p.Hout, p.Wout);
 }
 
-// ---- geometry: which form of the kernel a descriptor takes (0: none)
+// ---- geometry: which form of the kernel a descriptor takes (-1: none)
+//   0  3x3, stride 1, pad 1 (row units)          1  tap list: k x k (k <= 3) pad 0, stride (1|2, 1|2) -- 1x1 and strided VALID layers
+//   2  tap list: 1x1 transposed stride           3  tap list: k x k (k = 2, 3) transposed with stride (1|2, 1|2), as output-parity classes
 static int small_mode(const tbg_conv_desc *d) {
   if (d->ksplit != 1 || d->ldw < d->M || d->B < 1 || d->C < 1 || d->M < 1) return -1;
   if (d->KH == 3 && d->KW == 3 && !d->transposed && d->sy == 1 && d->sx == 1 && d->py == 1 && d->px == 1 && d->Hout == d->Hin &&
       d->Wout == d->Win && d->Wout >= 3)
     return 0;
-  if (d->KH == 1 && d->KW == 1 && d->py == 0 && d->px == 0 && d->sy >= 1 && d->sy <= 2 && d->sx >= 1 && d->sx <= 2) {
-    if (!d->transposed && d->Hout == (d->Hin - 1) / d->sy + 1 && d->Wout == (d->Win - 1) / d->sx + 1) return 1;
-    if (d->transposed && d->Hout >= (d->Hin - 1) * d->sy + 1 && d->Wout >= (d->Win - 1) * d->sx + 1) return 2;
+  if (d->KH < 1 || d->KH > 3 || d->KW < 1 || d->KW > 3 || d->py != 0 || d->px != 0) return -1;
+  if (d->sy < 1 || d->sy > 2 || d->sx < 1 || d->sx > 2) return -1;
+  if (!d->transposed) {
+    if (d->Hin < d->KH || d->Win < d->KW) return -1;
+    return (d->Hout == (d->Hin - d->KH) / d->sy + 1 && d->Wout == (d->Win - d->KW) / d->sx + 1) ? 1 : -1;
   }
-  return -1;
+  if (d->KH == 1 && d->KW == 1) return (d->Hout >= (d->Hin - 1) * d->sy + 1 && d->Wout >= (d->Win - 1) * d->sx + 1) ? 2 : -1;
+  return (d->Hout >= (d->Hin - 1) * d->sy + d->KH && d->Wout >= (d->Win - 1) * d->sx + d->KW) ? 3 : -1;  // (as tbg_conv2d_*)
 }
 
 static bool small_ok(const tbg_conv_desc *d, int planes) {
@@ -303,39 +358,90 @@ static bool small_ok(const tbg_conv_desc *d, int planes) {
   return small_mode(d) >= 0 && (planes == 3 || (c8 & 1) == 0);
 }
 
+// the classes of a descriptor: grids, taps; returns the number of classes
+static int small_classes(const tbg_conv_desc *d, int mode, SmallCls *cls) {
+  const int T = d->KH * d->KW;
+  if (mode != 3) {
+    SmallCls &c = cls[0];
+    c = SmallCls{};
+    c.Ug = d->Hout; c.Vg = d->Wout; c.ooy = 0; c.oox = 0; c.blk0 = 0;
+    c.ntaps = mode == 0 ? 9 : T;
+    for (int t = 0; t < T && mode == 1; ++t) {
+      c.dy[t] = (signed char)(t / d->KW); c.dx[t] = (signed char)(t % d->KW); c.wt[t] = (signed char)(d->flip ? T - 1 - t : t);
+    }
+    return 1;
+  }
+  int k = 0;
+  for (int cy = 0; cy < d->sy; ++cy)
+    for (int cx = 0; cx < d->sx; ++cx) {
+      const int KHc = cy < d->KH ? ceil_div(d->KH - cy, d->sy) : 0, KWc = cx < d->KW ? ceil_div(d->KW - cx, d->sx) : 0;
+      SmallCls &c = cls[k];
+      c = SmallCls{};
+      c.Ug = d->Hout > cy ? ceil_div(d->Hout - cy, d->sy) : 0;
+      c.Vg = d->Wout > cx ? ceil_div(d->Wout - cx, d->sx) : 0;
+      c.ooy = cy; c.oox = cx;
+      if (KHc * KWc < 1 || c.Ug < 1 || c.Vg < 1) continue;  // (a class without taps cannot exist for k >= stride)
+      for (int i = 0; i < KHc; ++i)
+        for (int j = 0; j < KWc; ++j) {
+          const int t = (cy + d->sy * i) * d->KW + cx + d->sx * j;
+          c.dy[c.ntaps] = (signed char)-i; c.dx[c.ntaps] = (signed char)-j; c.wt[c.ntaps] = (signed char)(d->flip ? T - 1 - t : t);
+          ++c.ntaps;
+        }
+      ++k;
+    }
+  return k;
+}
+
 // pixels per tile: 64 where 32-pixel tiles would be more than one round of one block per CU (every pixel tile re-reads the filter
 // slice of its channel tile: two rounds of 32 pixels stream it twice, one round of 64 once)
-static int small_tn(const tbg_conv_desc *d) {
-  const long long n = (long long)d->B * d->Hout * d->Wout;
-  return (long long)ceil_div(d->M, 32) * ((n + 31) / 32) > 256 ? 2 : 1;
+static long long small_blocks(const tbg_conv_desc *d, int mode, const SmallCls *cls, int ncls, int tn) {
+  long long b = 0;
+  for (int k = 0; k < ncls; ++k) b += (long long)ceil_div(d->M, 32) * (((long long)d->B * cls[k].Ug * cls[k].Vg + 32 * tn - 1) / (32 * tn));
+  return b;
+}
+
+static int small_tn(const tbg_conv_desc *d, int mode, const SmallCls *cls, int ncls) {
+  return small_blocks(d, mode, cls, ncls, 1) > 256 ? 2 : 1;
 }
 
 extern "C" int tbg_conv2d_units_small_blocks(const tbg_conv_desc *d, int planes) {
   if (!d) return TBG_EINVAL;
   if (!small_ok(d, planes)) return TBG_EUNSUPPORTED;
-  const long long n = (long long)d->B * d->Hout * d->Wout;
-  const int px = 32 * small_tn(d);
-  const long long b = (long long)ceil_div(d->M, 32) * ((n + px - 1) / px);
+  SmallCls cls[4];
+  const int mode = small_mode(d), ncls = small_classes(d, mode, cls);
+  const long long b = small_blocks(d, mode, cls, ncls, small_tn(d, mode, cls, ncls));
   return b > 2147483647LL ? TBG_ERANGE : (int)b;
 }
 
-// slots of the fused dot product per (b, m): one per 32 pixels of the map; 0 = a tile would straddle two images (not served)
+// pixels of a block's tile (32 | 64): profile labels, tests
+extern "C" int tbg_conv2d_units_small_tile_pixels(const tbg_conv_desc *d, int planes) {
+  if (!d) return TBG_EINVAL;
+  if (!small_ok(d, planes)) return TBG_EUNSUPPORTED;
+  SmallCls cls[4];
+  const int mode = small_mode(d), ncls = small_classes(d, mode, cls);
+  return 32 * small_tn(d, mode, cls, ncls);
+}
+
+// slots of the fused dot product per (b, m): one per 32 pixels of the map; 0 = a tile would straddle two images, or the outputs
+// of a tile are not one contiguous pixel range (transposed classes): not served
 extern "C" int tbg_conv2d_units_small_dot_slots(const tbg_conv_desc *d, int planes) {
   if (!d) return TBG_EINVAL;
   if (!small_ok(d, planes)) return TBG_EUNSUPPORTED;
+  SmallCls cls[4];
+  const int mode = small_mode(d), ncls = small_classes(d, mode, cls);
   const int hw = d->Hout * d->Wout;
-  return hw % (32 * small_tn(d)) == 0 ? hw / 32 : 0;
+  return (mode != 3 && hw % (32 * small_tn(d, mode, cls, ncls)) == 0) ? hw / 32 : 0;
 }
 
 template <int NP, int KW, int TN>
-static int launch_small(const ConvSmallP &p, int tilesN, hipStream_t st) {
+static int launch_small(const ConvSmallP &p, int blocks, hipStream_t st) {
   constexpr int ROWS = NP == 3 ? 3 : 2, LPU = KW == 3 ? TN : 1;
   const size_t lds = (size_t)8 * ROWS * LPU * 64 * 16 + (size_t)8 * TN * 4096;
   auto kern = conv_small_kernel<NP, KW, TN>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return TBG_EHIP;
-  hipLaunchKernelGGL(kern, dim3(p.tilesM * tilesN), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
@@ -354,22 +460,31 @@ extern "C" int tbg_conv2d_units_small(const tbg_conv_desc *d, const void *XU, in
   p.w_plane = (long long)d->KH * d->KW * p.C8 * d->ldw;
   if (p.x_plane * planes > 2147483647LL / 2 || p.w_plane * planes > 2147483647LL / 2) return TBG_ERANGE;
   p.y = y; p.B = d->B; p.M = d->M; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.ldw = d->ldw;
-  p.sy = d->sy; p.sx = d->sx; p.flip = d->flip; p.mode = small_mode(d);
-  p.Ntot = d->B * d->Hout * d->Wout;
+  p.flip = d->flip;
+  const int mode = small_mode(d);
+  p.mode = mode == 3 ? 1 : mode;
+  p.isy = mode == 3 ? 1 : d->sy; p.isx = mode == 3 ? 1 : d->sx;
+  p.osy = mode == 3 ? d->sy : 1; p.osx = mode == 3 ? d->sx : 1;
+  p.ncls = small_classes(d, mode, p.cls);
+  const int tn = small_tn(d, mode, p.cls, p.ncls);
   p.tilesM = ceil_div(d->M, 32);
-  const int tn = small_tn(d);
-  const int tilesN = ceil_div(p.Ntot, 32 * tn);
-  p.nunits = (p.C8 / (planes == 3 ? 1 : 2)) * d->KH;
+  int blocks = 0;
+  for (int k = 0; k < p.ncls; ++k) {
+    p.cls[k].blk0 = blocks;
+    blocks += p.tilesM * ceil_div(d->B * p.cls[k].Ug * p.cls[k].Vg, 32 * tn);
+  }
+  p.nchunks = p.C8 / (planes == 3 ? 1 : 2);
   p.e = make_epi(epi);
   const int hw = d->Hout * d->Wout;
-  p.dot_slots = hw % (32 * tn) == 0 ? hw / 32 : 0;
+  p.dot_slots = (mode != 3 && hw % (32 * tn) == 0) ? hw / 32 : 0;
   if (p.e.dot_aux && p.dot_slots == 0) return TBG_EUNSUPPORTED;
+  if (p.e.units_out && mode == 3) return TBG_EUNSUPPORTED;  // (a class writes a strided part of the output: no sink)
   if (const int rcs = epi_sink_geometry(p.e, d->B, d->M, d->Hout, d->Wout)) return rcs;
   hipStream_t st = tbg_stream(stream);
-  if (d->KH == 3) {
-    if (planes == 3) return tn == 2 ? launch_small<3, 3, 2>(p, tilesN, st) : launch_small<3, 3, 1>(p, tilesN, st);
-    return tn == 2 ? launch_small<1, 3, 2>(p, tilesN, st) : launch_small<1, 3, 1>(p, tilesN, st);
+  if (mode == 0) {
+    if (planes == 3) return tn == 2 ? launch_small<3, 3, 2>(p, blocks, st) : launch_small<3, 3, 1>(p, blocks, st);
+    return tn == 2 ? launch_small<1, 3, 2>(p, blocks, st) : launch_small<1, 3, 1>(p, blocks, st);
   }
-  if (planes == 3) return tn == 2 ? launch_small<3, 1, 2>(p, tilesN, st) : launch_small<3, 1, 1>(p, tilesN, st);
-  return tn == 2 ? launch_small<1, 1, 2>(p, tilesN, st) : launch_small<1, 1, 1>(p, tilesN, st);
+  if (planes == 3) return tn == 2 ? launch_small<3, 1, 2>(p, blocks, st) : launch_small<3, 1, 1>(p, blocks, st);
+  return tn == 2 ? launch_small<1, 1, 2>(p, blocks, st) : launch_small<1, 1, 1>(p, blocks, st);
 }

@@ -112,6 +112,7 @@ class _Tuning:
         # ---- small maps (tbg.h "SMALL MAPS", csrc/conv_small.hip)
         self.use_small = True        # small-map convolutions take tbg_conv2d_units_small (K split inside the block, one launch) instead
                                      # of the NCHW kernel's split-K pair (convolution into HBM slabs + tbg_slab_epilogue_f32)
+        self.small_max_blocks_taps = 640  # the same bound for the tap-list form of the stride-2 transposed k x k layers
         self.small_max_blocks = 512  # ... when the launch is at most this many blocks (two rounds of one block per CU): beyond, every
                                      # pixel tile re-reads its filter slice too often and the 128 x 128 NCHW tiles win
         # ---- split-K of the small-map launches
@@ -295,7 +296,7 @@ def upfirdn2d_raw(x: torch.Tensor, k: torch.Tensor, up=(1, 1), down=(1, 1), pad=
 def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_hw: Tuple[int, int], stride=(1, 1),
                pad=(0, 0), transposed=False, flip=False, in_scale=None, epi: Optional[N.Epilogue] = None,
                ldw: Optional[int] = None, allow_split=True, dot=None, out: Optional[torch.Tensor] = None,
-               sink: Optional["UnitSink"] = None):
+               sink: Optional["UnitSink"] = None, allow_small=True):
     """w: a PackedFilter (pack_filter), or a tensor in GEMM layout [KH*KW, C, ldw] (any view with that memory layout,
     e.g. the HWIO parameter) which is packed here.
     dot = (aux, out): out[b,m] = sum_p (alpha*acc)[b,m,p] * aux[b,m,p]  (fused when K is not split).  dot = (aux, None): the
@@ -307,7 +308,7 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         assert dot is None and out is None
         epi = N.epilogue() if epi is None else epi
         epi_s, U = _sink_epi(epi, sink, x.shape[0], M, out_hw[0], out_hw[1], x.device)
-        y = conv2d_raw(x, w, M, KH, KW, out_hw, stride, pad, transposed, flip, in_scale, epi_s, ldw, allow_split)
+        y = conv2d_raw(x, w, M, KH, KW, out_hw, stride, pad, transposed, flip, in_scale, epi_s, ldw, allow_split, allow_small=allow_small)
         return y, U
     B, Cc, Hin, Win = x.shape
     if not isinstance(w, PackedFilter):
@@ -322,8 +323,23 @@ def conv2d_raw(x: torch.Tensor, w: torch.Tensor, M: int, KH: int, KW: int, out_h
         _v, _fn = TUNING.force_variant, (N.lib().tbg_conv2d_f32_variant, N.lib().tbg_conv2d_bf16_variant,
                                   N.lib().tbg_conv2d_x3_variant)[fmt]
         _conv = lambda d_, x_, w_, y_, s_, e_, st_: _fn(d_, x_, w_, y_, s_, e_, _v, st_)
-    w = w.data
     Hout, Wout = out_hw
+    if fmt != FMT_F32 and TUNING.use_small and allow_small and allow_split and TUNING.force_variant == 0 and TUNING.force_ksplit is None:
+        # small map: tbg_conv2d_units_small (K split inside the block, the real epilogue in the same launch) instead of this entry's
+        # slabs + second half, reading units(x * in_scale) -- attached by the launch that produced x, or packed here
+        d0 = N.ConvDesc(B, Cc, M, Hin, Win, Hout, Wout, KH, KW, stride[0], stride[1], pad[0], pad[1], int(transposed), int(flip), ldw, 1)
+        nb = N.lib().tbg_conv2d_units_small_blocks(C.byref(d0), unit_planes(fmt))
+        taps = not (KH == 3 and KW == 3 and tuple(stride) == (1, 1) and not transposed) and KH * KW > 1
+        # (tap-list forms of k x k layers: the transposed ones win 1.5 - 3x over this entry's output-parity classes; the strided
+        # VALID ones -- few output tiles under a long reduction -- need the split over BLOCKS and stay here: 17 vs 53 us on
+        # 5x17 -> 2x8 512 -> 128, profiles/r06_j_bench_taps_x3.txt)
+        limit = (TUNING.small_max_blocks_taps if transposed else 0) if taps else TUNING.small_max_blocks
+        if 0 < nb <= limit and (
+                dot is None or N.lib().tbg_conv2d_units_small_dot_slots(C.byref(d0), unit_planes(fmt)) > 0):
+            XU = take_units(x, in_scale, unit_planes(fmt)) if x.is_contiguous() else None
+            XU = units_pack(x.contiguous(), in_scale, unit_planes(fmt)) if XU is None else XU
+            return conv2d_small_raw(XU, w, M, KH, out_hw, stride, transposed, flip, epi, dot, out, KW=KW, pad=pad)
+    w = w.data
     nchunks = math.ceil(Cc / (16 if fmt == FMT_BF16 else 8))
     ksplit = 1
     if allow_split:
@@ -627,19 +643,22 @@ def conv_small_ok(C_in, M, Hin, Win, Hout, Wout, KH, KW, stride, pad, transposed
 
 def conv2d_small_raw(XU: UnitTensor, w: "PackedFilter", M: int, KH: int, out_hw, stride=(1, 1), transposed=False, flip=False,
                      epi: Optional[N.Epilogue] = None, dot=None, out: Optional[torch.Tensor] = None,
-                     sink: Optional["UnitSink"] = None, want_y=True):
-    """tbg_conv2d_units_small: a small-map convolution (3x3 stride-1 pad-1, or 1x1 with stride / transposed stride) of the
-    activation behind the unit tensor XU with the K split inside the block -- one launch, no slabs.  Arguments and return forms as
-    conv2d_units_raw (dot = (aux, out | None), sink -> (y, UnitTensor | None)); want_y = False (with a sink that is wanted): the
-    result leaves as a unit tensor only (y = None)."""
-    assert w.fmt == (FMT_X3 if XU.planes == 3 else FMT_BF16) and w.C == XU.C and w.M >= M and w.T == KH * KH
+                     sink: Optional["UnitSink"] = None, want_y=True, KW: Optional[int] = None, pad=None):
+    """tbg_conv2d_units_small: a small-map convolution of the activation behind the unit tensor XU with the K split inside the block --
+    one launch, no slabs.  Geometries: tbg.h "SMALL MAPS" (3x3 stride-1 pad-1; k x k pad-0 with stride; 1x1 / k x k transposed);
+    pad defaults to (1, 1) for a 3x3 stride-1 layer and (0, 0) otherwise.  Arguments and return forms as conv2d_units_raw (dot = (aux,
+    out | None), sink -> (y, UnitTensor | None)); want_y = False (with a sink that is wanted): the result leaves as a unit tensor
+    only (y = None)."""
+    KW = KH if KW is None else KW
+    assert w.fmt == (FMT_X3 if XU.planes == 3 else FMT_BF16) and w.C == XU.C and w.M >= M and w.T == KH * KW
     B, Hin, Win = XU.B, XU.H, XU.W
     Hout, Wout = out_hw
+    if pad is None:
+        pad = (1, 1) if (KH == 3 and KW == 3 and tuple(stride) == (1, 1) and not transposed) else (0, 0)
     if sink is not None:
         epi_s, U = _sink_epi(N.epilogue() if epi is None else epi, sink, B, M, Hout, Wout, XU.data.device)
-        return conv2d_small_raw(XU, w, M, KH, out_hw, stride, transposed, flip, epi_s, dot, out, None, want_y or U is None), U
-    pad = KH // 2
-    d = N.ConvDesc(B, XU.C, M, Hin, Win, Hout, Wout, KH, KH, stride[0], stride[1], pad, pad, int(transposed), int(flip), w.M, 1)
+        return conv2d_small_raw(XU, w, M, KH, out_hw, stride, transposed, flip, epi_s, dot, out, None, want_y or U is None, KW, pad), U
+    d = N.ConvDesc(B, XU.C, M, Hin, Win, Hout, Wout, KH, KW, stride[0], stride[1], pad[0], pad[1], int(transposed), int(flip), w.M, 1)
     epi = N.epilogue() if epi is None else epi
     partial = None
     if dot is not None:
@@ -652,13 +671,13 @@ def conv2d_small_raw(XU: UnitTensor, w: "PackedFilter", M: int, KH: int, out_hw,
     y = out
     if y is None and (want_y or not epi.units_out):
         y = torch.empty((B, M, Hout, Wout), device=XU.data.device, dtype=torch.float32)
-    _flops = 2.0 * B * M * XU.C * KH * KH * (Hin * Win if transposed else Hout * Wout)
-    _blocks = N.lib().tbg_conv2d_units_small_blocks(C.byref(d), XU.planes)
-    _tn = 1 if _blocks == math.ceil(M / 32) * math.ceil(B * Hout * Wout / 32) else 2
-    N.check(PROFILE.launch(f"conv_small_kernel<{XU.planes}, {KH}, {_tn}>", _flops, lambda: N.lib().tbg_conv2d_units_small(
+    _flops = 2.0 * B * M * XU.C * KH * KW * (Hin * Win if transposed else Hout * Wout)
+    _tn = N.lib().tbg_conv2d_units_small_tile_pixels(C.byref(d), XU.planes) // 32
+    _kw = 3 if (KH == 3 and KW == 3 and tuple(stride) == (1, 1) and not transposed and tuple(pad) == (1, 1)) else 1
+    N.check(PROFILE.launch(f"conv_small_kernel<{XU.planes}, {_kw}, {_tn}>", _flops, lambda: N.lib().tbg_conv2d_units_small(
         C.byref(d), N.ptr(XU.data), XU.planes, N.ptr(w.data), N.ptr(y), C.byref(epi), N.stream()),
-        f"conv_small[B={B} C={XU.C} M={M} in={Hin}x{Win} out={Hout}x{Wout} k={KH} s={tuple(stride)} T={int(transposed)}]",
-        2.0 * XU.data.numel() + (4.0 if y is not None else 0.0) * B * M * Hout * Wout + 2.0 * XU.planes * KH * KH * XU.C * M),
+        f"conv_small[B={B} C={XU.C} M={M} in={Hin}x{Win} out={Hout}x{Wout} k={KH}x{KW} s={tuple(stride)} T={int(transposed)}]",
+        2.0 * XU.data.numel() + (4.0 if y is not None else 0.0) * B * M * Hout * Wout + 2.0 * XU.planes * KH * KW * XU.C * M),
         "tbg_conv2d_units_small")
     if partial is not None:
         if dot[1] is None:
