@@ -423,6 +423,19 @@ int tbg_lstm_step_bwd_f32(const float *dseq, const float *dh_rec, float *dc, con
                           const float *cs, float *dg, float *dgates, int D, int T, int B, int H, int s,
                           int first, void *stream);
 
+/* FUSED recurrent steps (round 6): one launch per time step does the step's recurrent projection AND its pointwise half for both
+ * directions (the library GEMM h @ Whh^T + tbg_lstm_step_* pair: two launches and two memory round trips per step).  A block owns 8
+ * hidden units (all four gates) of one direction and up to 16 samples; the state travels transposed between launches in two
+ * alternating buffers: hT [D][H][B] forward, dgT [D][4H][B] backward.  Same arithmetic, layouts of gx / act / cs / seq / dg / dc and
+ * step order as tbg_lstm_step_*; H % 32 == 0 (TBG_EUNSUPPORTED otherwise: the caller keeps the two-launch form).
+ * forward:  s = 0 .. T-1; hT_in is not read at s = 0.  backward: s = T-1 .. 0, first = 1 at s = T-1 (dgT_in, dc not read);
+ * w_hhT [D][H][4H] is the transposed copy of w_hh [D][4H][H].  Replaces the per-sample SavedModel call of aster_inferer.py:28-37
+ * (encoder BiLSTM, weigths_tf1_to_tf2.py:3-19) together with tbg_lstm_step_*. */
+int tbg_lstm_fused_fwd_f32(const float *gx, const float *w_hh, const float *hT_in, float *hT_out, float *act, float *cs, float *seq,
+                           int D, int T, int B, int H, int s, void *stream);
+int tbg_lstm_fused_bwd_f32(const float *dseq, const float *w_hhT, const float *dgT_in, float *dgT_out, float *dc, const float *act,
+                           const float *cs, float *dg, int D, int T, int B, int H, int s, int first, void *stream);
+
 /* Bahdanau attention context of the OCR decoder (frozen weights), one launch per decoder step:
  *   e[t] = sum_k v[k] tanh(enc_proj[b,t,k] + q[b,k]);  a = softmax_t(e) -> a [B][T];  ctx[b,:] = sum_t a[t] enc[b,t,:]
  * bwd: dq [B][H] written; denc_proj [B][T][H] and (if not NULL) denc [B][T][E] ACCUMULATED (+=).  T <= 64. */

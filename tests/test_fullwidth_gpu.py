@@ -316,6 +316,7 @@ def _conv_cases_for_coverage():
         (4, 512, 256, 4, 16, 3, (2, 2), (0, 0), True),     # transposed 64x64
         (2, 3, 64, 16, 64, 1, (1, 1), (0, 0), False),      # 1x1
         (2, 128, 256, 16, 64, 1, (2, 2), (0, 0), False),   # 1x1 strided (skip branch geometry)
+        (2, 32, 32, 16, 50, 1, (2, 2), (0, 0), True),      # 1x1 transposed stride (the recogniser's first stage, data gradient): BM = 32 few-tap
     ]
 
 
@@ -421,10 +422,25 @@ def _covered(dev, arith):
     kernels) at the real channel widths."""
     if arith not in _COVERED:
         cov = set()
-        for i, case in enumerate(_conv_cases_for_coverage()):
-            cov |= _run_conv_case(dev, case, 500 + i, arith)
-            if arith == "bf16":  # the frozen OCR branch of a bf16 step runs on the f32x3 kernels (training_step.py)
-                cov |= _run_conv_case(dev, case, 500 + i, "f32x3")
+        from textboxgan_amd import ops as _ops
+        for small in ((True, False) if arith != "f32" else (True,)):
+            # round 6: small geometries take tbg_conv2d_units_small; the NCHW instantiations they used to select still serve the
+            # launches beyond its block limit (and every step in exact fp32), so each case is compared on both routes
+            _ops.TUNING.use_small = small
+            try:
+                for i, case in enumerate(_conv_cases_for_coverage()):
+                    cov |= _run_conv_case(dev, case, 500 + i, arith)
+                    if arith == "bf16":  # the frozen OCR branch of a bf16 step runs on the f32x3 kernels (training_step.py)
+                        cov |= _run_conv_case(dev, case, 500 + i, "f32x3")
+                if arith != "f32":
+                    import test_units_gpu as TU
+                    from textboxgan_amd import native as N
+                    with N.record_calls() as log:
+                        for case in TU.SINK_CONVS:
+                            TU.test_conv_unit_sink_equals_units_pack(dev, arith, case)
+                    cov |= set(log)
+            finally:
+                _ops.TUNING.use_small = True
         if arith != "f32":  # the 3x3 stride-1 layers of these arithmetics consume unit tensors
             cov |= _run_units_case(dev, arith, 128, 700) | _run_units_case(dev, arith, 64, 701)
             cov |= _run_units_s2_case(dev, arith, 128, 702) | _run_units_s2_case(dev, arith, 64, 703)
@@ -474,5 +490,7 @@ def test_every_step_instantiation_is_oracle_compared(dev, arith, B, reg):
     if reg == (False, False):
         # round 5: unit tensors are written by the launch that PRODUCES the activation (tbg_epilogue.units_out), never by a
         # stand-alone pass over a finished fp32 tensor: no plain step of the benchmarked configurations launches units_pack
-        packs = sorted(k for k in used if k.startswith("units_pack_kernel"))
+        # (round 6: except for the inputs of small-map launches that nothing of ours produced -- word-encoder output, pooled maps,
+        # decimated skips: at most 2M elements, recorded as "[small]")
+        packs = sorted(k for k in used if k.startswith("units_pack_kernel") and not k.endswith("[small]"))
         assert not packs, f"the {arith} B={B} plain step still launches the stand-alone unit producer: {packs}"

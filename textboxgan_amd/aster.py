@@ -505,10 +505,10 @@ class AsterLikeOCRHip(AsterLikeOCR):
                 for l in range(self.rnn.num_layers):
                     g = lambda n: torch.stack([getattr(self.rnn, f"{n}_l{l}"), getattr(self.rnn, f"{n}_l{l}_reverse")])
                     layers.append((g("weight_ih").contiguous(), g("weight_hh").contiguous(),
-                                   (g("bias_ih") + g("bias_hh")).contiguous()))
+                                   (g("bias_ih") + g("bias_hh")).contiguous(), g("weight_hh").transpose(1, 2).contiguous()))
                 self._cache["rnn"] = layers
-        for w_ih, w_hh, b in self._cache["rnn"]:
-            seq = ops.frozen_bilstm_layer(seq, w_ih, w_hh, b)
+        for w_ih, w_hh, b, w_hhT in self._cache["rnn"]:
+            seq = ops.frozen_bilstm_layer(seq, w_ih, w_hh, b, w_hhT)
         return seq
 
     def _decode(self, enc):

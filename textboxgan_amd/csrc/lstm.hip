@@ -223,3 +223,274 @@ extern "C" int tbg_attn_ctx_bwd_f32(const float *dctx, const float *a, const flo
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
+
+// ============================================================================================
+// FUSED recurrent steps (round 6): the step's recurrent projection AND its pointwise half in ONE launch for both directions.
+//
+// The per-step pair (library GEMM  hw = h @ Whh^T  of [B, H] x [H, 4H], then tbg_lstm_step_*) cost 7.7 + 5.1 us per step and layer
+// under graph replay -- two launch floors and two memory round trips for 2 MFLOP.  Here a block owns LSF_UB hidden units of one
+// direction (all four gates: a 4 LSF_UB x H slice of Whh, 32 KB) and up to 16 samples: it forms its slice of the projection from the
+// previous state and finishes the cell for its units -- the kernel boundary between two steps is the only synchronisation the
+// recurrence needs.  The state travels TRANSPOSED between launches (hT [D][H][B], dgT [D][4H][B]: a block's units are contiguous
+// runs for the producer and the whole state is a linear LDS image for the consumer) in two buffers used alternately (every block of
+// step s reads ALL of step s-1's state while it writes its own part of step s's).
+//   forward   pre[b, j] = gx[d, t, b, j] + sum_k hT[k, b] Whh[d, j, k]            (j = g H + u over the block's units u)
+//   backward  dh[b, u]  = dseq[b, t, d H + u] + sum_j dgT[j, b] WhhT[d, u, j]     (WhhT [D][H][4H]: the transposed copy)
+// followed by exactly the arithmetic of lstm_step_fwd_kernel / lstm_step_bwd_kernel.  Threads: (row r, K slice) pairs, the row's
+// weights in registers (128 contiguous bytes per thread), the state read from LDS as 16-byte broadcasts, partial sums through LDS.
+// ============================================================================================
+#define LSF_UB 8
+
+struct LstmFusedP {
+  const float *gx, *w, *state_in, *dseq, *act_in, *cs_in;
+  float *act, *cs, *state_out, *seq, *dc, *dg;
+  int D, T, B, H, s, first;
+};
+
+// the state of one direction (rows x B floats, row-major) -> this batch group's LDS image [rows][BB].  Whole batch groups of a
+// batch that is a multiple of 4: 16-byte loads, eight in flight per thread (a loop of dependent scalar load / store pairs cost one
+// memory round trip per iteration: 16 of them per forward step, 64 per backward step)
+#define LSF_THREADS 512
+#define LSF_CH 16  // columns of a weight chunk held in registers per thread
+template <int BB>
+__device__ __forceinline__ void lstm_stage_state(float *dst, const float *src, int rows, int B, int b0, int nb, int tid) {
+  if (nb == BB && (B & 3) == 0) {
+    constexpr int Q4 = BB / 4;
+    const int total = rows * Q4;
+    for (int base = 0; base < total; base += LSF_THREADS * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = min(base + u * LSF_THREADS + tid, total - 1);
+        const int k = e / Q4, q = e - k * Q4;
+        v[u] = *reinterpret_cast<const float4 *>(src + (size_t)k * B + b0 + 4 * q);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = base + u * LSF_THREADS + tid;
+        if (e < total) reinterpret_cast<float4 *>(dst)[e] = v[u];
+      }
+    }
+  } else {
+    for (int e = tid; e < rows * BB; e += LSF_THREADS) {
+      const int k = e / BB, bb = e - k * BB;
+      dst[e] = bb < nb ? src[(size_t)k * B + b0 + bb] : 0.f;
+    }
+  }
+}
+
+// acc[bb] += sum_i wv[i] * st[(k0 + i) * BB + bb]
+template <int BB>
+__device__ __forceinline__ void lstm_chunk_fma(float (&acc)[BB], const float (&wv)[LSF_CH], const float *st) {
+#pragma unroll
+  for (int i = 0; i < LSF_CH; ++i) {
+#pragma unroll
+    for (int bb = 0; bb < BB; bb += 4) {
+      const float4 h4 = *reinterpret_cast<const float4 *>(st + (size_t)i * BB + bb);
+      acc[bb] += wv[i] * h4.x; acc[bb + 1] += wv[i] * h4.y; acc[bb + 2] += wv[i] * h4.z; acc[bb + 3] += wv[i] * h4.w;
+    }
+  }
+}
+
+template <int BB>  // samples per block (power of two <= 16; the batch is split over blockIdx.z)
+__global__ __launch_bounds__(LSF_THREADS) void lstm_fused_fwd_kernel(const LstmFusedP p) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  const int H = p.H, B = p.B, T = p.T, s = p.s;
+  constexpr int KS = LSF_THREADS / 32;           // K slices: thread (row r, slice ks) takes the chunks ks, ks + KS, ... of LSF_CH columns
+  float *hs = lsm;                               // [H][BB]   previous hidden state of this batch group
+  float *part = lsm + (size_t)H * BB;            // [KS][32][BB] partial projections
+  const int tid = threadIdx.x;
+  const int d = blockIdx.y, u0 = blockIdx.x * LSF_UB, b0 = blockIdx.z * BB;
+  const int nb = min(BB, B - b0);
+  const int t = d == 0 ? s : T - 1 - s;
+  const int r = tid & 31, ks = tid >> 5;         // row: gate g = r / UB, unit u0 + r % UB
+  const int NCH = H / LSF_CH;                    // (H % 32 == 0 checked on the host)
+  const int j = (r / LSF_UB) * H + u0 + (r % LSF_UB);
+  // pointwise ownership: thread (b, ul) for tid < BB * UB
+  const int pb = tid / LSF_UB, pu = tid % LSF_UB;
+  const bool pw = tid < BB * LSF_UB && pb < nb;
+  float gv[4] = {0.f, 0.f, 0.f, 0.f}, cp = 0.f;
+  if (pw) {
+    const float *g = p.gx + (((size_t)d * T + t) * B + b0 + pb) * 4 * H + u0 + pu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gv[q] = g[q * H];
+    if (s > 0) cp = p.cs[(((size_t)d * T + s - 1) * B + b0 + pb) * H + u0 + pu];
+  }
+  if (s > 0) {
+    // this thread's weights of its first chunk go out BEFORE the state is staged: one memory round trip per step, not two
+    float wv[LSF_CH];
+    const float *wrow = p.w + ((size_t)d * 4 * H + j) * H;
+#pragma unroll
+    for (int i = 0; i < LSF_CH; i += 4)
+      *reinterpret_cast<float4 *>(&wv[i]) = *reinterpret_cast<const float4 *>(wrow + min(ks, NCH - 1) * LSF_CH + i);
+    lstm_stage_state<BB>(hs, p.state_in + (size_t)d * H * B, H, B, b0, nb, tid);
+    float acc[BB];
+#pragma unroll
+    for (int bb = 0; bb < BB; ++bb) acc[bb] = 0.f;
+    __syncthreads();
+    for (int ch = ks; ch < NCH; ch += KS) {
+      if (ch != ks) {
+#pragma unroll
+        for (int i = 0; i < LSF_CH; i += 4) *reinterpret_cast<float4 *>(&wv[i]) = *reinterpret_cast<const float4 *>(wrow + ch * LSF_CH + i);
+      }
+      lstm_chunk_fma<BB>(acc, wv, hs + (size_t)ch * LSF_CH * BB);
+    }
+#pragma unroll
+    for (int bb = 0; bb < BB; bb += 4)
+      *reinterpret_cast<float4 *>(part + ((size_t)ks * 32 + r) * BB + bb) = make_float4(acc[bb], acc[bb + 1], acc[bb + 2], acc[bb + 3]);
+    __syncthreads();
+    if (pw) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < KS; ++k2) a += part[((size_t)k2 * 32 + q * LSF_UB + pu) * BB + pb];  // fixed order: deterministic
+        gv[q] += a;
+      }
+    }
+  }
+  if (!pw) return;
+  const int b = b0 + pb, u = u0 + pu;
+  const float i_ = sigmoidf_(gv[0]), f_ = sigmoidf_(gv[1]), g_ = tanhf(gv[2]), o_ = sigmoidf_(gv[3]);
+  const float c = f_ * cp + i_ * g_;
+  const float hh = o_ * tanhf(c);
+  float *a = p.act + (((size_t)d * T + s) * B + b) * 4 * H + u;
+  a[0] = i_; a[H] = f_; a[2 * H] = g_; a[3 * H] = o_;
+  p.cs[(((size_t)d * T + s) * B + b) * H + u] = c;
+  p.state_out[((size_t)d * H + u) * B + b] = hh;
+  if (p.seq) p.seq[((size_t)b * T + t) * (p.D * H) + d * H + u] = hh;
+}
+
+template <int BB>
+__global__ __launch_bounds__(LSF_THREADS) void lstm_fused_bwd_kernel(const LstmFusedP p) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  const int H = p.H, B = p.B, T = p.T, s = p.s, G = 4 * H;
+  constexpr int JS = LSF_THREADS / LSF_UB;       // J slices: thread (unit ul, slice js) takes the chunks js, js + JS, ... of LSF_CH gate rows
+  float *dgs = lsm;                              // [4H][BB]  gate gradients of the step after this one
+  float *part = lsm + (size_t)G * BB;            // [JS][UB][BB]
+  const int tid = threadIdx.x;
+  const int d = blockIdx.y, u0 = blockIdx.x * LSF_UB, b0 = blockIdx.z * BB;
+  const int nb = min(BB, B - b0);
+  const int t = d == 0 ? s : T - 1 - s;
+  const int ul = tid & (LSF_UB - 1), js = tid / LSF_UB;
+  const int NCH = G / LSF_CH;
+  const int pb = tid / LSF_UB, pu = tid % LSF_UB;
+  const bool pw = tid < BB * LSF_UB && pb < nb;
+  float dh = 0.f, av[4] = {0.f, 0.f, 0.f, 0.f}, c = 0.f, cp = 0.f, dcin = 0.f;
+  if (pw) {
+    const int b = b0 + pb, u = u0 + pu;
+    if (p.dseq) dh = p.dseq[((size_t)b * T + t) * (p.D * H) + d * H + u];
+    const float *a = p.act_in + (((size_t)d * T + s) * B + b) * 4 * H + u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) av[q] = a[q * H];
+    c = p.cs_in[(((size_t)d * T + s) * B + b) * H + u];
+    if (s > 0) cp = p.cs_in[(((size_t)d * T + s - 1) * B + b) * H + u];
+    if (!p.first) dcin = p.dc[((size_t)d * B + b) * H + u];
+  }
+  if (!p.first) {
+    const float *wrow = p.w + ((size_t)d * H + u0 + ul) * G;  // WhhT[d][u][j]
+    float wv[LSF_CH];
+#pragma unroll
+    for (int i = 0; i < LSF_CH; i += 4)
+      *reinterpret_cast<float4 *>(&wv[i]) = *reinterpret_cast<const float4 *>(wrow + min(js, NCH - 1) * LSF_CH + i);
+    lstm_stage_state<BB>(dgs, p.state_in + (size_t)d * G * B, G, B, b0, nb, tid);
+    float acc[BB];
+#pragma unroll
+    for (int bb = 0; bb < BB; ++bb) acc[bb] = 0.f;
+    __syncthreads();
+    for (int ch = js; ch < NCH; ch += JS) {
+      if (ch != js) {
+#pragma unroll
+        for (int i = 0; i < LSF_CH; i += 4) *reinterpret_cast<float4 *>(&wv[i]) = *reinterpret_cast<const float4 *>(wrow + ch * LSF_CH + i);
+      }
+      lstm_chunk_fma<BB>(acc, wv, dgs + (size_t)ch * LSF_CH * BB);
+    }
+#pragma unroll
+    for (int bb = 0; bb < BB; bb += 4)
+      *reinterpret_cast<float4 *>(part + ((size_t)js * LSF_UB + ul) * BB + bb) = make_float4(acc[bb], acc[bb + 1], acc[bb + 2], acc[bb + 3]);
+    __syncthreads();
+    if (pw) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four chains, combined in a fixed order: deterministic
+      for (int k2 = 0; k2 < JS; k2 += 4) {
+        a0 += part[((size_t)(k2 + 0) * LSF_UB + pu) * BB + pb]; a1 += part[((size_t)(k2 + 1) * LSF_UB + pu) * BB + pb];
+        a2 += part[((size_t)(k2 + 2) * LSF_UB + pu) * BB + pb]; a3 += part[((size_t)(k2 + 3) * LSF_UB + pu) * BB + pb];
+      }
+      dh += (a0 + a1) + (a2 + a3);
+    }
+  }
+  if (!pw) return;
+  const int b = b0 + pb, u = u0 + pu;
+  const float i_ = av[0], f_ = av[1], g_ = av[2], o_ = av[3];
+  const float tc = tanhf(c);
+  const float dcc = dh * o_ * (1.f - tc * tc) + dcin;
+  const float d_o = dh * tc * o_ * (1.f - o_);
+  const float d_i = dcc * g_ * i_ * (1.f - i_);
+  const float d_f = dcc * cp * f_ * (1.f - f_);
+  const float d_g = dcc * i_ * (1.f - g_ * g_);
+  p.dc[((size_t)d * B + b) * H + u] = dcc * f_;
+  float *q = p.state_out + ((size_t)d * G + u) * B + b;  // dgT[d][g H + u][b]
+  q[0] = d_i; q[(size_t)H * B] = d_f; q[(size_t)2 * H * B] = d_g; q[(size_t)3 * H * B] = d_o;
+  if (p.dg) {
+    float *w = p.dg + (((size_t)d * T + t) * B + b) * 4 * H + u;
+    w[0] = d_i; w[H] = d_f; w[2 * H] = d_g; w[3 * H] = d_o;
+  }
+}
+
+static int lstm_fused_bb(int B) { return B <= 4 ? 4 : B <= 8 ? 8 : 16; }
+
+static bool lstm_fused_ok(int D, int T, int B, int H, int s) {
+  return lstm_args_ok(D, T, B, H, s) && H % 32 == 0 && H >= 32 && H <= 1024;
+}
+
+template <int BB, bool FWD>
+static int lstm_fused_launch(const LstmFusedP &p, hipStream_t st) {
+  const int groups = (p.B + BB - 1) / BB;
+  const size_t lds = FWD ? ((size_t)p.H * BB + (size_t)(LSF_THREADS / 32) * 32 * BB) * sizeof(float)
+                         : ((size_t)4 * p.H * BB + (size_t)LSF_THREADS * BB) * sizeof(float);
+  auto kern = FWD ? lstm_fused_fwd_kernel<BB> : lstm_fused_bwd_kernel<BB>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return TBG_EHIP;
+  if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3(p.H / LSF_UB, p.D, groups), dim3(LSF_THREADS), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// one forward step (s = 0 .. T-1 in order) of a frozen (bi)directional LSTM layer, projection included.
+//   gx [D][T][B][4H], w_hh [D][4H][H], hT_in / hT_out [D][H][B] (two different buffers, used alternately; hT_in unused at s = 0),
+//   act [D][T][B][4H], cs [D][T][B][H] (written at step index s, read at s - 1), seq [B][T][D H] or NULL
+extern "C" int tbg_lstm_fused_fwd_f32(const float *gx, const float *w_hh, const float *hT_in, float *hT_out, float *act, float *cs,
+                                      float *seq, int D, int T, int B, int H, int s, void *stream) {
+  if (!gx || !w_hh || !hT_out || !act || !cs || (s > 0 && !hT_in) || hT_in == hT_out) return TBG_EINVAL;
+  if (!lstm_fused_ok(D, T, B, H, s)) return lstm_args_ok(D, T, B, H, s) ? TBG_EUNSUPPORTED : TBG_EINVAL;
+  LstmFusedP p{};
+  p.gx = gx; p.w = w_hh; p.state_in = hT_in; p.state_out = hT_out; p.act = act; p.cs = cs; p.seq = seq;
+  p.D = D; p.T = T; p.B = B; p.H = H; p.s = s;
+  hipStream_t st = tbg_stream(stream);
+  switch (lstm_fused_bb(B)) {
+    case 4: return lstm_fused_launch<4, true>(p, st);
+    case 8: return lstm_fused_launch<8, true>(p, st);
+    default: return lstm_fused_launch<16, true>(p, st);
+  }
+}
+
+// one backward step (s = T-1 .. 0; first = 1 at s = T-1: no incoming recurrent / cell gradient).
+//   dseq [B][T][D H] or NULL, w_hhT [D][H][4H] (the transposed recurrent weights), dgT_in / dgT_out [D][4H][B] (alternating buffers),
+//   dc [D][B][H] (read unless first, then overwritten), act / cs as written by the forward steps, dg [D][T][B][4H] or NULL
+extern "C" int tbg_lstm_fused_bwd_f32(const float *dseq, const float *w_hhT, const float *dgT_in, float *dgT_out, float *dc,
+                                      const float *act, const float *cs, float *dg, int D, int T, int B, int H, int s, int first,
+                                      void *stream) {
+  if (!w_hhT || !dgT_out || !dc || !act || !cs || (!first && !dgT_in) || dgT_in == dgT_out) return TBG_EINVAL;
+  if (!dseq && first) return TBG_EINVAL;
+  if (!lstm_fused_ok(D, T, B, H, s)) return lstm_args_ok(D, T, B, H, s) ? TBG_EUNSUPPORTED : TBG_EINVAL;
+  LstmFusedP p{};
+  p.dseq = dseq; p.w = w_hhT; p.state_in = dgT_in; p.state_out = dgT_out; p.dc = dc; p.act_in = act; p.cs_in = cs; p.dg = dg;
+  p.D = D; p.T = T; p.B = B; p.H = H; p.s = s; p.first = first;
+  hipStream_t st = tbg_stream(stream);
+  switch (lstm_fused_bb(B)) {
+    case 4: return lstm_fused_launch<4, false>(p, st);
+    case 8: return lstm_fused_launch<8, false>(p, st);
+    default: return lstm_fused_launch<16, false>(p, st);
+  }
+}

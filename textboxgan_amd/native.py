@@ -25,7 +25,7 @@ EXPORTS = [
     "tbg_upfirdn2d_kernel_name", "tbg_upfirdn2d_f16", "tbg_weight_pack_x3_bytes", "tbg_weight_pack_x3", "tbg_conv2d_x3", "tbg_conv2d_x3_kernel_name", "tbg_conv2d_x3_variant", "tbg_conv2d_wgrad_x3", "tbg_conv2d_wgrad_x3_kernel_name", "tbg_conv2d_dot_slots", "tbg_conv2d_blocks", "tbg_units_bytes", "tbg_units_pack_f32",
     "tbg_conv2d_wgrad_units", "tbg_conv2d_wgrad_units_workspace_bytes", "tbg_conv2d_units", "tbg_conv2d_units_dot_slots", "tbg_conv2d_units_blocks", "tbg_conv2d_units_tile_channels", "tbg_bias_act_bwd_units", "tbg_bias_act_bwd_units_chunks",
     "tbg_units_s2_bytes", "tbg_units_pack_s2_f32", "tbg_upfirdn2d_units_s2_f32", "tbg_conv2d_units_s2_blocks", "tbg_conv2d_units_s2_tile_channels", "tbg_conv2d_units_s2_dot_slots", "tbg_conv2d_units_s2", "tbg_conv2d_wgrad_units_s2_workspace_bytes", "tbg_conv2d_wgrad_units_s2", "tbg_conv2d_units_t2_blocks", "tbg_conv2d_units_t2",
-    "tbg_slab_epilogue_units_f32", "tbg_conv2d_units_small", "tbg_conv2d_units_small_blocks", "tbg_conv2d_units_small_dot_slots", "tbg_conv2d_units_small_tile_pixels",
+    "tbg_slab_epilogue_units_f32", "tbg_conv2d_units_small", "tbg_conv2d_units_small_blocks", "tbg_conv2d_units_small_dot_slots", "tbg_conv2d_units_small_tile_pixels", "tbg_lstm_fused_fwd_f32", "tbg_lstm_fused_bwd_f32",
     "tbg_bias_act_bwd_f32", "tbg_axpby_planes_f32", "tbg_bias_act_bwd2_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_rgb_backproject_chunks", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -95,6 +95,8 @@ def lib():
         l.tbg_weight_pack_floats.argtypes = [ci, ci, ci, ci]
         l.tbg_weight_pack_floats.restype = C.c_longlong
         l.tbg_lstm_step_fwd_f32.argtypes = [vp] * 6 + [ci] * 5 + [vp]
+        l.tbg_lstm_fused_fwd_f32.argtypes = [vp] * 7 + [ci] * 5 + [vp]
+        l.tbg_lstm_fused_bwd_f32.argtypes = [vp] * 8 + [ci] * 6 + [vp]
         l.tbg_lstm_step_bwd_f32.argtypes = [vp] * 7 + [ci] * 6 + [vp]
         l.tbg_attn_ctx_fwd_f32.argtypes = [vp] * 6 + [ci] * 4 + [vp]
         l.tbg_attn_ctx_bwd_f32.argtypes = [vp] * 9 + [ci] * 4 + [vp]
@@ -228,7 +230,13 @@ def _call_key(name, a):
         if name == "tbg_slab_epilogue_units_f32":  # x y B M H W nslab epi stream
             return f"slab_epilogue_units_kernel<{a[7]._obj.units_planes}>"
         if name == "tbg_units_pack_f32":      # x scale U B C H W planes stream
-            return f"units_pack_kernel<{a[7]}>"
+            # [small]: the input of a small-map launch that no launch of ours produced (<= 2M elements, a 4-6 us launch); the
+            # plain steps must not run the producer over anything larger (tests/test_fullwidth_gpu.py)
+            return f"units_pack_kernel<{a[7]}>" + (" [small]" if a[3] * a[4] * a[5] * a[6] <= (1 << 21) else "")
+        if name == "tbg_conv2d_units_small":  # d XU planes w y epi stream
+            d = a[0]._obj
+            kw = 3 if (d.KH == 3 and d.KW == 3 and d.sy == 1 and d.sx == 1 and not d.transposed and d.py == 1) else 1
+            return f"conv_small_kernel<{a[2]}, {kw}, {_lib._l.tbg_conv2d_units_small_tile_pixels(a[0], a[2]) // 32}>"
         if name in ("tbg_upfirdn2d_f32", "tbg_upfirdn2d_ex_f32", "tbg_upfirdn2d_sep_f32"):
             if name == "tbg_upfirdn2d_f32":      # x k y major inH inW minor kH kW upx upy downx downy padx0 padx1 pady0 pady1
                 minor, g = a[6], a[7:17]
@@ -247,7 +255,7 @@ def _call_key(name, a):
     return name
 
 
-_NOT_COMPUTE = ("tbg_version", "tbg_strerror", "tbg_crc32c", "_kernel_name", "_bytes", "_floats", "_chunks", "_dot_slots", "_blocks", "_tile_channels")  # queries: no device work
+_NOT_COMPUTE = ("tbg_version", "tbg_strerror", "tbg_crc32c", "_kernel_name", "_bytes", "_floats", "_chunks", "_dot_slots", "_blocks", "_tile_channels", "_tile_pixels")  # queries: no device work
 
 
 class _LibProxy:

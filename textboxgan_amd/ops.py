@@ -125,6 +125,9 @@ class _Tuning:
         self.fold_res_scale = True   # DiscriminatorBlock folds its 1/sqrt(2) into both branches (fp32-grade arithmetics only)
         self.fuse_skip_grad = True   # DiscriminatorBlock: conv_0 + skip FIR as ONE node (False = two nodes + the engine's add)
         self.use_fused2 = True       # path-length pass on the twice-differentiable node pairs of ops2 (False = composable primitives)
+        # ---- recurrent layers of the frozen recogniser
+        self.fused_lstm = True       # one launch per BiLSTM step (tbg_lstm_fused_*: projection + cell) instead of a library GEMM + a
+                                     # pointwise launch
         # ---- dense layers
         self.dense_small_k = 768     # above: a library GEMM; below: launch-bound, one hand-written launch per direction
 
@@ -2239,10 +2242,11 @@ def dense_bias_act(x, w, b, coef, lrmul=1.0, lrelu=False, offset=0.0):
 # ----------------------------------------------------------------------------------------
 class _FrozenBiLSTMLayer(torch.autograd.Function):
     """x [B,T,In] -> [B,T,D*H]; w_ih [D,4H,In], w_hh [D,4H,H], bias [D,4H] (= b_ih + b_hh); gradient w.r.t. x only
-    (the OCR network is frozen).  Per step: ONE bmm over the directions + ONE pointwise launch (tbg_lstm_step_*)."""
+    (the OCR network is frozen).  Per step ONE launch for both directions (tbg_lstm_fused_*: recurrent projection + cell, round 6);
+    hidden sizes the fused kernels do not take keep the round-2 pair (one bmm over the directions + tbg_lstm_step_*)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, bias):
+    def forward(ctx, x, w_ih, w_hh, bias, w_hhT=None):
         B, T, In = x.shape
         D, H = w_hh.shape[0], w_hh.shape[2]
         dev = x.device
@@ -2250,42 +2254,60 @@ class _FrozenBiLSTMLayer(torch.autograd.Function):
         gx = torch.baddbmm(bias[:, None, :], x_tm.expand(D, T * B, In), w_ih.transpose(1, 2))  # [D, T*B, 4H]
         act = torch.empty((D, T, B, 4 * H), device=dev, dtype=torch.float32)
         cs = torch.empty((D, T, B, H), device=dev, dtype=torch.float32)
-        h = torch.empty((D, B, H), device=dev, dtype=torch.float32)
         seq = torch.empty((B, T, D * H), device=dev, dtype=torch.float32)
-        w_hhT = w_hh.transpose(1, 2)
-        hw = None
-        for s in range(T):
-            if s > 0:
-                hw = torch.bmm(h, w_hhT)
-            N.check(N.lib().tbg_lstm_step_fwd_f32(N.ptr(gx), N.ptr(hw), N.ptr(act), N.ptr(cs), N.ptr(h), N.ptr(seq), D, T, B,
-                                                  H, s, N.stream()), "tbg_lstm_step_fwd")
-        ctx.save_for_backward(act, cs, w_ih, w_hh)
+        fused = TUNING.fused_lstm and H % 32 == 0
+        if fused:
+            hT = torch.empty((2, D, H, B), device=dev, dtype=torch.float32)  # the state, transposed, in alternating buffers
+            for s in range(T):
+                N.check(PROFILE.launch("lstm_fused_fwd_kernel", 2.0 * D * B * 4 * H * H, lambda: N.lib().tbg_lstm_fused_fwd_f32(
+                    N.ptr(gx), N.ptr(w_hh), N.ptr(hT[(s + 1) & 1]), N.ptr(hT[s & 1]), N.ptr(act), N.ptr(cs), N.ptr(seq), D, T, B, H,
+                    s, N.stream())), "tbg_lstm_fused_fwd")
+        else:
+            h = torch.empty((D, B, H), device=dev, dtype=torch.float32)
+            w_hhT_ = w_hh.transpose(1, 2)
+            hw = None
+            for s in range(T):
+                if s > 0:
+                    hw = torch.bmm(h, w_hhT_)
+                N.check(N.lib().tbg_lstm_step_fwd_f32(N.ptr(gx), N.ptr(hw), N.ptr(act), N.ptr(cs), N.ptr(h), N.ptr(seq), D, T, B,
+                                                      H, s, N.stream()), "tbg_lstm_step_fwd")
+        ctx.save_for_backward(act, cs, w_ih, w_hh, w_hhT)
         ctx.dims = (B, T, In, D, H)
+        ctx.fused = fused
         return seq
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
-        act, cs, w_ih, w_hh = ctx.saved_tensors
+        act, cs, w_ih, w_hh, w_hhT = ctx.saved_tensors
         B, T, In, D, H = ctx.dims
         dev = dout.device
         dseq = dout.contiguous()
         dg = torch.empty((D, T, B, 4 * H), device=dev, dtype=torch.float32)
-        dgates = torch.empty((D, B, 4 * H), device=dev, dtype=torch.float32)
         dc = torch.empty((D, B, H), device=dev, dtype=torch.float32)
-        dh_rec = None
-        for s in range(T - 1, -1, -1):
-            N.check(N.lib().tbg_lstm_step_bwd_f32(N.ptr(dseq), N.ptr(dh_rec), N.ptr(dc), N.ptr(act), N.ptr(cs), N.ptr(dg),
-                                                  N.ptr(dgates), D, T, B, H, s, int(s == T - 1), N.stream()),
-                    "tbg_lstm_step_bwd")
-            if s > 0:
-                dh_rec = torch.bmm(dgates, w_hh)
+        if ctx.fused:
+            w_hhT = w_hh.transpose(1, 2).contiguous() if w_hhT is None else w_hhT  # [D, H, 4H]
+            dgT = torch.empty((2, D, 4 * H, B), device=dev, dtype=torch.float32)
+            for s in range(T - 1, -1, -1):
+                N.check(PROFILE.launch("lstm_fused_bwd_kernel", 2.0 * D * B * 4 * H * H, lambda: N.lib().tbg_lstm_fused_bwd_f32(
+                    N.ptr(dseq), N.ptr(w_hhT), N.ptr(dgT[(s + 1) & 1]), N.ptr(dgT[s & 1]), N.ptr(dc), N.ptr(act), N.ptr(cs),
+                    N.ptr(dg), D, T, B, H, s, int(s == T - 1), N.stream())), "tbg_lstm_fused_bwd")
+        else:
+            dgates = torch.empty((D, B, 4 * H), device=dev, dtype=torch.float32)
+            dh_rec = None
+            for s in range(T - 1, -1, -1):
+                N.check(N.lib().tbg_lstm_step_bwd_f32(N.ptr(dseq), N.ptr(dh_rec), N.ptr(dc), N.ptr(act), N.ptr(cs), N.ptr(dg),
+                                                      N.ptr(dgates), D, T, B, H, s, int(s == T - 1), N.stream()),
+                        "tbg_lstm_step_bwd")
+                if s > 0:
+                    dh_rec = torch.bmm(dgates, w_hh)
         dx_tm = torch.bmm(dg.view(D, T * B, 4 * H), w_ih).sum(dim=0)  # [T*B, In]
-        return dx_tm.view(T, B, In).transpose(0, 1), None, None, None
+        return dx_tm.view(T, B, In).transpose(0, 1), None, None, None, None
 
 
-def frozen_bilstm_layer(x, w_ih, w_hh, bias):
-    return _FrozenBiLSTMLayer.apply(x.contiguous(), w_ih, w_hh, bias)
+def frozen_bilstm_layer(x, w_ih, w_hh, bias, w_hhT=None):
+    """w_hhT: the owner's cached [D, H, 4H] transpose of w_hh (the backward steps read it; made on the spot when absent)"""
+    return _FrozenBiLSTMLayer.apply(x.contiguous(), w_ih, w_hh, bias, w_hhT)
 
 
 # ----------------------------------------------------------------------------------------
