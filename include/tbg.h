@@ -436,6 +436,34 @@ int tbg_lstm_fused_fwd_f32(const float *gx, const float *w_hh, const float *hT_i
 int tbg_lstm_fused_bwd_f32(const float *dseq, const float *w_hhT, const float *dgT_in, float *dgT_out, float *dc, const float *act,
                            const float *cs, float *dg, int D, int T, int B, int H, int s, int first, void *stream);
 
+/* The attention decoder's step in TWO launches per direction of the pass (round 6; 8 forward / 6 backward launches of library GEMMs,
+ * tbg_attn_ctx_*, tbg_lstm_step_* and index / argmax ops before).  All state between launches is TRANSPOSED ([rows][B]).
+ *   tbg_lstm_cell_fused_fwd_f32: tbg_lstm_fused_fwd_f32 for ONE direction whose input is [context; hidden]: stateT_in [K][B], K = E + H,
+ *     w [4H][K] = [W_ih(context columns) | W_hh], gx [steps][B][4H] = embedding row of the previous symbol + biases; the projection runs
+ *     at every step (s = 0 included: the first context is not zero); hT_out [H][B] = rows E.. of the NEXT step's state buffer.
+ *   tbg_dec_sample_fwd_f32 (one block per sample; after the cell of step s): logits[s] = b_o + h W_o^T (w_oT [H][C]), the greedy symbol
+ *     = first maximum, gx_next = etab[symbol] ([C+1][4H]), q = b_d + h W_d^T (w_dT [H][H]), the attention of tbg_attn_ctx_fwd_f32 with
+ *     that q: a_out [B][T], context -> ctxT_out [E][B] (rows 0..E of the next state buffer).  hT NULL: initial launch (h = 0, symbol =
+ *     go, no logits); gx_next NULL: last step (logits only).
+ *   tbg_rows_gemv_t_f32: outT [R][B] = sum_j stateT[j][b] w[r][j] (w [R][J]); backward: stateT = the step's gate gradients dgT [4H][B],
+ *     w = [W_ih(context)^T; W_hh^T] ([E + H][4H]) -> rows 0..E = d(context)^T, rows E.. = the recurrent part of d(hidden)^T.
+ *   tbg_dec_sample_bwd_f32 (one block per sample; after the rows launch of step s): tbg_attn_ctx_bwd_f32 with dctx = column b of
+ *     dctxT (also stored as dctx_out [B][E]; denc_proj accumulated), then for step s - 1: dh = dlo [B][H] (= dlogits[s-1] W_o,
+ *     precomputed) + dhpT column + dq W_d (w_d [H][H]), and tbg_lstm_step_bwd_f32's cell arithmetic with act / cs_cur / cs_prev of
+ *     that step -> dgT_out [4H][B], dc [B][H].  dctxT NULL: first launch of the pass (cell part of the last step only, first = 1);
+ *     act NULL: last launch (attention part of step 0 only).
+ * Replaces the decoder behind aster_inferer.py:28-37 (Bahdanau attention + LSTM predictor, weigths_tf1_to_tf2.py:3-19). */
+int tbg_lstm_cell_fused_fwd_f32(const float *gx, const float *w, const float *stateT_in, float *hT_out, float *act, float *cs,
+                                int steps, int B, int H, int K, int s, void *stream);
+int tbg_rows_gemv_t_f32(const float *stateT, const float *w, float *outT, int J, int R, int B, void *stream);
+int tbg_dec_sample_fwd_f32(const float *hT, const float *w_oT, const float *b_o, const float *w_dT, const float *b_d,
+                           const float *enc_proj, const float *enc, const float *v, const float *etab, float *logits, float *gx_next,
+                           float *q_out, float *a_out, float *ctxT_out, int B, int T, int H, int E, int C, int go, void *stream);
+int tbg_dec_sample_bwd_f32(const float *dctxT, const float *dhpT, const float *a, const float *q, const float *enc_proj,
+                           const float *enc, const float *v, const float *w_d, float *denc_proj, float *dctx_out, const float *dlo,
+                           const float *act, const float *cs_cur, const float *cs_prev, float *dc, float *dgT_out, int B, int T,
+                           int H, int E, int first, void *stream);
+
 /* Bahdanau attention context of the OCR decoder (frozen weights), one launch per decoder step:
  *   e[t] = sum_k v[k] tanh(enc_proj[b,t,k] + q[b,k]);  a = softmax_t(e) -> a [B][T];  ctx[b,:] = sum_t a[t] enc[b,t,:]
  * bwd: dq [B][H] written; denc_proj [B][T][H] and (if not NULL) denc [B][T][E] ACCUMULATED (+=).  T <= 64. */

@@ -525,7 +525,8 @@ class AsterLikeOCRHip(AsterLikeOCR):
                     w_d=c(self.att_dec.weight), v=c(self.att_v.weight.reshape(-1)),
                     etab=c(self.emb.weight @ w_ih[:, E:].t() + self.cell.bias_ih + self.cell.bias_hh),
                     w_ctx=c(w_ih[:, :E]), w_ctxT=c(w_ih[:, :E].t()), w_hh=c(w_hh), w_hhT=c(w_hh.t()),
-                    w_o=c(self.out.weight), w_oT=c(self.out.weight.t()), b_o=c(self.out.bias))
+                    w_o=c(self.out.weight), w_oT=c(self.out.weight.t()), b_o=c(self.out.bias),
+                    w_cat=c(torch.cat([w_ih[:, :E], w_hh], dim=1)), w_catT=c(torch.cat([w_ih[:, :E], w_hh], dim=1).t()))
         return ops.frozen_attn_decoder(enc, self._cache["dec"], self.max_steps, self.num_classes)
 
     def encode(self, x):

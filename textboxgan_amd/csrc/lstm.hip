@@ -245,6 +245,8 @@ struct LstmFusedP {
   const float *gx, *w, *state_in, *dseq, *act_in, *cs_in;
   float *act, *cs, *state_out, *seq, *dc, *dg;
   int D, T, B, H, s, first;
+  int K, project;  // forward: rows of the state / columns of a weight row (H for a plain LSTM layer; E + H for the decoder's cell,
+                   // whose input is [context; hidden]); project = 0: no recurrent term at all (s = 0 of a layer)
 };
 
 // the state of one direction (rows x B floats, row-major) -> this batch group's LDS image [rows][BB].  Whole batch groups of a
@@ -295,16 +297,16 @@ __device__ __forceinline__ void lstm_chunk_fma(float (&acc)[BB], const float (&w
 template <int BB>  // samples per block (power of two <= 16; the batch is split over blockIdx.z)
 __global__ __launch_bounds__(LSF_THREADS) void lstm_fused_fwd_kernel(const LstmFusedP p) {
   extern __shared__ __attribute__((aligned(16))) float lsm[];
-  const int H = p.H, B = p.B, T = p.T, s = p.s;
+  const int H = p.H, B = p.B, T = p.T, s = p.s, K = p.K;
   constexpr int KS = LSF_THREADS / 32;           // K slices: thread (row r, slice ks) takes the chunks ks, ks + KS, ... of LSF_CH columns
-  float *hs = lsm;                               // [H][BB]   previous hidden state of this batch group
-  float *part = lsm + (size_t)H * BB;            // [KS][32][BB] partial projections
+  float *hs = lsm;                               // [K][BB]   previous state of this batch group
+  float *part = lsm + (size_t)K * BB;            // [KS][32][BB] partial projections
   const int tid = threadIdx.x;
   const int d = blockIdx.y, u0 = blockIdx.x * LSF_UB, b0 = blockIdx.z * BB;
   const int nb = min(BB, B - b0);
   const int t = d == 0 ? s : T - 1 - s;
   const int r = tid & 31, ks = tid >> 5;         // row: gate g = r / UB, unit u0 + r % UB
-  const int NCH = H / LSF_CH;                    // (H % 32 == 0 checked on the host)
+  const int NCH = K / LSF_CH;                    // (K % 16 == 0 checked on the host)
   const int j = (r / LSF_UB) * H + u0 + (r % LSF_UB);
   // pointwise ownership: thread (b, ul) for tid < BB * UB
   const int pb = tid / LSF_UB, pu = tid % LSF_UB;
@@ -316,14 +318,14 @@ __global__ __launch_bounds__(LSF_THREADS) void lstm_fused_fwd_kernel(const LstmF
     for (int q = 0; q < 4; ++q) gv[q] = g[q * H];
     if (s > 0) cp = p.cs[(((size_t)d * T + s - 1) * B + b0 + pb) * H + u0 + pu];
   }
-  if (s > 0) {
+  if (p.project) {
     // this thread's weights of its first chunk go out BEFORE the state is staged: one memory round trip per step, not two
     float wv[LSF_CH];
-    const float *wrow = p.w + ((size_t)d * 4 * H + j) * H;
+    const float *wrow = p.w + ((size_t)d * 4 * H + j) * K;
 #pragma unroll
     for (int i = 0; i < LSF_CH; i += 4)
       *reinterpret_cast<float4 *>(&wv[i]) = *reinterpret_cast<const float4 *>(wrow + min(ks, NCH - 1) * LSF_CH + i);
-    lstm_stage_state<BB>(hs, p.state_in + (size_t)d * H * B, H, B, b0, nb, tid);
+    lstm_stage_state<BB>(hs, p.state_in + (size_t)d * K * B, K, B, b0, nb, tid);
     float acc[BB];
 #pragma unroll
     for (int bb = 0; bb < BB; ++bb) acc[bb] = 0.f;
@@ -445,7 +447,7 @@ static bool lstm_fused_ok(int D, int T, int B, int H, int s) {
 template <int BB, bool FWD>
 static int lstm_fused_launch(const LstmFusedP &p, hipStream_t st) {
   const int groups = (p.B + BB - 1) / BB;
-  const size_t lds = FWD ? ((size_t)p.H * BB + (size_t)(LSF_THREADS / 32) * 32 * BB) * sizeof(float)
+  const size_t lds = FWD ? ((size_t)p.K * BB + (size_t)(LSF_THREADS / 32) * 32 * BB) * sizeof(float)
                          : ((size_t)4 * p.H * BB + (size_t)LSF_THREADS * BB) * sizeof(float);
   auto kern = FWD ? lstm_fused_fwd_kernel<BB> : lstm_fused_bwd_kernel<BB>;
   if (lds > 64 * 1024 &&
@@ -466,7 +468,7 @@ extern "C" int tbg_lstm_fused_fwd_f32(const float *gx, const float *w_hh, const 
   if (!lstm_fused_ok(D, T, B, H, s)) return lstm_args_ok(D, T, B, H, s) ? TBG_EUNSUPPORTED : TBG_EINVAL;
   LstmFusedP p{};
   p.gx = gx; p.w = w_hh; p.state_in = hT_in; p.state_out = hT_out; p.act = act; p.cs = cs; p.seq = seq;
-  p.D = D; p.T = T; p.B = B; p.H = H; p.s = s;
+  p.D = D; p.T = T; p.B = B; p.H = H; p.s = s; p.K = H; p.project = s > 0;
   hipStream_t st = tbg_stream(stream);
   switch (lstm_fused_bb(B)) {
     case 4: return lstm_fused_launch<4, true>(p, st);
@@ -493,4 +495,314 @@ extern "C" int tbg_lstm_fused_bwd_f32(const float *dseq, const float *w_hhT, con
     case 8: return lstm_fused_launch<8, false>(p, st);
     default: return lstm_fused_launch<16, false>(p, st);
   }
+}
+
+// the decoder's cell (one direction, `steps` steps): the same launch with the input [context; hidden] -- stateT_in [K][B], K = E + H,
+// w [4H][K] = [W_ih(context part) | W_hh] -- and gx[s] = the embedding row of the previous symbol (+ biases).  hT_out [H][B].
+extern "C" int tbg_lstm_cell_fused_fwd_f32(const float *gx, const float *w, const float *stateT_in, float *hT_out, float *act,
+                                           float *cs, int steps, int B, int H, int K, int s, void *stream) {
+  if (!gx || !w || !stateT_in || !hT_out || !act || !cs || stateT_in == hT_out) return TBG_EINVAL;
+  if (!lstm_args_ok(1, steps, B, H, s) || K < 1) return TBG_EINVAL;
+  if (H % 32 != 0 || H > 1024 || K % LSF_CH != 0 || K > 2048) return TBG_EUNSUPPORTED;
+  LstmFusedP p{};
+  p.gx = gx; p.w = w; p.state_in = stateT_in; p.state_out = hT_out; p.act = act; p.cs = cs; p.seq = nullptr;
+  p.D = 1; p.T = steps; p.B = B; p.H = H; p.s = s; p.K = K; p.project = 1;
+  hipStream_t st = tbg_stream(stream);
+  switch (lstm_fused_bb(B)) {
+    case 4: return lstm_fused_launch<4, true>(p, st);
+    case 8: return lstm_fused_launch<8, true>(p, st);
+    default: return lstm_fused_launch<16, true>(p, st);
+  }
+}
+
+// outT [R][B] = Wt [R][J] applied to a transposed state: outT[r][b] = sum_j stateT[j][b] Wt[r][j] -- the GEMV of
+// lstm_fused_bwd_kernel without a cell behind it (the decoder's backward: rows = [d(context); recurrent part of d(hidden)]).
+struct RowsGemvP { const float *stateT, *w; float *outT; int J, R, B; };
+
+template <int BB>
+__global__ __launch_bounds__(LSF_THREADS) void rows_gemv_kernel(const RowsGemvP p) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  constexpr int JS = LSF_THREADS / LSF_UB;
+  const int J = p.J, B = p.B;
+  float *st = lsm, *part = lsm + (size_t)J * BB;
+  const int tid = threadIdx.x, r0 = blockIdx.x * LSF_UB, b0 = blockIdx.z * BB;
+  const int nb = min(BB, B - b0);
+  const int ul = tid & (LSF_UB - 1), js = tid / LSF_UB, NCH = J / LSF_CH;
+  const float *wrow = p.w + (size_t)min(r0 + ul, p.R - 1) * J;
+  float wv[LSF_CH];
+#pragma unroll
+  for (int i = 0; i < LSF_CH; i += 4) *reinterpret_cast<float4 *>(&wv[i]) = *reinterpret_cast<const float4 *>(wrow + min(js, NCH - 1) * LSF_CH + i);
+  lstm_stage_state<BB>(st, p.stateT, J, B, b0, nb, tid);
+  float acc[BB];
+#pragma unroll
+  for (int bb = 0; bb < BB; ++bb) acc[bb] = 0.f;
+  __syncthreads();
+  for (int ch = js; ch < NCH; ch += JS) {
+    if (ch != js) {
+#pragma unroll
+      for (int i = 0; i < LSF_CH; i += 4) *reinterpret_cast<float4 *>(&wv[i]) = *reinterpret_cast<const float4 *>(wrow + ch * LSF_CH + i);
+    }
+    lstm_chunk_fma<BB>(acc, wv, st + (size_t)ch * LSF_CH * BB);
+  }
+#pragma unroll
+  for (int bb = 0; bb < BB; bb += 4)
+    *reinterpret_cast<float4 *>(part + ((size_t)js * LSF_UB + ul) * BB + bb) = make_float4(acc[bb], acc[bb + 1], acc[bb + 2], acc[bb + 3]);
+  __syncthreads();
+  const int pb = tid / LSF_UB, pu = tid % LSF_UB;
+  if (tid < BB * LSF_UB && pb < nb && r0 + pu < p.R) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k2 = 0; k2 < JS; k2 += 4) {
+      a0 += part[((size_t)(k2 + 0) * LSF_UB + pu) * BB + pb]; a1 += part[((size_t)(k2 + 1) * LSF_UB + pu) * BB + pb];
+      a2 += part[((size_t)(k2 + 2) * LSF_UB + pu) * BB + pb]; a3 += part[((size_t)(k2 + 3) * LSF_UB + pu) * BB + pb];
+    }
+    p.outT[(size_t)(r0 + pu) * B + b0 + pb] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+template <int BB>
+static int rows_gemv_launch(const RowsGemvP &p, hipStream_t st) {
+  const size_t lds = ((size_t)p.J * BB + (size_t)LSF_THREADS * BB) * sizeof(float);
+  if (lds > 160 * 1024) return TBG_EUNSUPPORTED;
+  auto kern = rows_gemv_kernel<BB>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return TBG_EHIP;
+  hipLaunchKernelGGL(kern, dim3((p.R + LSF_UB - 1) / LSF_UB, 1, (p.B + BB - 1) / BB), dim3(LSF_THREADS), lds, st, p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+extern "C" int tbg_rows_gemv_t_f32(const float *stateT, const float *w, float *outT, int J, int R, int B, void *stream) {
+  if (!stateT || !w || !outT || J < 1 || R < 1 || B < 1) return TBG_EINVAL;
+  if (J % LSF_CH != 0) return TBG_EUNSUPPORTED;
+  const RowsGemvP p{stateT, w, outT, J, R, B};
+  hipStream_t st = tbg_stream(stream);
+  switch (lstm_fused_bb(B)) {
+    case 4: return rows_gemv_launch<4>(p, st);
+    case 8: return rows_gemv_launch<8>(p, st);
+    default: return rows_gemv_launch<16>(p, st);
+  }
+}
+
+// ============================================================================================
+// The decoder's per-SAMPLE halves of a step (one block per image), fused around the two launches above:
+//   forward  (after the cell of step s): logits[s] = b_o + h W_o^T, greedy symbol = argmax (first maximum, as torch), the next
+//            step's embedding row, its attention query q = b_d + h W_d^T, the attention context of attn_ctx_fwd_kernel -- and the
+//            context stored TRANSPOSED as the first E rows of the next cell launch's state.
+//   backward (after the rows launch of step s): attention backward of attn_ctx_bwd_kernel (d(enc_proj) accumulated, dq), dh of the
+//            step before = rows part + dq W_d + dl[s-1] W_o (precomputed), and that step's cell backward (lstm_step_bwd_kernel's
+//            arithmetic) writing its gate gradients transposed for the next rows launch.
+// Replaces, per step, 8 forward / 6 backward launches of library GEMMs, tbg_attn_ctx_*, tbg_lstm_step_* and torch index / argmax ops.
+// ============================================================================================
+struct DecFwdP {
+  const float *hT, *w_oT, *b_o, *w_dT, *b_d, *ep, *enc, *v, *etab;
+  float *logits, *gx_next, *q_out, *a_out, *ctxT_out;
+  int B, T, H, E, C, go;
+};
+
+__global__ __launch_bounds__(256) void dec_sample_fwd_kernel(const DecFwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int B = p.B, T = p.T, H = p.H, E = p.E, Cn = p.C;
+  float *hs = dsm, *qv = dsm + H, *lg = dsm + 2 * H;      // [H], [H], [C]
+  __shared__ float part[4][ATT_MAXT];
+  __shared__ float a_s[ATT_MAXT];
+  __shared__ int prev_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = tid; k < H; k += 256) hs[k] = p.hT ? p.hT[(size_t)k * B + b] : 0.f;
+  __syncthreads();
+  int prev = p.go;
+  if (p.logits) {
+    for (int c = tid; c < Cn; c += 256) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (int k = 0; k < H; k += 4) {
+        a0 += hs[k] * p.w_oT[(size_t)k * Cn + c]; a1 += hs[k + 1] * p.w_oT[(size_t)(k + 1) * Cn + c];
+        a2 += hs[k + 2] * p.w_oT[(size_t)(k + 2) * Cn + c]; a3 += hs[k + 3] * p.w_oT[(size_t)(k + 3) * Cn + c];
+      }
+      const float l = p.b_o[c] + ((a0 + a1) + (a2 + a3));
+      lg[c] = l;
+      p.logits[(size_t)b * Cn + c] = l;
+    }
+    __syncthreads();
+    if (wave == 0) {  // first maximum
+      float best = -3.4e38f;
+      int bi = 0x7fffffff;
+      for (int c = lane; c < Cn; c += 64)
+        if (lg[c] > best) { best = lg[c]; bi = c; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (lane == 0) prev_s = bi == 0x7fffffff ? 0 : bi;
+    }
+    __syncthreads();
+    prev = prev_s;
+  }
+  if (!p.gx_next) return;
+  for (int j = tid; j < 4 * H; j += 256) p.gx_next[(size_t)b * 4 * H + j] = p.etab[(size_t)prev * 4 * H + j];
+  for (int j = tid; j < H; j += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (p.hT)
+      for (int k = 0; k < H; k += 4) {
+        a0 += hs[k] * p.w_dT[(size_t)k * H + j]; a1 += hs[k + 1] * p.w_dT[(size_t)(k + 1) * H + j];
+        a2 += hs[k + 2] * p.w_dT[(size_t)(k + 2) * H + j]; a3 += hs[k + 3] * p.w_dT[(size_t)(k + 3) * H + j];
+      }
+    const float q = p.b_d[j] + ((a0 + a1) + (a2 + a3));
+    qv[j] = q;
+    p.q_out[(size_t)b * H + j] = q;
+  }
+  __syncthreads();
+  const float *epb = p.ep + (size_t)b * T * H;
+  for (int t = 0; t < T; ++t) {
+    float s = 0.f;
+    for (int k = tid; k < H; k += 256) s += p.v[k] * tanhf(epb[(size_t)t * H + k] + qv[k]);
+    s = wave_sum(s);
+    if (lane == 0) part[wave][t] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float e = lane < T ? part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane] : -3.0e38f;
+    float mx = e;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float ex = lane < T ? expf(e - mx) : 0.f;
+    const float den = wave_sum(ex);
+    if (lane < T) {
+      const float a = ex / den;
+      a_s[lane] = a;
+      p.a_out[(size_t)b * T + lane] = a;
+    }
+  }
+  __syncthreads();
+  const float *eb = p.enc + (size_t)b * T * E;
+  for (int j = tid; j < E; j += 256) {
+    float c = 0.f;
+    for (int t = 0; t < T; ++t) c += a_s[t] * eb[(size_t)t * E + j];
+    p.ctxT_out[(size_t)j * B + b] = c;
+  }
+}
+
+struct DecBwdP {
+  const float *dctxT, *dhpT, *a, *q, *ep, *enc, *v, *w_d, *dlo, *act, *cs_cur, *cs_prev;
+  float *dep, *dctx_out, *dc, *dgT_out;
+  int B, T, H, E, first;
+};
+
+__global__ __launch_bounds__(256) void dec_sample_bwd_kernel(const DecBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int B = p.B, T = p.T, H = p.H, E = p.E;
+  float *dcx = dsm, *dq_s = dsm + E;                       // [E], [H]
+  __shared__ float part[4][ATT_MAXT];
+  __shared__ float de_s[ATT_MAXT], a_s[ATT_MAXT];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool att = p.dctxT != nullptr;
+  if (att) {
+    for (int e = tid; e < E; e += 256) {
+      const float d = p.dctxT[(size_t)e * B + b];
+      dcx[e] = d;
+      p.dctx_out[(size_t)b * E + e] = d;
+    }
+    if (tid < T) a_s[tid] = p.a[(size_t)b * T + tid];
+    __syncthreads();
+    const float *eb = p.enc + (size_t)b * T * E;
+    for (int t = 0; t < T; ++t) {  // da[t] = <dctx, enc[t]>
+      float s = 0.f;
+      for (int j = tid; j < E; j += 256) s += dcx[j] * eb[(size_t)t * E + j];
+      s = wave_sum(s);
+      if (lane == 0) part[wave][t] = s;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const float da = lane < T ? part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane] : 0.f;
+      const float a = lane < T ? a_s[lane] : 0.f;
+      const float dot = wave_sum(a * da);
+      if (lane < T) de_s[lane] = a * (da - dot);
+    }
+    __syncthreads();
+    const float *epb = p.ep + (size_t)b * T * H;
+    for (int k = tid; k < H; k += 256) {
+      const float qk = p.q[(size_t)b * H + k], vk = p.v[k];
+      float acc = 0.f;
+      for (int t0 = 0; t0 < T; t0 += 8) {
+        float e8[8], o8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = min(t0 + u, T - 1);
+          e8[u] = epb[(size_t)t * H + k];
+          o8[u] = p.dep[((size_t)b * T + t) * H + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (t0 + u < T) {
+            const float th = tanhf(e8[u] + qk);
+            const float dp = de_s[t0 + u] * vk * (1.f - th * th);
+            p.dep[((size_t)b * T + t0 + u) * H + k] = o8[u] + dp;
+            acc += dp;
+          }
+        }
+      }
+      dq_s[k] = acc;
+    }
+    __syncthreads();
+  }
+  if (!p.act) return;
+  for (int u = tid; u < H; u += 256) {
+    float dh = p.dlo[(size_t)b * H + u];
+    if (att) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (int j = 0; j < H; j += 4) {
+        a0 += dq_s[j] * p.w_d[(size_t)j * H + u]; a1 += dq_s[j + 1] * p.w_d[(size_t)(j + 1) * H + u];
+        a2 += dq_s[j + 2] * p.w_d[(size_t)(j + 2) * H + u]; a3 += dq_s[j + 3] * p.w_d[(size_t)(j + 3) * H + u];
+      }
+      dh += p.dhpT[(size_t)u * B + b] + ((a0 + a1) + (a2 + a3));
+    }
+    const float *a = p.act + (size_t)b * 4 * H;
+    const float i_ = a[u], f_ = a[H + u], g_ = a[2 * H + u], o_ = a[3 * H + u];
+    const float c = p.cs_cur[(size_t)b * H + u];
+    const float cp = p.cs_prev ? p.cs_prev[(size_t)b * H + u] : 0.f;
+    const float tc = tanhf(c);
+    const float dcc = dh * o_ * (1.f - tc * tc) + (p.first ? 0.f : p.dc[(size_t)b * H + u]);
+    p.dc[(size_t)b * H + u] = dcc * f_;
+    p.dgT_out[(size_t)u * B + b] = dcc * g_ * i_ * (1.f - i_);
+    p.dgT_out[(size_t)(H + u) * B + b] = dcc * cp * f_ * (1.f - f_);
+    p.dgT_out[(size_t)(2 * H + u) * B + b] = dcc * i_ * (1.f - g_ * g_);
+    p.dgT_out[(size_t)(3 * H + u) * B + b] = dh * tc * o_ * (1.f - o_);
+  }
+}
+
+// forward half of a decoder step for every sample.  hT NULL: the initial launch (h = 0, symbol = go); logits NULL: no logits / argmax
+// (the initial launch); gx_next NULL: last step (only the logits).  Shapes in the DecFwdP comment above; H % 4 == 0, T <= 64.
+extern "C" int tbg_dec_sample_fwd_f32(const float *hT, const float *w_oT, const float *b_o, const float *w_dT, const float *b_d,
+                                      const float *enc_proj, const float *enc, const float *v, const float *etab, float *logits,
+                                      float *gx_next, float *q_out, float *a_out, float *ctxT_out, int B, int T, int H, int E, int C,
+                                      int go, void *stream) {
+  if (B < 1 || T < 1 || H < 1 || E < 1 || C < 1 || go < 0 || (!logits && !gx_next)) return TBG_EINVAL;
+  if (logits && (!hT || !w_oT || !b_o)) return TBG_EINVAL;
+  if (gx_next && (!w_dT || !b_d || !enc_proj || !enc || !v || !etab || !q_out || !a_out || !ctxT_out)) return TBG_EINVAL;
+  if (T > ATT_MAXT || (H & 3) != 0) return TBG_EUNSUPPORTED;
+  const DecFwdP p{hT, w_oT, b_o, w_dT, b_d, enc_proj, enc, v, etab, logits, gx_next, q_out, a_out, ctxT_out, B, T, H, E, C, go};
+  const size_t lds = ((size_t)2 * H + C) * sizeof(float);
+  if (lds > 48 * 1024) return TBG_EUNSUPPORTED;
+  hipLaunchKernelGGL(dec_sample_fwd_kernel, dim3(B), dim3(256), lds, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
+}
+
+// backward half of a decoder step for every sample: dctxT NULL: no attention part (the first launch of the backward pass);
+// act NULL: no cell part (the last).  first = 1: the cell part is the last step's (dc not read).
+extern "C" int tbg_dec_sample_bwd_f32(const float *dctxT, const float *dhpT, const float *a, const float *q, const float *enc_proj,
+                                      const float *enc, const float *v, const float *w_d, float *denc_proj, float *dctx_out,
+                                      const float *dlo, const float *act, const float *cs_cur, const float *cs_prev, float *dc,
+                                      float *dgT_out, int B, int T, int H, int E, int first, void *stream) {
+  if (B < 1 || T < 1 || H < 1 || E < 1 || (!dctxT && !act)) return TBG_EINVAL;
+  if (dctxT && (!a || !q || !enc_proj || !enc || !v || !denc_proj || !dctx_out)) return TBG_EINVAL;
+  if (act && (!dlo || !cs_cur || !dc || !dgT_out || (dctxT && (!dhpT || !w_d)))) return TBG_EINVAL;
+  if (T > ATT_MAXT || (H & 3) != 0) return TBG_EUNSUPPORTED;
+  const DecBwdP p{dctxT, dhpT, a, q, enc_proj, enc, v, w_d, dlo, act, cs_cur, cs_prev, denc_proj, dctx_out, dc, dgT_out, B, T, H, E, first};
+  const size_t lds = ((size_t)E + H) * sizeof(float);
+  if (lds > 48 * 1024) return TBG_EUNSUPPORTED;
+  hipLaunchKernelGGL(dec_sample_bwd_kernel, dim3(B), dim3(256), lds, tbg_stream(stream), p);
+  TBG_LAUNCH_CHECK();
+  return TBG_OK;
 }

@@ -25,7 +25,7 @@ EXPORTS = [
     "tbg_upfirdn2d_kernel_name", "tbg_upfirdn2d_f16", "tbg_weight_pack_x3_bytes", "tbg_weight_pack_x3", "tbg_conv2d_x3", "tbg_conv2d_x3_kernel_name", "tbg_conv2d_x3_variant", "tbg_conv2d_wgrad_x3", "tbg_conv2d_wgrad_x3_kernel_name", "tbg_conv2d_dot_slots", "tbg_conv2d_blocks", "tbg_units_bytes", "tbg_units_pack_f32",
     "tbg_conv2d_wgrad_units", "tbg_conv2d_wgrad_units_workspace_bytes", "tbg_conv2d_units", "tbg_conv2d_units_dot_slots", "tbg_conv2d_units_blocks", "tbg_conv2d_units_tile_channels", "tbg_bias_act_bwd_units", "tbg_bias_act_bwd_units_chunks",
     "tbg_units_s2_bytes", "tbg_units_pack_s2_f32", "tbg_upfirdn2d_units_s2_f32", "tbg_conv2d_units_s2_blocks", "tbg_conv2d_units_s2_tile_channels", "tbg_conv2d_units_s2_dot_slots", "tbg_conv2d_units_s2", "tbg_conv2d_wgrad_units_s2_workspace_bytes", "tbg_conv2d_wgrad_units_s2", "tbg_conv2d_units_t2_blocks", "tbg_conv2d_units_t2",
-    "tbg_slab_epilogue_units_f32", "tbg_conv2d_units_small", "tbg_conv2d_units_small_blocks", "tbg_conv2d_units_small_dot_slots", "tbg_conv2d_units_small_tile_pixels", "tbg_lstm_fused_fwd_f32", "tbg_lstm_fused_bwd_f32",
+    "tbg_slab_epilogue_units_f32", "tbg_conv2d_units_small", "tbg_conv2d_units_small_blocks", "tbg_conv2d_units_small_dot_slots", "tbg_conv2d_units_small_tile_pixels", "tbg_lstm_fused_fwd_f32", "tbg_lstm_fused_bwd_f32", "tbg_lstm_cell_fused_fwd_f32", "tbg_rows_gemv_t_f32", "tbg_dec_sample_fwd_f32", "tbg_dec_sample_bwd_f32",
     "tbg_bias_act_bwd_f32", "tbg_axpby_planes_f32", "tbg_bias_act_bwd2_f32", "tbg_rgb_project_f32", "tbg_rgb_backproject_f32", "tbg_rgb_backproject_chunks", "tbg_adam_tf_f32", "tbg_ema_lerp_f32", "tbg_demod_coefs_f32",
 ]
 
@@ -97,6 +97,10 @@ def lib():
         l.tbg_lstm_step_fwd_f32.argtypes = [vp] * 6 + [ci] * 5 + [vp]
         l.tbg_lstm_fused_fwd_f32.argtypes = [vp] * 7 + [ci] * 5 + [vp]
         l.tbg_lstm_fused_bwd_f32.argtypes = [vp] * 8 + [ci] * 6 + [vp]
+        l.tbg_lstm_cell_fused_fwd_f32.argtypes = [vp] * 6 + [ci] * 5 + [vp]
+        l.tbg_rows_gemv_t_f32.argtypes = [vp] * 3 + [ci] * 3 + [vp]
+        l.tbg_dec_sample_fwd_f32.argtypes = [vp] * 14 + [ci] * 6 + [vp]
+        l.tbg_dec_sample_bwd_f32.argtypes = [vp] * 16 + [ci] * 5 + [vp]
         l.tbg_lstm_step_bwd_f32.argtypes = [vp] * 7 + [ci] * 6 + [vp]
         l.tbg_attn_ctx_fwd_f32.argtypes = [vp] * 6 + [ci] * 4 + [vp]
         l.tbg_attn_ctx_bwd_f32.argtypes = [vp] * 9 + [ci] * 4 + [vp]

@@ -126,6 +126,8 @@ class _Tuning:
         self.fuse_skip_grad = True   # DiscriminatorBlock: conv_0 + skip FIR as ONE node (False = two nodes + the engine's add)
         self.use_fused2 = True       # path-length pass on the twice-differentiable node pairs of ops2 (False = composable primitives)
         # ---- recurrent layers of the frozen recogniser
+        self.fused_decoder = True    # two launches per decoder step and direction of the pass (tbg.h: cell over [context; hidden] + the
+                                     # per-sample half) instead of 8 / 6 library-GEMM, attention, cell and index launches
         self.fused_lstm = True       # one launch per BiLSTM step (tbg_lstm_fused_*: projection + cell) instead of a library GEMM + a
                                      # pointwise launch
         # ---- dense layers
@@ -2331,6 +2333,8 @@ class FrozenDecoderWeights(NamedTuple):
     w_o: torch.Tensor
     w_oT: torch.Tensor
     b_o: torch.Tensor
+    w_cat: Optional[torch.Tensor] = None   # [4H, E + H] = [w_ctx | w_hh]: the cell's weights over its input [context; hidden]
+    w_catT: Optional[torch.Tensor] = None  # [E + H, 4H]: its transpose (the fused backward steps)
 
 
 class _FrozenAttnDecoder(torch.autograd.Function):
@@ -2349,27 +2353,48 @@ class _FrozenAttnDecoder(torch.autograd.Function):
         ep = torch.matmul(enc, W.w_enc.t())  # [B,T,H]
         qs = torch.empty((steps, B, H), **f32)
         a_all = torch.empty((steps, B, T), **f32)
-        ctxs = torch.empty((steps, B, E), **f32)
         gbuf = torch.empty((1, steps, B, 4 * H), **f32)   # gate pre-activations, the layout tbg_lstm_step_fwd reads
         act = torch.empty((1, steps, B, 4 * H), **f32)
         cs = torch.empty((1, steps, B, H), **f32)
-        h = torch.zeros((1, B, H), **f32)
         lbuf = torch.empty((steps, B, Cn), **f32)
-        prev = torch.full((B,), go, dtype=torch.long, device=dev)
-        for s in range(steps):
-            torch.addmm(W.b_d, h[0], W.w_dT, out=qs[s])
-            N.check(N.lib().tbg_attn_ctx_fwd_f32(N.ptr(qs[s]), N.ptr(ep), N.ptr(enc), N.ptr(W.v), N.ptr(ctxs[s]),
-                                                 N.ptr(a_all[s]), B, T, H, E, N.stream()), "tbg_attn_ctx_fwd")
-            # gates = etab[prev] + ctx @ w_ctx^T + h @ w_hh^T, accumulated IN PLACE in the buffer the cell kernel reads (addmm with a
-            # full-matrix `self` first copies it into the result: two device copies per step)
-            gs = gbuf[0, s]
-            torch.index_select(W.etab, 0, prev, out=gs)
-            gs.addmm_(ctxs[s], W.w_ctxT)
-            gs.addmm_(h[0], W.w_hhT)
-            N.check(N.lib().tbg_lstm_step_fwd_f32(N.ptr(gbuf), None, N.ptr(act), N.ptr(cs), N.ptr(h), None, 1, steps, B, H, s,
-                                                  N.stream()), "tbg_lstm_step_fwd")
-            torch.addmm(W.b_o, h[0], W.w_oT, out=lbuf[s])
-            prev = lbuf[s].argmax(dim=1)  # greedy feedback (non-differentiable, as in the TF decoder)
+        fused = (TUNING.fused_decoder and W.w_cat is not None and H % 32 == 0 and (E + H) % 16 == 0 and T <= 64)
+        ctx.fused = fused
+        if fused:
+            # two launches per step (tbg.h): the cell over [context; hidden] for every sample, then the per-sample half (logits,
+            # greedy symbol, next embedding row, next query, next attention context); the state travels transposed
+            K = E + H
+            stT = torch.zeros((2, K, B), **f32)  # [context^T; hidden^T] of the step about to run, alternating
+            L = N.lib()
+            samp = lambda hT, lg, gxn, s1, out: N.check(PROFILE.launch("dec_sample_fwd_kernel", 0.0, lambda: L.tbg_dec_sample_fwd_f32(
+                N.ptr(hT), N.ptr(W.w_oT), N.ptr(W.b_o), N.ptr(W.w_dT), N.ptr(W.b_d), N.ptr(ep), N.ptr(enc), N.ptr(W.v), N.ptr(W.etab),
+                N.ptr(lg), N.ptr(gxn), N.ptr(qs[s1]) if gxn is not None else None, N.ptr(a_all[s1]) if gxn is not None else None,
+                N.ptr(out[:E]) if gxn is not None else None, B, T, H, E, Cn, int(go), N.stream())), "tbg_dec_sample_fwd")
+            samp(None, None, gbuf[0, 0], 0, stT[0])
+            for s in range(steps):
+                cur, nxt = stT[s & 1], stT[(s + 1) & 1]
+                N.check(PROFILE.launch("lstm_fused_fwd_kernel", 2.0 * B * 4 * H * K, lambda: L.tbg_lstm_cell_fused_fwd_f32(
+                    N.ptr(gbuf), N.ptr(W.w_cat), N.ptr(cur), N.ptr(nxt[E:]), N.ptr(act), N.ptr(cs), steps, B, H, K, s, N.stream())),
+                    "tbg_lstm_cell_fused_fwd")
+                last = s == steps - 1
+                samp(nxt[E:], lbuf[s], None if last else gbuf[0, s + 1], min(s + 1, steps - 1), nxt)
+        else:
+            ctxs = torch.empty((steps, B, E), **f32)
+            h = torch.zeros((1, B, H), **f32)
+            prev = torch.full((B,), go, dtype=torch.long, device=dev)
+            for s in range(steps):
+                torch.addmm(W.b_d, h[0], W.w_dT, out=qs[s])
+                N.check(N.lib().tbg_attn_ctx_fwd_f32(N.ptr(qs[s]), N.ptr(ep), N.ptr(enc), N.ptr(W.v), N.ptr(ctxs[s]),
+                                                     N.ptr(a_all[s]), B, T, H, E, N.stream()), "tbg_attn_ctx_fwd")
+                # gates = etab[prev] + ctx @ w_ctx^T + h @ w_hh^T, accumulated IN PLACE in the buffer the cell kernel reads (addmm with a
+                # full-matrix `self` first copies it into the result: two device copies per step)
+                gs = gbuf[0, s]
+                torch.index_select(W.etab, 0, prev, out=gs)
+                gs.addmm_(ctxs[s], W.w_ctxT)
+                gs.addmm_(h[0], W.w_hhT)
+                N.check(N.lib().tbg_lstm_step_fwd_f32(N.ptr(gbuf), None, N.ptr(act), N.ptr(cs), N.ptr(h), None, 1, steps, B, H, s,
+                                                      N.stream()), "tbg_lstm_step_fwd")
+                torch.addmm(W.b_o, h[0], W.w_oT, out=lbuf[s])
+                prev = lbuf[s].argmax(dim=1)  # greedy feedback (non-differentiable, as in the TF decoder)
         ctx.save_for_backward(enc, ep, qs, a_all, act, cs)
         ctx.W, ctx.dims = W, (B, T, E, H, Cn, steps)
         return lbuf.transpose(0, 1)
@@ -2385,25 +2410,47 @@ class _FrozenAttnDecoder(torch.autograd.Function):
         dl = dlogits.transpose(0, 1).contiguous()  # [S,B,C]
         dep = torch.zeros((B, T, H), **f32)
         dctxs = torch.empty((steps, B, E), **f32)
-        dgates = torch.empty((1, B, 4 * H), **f32)
-        dc = torch.empty((1, B, H), **f32)
-        dq = torch.empty((B, H), **f32)
-        dh = torch.empty((1, B, H), **f32)
-        dh_next = None
-        for s in range(steps - 1, -1, -1):
-            if dh_next is None:
-                torch.mm(dl[s], W.w_o, out=dh[0])
-            else:  # dh = dh_next + dl[s] @ w_o, in place in dh_next's buffer (no copy into a second one)
-                dh_next.addmm_(dl[s], W.w_o)
-                dh = dh_next.view(1, B, H)
-            N.check(N.lib().tbg_lstm_step_bwd_f32(None, N.ptr(dh), N.ptr(dc), N.ptr(act), N.ptr(cs), None, N.ptr(dgates), 1,
-                                                  steps, B, H, s, int(s == steps - 1), N.stream()), "tbg_lstm_step_bwd")
-            torch.mm(dgates[0], W.w_ctx, out=dctxs[s])
-            N.check(N.lib().tbg_attn_ctx_bwd_f32(N.ptr(dctxs[s]), N.ptr(a_all[s]), N.ptr(qs[s]), N.ptr(ep), N.ptr(enc), N.ptr(W.v),
-                                                 N.ptr(dq), N.ptr(dep), None, B, T, H, E, N.stream()),
-                    "tbg_attn_ctx_bwd")
-            if s > 0:  # h_{s-1} feeds the cell (W_hh) and the attention query (att_dec)
-                dh_next = torch.mm(dgates[0], W.w_hh).addmm_(dq, W.w_d)
+        if ctx.fused:
+            K = E + H
+            dlo = torch.mm(dl.view(steps * B, Cn), W.w_o).view(steps, B, H)  # d(hidden) through the logits, every step at once
+            dc = torch.empty((B, H), **f32)
+            dgT = torch.empty((4 * H, B), **f32)
+            outT = torch.empty((K, B), **f32)
+            L = N.lib()
+
+            def samp(s, att, cell_s, first):  # attention part of step s (att) + cell part of step cell_s (or None)
+                c = cell_s
+                N.check(PROFILE.launch("dec_sample_bwd_kernel", 0.0, lambda: L.tbg_dec_sample_bwd_f32(
+                    N.ptr(outT[:E]) if att else None, N.ptr(outT[E:]) if att else None, N.ptr(a_all[s]), N.ptr(qs[s]), N.ptr(ep),
+                    N.ptr(enc), N.ptr(W.v), N.ptr(W.w_d), N.ptr(dep), N.ptr(dctxs[s]),
+                    N.ptr(dlo[c]) if c is not None else None, N.ptr(act[0, c]) if c is not None else None,
+                    N.ptr(cs[0, c]) if c is not None else None, N.ptr(cs[0, c - 1]) if (c is not None and c > 0) else None,
+                    N.ptr(dc), N.ptr(dgT), B, T, H, E, int(first), N.stream())), "tbg_dec_sample_bwd")
+            samp(steps - 1, False, steps - 1, True)
+            for s in range(steps - 1, -1, -1):
+                N.check(PROFILE.launch("rows_gemv_kernel", 2.0 * B * 4 * H * K, lambda: L.tbg_rows_gemv_t_f32(
+                    N.ptr(dgT), N.ptr(W.w_catT), N.ptr(outT), 4 * H, K, B, N.stream())), "tbg_rows_gemv_t")
+                samp(s, True, s - 1 if s > 0 else None, False)
+        else:
+            dgates = torch.empty((1, B, 4 * H), **f32)
+            dc = torch.empty((1, B, H), **f32)
+            dq = torch.empty((B, H), **f32)
+            dh = torch.empty((1, B, H), **f32)
+            dh_next = None
+            for s in range(steps - 1, -1, -1):
+                if dh_next is None:
+                    torch.mm(dl[s], W.w_o, out=dh[0])
+                else:  # dh = dh_next + dl[s] @ w_o, in place in dh_next's buffer (no copy into a second one)
+                    dh_next.addmm_(dl[s], W.w_o)
+                    dh = dh_next.view(1, B, H)
+                N.check(N.lib().tbg_lstm_step_bwd_f32(None, N.ptr(dh), N.ptr(dc), N.ptr(act), N.ptr(cs), None, N.ptr(dgates), 1,
+                                                      steps, B, H, s, int(s == steps - 1), N.stream()), "tbg_lstm_step_bwd")
+                torch.mm(dgates[0], W.w_ctx, out=dctxs[s])
+                N.check(N.lib().tbg_attn_ctx_bwd_f32(N.ptr(dctxs[s]), N.ptr(a_all[s]), N.ptr(qs[s]), N.ptr(ep), N.ptr(enc), N.ptr(W.v),
+                                                     N.ptr(dq), N.ptr(dep), None, B, T, H, E, N.stream()),
+                        "tbg_attn_ctx_bwd")
+                if s > 0:  # h_{s-1} feeds the cell (W_hh) and the attention query (att_dec)
+                    dh_next = torch.mm(dgates[0], W.w_hh).addmm_(dq, W.w_d)
         # d(enc) through the context sums: sum_s a_s (x) dctx_s as ONE batched GEMM over the images, + through enc_proj
         denc = torch.bmm(a_all.permute(1, 2, 0), dctxs.permute(1, 0, 2))  # [B,T,S] @ [B,S,E]
         denc.view(B * T, E).addmm_(dep.view(B * T, H), W.w_enc)

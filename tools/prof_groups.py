@@ -15,7 +15,7 @@ def family(n):
     if "bias_act" in n: return "tbg bias_act"
     if "rgb_" in n: return "tbg rgb"
     if "slab_epilogue" in n: return "tbg split-K epilogue"
-    if "lstm_step" in n or "attn_ctx" in n: return "tbg OCR recurrent (lstm_step / attn_ctx)"
+    if "lstm_step" in n or "lstm_fused" in n or "attn_ctx" in n or "dec_" in n: return "tbg OCR recurrent (lstm_step / attn_ctx)"
     if "dense_" in n or "smalls" in n or "mbstd" in n: return "tbg small-tensor kernels (dense / tails / mbstd)"
     if "weight_pack" in n or "weight_transpose" in n or "demod" in n or "wsq" in n or "adam" in n or "ema_" in n or "axpby" in n: return "tbg misc (pack/demod/adam/ema)"
     if n.startswith("Cijk") or "gemm" in n.lower(): return "rocBLAS/hipBLASLt GEMM"
