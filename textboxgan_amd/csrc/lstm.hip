@@ -600,25 +600,42 @@ struct DecFwdP {
   int B, T, H, E, C, go;
 };
 
-__global__ __launch_bounds__(256) void dec_sample_fwd_kernel(const DecFwdP p) {
+// 1024 threads per sample: every matvec is split over K as well, its weights fetched as ONE batch of independent loads per thread
+// (the first version -- 256 threads walking K in a loop of load / multiply-add pairs -- paid one memory round trip per iteration:
+// 27 us per launch).
+#define DEC_THREADS 1024
+__global__ __launch_bounds__(DEC_THREADS) void dec_sample_fwd_kernel(const DecFwdP p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int B = p.B, T = p.T, H = p.H, E = p.E, Cn = p.C;
   float *hs = dsm, *qv = dsm + H, *lg = dsm + 2 * H;      // [H], [H], [C]
-  __shared__ float part[4][ATT_MAXT];
+  float *scr = dsm + 2 * H + Cn;                           // partial sums: max(8 C, 4 H, 2 E) floats
+  __shared__ float part[16][ATT_MAXT];
   __shared__ float a_s[ATT_MAXT];
   __shared__ int prev_s;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int k = tid; k < H; k += 256) hs[k] = p.hT ? p.hT[(size_t)k * B + b] : 0.f;
+  for (int k = tid; k < H; k += DEC_THREADS) hs[k] = p.hT ? p.hT[(size_t)k * B + b] : 0.f;
   __syncthreads();
-  int prev = p.go;
+  const bool nxt = p.gx_next != nullptr;
+  // ---- logits partials (8 K slices) and query partials (4 K slices): all weight loads of a thread in flight together
+  const int KL = H / 8, KQ = H / 4;  // (H % 32 == 0 checked on the host)
   if (p.logits) {
-    for (int c = tid; c < Cn; c += 256) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      for (int k = 0; k < H; k += 4) {
-        a0 += hs[k] * p.w_oT[(size_t)k * Cn + c]; a1 += hs[k + 1] * p.w_oT[(size_t)(k + 1) * Cn + c];
-        a2 += hs[k + 2] * p.w_oT[(size_t)(k + 2) * Cn + c]; a3 += hs[k + 3] * p.w_oT[(size_t)(k + 3) * Cn + c];
+    const int c0 = tid & 127, ks = tid >> 7;
+    for (int c = c0; c < Cn; c += 128) {
+      float acc = 0.f;
+      for (int k0 = ks * KL; k0 < (ks + 1) * KL; k0 += 32) {
+        float w[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) w[i] = p.w_oT[(size_t)(k0 + i) * Cn + c];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc += hs[k0 + i] * w[i];
       }
-      const float l = p.b_o[c] + ((a0 + a1) + (a2 + a3));
+      scr[ks * Cn + c] = acc;
+    }
+    __syncthreads();
+    for (int c = tid; c < Cn; c += DEC_THREADS) {
+      float l = p.b_o[c];
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) l += scr[k2 * Cn + c];
       lg[c] = l;
       p.logits[(size_t)b * Cn + c] = l;
     }
@@ -636,29 +653,52 @@ __global__ __launch_bounds__(256) void dec_sample_fwd_kernel(const DecFwdP p) {
       }
       if (lane == 0) prev_s = bi == 0x7fffffff ? 0 : bi;
     }
-    __syncthreads();
-    prev = prev_s;
   }
-  if (!p.gx_next) return;
-  for (int j = tid; j < 4 * H; j += 256) p.gx_next[(size_t)b * 4 * H + j] = p.etab[(size_t)prev * 4 * H + j];
-  for (int j = tid; j < H; j += 256) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (p.hT)
-      for (int k = 0; k < H; k += 4) {
-        a0 += hs[k] * p.w_dT[(size_t)k * H + j]; a1 += hs[k + 1] * p.w_dT[(size_t)(k + 1) * H + j];
-        a2 += hs[k + 2] * p.w_dT[(size_t)(k + 2) * H + j]; a3 += hs[k + 3] * p.w_dT[(size_t)(k + 3) * H + j];
-      }
-    const float q = p.b_d[j] + ((a0 + a1) + (a2 + a3));
+  if (!nxt) return;
+  {
+    const int j0 = tid & 255, ks = tid >> 8;
+    for (int j = j0; j < H; j += 256) {
+      float acc = 0.f;
+      if (p.hT)
+        for (int k0 = ks * KQ; k0 < (ks + 1) * KQ; k0 += 32) {
+          float w[32];
+#pragma unroll
+          for (int i = 0; i < 32; ++i) w[i] = p.w_dT[(size_t)(k0 + i) * H + j];
+#pragma unroll
+          for (int i = 0; i < 32; ++i) acc += hs[k0 + i] * w[i];
+        }
+      scr[8 * Cn + ks * H + j] = acc;
+    }
+  }
+  __syncthreads();  // (also orders prev_s)
+  const int prev = p.logits ? prev_s : p.go;
+  for (int j = tid; j < 4 * H; j += DEC_THREADS) p.gx_next[(size_t)b * 4 * H + j] = p.etab[(size_t)prev * 4 * H + j];
+  for (int j = tid; j < H; j += DEC_THREADS) {
+    const float q = p.b_d[j] + ((scr[8 * Cn + j] + scr[8 * Cn + H + j]) + (scr[8 * Cn + 2 * H + j] + scr[8 * Cn + 3 * H + j]));
     qv[j] = q;
     p.q_out[(size_t)b * H + j] = q;
   }
   __syncthreads();
-  const float *epb = p.ep + (size_t)b * T * H;
-  for (int t = 0; t < T; ++t) {
-    float s = 0.f;
-    for (int k = tid; k < H; k += 256) s += p.v[k] * tanhf(epb[(size_t)t * H + k] + qv[k]);
-    s = wave_sum(s);
-    if (lane == 0) part[wave][t] = s;
+  // ---- attention energies: thread (k, t residue): the T / 4 time steps of its residue class, loads first
+  {
+    const float *epb = p.ep + (size_t)b * T * H;
+    const int tq = tid >> 8, k = tid & 255;  // 4 residue classes of t (1024 threads / 256 columns; H <= 256 checked on the host)
+    const bool kok = k < H;
+    float e[(ATT_MAXT + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (ATT_MAXT + 3) / 4; ++i) {
+      const int t = tq + 4 * i;
+      e[i] = (kok && t < T) ? epb[(size_t)t * H + k] : 0.f;
+    }
+    const float vk = kok ? p.v[k] : 0.f, qk = kok ? qv[k] : 0.f;
+#pragma unroll
+    for (int i = 0; i < (ATT_MAXT + 3) / 4; ++i) {
+      const int t = tq + 4 * i;  // (uniform in a wave)
+      if (t < T) {
+        const float sgm = wave_sum(vk * tanhf(e[i] + qk));
+        if (lane == 0) part[wave & 3][t] = sgm;
+      }
+    }
   }
   __syncthreads();
   if (wave == 0) {
@@ -675,11 +715,30 @@ __global__ __launch_bounds__(256) void dec_sample_fwd_kernel(const DecFwdP p) {
     }
   }
   __syncthreads();
-  const float *eb = p.enc + (size_t)b * T * E;
-  for (int j = tid; j < E; j += 256) {
-    float c = 0.f;
-    for (int t = 0; t < T; ++t) c += a_s[t] * eb[(size_t)t * E + j];
-    p.ctxT_out[(size_t)j * B + b] = c;
+  // ---- context: thread (column j, half of the time steps)
+  {
+    const float *eb = p.enc + (size_t)b * T * E;
+    const int th = tid >> 9, TH = (T + 1) / 2;
+    float *cp = scr;  // [2][E]
+    for (int j = tid & 511; j < E; j += 512) {
+      float c = 0.f;
+      for (int i0 = 0; i0 < TH; i0 += 8) {  // eight loads in flight
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int t = th * TH + i0 + i;
+          x[i] = (i0 + i < TH && t < T) ? eb[(size_t)t * E + j] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int t = th * TH + i0 + i;
+          if (i0 + i < TH && t < T) c += a_s[t] * x[i];
+        }
+      }
+      cp[th * E + j] = c;
+    }
+    __syncthreads();
+    for (int j = tid; j < E; j += DEC_THREADS) p.ctxT_out[(size_t)j * B + b] = cp[j] + cp[E + j];
   }
 }
 
@@ -689,74 +748,109 @@ struct DecBwdP {
   int B, T, H, E, first;
 };
 
-__global__ __launch_bounds__(256) void dec_sample_bwd_kernel(const DecBwdP p) {
+__global__ __launch_bounds__(DEC_THREADS) void dec_sample_bwd_kernel(const DecBwdP p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int B = p.B, T = p.T, H = p.H, E = p.E;
-  float *dcx = dsm, *dq_s = dsm + E;                       // [E], [H]
-  __shared__ float part[4][ATT_MAXT];
+  float *dcx = dsm, *dq_s = dsm + E, *scr = dsm + E + H;   // [E], [H], partial sums: 4 H floats
+  __shared__ float part[16][ATT_MAXT];
   __shared__ float de_s[ATT_MAXT], a_s[ATT_MAXT];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool att = p.dctxT != nullptr;
   if (att) {
-    for (int e = tid; e < E; e += 256) {
+    for (int e = tid; e < E; e += DEC_THREADS) {
       const float d = p.dctxT[(size_t)e * B + b];
       dcx[e] = d;
       p.dctx_out[(size_t)b * E + e] = d;
     }
     if (tid < T) a_s[tid] = p.a[(size_t)b * T + tid];
     __syncthreads();
-    const float *eb = p.enc + (size_t)b * T * E;
-    for (int t = 0; t < T; ++t) {  // da[t] = <dctx, enc[t]>
-      float s = 0.f;
-      for (int j = tid; j < E; j += 256) s += dcx[j] * eb[(size_t)t * E + j];
-      s = wave_sum(s);
-      if (lane == 0) part[wave][t] = s;
+    {  // da[t] = <dctx, enc[t]>: thread (column j, half of the time steps), loads first, one wave reduction per time step
+      const float *eb = p.enc + (size_t)b * T * E;
+      const int th = tid >> 9, TH = (T + 1) / 2;
+      for (int i0 = 0; i0 < TH; i0 += 8) {  // eight time steps at a time: loads first, one wave reduction per time step
+        float da[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) da[i] = 0.f;
+        for (int j = tid & 511; j < E; j += 512) {
+          float x[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int t = th * TH + i0 + i;
+            x[i] = (i0 + i < TH && t < T) ? eb[(size_t)t * E + j] : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) da[i] += dcx[j] * x[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float r = wave_sum(da[i]);
+          const int t = th * TH + i0 + i;
+          if (lane == 0 && i0 + i < TH && t < T) part[wave & 7][t] = r;  // (8 waves per half)
+        }
+      }
     }
     __syncthreads();
     if (wave == 0) {
-      const float da = lane < T ? part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane] : 0.f;
+      float da = 0.f;
+      if (lane < T)
+#pragma unroll
+        for (int w2 = 0; w2 < 8; ++w2) da += part[w2][lane];
       const float a = lane < T ? a_s[lane] : 0.f;
       const float dot = wave_sum(a * da);
       if (lane < T) de_s[lane] = a * (da - dot);
     }
     __syncthreads();
-    const float *epb = p.ep + (size_t)b * T * H;
-    for (int k = tid; k < H; k += 256) {
-      const float qk = p.q[(size_t)b * H + k], vk = p.v[k];
-      float acc = 0.f;
-      for (int t0 = 0; t0 < T; t0 += 8) {
-        float e8[8], o8[8];
+    {  // d(enc_proj) accumulated, dq: thread (column k, residue class of t)
+      const float *epb = p.ep + (size_t)b * T * H;
+      const int tq = tid >> 8;
+      for (int k = tid & 255; k < H; k += 256) {
+        const float qk = p.q[(size_t)b * H + k], vk = p.v[k];
+        float acc = 0.f;
+        for (int i0 = 0; tq + 4 * i0 < T; i0 += 8) {  // eight read-modify-writes in flight
+          float e8[8], o8[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int t = min(t0 + u, T - 1);
-          e8[u] = epb[(size_t)t * H + k];
-          o8[u] = p.dep[((size_t)b * T + t) * H + k];
-        }
+          for (int i = 0; i < 8; ++i) {
+            const int t = min(tq + 4 * (i0 + i), T - 1);
+            e8[i] = epb[(size_t)t * H + k];
+            o8[i] = p.dep[((size_t)b * T + t) * H + k];
+          }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (t0 + u < T) {
-            const float th = tanhf(e8[u] + qk);
-            const float dp = de_s[t0 + u] * vk * (1.f - th * th);
-            p.dep[((size_t)b * T + t0 + u) * H + k] = o8[u] + dp;
-            acc += dp;
+          for (int i = 0; i < 8; ++i) {
+            const int t = tq + 4 * (i0 + i);
+            if (t < T) {
+              const float th = tanhf(e8[i] + qk);
+              const float dp = de_s[t] * vk * (1.f - th * th);
+              p.dep[((size_t)b * T + t) * H + k] = o8[i] + dp;
+              acc += dp;
+            }
           }
         }
+        scr[tq * H + k] = acc;
       }
-      dq_s[k] = acc;
     }
+    __syncthreads();
+    for (int k = tid; k < H; k += DEC_THREADS) dq_s[k] = (scr[k] + scr[H + k]) + (scr[2 * H + k] + scr[3 * H + k]);
     __syncthreads();
   }
   if (!p.act) return;
-  for (int u = tid; u < H; u += 256) {
-    float dh = p.dlo[(size_t)b * H + u];
-    if (att) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      for (int j = 0; j < H; j += 4) {
-        a0 += dq_s[j] * p.w_d[(size_t)j * H + u]; a1 += dq_s[j + 1] * p.w_d[(size_t)(j + 1) * H + u];
-        a2 += dq_s[j + 2] * p.w_d[(size_t)(j + 2) * H + u]; a3 += dq_s[j + 3] * p.w_d[(size_t)(j + 3) * H + u];
+  if (att) {  // dq W_d: thread (column u, quarter of the rows), the rows' weights as batches of independent loads
+    const int KQ = H / 4, js = tid >> 8;
+    for (int u = tid & 255; u < H; u += 256) {
+      float acc = 0.f;
+      for (int j0 = js * KQ; j0 < (js + 1) * KQ; j0 += 16) {
+        float w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = p.w_d[(size_t)(j0 + i) * H + u];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += dq_s[j0 + i] * w[i];
       }
-      dh += p.dhpT[(size_t)u * B + b] + ((a0 + a1) + (a2 + a3));
+      scr[js * H + u] = acc;
     }
+    __syncthreads();
+  }
+  for (int u = tid; u < H; u += DEC_THREADS) {
+    float dh = p.dlo[(size_t)b * H + u];
+    if (att) dh += p.dhpT[(size_t)u * B + b] + ((scr[u] + scr[H + u]) + (scr[2 * H + u] + scr[3 * H + u]));
     const float *a = p.act + (size_t)b * 4 * H;
     const float i_ = a[u], f_ = a[H + u], g_ = a[2 * H + u], o_ = a[3 * H + u];
     const float c = p.cs_cur[(size_t)b * H + u];
@@ -780,11 +874,12 @@ extern "C" int tbg_dec_sample_fwd_f32(const float *hT, const float *w_oT, const 
   if (B < 1 || T < 1 || H < 1 || E < 1 || C < 1 || go < 0 || (!logits && !gx_next)) return TBG_EINVAL;
   if (logits && (!hT || !w_oT || !b_o)) return TBG_EINVAL;
   if (gx_next && (!w_dT || !b_d || !enc_proj || !enc || !v || !etab || !q_out || !a_out || !ctxT_out)) return TBG_EINVAL;
-  if (T > ATT_MAXT || (H & 3) != 0) return TBG_EUNSUPPORTED;
+  if (T > ATT_MAXT || (H & 31) != 0 || H > 256 || E > 512 * 8) return TBG_EUNSUPPORTED;
   const DecFwdP p{hT, w_oT, b_o, w_dT, b_d, enc_proj, enc, v, etab, logits, gx_next, q_out, a_out, ctxT_out, B, T, H, E, C, go};
-  const size_t lds = ((size_t)2 * H + C) * sizeof(float);
+  const size_t scr = (size_t)8 * C + 4 * H > (size_t)2 * E ? (size_t)8 * C + 4 * H : (size_t)2 * E;
+  const size_t lds = ((size_t)2 * H + C + scr) * sizeof(float);
   if (lds > 48 * 1024) return TBG_EUNSUPPORTED;
-  hipLaunchKernelGGL(dec_sample_fwd_kernel, dim3(B), dim3(256), lds, tbg_stream(stream), p);
+  hipLaunchKernelGGL(dec_sample_fwd_kernel, dim3(B), dim3(DEC_THREADS), lds, tbg_stream(stream), p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
@@ -798,11 +893,11 @@ extern "C" int tbg_dec_sample_bwd_f32(const float *dctxT, const float *dhpT, con
   if (B < 1 || T < 1 || H < 1 || E < 1 || (!dctxT && !act)) return TBG_EINVAL;
   if (dctxT && (!a || !q || !enc_proj || !enc || !v || !denc_proj || !dctx_out)) return TBG_EINVAL;
   if (act && (!dlo || !cs_cur || !dc || !dgT_out || (dctxT && (!dhpT || !w_d)))) return TBG_EINVAL;
-  if (T > ATT_MAXT || (H & 3) != 0) return TBG_EUNSUPPORTED;
+  if (T > ATT_MAXT || (H & 31) != 0 || H > 256) return TBG_EUNSUPPORTED;
   const DecBwdP p{dctxT, dhpT, a, q, enc_proj, enc, v, w_d, dlo, act, cs_cur, cs_prev, denc_proj, dctx_out, dc, dgT_out, B, T, H, E, first};
-  const size_t lds = ((size_t)E + H) * sizeof(float);
+  const size_t lds = ((size_t)E + 5 * H) * sizeof(float);
   if (lds > 48 * 1024) return TBG_EUNSUPPORTED;
-  hipLaunchKernelGGL(dec_sample_bwd_kernel, dim3(B), dim3(256), lds, tbg_stream(stream), p);
+  hipLaunchKernelGGL(dec_sample_bwd_kernel, dim3(B), dim3(DEC_THREADS), lds, tbg_stream(stream), p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
