@@ -550,6 +550,13 @@ def main():
                                     "g_clone EMA included; OCR = ASTER-shaped frozen net (synthetic weights)"),
                        "arithmetic": args.dtype,
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       # which BASELINE.json configuration this line is: N = 1 -> configs[1] / configs[2]; N > 1 -> the SAME per-GPU
+                       # workload on every rank (weak scaling, the reference's own rule batch_size = per_gpu x replicas,
+                       # config/config.py:140-141), so that the driver's 1/2/4/8 efficiency compares like with like; BASELINE
+                       # configs[3] (8 GPUs, global 256 = 8 x 32) is this command with --batch 32 (any --dtype)
+                       "baseline_config": ("configs[3] (8 x 32 = global 256)" if (world == 8 and args.batch == 32) else
+                                           cfgname.split()[-1] + (f" per GPU x {world} ranks (weak scaling; configs[3] = --gpus 8 --batch 32)"
+                                                                  if world > 1 else "")),
                        "conv_gflop_per_image_nonreg_step": CONV_GFLOP_PER_IMAGE},
             "conv_tflops_vs_step_time": round(value * CONV_GFLOP_PER_IMAGE / 1e3 / world, 2),
             "graph_mode": graph_mode(ts), "capture_error": ts.capture_error,

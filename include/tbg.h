@@ -245,8 +245,7 @@ int tbg_conv2d_bf16(const tbg_conv_desc *d, const float *x, const void *w, float
 int tbg_conv2d_bf16_kernel_name(const tbg_conv_desc *d, int has_in_scale, char *buf, int n);
 /* explicit instantiation family (tuning / test aid): 0 = library's choice, 1 = 128x256 tile, 2 = 32-channel chunks,
  * 3 = the register-prefetch K loop (128x128 tile; the library's choice for stride-1 layers), 4 / 5 = class-per-block /
- * merged-class transposed form (both with the plain K loop); 10 .. 13 = an explicit (channel x pixel) tile -- 32x256, 64x256,
- * 64x64, 128x128 -- for any non-merged launch (tools/bench_ksplit_ocr.py: the small-map tile choice, profiles/r05_l_*). */
+ * merged-class transposed form (both with the plain K loop). */
 int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                             const float *in_scale, const tbg_epilogue *epi, int variant, void *stream);
 /* filter gradient; tile rows narrower than 8 pixels (Ws <= 4) fall back to the exact fp32 kernel.  Workspace size =
@@ -283,7 +282,7 @@ int tbg_conv2d_wgrad_x3(const tbg_wgrad_desc *d, const float *S, const float *L,
                         long long workspace_bytes, void *stream);
 int tbg_conv2d_wgrad_x3_kernel_name(const tbg_wgrad_desc *d, char *buf, int n);
 /* explicit form of the stride-2 transposed 3x3 launches (tuning / test aid): 0 = library's choice, 4 / 5 = class-per-block /
- * merged-class; 1 / 2 = force / forbid the 128x256 tile; 10 .. 13 = an explicit tile as tbg_conv2d_bf16_variant. */
+ * merged-class; 1 / 2 = force / forbid the 128x256 tile. */
 int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y, const float *in_scale,
                           const tbg_epilogue *epi, int variant, void *stream);
 

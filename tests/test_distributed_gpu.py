@@ -196,6 +196,7 @@ def test_bench_launcher_two_ranks_gloo_smoke(dev):
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["per_gpu_batch"] == 4 and "x 2 ranks" in rec["config"]["baseline_config"]  # (names what the line measures)
 
 
 def _forced_exchange_worker(port, q):

@@ -769,10 +769,7 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
   int BM, BN;
   if (merged) { BM = 64; BN = 128; }  // 4 classes x (1 x 2) MFMA tiles per wave = 128 accumulators
   else if (force64) { BM = 64; BN = 64; }
-  else if (variant >= 10 && variant <= 13) {  // measurement aid: an explicit (channel x pixel) tile, tools/bench_ksplit_ocr.py
-    BM = variant == 10 ? 32 : variant == 13 ? 128 : 64;
-    BN = variant <= 11 ? 256 : variant == 12 ? 64 : 128;
-  } else {
+  else {
     const long long npix = (long long)d->B * maxUg * maxVg;  // N of the (largest class) GEMM
     if (d->M <= 32) { BM = 32; BN = 256; }
     else if (d->M <= 64) { BM = 64; BN = (npix + 255) / 256 < 96 ? 64 : 256; }
@@ -848,7 +845,7 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
   hipStream_t st = tbg_stream(stream);
   if (x3) {  // f32x3: the tile shapes of the fp32 path, 8-channel chunks (16 for the few-tap classes), 2 blocks/CU
     if (merged) return launch_fprop<2, 2, 1, 2, 8, MAXTAPS, 0, 2, true, true, true>(p, st, maxtaps, maxTilesN, name);
-    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 5 && variant < 10) return TBG_EUNSUPPORTED;
+    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 5) return TBG_EUNSUPPORTED;
     // (The 64 x 64 tile -- the small maps of both networks and the whole frozen-OCR stack, 1.6 ms of GPU time per step -- is
     // bound by the latency of its filter stream, not by chunk count or staging: under graph replay a C = 256, M = 256 layer on
     // 2 x 25 maps takes 56 us unsplit = 1.7 us per 8-channel chunk against 0.4 us of MFMA; 16- and 32-channel chunks and the
@@ -909,7 +906,7 @@ static int conv2d_tiled(const tbg_conv_desc *d, const float *x, const float *w, 
         (variant == 3 || (variant == 0 && !d->transposed && d->sy == 1 && d->sx == 1)))
       return launch_fprop<2, 2, 2, 2, 16, MAXTAPS, -1, 3, true>(p, st, maxtaps, maxTilesN, name);
     if (variant == 3) return TBG_EUNSUPPORTED;
-    if (variant != 0 && variant != 4 && variant != 5 && variant < 10) return TBG_EUNSUPPORTED;
+    if (variant != 0 && variant != 4 && variant != 5) return TBG_EUNSUPPORTED;
     if (maxtaps > 1 && maxtaps <= 4) {
       if (BM == 32) return launch_fprop<1, 4, 1, 2, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
       if (BM == 64 && BN == 64) return launch_fprop<2, 2, 1, 1, 32, 4, 0, 3, true>(p, st, maxtaps, maxTilesN, name);
@@ -986,7 +983,7 @@ extern "C" int tbg_conv2d_f32_variant(const tbg_conv_desc *d, const float *x, co
 
 extern "C" int tbg_conv2d_bf16_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                                        const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant < 0 || (variant > 5 && variant < 10) || variant > 13) return TBG_EINVAL;
+  if (variant < 0 || variant > 5) return TBG_EINVAL;
   return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, 1, variant);
 }
 
@@ -1002,7 +999,7 @@ extern "C" int tbg_conv2d_x3(const tbg_conv_desc *d, const float *x, const void 
 
 extern "C" int tbg_conv2d_x3_variant(const tbg_conv_desc *d, const float *x, const void *w, float *y,
                                      const float *in_scale, const tbg_epilogue *epi, int variant, void *stream) {
-  if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 5 && (variant < 10 || variant > 13)) return TBG_EINVAL;
+  if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 5) return TBG_EINVAL;
   return conv2d_impl(d, x, reinterpret_cast<const float *>(w), y, in_scale, epi, stream, nullptr, 2, variant);
 }
 

@@ -134,7 +134,15 @@ class _Tuning:
         self.dense_small_k = 768     # above: a library GEMM; below: launch-bound, one hand-written launch per direction
 
 
+    def __setattr__(self, name, value):
+        # a misspelt knob (tools/ab_*.py set attributes from the command line) must not silently create a new one
+        if getattr(self, "_sealed", False) and not hasattr(self, name):
+            raise AttributeError(f"ops.TUNING has no knob {name!r}")
+        object.__setattr__(self, name, value)
+
+
 TUNING = _Tuning()
+object.__setattr__(TUNING, "_sealed", True)
 
 
 # ----------------------------------------------------------------------------------------
@@ -549,7 +557,7 @@ def _sink_epi(epi: N.Epilogue, sink: Optional[UnitSink], B, M, H, W, device):
 def attach_units(t: torch.Tensor, U: Optional[UnitTensor], scale) -> torch.Tensor:
     """remember on the activation tensor ``t`` that units(t * scale) exists (a Python attribute: the consumer layer finds it)"""
     if U is not None:
-        t._tbg_units = (U, scale, None if scale is None else scale._version)
+        t._tbg_units = (U, scale, None if scale is None else scale._version, t._version)
     return t
 
 
@@ -558,7 +566,9 @@ def take_units(x: torch.Tensor, scale, planes: Optional[int] = None) -> Optional
     hit = getattr(x, "_tbg_units", None)
     if hit is None:
         return None
-    U, sc, ver = hit
+    U, sc, ver, xver = hit
+    if x._version != xver:  # x was modified in place after its producer wrote the unit tensor
+        return None
     planes = unit_planes() if planes is None else planes
     same = (sc is None and scale is None) or (sc is not None and scale is not None and sc.data_ptr() == scale.data_ptr() and
                                               sc.shape == scale.shape and sc._version == ver)
