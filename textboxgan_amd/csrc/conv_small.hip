@@ -70,6 +70,10 @@ template <int V> using IC = std::integral_constant<int, V>;
 #ifndef SMALL_EXP
 #define SMALL_EXP 0
 #endif
+// scheduling experiments (0 = product): 1 pin the loads of a row unit in front of its MFMAs, 2 also raise the wave's priority over the MFMAs
+#ifndef SMALL_SCHED
+#define SMALL_SCHED 0
+#endif
 
 template <class F, int... I>
 __device__ __forceinline__ void small_ring(F &body, int s, int count, std::integer_sequence<int, I...>) {
@@ -274,6 +278,8 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
   auto body = [&](auto S_, int s) {
     constexpr int S = decltype(S_)::value, S1 = (S + 1) % R, SP = (S + PD) % R;
     issue(IC<SP>{}, s + PD);
+    if constexpr (SMALL_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SMALL_SCHED >= 2) __builtin_amdgcn_s_setprio(2);
     if constexpr (KW == 3) {
       read_ops(IC<1>{}, 1);
       mfmas(IC<S>{}, IC<0>{}, IC<0>{});
@@ -287,6 +293,7 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
       read_ops(IC<S1>{}, 0);
       mfmas(IC<S>{}, IC<S>{}, IC<0>{});
     }
+    if constexpr (SMALL_SCHED >= 2) __builtin_amdgcn_s_setprio(0);
   };
   if (n_w > 0) {
     auto pro = [&](auto S_, int s) { issue(S_, s); };
