@@ -438,7 +438,14 @@ __global__ __launch_bounds__(LSF_THREADS) void lstm_fused_bwd_kernel(const LstmF
   }
 }
 
-static int lstm_fused_bb(int B) { return B <= 4 ? 4 : B <= 8 ? 8 : 16; }
+// samples per block: the smallest group that still leaves the launch within one block per CU -- every block stages the WHOLE state of
+// its samples, so smaller groups mean less staging per block and more blocks in flight (B = 16, one BiLSTM layer forward + backward,
+// 50 launches: 429 us with 16-sample groups, 349 with 8, 287 with 4; B = 32: 8-sample groups are best -- profiles/r06_lstm_groups.txt)
+static int lstm_fused_bb(int B, int blocks_per_group) {
+  for (int bb = 4; bb < 16; bb *= 2)
+    if (B <= bb || (long long)blocks_per_group * ((B + bb - 1) / bb) <= 256) return bb;
+  return 16;
+}
 
 static bool lstm_fused_ok(int D, int T, int B, int H, int s) {
   return lstm_args_ok(D, T, B, H, s) && H % 32 == 0 && H >= 32 && H <= 1024;
@@ -470,7 +477,7 @@ extern "C" int tbg_lstm_fused_fwd_f32(const float *gx, const float *w_hh, const 
   p.gx = gx; p.w = w_hh; p.state_in = hT_in; p.state_out = hT_out; p.act = act; p.cs = cs; p.seq = seq;
   p.D = D; p.T = T; p.B = B; p.H = H; p.s = s; p.K = H; p.project = s > 0;
   hipStream_t st = tbg_stream(stream);
-  switch (lstm_fused_bb(B)) {
+  switch (lstm_fused_bb(B, D * (H / LSF_UB))) {
     case 4: return lstm_fused_launch<4, true>(p, st);
     case 8: return lstm_fused_launch<8, true>(p, st);
     default: return lstm_fused_launch<16, true>(p, st);
@@ -490,7 +497,7 @@ extern "C" int tbg_lstm_fused_bwd_f32(const float *dseq, const float *w_hhT, con
   p.dseq = dseq; p.w = w_hhT; p.state_in = dgT_in; p.state_out = dgT_out; p.dc = dc; p.act_in = act; p.cs_in = cs; p.dg = dg;
   p.D = D; p.T = T; p.B = B; p.H = H; p.s = s; p.first = first;
   hipStream_t st = tbg_stream(stream);
-  switch (lstm_fused_bb(B)) {
+  switch (lstm_fused_bb(B, D * (H / LSF_UB))) {
     case 4: return lstm_fused_launch<4, false>(p, st);
     case 8: return lstm_fused_launch<8, false>(p, st);
     default: return lstm_fused_launch<16, false>(p, st);
@@ -508,7 +515,7 @@ extern "C" int tbg_lstm_cell_fused_fwd_f32(const float *gx, const float *w, cons
   p.gx = gx; p.w = w; p.state_in = stateT_in; p.state_out = hT_out; p.act = act; p.cs = cs; p.seq = nullptr;
   p.D = 1; p.T = steps; p.B = B; p.H = H; p.s = s; p.K = K; p.project = 1;
   hipStream_t st = tbg_stream(stream);
-  switch (lstm_fused_bb(B)) {
+  switch (lstm_fused_bb(B, H / LSF_UB)) {
     case 4: return lstm_fused_launch<4, true>(p, st);
     case 8: return lstm_fused_launch<8, true>(p, st);
     default: return lstm_fused_launch<16, true>(p, st);
@@ -577,7 +584,7 @@ extern "C" int tbg_rows_gemv_t_f32(const float *stateT, const float *w, float *o
   if (J % LSF_CH != 0) return TBG_EUNSUPPORTED;
   const RowsGemvP p{stateT, w, outT, J, R, B};
   hipStream_t st = tbg_stream(stream);
-  switch (lstm_fused_bb(B)) {
+  switch (lstm_fused_bb(B, (R + LSF_UB - 1) / LSF_UB)) {
     case 4: return rows_gemv_launch<4>(p, st);
     case 8: return rows_gemv_launch<8>(p, st);
     default: return rows_gemv_launch<16>(p, st);

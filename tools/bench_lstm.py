@@ -4,6 +4,10 @@ import sys; sys.path.insert(0, '.')
 import torch
 from textboxgan_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+if len(sys.argv) > 2:
+    import os
+    from textboxgan_amd import native
+    native.LIB_PATH = os.path.abspath(sys.argv[2])
 dev = torch.device('cuda:0')
 T, In, H, D = 25, 512, 256, 2
 g = torch.Generator().manual_seed(0)
