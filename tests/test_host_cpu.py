@@ -56,6 +56,49 @@ def test_header_symbols_are_exported_by_the_library():
     assert lib.tbg_bias_act_bwd_chunks(0) == 0
 
 
+def test_small_map_and_recurrent_entries_answer_their_queries_and_refuse_bad_arguments():
+    """round 6 entries, host side only (no launch): the dispatch queries of tbg_conv2d_units_small are pure functions of the
+    descriptor -- block counts of the geometries a step launches, the 32 / 64-pixel tile rule, the fused dot only where a tile stays
+    inside one sample -- and every entry answers bad arguments with an error code BEFORE touching a pointer (upfirdn_2d.cu:241-266
+    convention: TBG_EINVAL -1 / TBG_EUNSUPPORTED -4)."""
+    import ctypes as C
+    from textboxgan_amd import native as N
+    lib = N.lib()
+    D = N.ConvDesc
+    q = lambda d, planes=3: (lib.tbg_conv2d_units_small_blocks(C.byref(d), planes), lib.tbg_conv2d_units_small_tile_pixels(C.byref(d), planes),
+                             lib.tbg_conv2d_units_small_dot_slots(C.byref(d), planes))
+    # recogniser stage 4 (2x25 maps, B = 16): 800 pixels = 25 tiles of 32 x 8 channel tiles; a tile straddles samples -> no fused dot
+    assert q(D(16, 256, 256, 2, 25, 2, 25, 3, 3, 1, 1, 1, 1, 0, 0, 256, 1)) == (200, 32, 0)
+    # generator 4x16 512 -> 512: 512 blocks of 32 pixels would be two rounds -> 64-pixel tiles, one sample per tile, 2 dot slots
+    assert q(D(16, 512, 512, 4, 16, 4, 16, 3, 3, 1, 1, 1, 1, 0, 0, 512, 1)) == (256, 64, 2)
+    # 1x1 stride (2, 1) of a stage's first unit, and its transposed data gradient
+    assert q(D(16, 128, 256, 4, 25, 2, 25, 1, 1, 2, 1, 0, 0, 0, 0, 256, 1))[:2] == (200, 32)
+    assert q(D(16, 256, 128, 2, 25, 4, 25, 1, 1, 2, 1, 0, 0, 1, 0, 128, 1))[:2] == (200, 32)
+    # stride-2 transposed 3x3 (4x16 -> 9x33): four output-parity classes in one launch, no dot
+    b, px, slots = q(D(16, 512, 256, 4, 16, 9, 33, 3, 3, 2, 2, 0, 0, 1, 0, 256, 1))
+    assert px == 64 and slots == 0 and b == 8 * sum(-(-16 * u * v // 64) for u, v in ((5, 17), (5, 16), (4, 17), (4, 16)))
+    for bad in (D(2, 64, 64, 8, 32, 8, 32, 3, 3, 1, 1, 1, 1, 0, 0, 64, 2),      # split K belongs to the NCHW entry
+                D(2, 64, 64, 8, 32, 4, 16, 3, 3, 2, 2, 1, 1, 0, 0, 64, 1),      # padded strided 3x3
+                D(2, 64, 64, 8, 2, 8, 2, 3, 3, 1, 1, 1, 1, 0, 0, 64, 1),        # 2-wide rows
+                D(2, 64, 64, 8, 32, 8, 32, 5, 5, 1, 1, 2, 2, 0, 0, 64, 1)):     # 5x5
+        assert q(bad) == (-4, -4, -4)
+    assert q(D(2, 24, 64, 8, 32, 8, 32, 3, 3, 1, 1, 1, 1, 0, 0, 64, 1), planes=1) == (-4, -4, -4)  # bf16: whole 16-channel chunks
+    assert lib.tbg_conv2d_units_small_blocks(None, 3) == -1 and q(D(2, 64, 64, 8, 32, 8, 32, 3, 3, 1, 1, 1, 1, 0, 0, 64, 1), planes=2)[0] == -4
+    d = D(2, 64, 64, 8, 32, 8, 32, 3, 3, 1, 1, 1, 1, 0, 0, 64, 1)
+    assert lib.tbg_conv2d_units_small(C.byref(d), None, 3, None, None, None, None) == -1          # NULL operands
+    assert lib.tbg_conv2d_units_small(C.byref(d), C.c_void_p(8), 3, C.c_void_p(16), C.c_void_p(16), None, None) == -1  # misaligned unit tensor
+    one = C.c_void_p(64)  # (never dereferenced: the entries validate first)
+    assert lib.tbg_lstm_fused_fwd_f32(one, one, one, C.c_void_p(128), one, one, None, 2, 25, 16, 8, 0, None) == -4   # H % 32 != 0
+    assert lib.tbg_lstm_fused_fwd_f32(one, one, one, one, one, one, None, 2, 25, 16, 256, 1, None) == -1             # hT_in == hT_out
+    assert lib.tbg_lstm_fused_fwd_f32(one, one, None, C.c_void_p(128), one, one, None, 2, 25, 16, 256, 25, None) == -1  # s out of range
+    assert lib.tbg_lstm_fused_bwd_f32(None, one, None, C.c_void_p(128), one, one, one, None, 2, 25, 16, 256, 24, 1, None) == -1  # first step needs dseq
+    assert lib.tbg_lstm_cell_fused_fwd_f32(one, one, one, C.c_void_p(128), one, one, 8, 16, 256, 770, 0, None) == -4  # K % 16 != 0
+    assert lib.tbg_rows_gemv_t_f32(one, one, one, 1000, 768, 16, None) == -4 and lib.tbg_rows_gemv_t_f32(None, one, one, 1024, 768, 16, None) == -1
+    assert lib.tbg_dec_sample_fwd_f32(*([None] * 14), 16, 25, 256, 512, 97, 97, None) == -1   # neither logits nor a next step
+    assert lib.tbg_dec_sample_fwd_f32(one, one, one, one, one, one, one, one, one, one, one, one, one, one, 16, 65, 256, 512, 97, 97, None) == -4  # T > 64
+    assert lib.tbg_dec_sample_bwd_f32(*([None] * 16), 16, 25, 256, 512, 0, None) == -1
+
+
 def test_ctypes_struct_layout_matches_header(tmp_path):
     """sizes and EVERY field offset of the ctypes mirrors against what a C compiler makes of include/tbg.h (gcc, host only)"""
     import subprocess
