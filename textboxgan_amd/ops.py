@@ -112,7 +112,8 @@ class _Tuning:
         # ---- small maps (tbg.h "SMALL MAPS", csrc/conv_small.hip)
         self.use_small = True        # small-map convolutions take tbg_conv2d_units_small (K split inside the block, one launch) instead
                                      # of the NCHW kernel's split-K pair (convolution into HBM slabs + tbg_slab_epilogue_f32)
-        self.small_max_blocks_taps = 640  # the same bound for the tap-list form of the stride-2 transposed k x k layers
+        self.small_max_blocks_taps = 1280  # the same bound for the tap-list form of the stride-2 transposed k x k layers (their NCHW
+                                     # alternative -- four class launches of mostly-empty tiles -- loses later: 640 -> 1280 = 17.81 -> 17.73 ms)
         self.small_max_blocks = 512  # ... when the launch is at most this many blocks (two rounds of one block per CU): beyond, every
                                      # pixel tile re-reads its filter slice too often and the 128 x 128 NCHW tiles win
         # ---- split-K of the small-map launches
