@@ -304,6 +304,7 @@ struct WgUnitsP {
   int CS8, CL8, Hps, Wps, Hpl, Wpl;
   int tilesU, tilesV, nchunks, ksplit;
   float *ws;
+  int tx, ty;  // channel tiles (S, L); the launch is 1-D: tx * ty * ksplit blocks
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -343,7 +344,25 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_units_kernel(const WgUnitsP
       isl |= 1u << k;
     }
   }
-  const int cs8 = blockIdx.x * 8, cl8 = blockIdx.y * 8;
+  // block -> (S tile, L tile, K slice).  The hardware deals consecutive blocks round-robin over the 8 XCDs, and the tx * ty blocks of
+  // one K slice read the SAME pixel chunks (each S tile ty times, each L tile tx times): numbered consecutively they would sit on
+  // tx * ty different XCDs and every re-read would go to memory (2 x 2 tiles: 1.87 x the algorithmic bytes, profiles/r06_z_pmc_report).
+  // With whole groups of 8 slices the slices are dealt over the XCDs instead and a slice's blocks share one L2.
+  const int tiles = p.tx * p.ty;
+  int bt, bz;
+#ifndef WGU_NO_XCD_MAP
+  if ((p.ksplit & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    bt = slot % tiles;
+    bz = (slot / tiles) * 8 + xcd;
+  } else
+#endif
+  {
+    bt = blockIdx.x % tiles;
+    bz = blockIdx.x / tiles;
+  }
+  const int bx = bt % p.tx, by = bt / p.tx;
+  const int cs8 = bx * 8, cl8 = by * 8;
 
   auto chunk_bases = [&](int chunk, int &sb, int &lb) {
     const int tv = chunk % p.tilesV;
@@ -381,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_units_kernel(const WgUnitsP
     return __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
   };
 
-  int chunk = blockIdx.z;
+  int chunk = bz;
   int sb = 0, lb = 0;
   if (chunk < p.nchunks) {
     chunk_bases(chunk, sb, lb);
@@ -445,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_units_kernel(const WgUnitsP
     buf ^= 1;
   }
 
-  const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const size_t blk = ((size_t)bz * p.ty + by) * p.tx + bx;
   float *wsp = p.ws + blk * (size_t)(NT * 16 * 256);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -480,7 +499,8 @@ static int launch_wgrad_units(WgUnitsP &u, WgradP &p, hipStream_t st, const char
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return TBG_EHIP;
   const int tx = p.CS / 64, ty = p.CL / 64;
-  hipLaunchKernelGGL(kern, dim3(tx, ty, u.ksplit), dim3(256), lds, st, u);
+  u.tx = tx; u.ty = ty;
+  hipLaunchKernelGGL(kern, dim3(tx * ty * u.ksplit), dim3(256), lds, st, u);
   TBG_LAUNCH_CHECK();
   if (tx * ty * 9 >= 256)
     hipLaunchKernelGGL((conv_wgrad_reduce_kernel<2, 2, 9>), dim3(tx, ty, 9), dim3(256), 0, st, p);
@@ -556,10 +576,19 @@ __global__ __launch_bounds__(512, 2) void conv_units_fprop_kernel(const ConvUnit
   const int wm = wave >> 2, wn = wave & 3, half = lane >> 5;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
 
-  const int tn = blockIdx.x;
+  // block -> (pixel tile, channel tile).  The hardware deals consecutive blocks round-robin over the 8 XCDs; dealt in tile order,
+  // the tiles that share halo rows / columns and the channel tiles that read the SAME pixel tile would sit in 8 different L2s and
+  // every shared unit would come from memory again.  Each XCD takes one contiguous eighth of the (pixel tile, channel tile) list
+  // instead (channel tiles of a pixel tile adjacent, then the tiles of a row, then the rows of an image).
+  const int mtiles = p.M / BM, total = gridDim.x;
+  int lin = blockIdx.x;
+#ifndef CU_NO_XCD_MAP
+  if ((total & 7) == 0) lin = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+#endif
+  const int tn = lin / mtiles, mt = lin - tn * mtiles;
   const int tv = tn % p.tilesV, t2 = tn / p.tilesV;
   const int tu = t2 % p.tilesU, b = t2 / p.tilesU;
-  const int m0 = blockIdx.y * BM, y0 = tu * 8, x0 = tv * 32;
+  const int m0 = mt * BM, y0 = tu * 8, x0 = tv * 32;
   const int Hp = p.H + 2, Wp = p.W + 2;
 
   // ---- DMA descriptors of this wave's pieces (piece q = wave + 8 k): the per-lane source ADDRESS for chunk 0 (registers:
@@ -741,7 +770,7 @@ static int launch_conv_units(ConvUnitsP &p, hipStream_t st) {
   auto kern = conv_units_fprop_kernel<NP, WTM>;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return TBG_EHIP;
-  hipLaunchKernelGGL(kern, dim3(p.B * p.tilesU * p.tilesV, p.M / BM), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tilesU * p.tilesV * (p.M / BM)), dim3(512), lds, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }

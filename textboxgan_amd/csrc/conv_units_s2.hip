@@ -276,10 +276,15 @@ __global__ __launch_bounds__(512, 2) void conv_units_s2_fprop_kernel(const ConvS
   const int wm = wave >> 2, wn = wave & 3, half = lane >> 5;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
 
-  const int tn = blockIdx.x;
+  // block -> (pixel tile, channel tile): one contiguous eighth of the list per XCD (conv_units_fprop_kernel: tiles that share halo
+  // units and the channel tiles of one pixel tile meet in one L2 instead of eight)
+  const int mtiles = p.M / BM, total = gridDim.x;
+  int lin = blockIdx.x;
+  if ((total & 7) == 0) lin = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+  const int tn = lin / mtiles, mt = lin - tn * mtiles;
   const int tv = tn % p.tilesV, t2 = tn / p.tilesV;
   const int tu = t2 % p.tilesU, b = t2 / p.tilesU;
-  const int m0 = blockIdx.y * BM, y0 = tu * 8, x0 = tv * 32;
+  const int m0 = mt * BM, y0 = tu * 8, x0 = tv * 32;
 
   // ---- DMA descriptors (registers, as conv_units_fprop_kernel): per-lane source address at chunk 0 of every piece this wave
   // issues in stage 0 / stage 1 (piece q = wave + 8 k)
@@ -456,7 +461,7 @@ static int launch_conv_units_s2(ConvS2P &p, hipStream_t st) {
   auto kern = conv_units_s2_fprop_kernel<NP, WTM>;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return TBG_EHIP;
-  hipLaunchKernelGGL(kern, dim3(p.B * p.tilesU * p.tilesV, p.M / Cf::BM), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tilesU * p.tilesV * (p.M / Cf::BM)), dim3(512), lds, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }
@@ -511,6 +516,7 @@ struct WgS2P {
   int CS8, CL8, Hps, Wps, Hq, Wq;
   int Ho, tilesV, nchunks, ksplit;
   float *ws;
+  int tx2, ty;  // 128-channel S tiles, 64-channel L tiles; the launch is 1-D: tx2 * ty * ksplit blocks
 };
 
 template <int NP>
@@ -554,7 +560,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_units_s2_kernel(const WgS2P
 #pragma unroll
   for (int k = 0; k < PPW_B; ++k) offB[k] = l_off(0, min(wave + 8 * k, L_PIECES - 1));
   const char *const su_ = p.SU, *const lu_ = p.LU;
-  const int cs8 = blockIdx.x * 16, cl8 = blockIdx.y * 8;
+  // block -> (S tile, L tile, K slice): the blocks of one K slice read the same pixel chunks, so whole groups of 8 slices are dealt
+  // over the XCDs and a slice's blocks share one L2 (conv_wgrad_units_kernel)
+  const int tiles = p.tx2 * p.ty;
+  int bt, bz;
+  if ((p.ksplit & 7) == 0) {
+    const int slot = blockIdx.x >> 3;
+    bt = slot % tiles;
+    bz = (slot / tiles) * 8 + (blockIdx.x & 7);
+  } else {
+    bt = blockIdx.x % tiles;
+    bz = blockIdx.x / tiles;
+  }
+  const int bx = bt % p.tx2, by = bt / p.tx2;
+  const int cs8 = bx * 16, cl8 = by * 8;
 
   auto chunk_bases = [&](int chunk, int &sb, int &lb) {
     const int tv = chunk % p.tilesV;
@@ -639,7 +658,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_units_s2_kernel(const WgS2P
     __syncthreads();
   };
 
-  int chunk = blockIdx.z;
+  int chunk = bz;
   int sb = 0, lb = 0, sbn = 0, lbn = 0;
   if (chunk < p.nchunks) {  // prologue: S tile and stage-0 L tiles of the first chunk
     chunk_bases(chunk, sb, lb);
@@ -664,7 +683,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_units_s2_kernel(const WgS2P
 
   // partial tile, in the 64 x 64 layout of the 4-wave kernels
   const int tile = sgrp >> 1, tid4 = ((sgrp & 1) * 2 + wl) * 64 + lane;
-  const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * (2 * gridDim.x) + 2 * blockIdx.x + tile;
+  const size_t blk = ((size_t)bz * p.ty + by) * (2 * p.tx2) + 2 * bx + tile;
   float *wsp = p.ws + blk * (size_t)(NT * 16 * 256);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -697,7 +716,8 @@ static int launch_wgrad_units_s2(WgS2P &u, WgradP &p, hipStream_t st) {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return TBG_EHIP;
   const int tx = p.CS / 64, ty = p.CL / 64;
-  hipLaunchKernelGGL(kern, dim3(p.CS / 128, ty, u.ksplit), dim3(512), lds, st, u);
+  u.tx2 = p.CS / 128; u.ty = ty;
+  hipLaunchKernelGGL(kern, dim3(u.tx2 * ty * u.ksplit), dim3(512), lds, st, u);
   TBG_LAUNCH_CHECK();
   if (tx * ty * 9 >= 256)
     hipLaunchKernelGGL((conv_wgrad_reduce_kernel<2, 2, 9>), dim3(tx, ty, 9), dim3(256), 0, st, p);
@@ -778,8 +798,12 @@ __global__ __launch_bounds__(512, 2) void conv_units_t2_kernel(const ConvT2P p) 
   const int wm = wave >> 2, wn = wave & 3, half = lane >> 5;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
 
-  const int tq = blockIdx.x % p.tilesQ, b = blockIdx.x / p.tilesQ;
-  const int m0 = blockIdx.y * BM;
+  const int mtiles = p.M / BM, total = gridDim.x;  // block -> (position tile, channel tile): one contiguous eighth per XCD, as above
+  int lin = blockIdx.x;
+  if ((total & 7) == 0) lin = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+  const int tn = lin / mtiles, mt = lin - tn * mtiles;
+  const int tq = tn % p.tilesQ, b = tn / p.tilesQ;
+  const int m0 = mt * BM;
   const int q0 = p.Wp + tq * 256, qmax = p.Hp * p.Wp - 1;
 
   const char *dsrc[PPW];
@@ -929,7 +953,7 @@ static int launch_conv_units_t2(ConvT2P &p, hipStream_t st) {
   auto kern = conv_units_t2_kernel<NP>;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return TBG_EHIP;
-  hipLaunchKernelGGL(kern, dim3(p.B * p.tilesQ, p.M / Cf::BM), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.tilesQ * (p.M / Cf::BM)), dim3(512), lds, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
 }

@@ -1,9 +1,14 @@
-"""isolated timings of the unit-tensor kernels against the NCHW kernels they replace: python tools/bench_units.py [B]"""
+"""isolated timings of the unit-tensor kernels against the NCHW kernels they replace: python tools/bench_units.py [B] [lib.so | -] [wgrad]"""
 import sys, torch
 sys.path.insert(0, ".")
 from textboxgan_amd import ops
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+if len(sys.argv) > 2 and sys.argv[2] != "-":  # a variant build of the library (tools/build_variant.sh)
+    import os
+    from textboxgan_amd import native
+    native.LIB_PATH = os.path.abspath(sys.argv[2])
+ONLY_WGRAD = len(sys.argv) > 3 and sys.argv[3] == "wgrad"
 def timeit(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -29,6 +34,8 @@ for (C, M, H, W) in [(128, 128, 64, 256), (128, 128, 32, 128), (256, 256, 16, 64
                 f"  pack {t_pack:6.1f} us ({(4 + 2 * planes) * x.numel() / t_pack / 1e6:5.2f} TB/s)")
     print(row, flush=True)
 
+if ONLY_WGRAD:
+    sys.exit(0)
 print("--- forward 3x3 s1 (with style scale, demod/noise/bias/lrelu epilogue)")
 from textboxgan_amd import native as N
 for (C, M, H, W, Bx) in [(128, 128, 64, 256, B), (128, 128, 32, 128, B), (128, 128, 32, 128, 2 * B), (64, 64, 64, 256, 2 * B), (256, 256, 16, 64, B),

@@ -2,6 +2,9 @@
 import sys, torch
 sys.path.insert(0, ".")
 from textboxgan_amd import ops, native as N
+if len(sys.argv) > 1:  # a variant build of the library (tools/build_variant.sh)
+    import os
+    N.LIB_PATH = os.path.abspath(sys.argv[1])
 dev = torch.device("cuda:0")
 B, C, M, H, W = 16, 128, 128, 64, 256
 x, dy = torch.randn(B, C, H, W, device=dev), torch.randn(B, M, H, W, device=dev)
