@@ -1,6 +1,10 @@
 import sys; sys.path.insert(0, '.')
 import torch
 from textboxgan_amd import ops
+if len(sys.argv) > 1:  # a variant build of the library (tools/build_variant.sh)
+    import os
+    from textboxgan_amd import native
+    native.LIB_PATH = os.path.abspath(sys.argv[1])
 dev = torch.device('cuda:0')
 def timeit(f, n=30):
     for _ in range(5): f()
