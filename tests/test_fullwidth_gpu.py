@@ -370,6 +370,7 @@ def _run_units_case(dev, arith, M, seed):
     xr, wr = q(x).requires_grad_(True), q(w).requires_grad_(True)
     ref = F.conv2d(xr, wr.permute(3, 2, 0, 1), padding=1)
     gx, gw = torch.autograd.grad(ref, (xr, wr), q(dy))
+    small_was, ops.TUNING.use_small = ops.TUNING.use_small, False  # (maps this small would take tbg_conv2d_units_small otherwise)
     with N.record_calls() as log, ops.compute_dtype(arith):
         xd, wd, dyd = x.float().to(dev), w.float().to(dev), dy.float().to(dev)
         XU, DU = ops.units_pack(xd), ops.units_pack(dyd)
@@ -377,6 +378,21 @@ def _run_units_case(dev, arith, M, seed):
         assert rel(ops.conv2d_units_raw(DU, ops.pack_filter(wd, True, True), Cc), gx) < 3e-5, ("units dgrad", arith, M)
         dw = torch.empty(3, 3, Cc, M, device=dev)
         assert rel(ops.wgrad_units_raw(DU, XU, dw, Cc * M, M, 1, 1.0), gw) < 5e-5, ("units wgrad", arith, M)
+        # the forward kernel's epilogue instantiations (conv_common.h OPT: residual operand, dot / gate operand, both, neither)
+        res, gate, aux = (torch.randn(B, M, H, W, generator=g, dtype=torch.float64) for _ in range(3))
+        resd, gated, auxd = res.float().to(dev), gate.float().to(dev), aux.float().to(dev)
+        pf, y0 = ops.pack_filter(wd, False, False), ref.detach()
+        y = ops.conv2d_units_raw(XU, pf, M, epi=N.epilogue(residual=resd, res_scale=0.5))
+        assert rel(y, (y0 + res) * 0.5) < 3e-5, ("units fwd + residual", arith, M)
+        y = ops.conv2d_units_raw(XU, pf, M, epi=N.epilogue(gate=gated))
+        assert rel(y, torch.where(gate > 0, y0, torch.zeros_like(y0))) < 3e-5, ("units fwd + gate", arith, M)
+        y = ops.conv2d_units_raw(XU, pf, M, epi=N.epilogue(residual=resd, res_scale=0.5, gate=gated))
+        assert rel(y, torch.where(gate > 0, (y0 + res) * 0.5, torch.zeros_like(y0))) < 3e-5, ("units fwd + residual + gate", arith, M)
+        dot = torch.empty(B, M, device=dev)
+        y = ops.conv2d_units_raw(XU, pf, M, dot=(auxd, dot))
+        assert rel(y, y0) < 3e-5 and rel(dot, (y0 * aux).sum((2, 3))) < 3e-5, ("units fwd + dot", arith, M)
+    ops.TUNING.use_small = small_was
+    assert any(k.startswith("conv_units_fprop_kernel") for k in log), sorted(log)
     return set(log)
 
 

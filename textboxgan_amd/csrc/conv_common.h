@@ -106,12 +106,16 @@ __device__ __forceinline__ void sink_zero(char *ub, long long plane_bytes, int p
 // registers pushed the 4-waves/SIMD builds into scratch -- 320 bytes per lane, exact-fp32 step 27.1 -> 31.7 ms).
 // NROW < 16 (conv_small.hip): the wave holds only accumulator rows 0 .. NROW-1 of its tile (one 4-channel row group after the
 // in-block K reduction) -- the loops stop there, everything else is unchanged.
-template <int WTM, int WTN, int RG, bool SINK = true, int NROW = 16>
+// OPT: which optional operand paths are compiled in -- bit 0 the residual, bit 1 the dot / gate operand.  A launch that has neither
+// runs the OPT = 0 instantiation: a third of the epilogue's code (loads, shuffle trees, branches on flags that are never set) is not
+// there (conv_units_fprop_kernel: -2 .. -4 % per launch in f32x3, -7 % in bf16, profiles/r06_epilogue_opt.txt).
+template <int WTM, int WTN, int RG, bool SINK = true, int NROW = 16, int OPT = 3>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], const EpiK &e, float *y, float *slab, int M_, int HWout,
                                               int mrow0, int lane, const int (&e_pix)[WTN], const int (&e_b)[WTN], bool dot_ok,
                                               int dot_b, int dot_slots, int dot_slot, int Hout = 0, int Wout = 0) {
-  const float *const e_os = e.out_scale, *const e_bias = e.bias, *const e_res = e.residual, *const e_aux = e.dot_aux;
-  const float *const e_gate = e.gate;
+  const float *const e_os = e.out_scale, *const e_bias = e.bias;
+  const float *const e_res = (OPT & 1) ? e.residual : nullptr;
+  const float *const e_aux = (OPT & 2) ? e.dot_aux : nullptr, *const e_gate = (OPT & 2) ? e.gate : nullptr;
   float *const e_dot = e.dot_out;
   const float e_alpha = e.alpha, e_bmul = e.bias_mul, e_slope = e.slope, e_gain = e.gain, e_rscale = e.res_scale;
   const bool e_lrelu = e.act == TBG_ACT_LRELU, e_rfirst = e.res_first != 0;
@@ -262,6 +266,9 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
     }
   }
 }
+
+// the OPT instantiation of conv_epilogue a launch needs
+static inline int epi_opt(const EpiK &e) { return (e.residual ? 1 : 0) | ((e.dot_aux || e.gate) ? 2 : 0); }
 
 #define WG_MAXNJ 4
 

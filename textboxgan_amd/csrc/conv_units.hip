@@ -564,7 +564,7 @@ struct ConvUnitsP {
 #else
 #define FPROP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
-template <int NP, int WTM>
+template <int NP, int WTM, int OPT>  // OPT: conv_epilogue's optional operand paths (conv_common.h)
 __global__ __launch_bounds__(512, 2) void conv_units_fprop_kernel(const ConvUnitsP p) {
   constexpr int WGN = 4, WTN = 2, BM = 2 * WTM * 32;
   constexpr int CKU = NP == 3 ? 1 : 2;       // channel units per chunk (x3: 8 channels x 3 planes; bf16: 16 channels)
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void conv_units_fprop_kernel(const ConvUnit
     if (sum == 123.f) p.y[0] = sum;
     return;
   }
-  conv_epilogue<WTM, WTN, 4>(acc, p.e, p.y, nullptr, p.M, p.H * p.W, m0 + wm * WTM * 32, lane, e_pix, e_b, true, b, p.dot_slots,
+  conv_epilogue<WTM, WTN, 4, true, 16, OPT>(acc, p.e, p.y, nullptr, p.M, p.H * p.W, m0 + wm * WTM * 32, lane, e_pix, e_b, true, b, p.dot_slots,
                              (tu * p.tilesV + tv) * WGN + wn, p.H, p.W);
 }
 
@@ -762,17 +762,27 @@ extern "C" int tbg_conv2d_units_dot_slots(const tbg_conv_desc *d, int planes) {
   return (d->Hin / 8) * (d->Win / 32) * 4;
 }
 
-template <int NP, int WTM>
-static int launch_conv_units(ConvUnitsP &p, hipStream_t st) {
+template <int NP, int WTM, int OPT>
+static int launch_conv_units_opt(ConvUnitsP &p, hipStream_t st) {
   constexpr int BM = 2 * WTM * 32, CKU = NP == 3 ? 1 : 2;
   constexpr int NPIECE = (NP * 9 * CKU * BM + NP * CKU * 340 + 63) / 64;
   const size_t lds = (size_t)2 * NPIECE * 64 * 16;
-  auto kern = conv_units_fprop_kernel<NP, WTM>;
+  auto kern = conv_units_fprop_kernel<NP, WTM, OPT>;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return TBG_EHIP;
   hipLaunchKernelGGL(kern, dim3(p.B * p.tilesU * p.tilesV * (p.M / BM)), dim3(512), lds, st, p);
   TBG_LAUNCH_CHECK();
   return TBG_OK;
+}
+
+template <int NP, int WTM>
+static int launch_conv_units(ConvUnitsP &p, hipStream_t st) {
+  switch (epi_opt(p.e)) {
+    case 0: return launch_conv_units_opt<NP, WTM, 0>(p, st);
+    case 1: return launch_conv_units_opt<NP, WTM, 1>(p, st);
+    case 2: return launch_conv_units_opt<NP, WTM, 2>(p, st);
+    default: return launch_conv_units_opt<NP, WTM, 3>(p, st);
+  }
 }
 
 extern "C" int tbg_conv2d_units(const tbg_conv_desc *d, const void *XU, int planes, const void *w, float *y,

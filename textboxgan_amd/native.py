@@ -209,6 +209,12 @@ _CONV_FMT = {"tbg_conv2d_f32": 0, "tbg_conv2d_f32_variant": 0, "tbg_conv2d_bf16"
 _WGRAD_FMT = {"tbg_conv2d_wgrad_f32": 0, "tbg_conv2d_wgrad_ex_f32": 0, "tbg_conv2d_wgrad_bf16": 1, "tbg_conv2d_wgrad_x3": 2}
 
 
+def epilogue_opt(epi) -> int:
+    """the epilogue instantiation a unit-tensor forward launch with this epilogue runs (third template argument of
+    conv_units_fprop_kernel; conv_common.h epi_opt): bit 0 = residual operand, bit 1 = dot / gate operand"""
+    return (1 if epi.residual else 0) | (2 if (epi.dot_aux or epi.gate) else 0)
+
+
 def _call_key(name, a):
     try:
         if name in _CONV_FMT and not name.endswith("_variant"):
@@ -216,7 +222,7 @@ def _call_key(name, a):
         if name in _WGRAD_FMT:
             return wgrad_kernel_name(a[0]._obj, _WGRAD_FMT[name])
         if name == "tbg_conv2d_units":        # d XU planes w y epi stream
-            return f"conv_units_fprop_kernel<{a[2]}, {_lib._l.tbg_conv2d_units_tile_channels(a[0], a[2]) // 64}>"
+            return f"conv_units_fprop_kernel<{a[2]}, {_lib._l.tbg_conv2d_units_tile_channels(a[0], a[2]) // 64}, {epilogue_opt(a[5]._obj)}>"
         if name == "tbg_conv2d_units_s2":
             return f"conv_units_s2_fprop_kernel<{a[2]}, {_lib._l.tbg_conv2d_units_s2_tile_channels(a[0], a[2]) // 64}>"
         if name == "tbg_upfirdn2d_units_s2_f32":

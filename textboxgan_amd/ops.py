@@ -640,7 +640,7 @@ def conv2d_units_raw(XU: UnitTensor, w: "PackedFilter", M: int, flip=False, epi:
     y = torch.empty((B, M, H, W), device=XU.data.device, dtype=torch.float32) if out is None else out
     _flops = 2.0 * B * M * XU.C * 9 * H * W
     _wtm = N.lib().tbg_conv2d_units_tile_channels(C.byref(d), XU.planes) // 64
-    N.check(PROFILE.launch(f"conv_units_fprop_kernel<{XU.planes}, {_wtm}>", _flops, lambda: N.lib().tbg_conv2d_units(
+    N.check(PROFILE.launch(f"conv_units_fprop_kernel<{XU.planes}, {_wtm}, {N.epilogue_opt(epi)}>", _flops, lambda: N.lib().tbg_conv2d_units(
         C.byref(d), N.ptr(XU.data), XU.planes, N.ptr(w.data), N.ptr(y), C.byref(epi), N.stream()),
         f"conv_units[B={B} C={XU.C} M={M} {H}x{W}]", 2.0 * XU.data.numel() + 4.0 * y.numel() + 2.0 * XU.planes * 9 * XU.C * M),
         "tbg_conv2d_units")

@@ -1,5 +1,6 @@
 """A/B of two builds of the library on the SAME box: graph-replayed plain step (f32x3, B=16), alternating child processes.
-usage: python tools/ab_lib.py <libA.so> <libB.so> [rounds]     (child: python tools/ab_lib.py --child <lib.so>)"""
+usage: python tools/ab_lib.py <libA.so> <libB.so> [rounds]     (child: python tools/ab_lib.py --child <lib.so>)
+environment: AB_DTYPE (f32x3), AB_BATCH (16)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if sys.argv[1] == "--child":
@@ -14,9 +15,9 @@ if sys.argv[1] == "--child":
     from textboxgan_amd.training_step import build_trainer_state
     from bench import synthetic_batch, bench_init_
     dev = torch.device('cuda:0')
-    cfg = Config(batch_size_per_gpu=16)
+    cfg = Config(batch_size_per_gpu=int(os.environ.get("AB_BATCH", "16")))
     b = synthetic_batch(cfg, dev, 1234)
-    st = build_trainer_state(cfg, dev, seed=0, use_graphs=True, compute_dtype="f32x3"); bench_init_(st)
+    st = build_trainer_state(cfg, dev, seed=0, use_graphs=True, compute_dtype=os.environ.get("AB_DTYPE", "f32x3")); bench_init_(st)
     ts = st["training_step"]
     args = (b["real_images"], b["ocr_images"], b["input_words"], b["ocr_labels"], False, False, 1e-4)
     for _ in range(4): ts.dist_train_step(*args)

@@ -11,7 +11,7 @@ with ops.compute_dtype("f32x3"):
     XU, DU = ops.units_pack(x), ops.units_pack(dy)
     pf = ops.pack_filter(w, False, False)
     dw = torch.empty(3, 3, C, M, device=dev)
-    for name, fn in (("conv_units_fprop_kernel<3, 2>", lambda: ops.conv2d_units_raw(XU, pf, M, epi=ops._lrelu_epi(alpha=0.1))),
+    for name, fn in (("conv_units_fprop_kernel<3, 2, 0>", lambda: ops.conv2d_units_raw(XU, pf, M, epi=ops._lrelu_epi(alpha=0.1))),
                      ("conv_wgrad_units_kernel<3>", lambda: ops.wgrad_units_raw(DU, XU, dw, C * M, M, 1, 1.0))):
         torch.cuda.synchronize(); t0 = time.time(); n = 0
         while time.time() - t0 < secs:
