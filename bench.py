@@ -16,7 +16,10 @@ Prints ONE JSON line (rank 0).  Extra objects:
                  or filter gradient) with the largest summed time -- algorithmic FLOPs of its
                  launches / their HIP-event durations, measured in a separate instrumented pass
                  over the same step (events on the launch stream); every other instantiation
-                 is listed under roofline.all_kernels.
+                 is listed under roofline.all_kernels.  The epilogue instantiations of
+                 conv_units_fprop_kernel<NP, WTM, OPT> (same main loop and tile, OPT = which optional
+                 epilogue operands are compiled in) count as ONE kernel "<NP, WTM, *>": its members and
+                 their committed rocprofv3 rows are listed in roofline.instantiations / timed_region.
   cpu_baseline : the CPU restatement of the same step (oracle/, PyTorch-oneDNN, "port") timed on
                  this box's host cores on a bounded sample.
 """
@@ -178,23 +181,49 @@ class _TinyOCR(torch.nn.Module):
 HBM_PEAK_TBS = 8.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 achievable)
 
 
+def _roofline_family(name):
+    import re
+    m = re.match(r"(conv_units_fprop_kernel<\d+, \d+), \d+>$", name)
+    return m.group(1) + ", *>" if m else name
+
+
 def roofline_record(recs, dtype="f32"):
     """dominant MFMA kernel instantiation (largest summed time over the forward / data-gradient AND filter-gradient
     instantiations): algorithmic FLOPs / HIP-event time of its launches.  (A filter-gradient record brackets the C-ABI call,
     i.e. the kernel plus its partial-tile reduce launch; rocprofv3's average in profiles/ is the kernel alone.)"""
     convs = {k: v for k, v in recs.items() if k.startswith("conv_")}
-    name, r = max(((k, v) for k, v in convs.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
+    # the epilogue instantiations of conv_units_fprop_kernel<NP, WTM, OPT> (OPT = which optional epilogue operands are compiled in:
+    # same main loop, same tile) are ONE roofline entry "<NP, WTM, *>"; its members and their rocprofv3 rows are listed beside it
+    fams = {}
+    for k, v in convs.items():
+        f = fams.setdefault(_roofline_family(k), {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "members": {}})
+        for q in ("n", "ms", "flops", "bytes"):
+            f[q] += v[q]
+        f["members"][k] = v
+    name, r = max(((k, v) for k, v in fams.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
+    members = r["members"]
     achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
     # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 --pmc passes over
     # `bench.py --roofline-only` (tools/pmc_report.sh, tools/make_traffic_json.py), matched by kernel instantiation; null if
     # none is committed
-    traffic, traffic_src, mfma_busy = None, None, None
+    traffic, traffic_src, mfma_busy, timed = None, None, None, None
     try:
         tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "latest_traffic.json")))
-        if name in tj["kernels"]:
-            traffic = tj["kernels"][name]["hbm_bytes_per_launch"]
-            traffic_src = tj["kernels"][name].get("source", tj["source"])
-            mfma_busy = tj["kernels"][name].get("mfma_busy")
+        rows = {k: tj["kernels"][k] for k in members if k in tj["kernels"]}
+        if rows and len(rows) == len(members):  # launch-weighted over the members' committed rows
+            nl = sum(x["launches"] for x in rows.values())
+            traffic = round(sum(x["hbm_bytes_per_launch"] * x["launches"] for x in rows.values()) / nl)
+            traffic_src = next(iter(rows.values())).get("source", tj["source"])
+            busy = [x for x in rows.values() if x.get("mfma_busy") is not None]
+            if busy:  # time-weighted
+                tw = sum(x["launches"] * x["avg_us"] for x in busy)
+                mfma_busy = round(sum(x["mfma_busy"] * x["launches"] * x["avg_us"] for x in busy) / tw, 3)
+            if len(rows) > 1:
+                timed = ("avg_launch_us is the launch-weighted average over the epilogue instantiations of one kernel; rocprofv3's rows in "
+                         f"{traffic_src}: " + "; ".join(f"{k}: {x['launches']} x {x['avg_us']} us" for k, x in sorted(rows.items())))
+            elif "wgrad" in name:  # what avg_launch_us brackets, and the committed kernel-only duration it has to be read against
+                timed = (f"avg_launch_us brackets one C-ABI call = {name} + its partial-tile reduce launch (conv_wgrad_reduce_*); "
+                         f"rocprofv3's row for the kernel alone in {traffic_src}: {rows[name].get('avg_us')} us")
     except (OSError, ValueError, KeyError):
         pass
     if dtype == "f32x3":
@@ -207,7 +236,7 @@ def roofline_record(recs, dtype="f32"):
                 "frac_of_exact_f32_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "algorithmic_bytes": round(r["bytes"] / r["n"]),
                 "traffic_unit": "bytes/launch (HBM, PMC); algorithmic_bytes = input + output + filter once each, per launch",
-                "traffic_source": traffic_src, "mfma_busy_pmc": mfma_busy,
+                "traffic_source": traffic_src, "mfma_busy_pmc": mfma_busy, "timed_region": timed, "instantiations": {k: {"n": v["n"], "avg_launch_us": round(1e3 * v["ms"] / v["n"], 2)} for k, v in members.items()},
                 "launches": r["n"], "avg_launch_us": round(1e3 * r["ms"] / r["n"], 2),
                 "gflop_per_launch": round(r["flops"] / r["n"] / 1e9, 3),
                 "all_kernels": {k: {"n": v["n"], "ms": round(v["ms"], 3),
@@ -226,7 +255,7 @@ def roofline_record(recs, dtype="f32"):
         tbs = r["bytes"] / (r["ms"] * 1e-3) / 1e12
         return {"bound": "hbm", "kernel": name, "achieved": round(tbs * 1e3, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
                 "frac": round(tbs / HBM_PEAK_TBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "mfma_busy_pmc": mfma_busy, "algorithmic_bytes": round(r["bytes"] / r["n"]),
+                "mfma_busy_pmc": mfma_busy, "timed_region": timed, "instantiations": {k: {"n": v["n"], "avg_launch_us": round(1e3 * v["ms"] / v["n"], 2)} for k, v in members.items()}, "algorithmic_bytes": round(r["bytes"] / r["n"]),
                 "launches": r["n"], "avg_launch_us": round(1e3 * r["ms"] / r["n"], 2),
                 "gflop_per_launch": round(r["flops"] / r["n"] / 1e9, 3), "achieved_tflops": round(achieved, 2),
                 "mfma_peak_tflops": BF16_MFMA_PEAK_TFLOPS, "frac_of_mfma_peak": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
@@ -243,7 +272,7 @@ def roofline_record(recs, dtype="f32"):
             "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "algorithmic_bytes": round(r["bytes"] / r["n"]),
             "traffic_unit": "bytes/launch (HBM, PMC); algorithmic_bytes = input + output + filter once each, per launch",
-            "traffic_source": traffic_src, "mfma_busy_pmc": mfma_busy,
+            "traffic_source": traffic_src, "mfma_busy_pmc": mfma_busy, "timed_region": timed, "instantiations": {k: {"n": v["n"], "avg_launch_us": round(1e3 * v["ms"] / v["n"], 2)} for k, v in members.items()},
             "launches": r["n"], "avg_launch_us": round(1e3 * r["ms"] / r["n"], 2),
             "gflop_per_launch": round(r["flops"] / r["n"] / 1e9, 3),
             "all_kernels": {k: {"n": v["n"], "ms": round(v["ms"], 3),
