@@ -102,6 +102,28 @@ __device__ __forceinline__ void sink_zero(char *ub, long long plane_bytes, int p
   for (int pl = 0; pl < planes; ++pl) *reinterpret_cast<u32x2v *>(ub + pl * plane_bytes + off) = u32x2v{0u, 0u};
 }
 
+// Sum every row's 32 pixel lanes (one half-wave) for all N rows of a lane together: at distance OFF a lane hands the half of its rows
+// its partner keeps and adds the partner's copy of the half it keeps itself (N / 2 exchanges), then the same on the kept half at
+// OFF / 2; a single remaining row is summed across the remaining distances.  All indices are compile-time (registers, no scratch).
+template <int NDOT, int N, int OFF>
+__device__ __forceinline__ void dot_tree(float (&a)[NDOT], const int lane) {
+  if constexpr (OFF > 0) {
+    if constexpr (N > 1) {
+      constexpr int H = N / 2;
+      const bool up = (lane & OFF) != 0;
+#pragma unroll
+      for (int k = 0; k < H; ++k) {
+        const float send = up ? a[k] : a[k + H], keep = up ? a[k + H] : a[k];
+        a[k] = keep + __shfl_xor(send, OFF, 64);
+      }
+      dot_tree<NDOT, H, OFF / 2>(a, lane);
+    } else {
+      a[0] += __shfl_xor(a[0], OFF, 64);
+      dot_tree<NDOT, 1, OFF / 2>(a, lane);
+    }
+  }
+}
+
 // SINK = false compiles the sink out (the exact-fp32 instantiations: no unit consumer exists in that arithmetic, and the sink's
 // registers pushed the 4-waves/SIMD builds into scratch -- 320 bytes per lane, exact-fp32 step 27.1 -> 31.7 ms).
 // NROW < 16 (conv_small.hip): the wave holds only accumulator rows 0 .. NROW-1 of its tile (one 4-channel row group after the
@@ -109,7 +131,14 @@ __device__ __forceinline__ void sink_zero(char *ub, long long plane_bytes, int p
 // OPT: which optional operand paths are compiled in -- bit 0 the residual, bit 1 the dot / gate operand.  A launch that has neither
 // runs the OPT = 0 instantiation: a third of the epilogue's code (loads, shuffle trees, branches on flags that are never set) is not
 // there (conv_units_fprop_kernel: -2 .. -4 % per launch in f32x3, -7 % in bf16, profiles/r06_epilogue_opt.txt).
-template <int WTM, int WTN, int RG, bool SINK = true, int NROW = 16, int OPT = 3>
+// BATCH (the 512-thread unit-tensor kernels: 256 registers per lane): the unit sink's scales are loaded with the row group's other
+// operands (one dependent load per element inside the arithmetic before), and -- BDOT -- the dot operand's per-row sums are kept for
+// all rows and reduced together after the stores (dot_tree: NDOT - 1 exchanges in five steps of independent instructions; one dependent
+// 5-exchange chain per row before, 160 exchanges for a 128-channel tile).  Measured per launch, forward + sink / data gradient + dot:
+// -4 .. -8 % / -5 .. -16 % in f32x3, -18 % / -20 % in bf16 (profiles/r06_epilogue_opt.txt).  The 256-thread NCHW kernels (128 registers
+// per lane) keep the old forms: the extra live registers sent them to scratch; BDOT is off for the bf16 64-channel tile, which its
+// registers would take from two resident blocks per CU to one.
+template <int WTM, int WTN, int RG, bool SINK = true, int NROW = 16, int OPT = 3, bool BATCH = false, bool BDOT = BATCH>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], const EpiK &e, float *y, float *slab, int M_, int HWout,
                                               int mrow0, int lane, const int (&e_pix)[WTN], const int (&e_b)[WTN], bool dot_ok,
                                               int dot_b, int dot_slots, int dot_slot, int Hout = 0, int Wout = 0) {
@@ -160,13 +189,17 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
       s_ring[j] = e_pix[j] < 0 ? 0 : ((X == 0 ? 1 : 0) | (X == Wout - 1 ? 2 : 0) | (Y == 0 ? 4 : 0) | (Y == Hout - 1 ? 8 : 0));
     }
   }
+  constexpr int NDOT = BDOT ? WTM * NROW : 1;  // accumulator rows of this lane (row k = i * NROW + r16)
+  float dacc[NDOT];
+#pragma unroll
+  for (int k = 0; k < NDOT; ++k) dacc[k] = 0.f;
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
 #pragma unroll
     for (int r0 = 0; r0 < NROW; r0 += RG) {  // accumulator rows r0 .. r0+RG-1
       int idx[RG][WTN];  // output offsets fit 31 bits (checked on the host)
       int mrow[RG];
-      float bias4[RG], osv[RG][WTN], rsv[RG][WTN], axv[RG][WTN];
+      float bias4[RG], osv[RG][WTN], rsv[RG][WTN], axv[RG][WTN], usv[RG][WTN];
 #pragma unroll
       for (int q = 0; q < RG; ++q) {
         const int r16 = r0 + q;
@@ -177,8 +210,14 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
 #pragma unroll
         for (int j = 0; j < WTN; ++j) {
           idx[q][j] = (okm && e_pix[j] >= 0) ? (e_b[j] * M + m) * HWout + e_pix[j] : -1;
-          osv[q][j] = 1.f; rsv[q][j] = 0.f; axv[q][j] = 0.f;
+          osv[q][j] = 1.f; rsv[q][j] = 0.f; axv[q][j] = 0.f; usv[q][j] = 1.f;
         }
+      }
+      if (BATCH && sink && e_us) {
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) usv[q][j] = e_us[idx[q][j] >= 0 ? e_b[j] * M + mrow[q] : 0];
       }
       if (e_os) {
 #pragma unroll
@@ -219,14 +258,17 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
           if (e_res && !e_rfirst) val = (val + rsv[q][j]) * e_rscale;
           if (e_gate) val = axv[q][j] > 0.f ? val : 0.f;
           if (okq && y) y[idx[q][j]] = val;
-          if (sink) uval[q][j] = val * (e_us ? e_us[okq ? e_b[j] * M + m : 0] : 1.f);
+          if (sink) uval[q][j] = val * (BATCH ? usv[q][j] : (e_us ? e_us[okq ? e_b[j] * M + m : 0] : 1.f));
         }
-        if (do_dot) {  // one image per tile (checked on the host): reduce the 32 pixel lanes of each half-wave and store the
-          // partial of this (tile, wave column) in its own slot -- no atomics, the caller sums the slots in a fixed order
+        if (do_dot) {  // one image per tile (checked on the host): the 32 pixel lanes of each half-wave are summed and the partial of
+          // this (tile, wave column) goes to its own slot -- no atomics, the caller sums the slots in a fixed order
+          if constexpr (BDOT) {
+            dacc[i * NROW + r0 + q] = dsum;  // reduced with all the other rows after the stores
+          } else {
 #pragma unroll
-          for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
-          if ((lane & 31) == 0 && m < M && dot_ok)
-            e_dot[((size_t)dot_b * M + m) * dot_slots + dot_slot] = dsum;
+            for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+            if ((lane & 31) == 0 && m < M && dot_ok) e_dot[((size_t)dot_b * M + m) * dot_slots + dot_slot] = dsum;
+          }
         }
       }
       if (sink && mrow[0] < M) {  // (M % 8 == 0: a 4-channel run is inside M or outside it as a whole)
@@ -263,6 +305,25 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[WTM][WTN], con
           }
         }
       }
+    }
+  }
+  if (BDOT && do_dot) {
+    dot_tree<NDOT, NDOT, 16>(dacc, lane);
+    // which rows this lane holds now: one bit per halving step, the lane bit of that step's distance (most significant first)
+    int k = 0, nn = NDOT;
+    for (int off = 16; off > 0; off >>= 1) {
+      if (nn > 1) { nn >>= 1; k += (lane & off) ? nn : 0; }
+    }
+    // lanes that differ only in the bits of the plain-sum steps hold the same totals: the lowest one writes
+    int plain_mask = 0, n2 = NDOT;
+    for (int off = 16; off > 0; off >>= 1) {
+      if (n2 > 1) n2 >>= 1; else plain_mask |= off;
+    }
+    constexpr int NLEFT = NDOT > 32 ? NDOT / 32 : 1;  // rows a lane still holds after the five steps (consecutive rows k, k + 1, ..)
+    for (int t = 0; t < NLEFT; ++t) {
+      const int kk = k + t, ki = kk / NROW, kr = kk - ki * NROW;
+      const int m = mrow0 + ki * 32 + (kr & 3) + 8 * (kr >> 2) + 4 * (lane >> 5);
+      if ((lane & plain_mask) == 0 && m < M && dot_ok) e_dot[((size_t)dot_b * M + m) * dot_slots + dot_slot] = dacc[t];
     }
   }
 }

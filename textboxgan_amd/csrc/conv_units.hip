@@ -721,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void conv_units_fprop_kernel(const ConvUnit
     if (sum == 123.f) p.y[0] = sum;
     return;
   }
-  conv_epilogue<WTM, WTN, 4, true, 16, OPT>(acc, p.e, p.y, nullptr, p.M, p.H * p.W, m0 + wm * WTM * 32, lane, e_pix, e_b, true, b, p.dot_slots,
+  conv_epilogue<WTM, WTN, 4, true, 16, OPT, true, !(NP == 1 && WTM == 1)>(acc, p.e, p.y, nullptr, p.M, p.H * p.W, m0 + wm * WTM * 32, lane, e_pix, e_b, true, b, p.dot_slots,
                              (tu * p.tilesV + tv) * WGN + wn, p.H, p.W);
 }
 

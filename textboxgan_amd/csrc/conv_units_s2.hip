@@ -415,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void conv_units_s2_fprop_kernel(const ConvS
     e_pix[j] = (y0 + wn * WTN + j) * p.Wo + x0 + (lane & 31);
     e_b[j] = b;
   }
-  conv_epilogue<WTM, WTN, 4>(acc, p.e, p.y, nullptr, p.M, p.Ho * p.Wo, m0 + wm * WTM * 32, lane, e_pix, e_b, true, b, p.dot_slots,
+  conv_epilogue<WTM, WTN, 4, true, 16, 3, true>(acc, p.e, p.y, nullptr, p.M, p.Ho * p.Wo, m0 + wm * WTM * 32, lane, e_pix, e_b, true, b, p.dot_slots,
                              (tu * p.tilesV + tv) * 4 + wn, p.Ho, p.Wo);
 }
 

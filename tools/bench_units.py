@@ -54,5 +54,16 @@ for (C, M, H, W, Bx) in [(128, 128, 64, 256, B), (128, 128, 32, 128, B), (128, 1
             t_old = timeit(lambda: ops.conv2d_raw(x, pf, M, 3, 3, (H, W), (1, 1), (1, 1), in_scale=xs, epi=epi(), out=out))
             XU = ops.units_pack(x, xs, planes=planes)
             t_new = timeit(lambda: ops.conv2d_units_raw(XU, pf, M, epi=epi(), out=out))
-        row += f"  [{mode}] nchw {t_old:7.1f} us ({fl / t_old / 1e6:6.1f} TF)  units {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF)"
+            # the data-gradient form (flipped transposed filter, per-channel output scale, fused dot with a second tensor: OPT = 2) and
+            # the forward with a unit sink (the next layer's operand written by this launch)
+            DU, pft, aux, dot = ops.units_pack(out, dd, planes=planes), ops.pack_filter(w, True, True), torch.randn_like(x), torch.empty(Bx, C, device=dev)
+            dx = torch.empty(Bx, C, H, W, device=dev)
+            t_dg = timeit(lambda: ops.conv2d_units_raw(DU, pft, C, epi=N.epilogue(out_scale=xs), dot=(aux, dot), out=dx)) if C == M else float("nan")
+            class _Sink(ops.UnitSink):
+                def wanted(self, *a):
+                    return True
+            sink = _Sink(dd, "s1", M)
+            t_sk = timeit(lambda: ops.conv2d_units_raw(XU, pf, M, epi=epi(), out=out, sink=sink))
+        row += (f"  [{mode}] nchw {t_old:7.1f} us ({fl / t_old / 1e6:6.1f} TF)  units {t_new:7.1f} us ({fl / t_new / 1e6:6.1f} TF)"
+                f"  +sink {t_sk:7.1f}  dgrad+dot {t_dg:7.1f}")
     print(row, flush=True)
