@@ -337,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvSmallP p) 
     e_pix[0] = (n < Ntot && Y < p.Hout && X < p.Wout) ? Y * p.Wout + X : -1;
   }
   const int dot_b = nb / HWg;
-  conv_epilogue<1, 1, 4, true, 4>(a1, p.e, p.y, nullptr, p.M, HWo, m0 + 8 * rg, lane, e_pix, e_b, true, dot_b, p.dot_slots,
+  conv_epilogue<1, 1, 4, true, 4, 3, true>(a1, p.e, p.y, nullptr, p.M, HWo, m0 + 8 * rg, lane, e_pix, e_b, true, dot_b, p.dot_slots,
                                   (nb - dot_b * HWg) >> 5, p.Hout, p.Wout);
 }
 
