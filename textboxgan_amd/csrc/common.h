@@ -79,3 +79,33 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+
+// N wave-wide sums at once (N a power of two <= 64): at distance OFF a lane hands its partner the half of the values the partner keeps
+// and adds the partner's copy of the half it keeps itself, then the same on the kept half at OFF / 2 -- N - 1 exchanges plus one per
+// remaining distance, in six steps of independent instructions, instead of N chains of six dependent exchanges.  Afterwards a[0] of lane l
+// is the total of value wave_tree_row<N>(l); lanes that differ only in the low (plain-sum) bits hold the same total.
+template <int NT, int N, int OFF>
+__device__ __forceinline__ void wave_tree_sum(float (&a)[NT], const int lane) {
+  if constexpr (OFF > 0) {
+    if constexpr (N > 1) {
+      constexpr int H = N / 2;
+      const bool up = (lane & OFF) != 0;
+#pragma unroll
+      for (int k = 0; k < H; ++k) {
+        const float send = up ? a[k] : a[k + H], keep = up ? a[k + H] : a[k];
+        a[k] = keep + __shfl_xor(send, OFF, 64);
+      }
+      wave_tree_sum<NT, H, OFF / 2>(a, lane);
+    } else {
+      a[0] += __shfl_xor(a[0], OFF, 64);
+      wave_tree_sum<NT, 1, OFF / 2>(a, lane);
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ int wave_tree_row(const int lane) {  // which of the N values lane `lane` holds after wave_tree_sum<N, N, 32>
+  int k = 0, nn = N;
+  for (int off = 32; off > 0; off >>= 1)
+    if (nn > 1) { nn >>= 1; k += (lane & off) ? nn : 0; }
+  return k;
+}

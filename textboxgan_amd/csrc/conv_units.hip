@@ -251,10 +251,13 @@ __global__ __launch_bounds__(256) void bias_act_bwd_units_kernel(const BabUnitsP
     }
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  {  // the 24 wave sums together (31 + 1 lane exchanges; 24 chains of 6 before)
+    float t[32];
 #pragma unroll
-  for (int cc = 0; cc < 8; ++cc) {
-    const float a = wave_sum(s_db[cc]), c = wave_sum(s_dn[cc]), d = wave_sum(s_dy[cc]);
-    if (lane == 0) { red[wave][cc] = a; red[wave][8 + cc] = c; red[wave][16 + cc] = d; }
+    for (int cc = 0; cc < 8; ++cc) { t[cc] = s_db[cc]; t[8 + cc] = s_dn[cc]; t[16 + cc] = s_dy[cc]; t[24 + cc] = 0.f; }
+    wave_tree_sum<32, 32, 32>(t, lane);
+    const int row = wave_tree_row<32>(lane);
+    if ((lane & 1) == 0 && row < 24) red[wave][row] = t[0];
   }
   __syncthreads();
   if (threadIdx.x < 24) {

@@ -203,9 +203,13 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const BiasActBwdP p) 
     if (p.dpre_out) p.dpre_out[(size_t)plane * p.HW + i] = dpre;
   }
   }
-  s_db = wave_sum(s_db); s_dn = wave_sum(s_dn); s_dyy = wave_sum(s_dyy);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) { red[0][wave] = s_db; red[1][wave] = s_dn; red[2][wave] = s_dyy; }
+  {  // the three wave sums together (common.h wave_tree_sum: 7 lane exchanges in six steps; three chains of six before)
+    float t[4] = {s_db, s_dn, s_dyy, 0.f};
+    wave_tree_sum<4, 4, 32>(t, lane);
+    const int row = wave_tree_row<4>(lane);
+    if ((lane & 15) == 0 && row < 3) red[row][wave] = t[0];
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     const size_t o = (size_t)plane * p.nchunks + blockIdx.y;
@@ -246,11 +250,12 @@ __global__ __launch_bounds__(256) void bias_act_bwd_small_kernel(const BiasActBw
     if (dxo) dxo[i] = dpre * sc;
     if (dpo) dpo[i] = dpre;
   }
-  s_db = wave_sum(s_db); s_dn = wave_sum(s_dn); s_dyy = wave_sum(s_dyy);
-  if (lane == 0) {
-    if (p.part_db) p.part_db[plane] = s_db;
-    if (p.part_dn) p.part_dn[plane] = s_dn;
-    if (p.part_dyy) p.part_dyy[plane] = s_dyy;
+  {  // the three wave sums together: lane 0 / 16 / 32 ends up with the total of db / dn / dyy
+    float t[4] = {s_db, s_dn, s_dyy, 0.f};
+    wave_tree_sum<4, 4, 32>(t, lane);
+    const int row = wave_tree_row<4>(lane);
+    float *dst = row == 0 ? p.part_db : row == 1 ? p.part_dn : row == 2 ? p.part_dyy : nullptr;
+    if ((lane & 15) == 0 && dst) dst[plane] = t[0];
   }
 }
 

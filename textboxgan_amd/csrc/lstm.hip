@@ -698,14 +698,14 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_sample_fwd_kernel(const DecFw
       e[i] = (kok && t < T) ? epb[(size_t)t * H + k] : 0.f;
     }
     const float vk = kok ? p.v[k] : 0.f, qk = kok ? qv[k] : 0.f;
+    // the wave sums of this residue class together (common.h wave_tree_sum: 15 + 2 lane exchanges; one chain of six per time step before)
+    constexpr int NE = (ATT_MAXT + 3) / 4;
+    static_assert(NE == 16, "wave_tree_sum takes a power of two");
 #pragma unroll
-    for (int i = 0; i < (ATT_MAXT + 3) / 4; ++i) {
-      const int t = tq + 4 * i;  // (uniform in a wave)
-      if (t < T) {
-        const float sgm = wave_sum(vk * tanhf(e[i] + qk));
-        if (lane == 0) part[wave & 3][t] = sgm;
-      }
-    }
+    for (int i = 0; i < NE; ++i) e[i] = (tq + 4 * i < T) ? vk * tanhf(e[i] + qk) : 0.f;
+    wave_tree_sum<NE, NE, 32>(e, lane);
+    const int ti = tq + 4 * wave_tree_row<NE>(lane);
+    if ((lane & 3) == 0 && ti < T) part[wave & 3][ti] = e[0];
   }
   __syncthreads();
   if (wave == 0) {
@@ -788,11 +788,10 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_sample_bwd_kernel(const DecBw
 #pragma unroll
           for (int i = 0; i < 8; ++i) da[i] += dcx[j] * x[i];
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float r = wave_sum(da[i]);
-          const int t = th * TH + i0 + i;
-          if (lane == 0 && i0 + i < TH && t < T) part[wave & 7][t] = r;  // (8 waves per half)
+        {  // the eight wave sums together (7 + 3 lane exchanges): lane 8 i ends up with the total of da[i]
+          wave_tree_sum<8, 8, 32>(da, lane);
+          const int i = wave_tree_row<8>(lane), t = th * TH + i0 + i;
+          if ((lane & 7) == 0 && i0 + i < TH && t < T) part[wave & 7][t] = da[0];  // (8 waves per half)
         }
       }
     }

@@ -194,12 +194,11 @@ __global__ __launch_bounds__(256) void rgb_backproject_kernel(const RgbP p) {
         }
       }
     }
-    if (p.G) {
-#pragma unroll
-      for (int o = 0; o < RGB_MAXO; ++o) {
-        const float s = wave_sum(g[o]);
-        if (lane == 0 && o < p.O) p.G[(((size_t)b * p.C + c) * gridDim.x + blockIdx.x) * p.O + o] = s;
-      }
+    if (p.G) {  // the RGB_MAXO wave sums together (common.h wave_tree_sum): lane 16 o ends up with the total of g[o]
+      static_assert(RGB_MAXO == 4, "four partial sums per channel");
+      wave_tree_sum<4, 4, 32>(g, lane);
+      const int o = wave_tree_row<4>(lane);
+      if ((lane & 15) == 0 && o < p.O) p.G[(((size_t)b * p.C + c) * gridDim.x + blockIdx.x) * p.O + o] = g[0];
     }
   }
 }

@@ -527,16 +527,17 @@ __device__ __forceinline__ void dense_bwd_body(const DenseP &p, const int bx) {
       }
     }
   }
+  {  // the 4 x DN_RT wave sums together (63 lane exchanges in six steps; 64 chains of six before): lane l ends up with value l = kr * 16 + r
+    static_assert(DN_RT == 16, "the 64 partial sums of a wave map one to one onto its 64 lanes");
+    float t[64];
 #pragma unroll
-  for (int kr = 0; kr < 4; ++kr) {
+    for (int kr = 0; kr < 4; ++kr)
+#pragma unroll
+      for (int r = 0; r < DN_RT; ++r) t[kr * DN_RT + r] = acc[kr][r];
+    wave_tree_sum<64, 64, 32>(t, l);
+    const int kr = l >> 4, r = l & 15;  // (wave_tree_row<64>(l) == l)
     const int k = tk * 16 + q * 4 + kr;
-    float mine = 0.f;  // lane r keeps row r's total
-#pragma unroll
-    for (int r = 0; r < DN_RT; ++r) {
-      const float s = wave_sum(acc[kr][r]);
-      if (l == r) mine = s;
-    }
-    if (k < p.K && l < DN_RT && r0 + l < p.R) p.dx[(size_t)(r0 + l) * p.ldx + k] = p.alpha * mine;
+    if (k < p.K && r0 + r < p.R) p.dx[(size_t)(r0 + r) * p.ldx + k] = p.alpha * t[0];
   }
 }
 
