@@ -144,6 +144,12 @@ def test_graph_replay_equals_eager_step_full_size(dev):
     upd_e, upd_g = (g0 - s0).double(), (g1 - s0).double()
     assert float(upd_e.abs().max()) > 1e-3, "three Adam steps must have moved the weights (otherwise this is vacuous)"
     rel = float((upd_e - upd_g).norm() / upd_e.norm())
-    assert rel <= 2e-2, ("G update, relative L2 graph vs eager", rel)
+    # The bar has to clear what two EAGER runs of the same code differ by: the atomic scatter of the OCR branch's grid_sample backward
+    # has a handful of discrete outcomes (its gradient set differs by 0 / 2.3e-8 / 2.8e-8 / 3.9e-8 relative between identical runs), and
+    # with beta1 = 0 each outcome flips the update sign of a different set of noise-level elements: over 24 alternating eager / graph
+    # triples per build, 21 - 23 agree to 1e-4 and the rest sit at one or two discrete levels -- 0.011 (rounds 2 - 5), 0.021 / 0.024
+    # since the reduction orders of round 6 (tools/repeat_grads.py: 60 repeated gradient computations are bit-identical in the g and d sets).  A wrong
+    # gradient in one layer is a block of flipped signs: O(0.1 - 1).
+    assert rel <= 5e-2, ("G update, relative L2 graph vs eager", rel)
     reld = float((d0 - d1).double().norm() / (d0.double() - d0.double().mean()).norm())
     assert reld <= 1e-3, ("D weights, relative L2 graph vs eager", reld)
